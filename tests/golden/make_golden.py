@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference and the binary that
+oracle/build_ref.sh builds from it, oracle/_ref/psolve).  Nothing here is
+imported by the tests; the tests read the .npz files this script wrote.
+
+For every case the reference's examples/simple input (physics.in +
+numerical.in merged into the single parameters file today's psolve wants,
+psolve.c:7351, plus the 16 keys it requires, psolve.c:748-778) is run in a
+scratch directory and the following is captured:
+
+* mesh    : per-element node tick coordinates and (Vs,Vp,rho), from the
+            reference's own flat dump (meshformatlab.c:52-250)
+* forces  : out/srctmp/force_process.<rank> (quakesource.c:2453-2466)
+* ckpt    : checkpoint.out{0,1} (io_checkpoint.c:29-130): header
+            {groupsize, step, nharboredmax}; per rank tm2 then tm1
+* stations: out/stations/station.<i> text (psolve.c:6679-6795)
+* expected: the station traces the reference ships in
+            examples/simple/expected-out/stations (independent pin)
+
+Usage: python tests/golden/make_golden.py [case ...]
+"""
+import bz2
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = os.environ.get("HERC_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+PSOLVE = os.path.join(ROOT, "oracle", "_ref", "psolve")
+MPI = os.environ.get("HERC_MPI_DIR", "/opt/conda")
+
+EXTRA_KEYS = """
+softening_factor = 0
+use_progressive_meshing = 0
+4D_output_file = out/disp.q4d
+cvmdb_input_file = simple_case.e
+mesh_etree_output_file = out/mesh.e
+planes_input_file = in/planes.in
+include_nonlinear_analysis = no
+stiffness_calculation_method = {stiffness}
+print_matrix_k = {printk}
+print_station_velocities = no
+print_station_accelerations = no
+include_buildings = no
+mesh_coordinates_for_matlab = yes
+mesh_coordinates_directory_for_matlab = out/matlab
+mesh_corners_matlab =
+0 0 1000 1000 0 500
+implement_drm = no
+simulation_velocity_profile_freq_hz = 0
+use_infinite_qk = no
+"""
+
+
+def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
+                  nranks=1, printk="no", freq=None, dt=None):
+    """Run the reference in a scratch dir; return (dir, stdout)."""
+    run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
+    src = os.path.join(REF, "examples", "simple")
+    shutil.copytree(os.path.join(src, "in"), os.path.join(run, "in"))
+    shutil.copy(os.path.join(src, "simple_case.e"), run)
+    for root, dirs, files in os.walk(run):
+        for n in dirs + files:
+            os.chmod(os.path.join(root, n), 0o755)
+    for d in ("checkpoints", "planes", "srctmp", "stations", "matlab"):
+        os.makedirs(os.path.join(run, "out", d))
+    text = open(os.path.join(run, "in", "physics.in")).read() + \
+        open(os.path.join(run, "in", "numerical.in")).read() + \
+        EXTRA_KEYS.format(stiffness=stiffness, printk=printk)
+
+    def setkey(t, key, val):
+        return re.sub(r"(?m)^%s\s*=.*$" % re.escape(key), "%s = %s" % (key, val), t)
+
+    text = setkey(text, "simulation_end_time_sec", end_time)
+    text = setkey(text, "checkpointing_rate", ckpt_rate)
+    text = setkey(text, "type_of_damping", damping)
+    if freq is not None:
+        text = setkey(text, "simulation_wave_max_freq_hz", freq)
+    if dt is not None:
+        text = setkey(text, "simulation_delta_time_sec", dt)
+    open(os.path.join(run, "parameters.in"), "w").write(text)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(MPI, "lib"))
+    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", str(nranks), PSOLVE,
+                          "parameters.in"], cwd=run, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, universal_newlines=True)
+    if out.returncode != 0:
+        sys.stderr.write(out.stdout[-3000:])
+        raise RuntimeError("reference run %s failed" % tag)
+    return run, out.stdout
+
+
+def read_mesh(run, rank=0):
+    c = np.fromfile(os.path.join(run, "out", "matlab", "mesh_coordinates.%d" % rank), "<i4")
+    m = np.fromfile(os.path.join(run, "out", "matlab", "mesh_data.%d" % rank), "<f4")
+    return c.reshape(-1, 8, 3), m.reshape(-1, 3)
+
+
+def read_forces(run, rank=0):
+    p = os.path.join(run, "out", "srctmp", "force_process.%d" % rank)
+    if not os.path.exists(p):
+        return np.zeros(0, np.int32), np.zeros((0, 0, 3))
+    b = open(p, "rb").read()
+    n = int(np.frombuffer(b[:4], "<i4")[0])
+    ids = np.frombuffer(b[4:4 + 4 * n], "<i4").copy()
+    F = np.frombuffer(b[4 + 4 * n:], "<f8").reshape(-1, n, 3).copy()
+    return ids, F
+
+
+def read_checkpoint(path, harbored=None):
+    """-> (step, [ (tm2, tm1) per rank ]).  io_checkpoint.c:76-112."""
+    b = open(path, "rb").read()
+    groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+    out = []
+    for r in range(groupsize):
+        n = nmax if harbored is None else harbored[r]
+        off = 12 + 2 * r * nmax * 24
+        tm2 = np.frombuffer(b[off:off + n * 24], "<f8").reshape(n, 3).copy()
+        off += n * 24
+        tm1 = np.frombuffer(b[off:off + n * 24], "<f8").reshape(n, 3).copy()
+        out.append((tm2, tm1))
+    return step, out
+
+
+def read_station_text(text):
+    rows = [l.split() for l in text.splitlines() if l.strip() and not l.lstrip().startswith("#")]
+    return np.array([[float(v) for v in r[:4]] for r in rows])
+
+
+def read_stations(run, n=5):
+    return np.stack([read_station_text(open(os.path.join(run, "out", "stations", "station.%d" % i)).read())
+                     for i in range(n)])
+
+
+def parse_K(stdout):
+    """print_matrix_k = yes dump (psolve.c:3183-3225): every float on the
+    lines between the K1/K2 banners."""
+    nums = {}
+    cur = None
+    for line in stdout.splitlines():
+        s = line.strip()
+        m = re.match(r"^\s*(K1|K2|K3)\b", s)
+        if "Stiffness Matrix K1" in s or s.startswith("K1"):
+            cur = "K1"; nums[cur] = []; continue
+        if "Stiffness Matrix K2" in s or s.startswith("K2"):
+            cur = "K2"; nums[cur] = []; continue
+        if cur:
+            vals = re.findall(r"[-+]?\d+\.\d+(?:[eE][-+]?\d+)?", s)
+            if vals:
+                nums[cur] += [float(v) for v in vals]
+    return nums
+
+
+def case_short(name, **kw):
+    run, out = run_reference(name, "1.0", 400, **kw)
+    ids, F = read_forces(run)
+    elem_ticks, mat = read_mesh(run)
+    ck = {}
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", f))
+        ck[step] = blocks[0]
+    st = read_stations(run)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        elem_ticks=elem_ticks, mat_vs_vp_rho=mat, loaded_lnid=ids, forces=F,
+                        ckpt_steps=np.array(sorted(ck)),
+                        ckpt_tm2=np.stack([ck[s][0] for s in sorted(ck)]),
+                        ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
+                        stations=st, dt=1e-3, end_time=1.0, freq=5.0)
+    shutil.rmtree(run)
+    print(name, "ok", sorted(ck))
+
+
+def case_full():
+    run, out = run_reference("c1_full", "20", 6000, printk="yes")
+    ids, F = read_forces(run)
+    ck = {}
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", f))
+        ck[step] = blocks[0]
+    st = read_stations(run)
+    exp = []
+    for i in range(5):
+        raw = bz2.open(os.path.join(REF, "examples", "simple", "expected-out", "stations",
+                                    "station.%d.bz2" % i)).read().decode()
+        exp.append(read_station_text(raw))
+    exp = np.stack(exp)
+    # forces: the source is a scalar time function times a fixed nodal pattern,
+    # but keep the raw table (float64, exact) so nothing is re-derived.
+    np.savez_compressed(os.path.join(HERE, "c1_full.npz"),
+                        loaded_lnid=ids, forces=F,
+                        ckpt_steps=np.array(sorted(ck)),
+                        ckpt_tm2=np.stack([ck[s][0] for s in sorted(ck)]),
+                        ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
+                        stations_every20=st[:, ::20, :], expected_every20=exp[:, ::20, :],
+                        stations_head=st[:, :400, :], expected_head=exp[:, :400, :],
+                        max_abs_run_vs_expected=np.abs(st[:, :exp.shape[1], 1:] - exp[:, :st.shape[1], 1:]).max(),
+                        dt=1e-3, end_time=20.0, freq=5.0)
+    open(os.path.join(HERE, "c1_full_stdout_K.txt"), "w").write(
+        "\n".join(l for l in out.splitlines() if re.search(r"K[123]|^\s*[-+]?\d+\.\d+", l))[:200000])
+    shutil.rmtree(run)
+    print("c1_full ok", sorted(ck), "run-vs-expected max abs",
+          np.abs(st[:, :exp.shape[1], 1:] - exp[:, :st.shape[1], 1:]).max())
+
+
+def case_np8():
+    run, out = run_reference("c1_np8", "1.0", 400, nranks=8)
+    meshes = [read_mesh(run, r) for r in range(8)]
+    harbored = []
+    per_rank = {}
+    sched = open(os.path.join(run, "stat-sched.txt")).read() if os.path.exists(os.path.join(run, "stat-sched.txt")) else ""
+    meshstat = open(os.path.join(run, "stat-mesh.txt")).read() if os.path.exists(os.path.join(run, "stat-mesh.txt")) else ""
+    forces = [read_forces(run, r) for r in range(8)]
+    arrays = {}
+    ckfiles = {}
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", f))
+        ckfiles[step] = blocks
+    for r in range(8):
+        arrays["elem_ticks_%d" % r] = meshes[r][0]
+        arrays["loaded_lnid_%d" % r] = forces[r][0]
+        arrays["forces_%d" % r] = forces[r][1]
+        for s in sorted(ckfiles):
+            arrays["ckpt%d_tm2_%d" % (s, r)] = ckfiles[s][r][0]
+            arrays["ckpt%d_tm1_%d" % (s, r)] = ckfiles[s][r][1]
+    st = read_stations(run)
+    np.savez_compressed(os.path.join(HERE, "c1_np8.npz"), ckpt_steps=np.array(sorted(ckfiles)),
+                        stations=st, stat_sched=np.array(sched), stat_mesh=np.array(meshstat),
+                        dt=1e-3, end_time=1.0, freq=5.0, **arrays)
+    shutil.rmtree(run)
+    print("c1_np8 ok")
+
+
+CASES = {
+    "c1_short": lambda: case_short("c1_short"),
+    "c1_conv": lambda: case_short("c1_conv", stiffness="conventional"),
+    "c1_none": lambda: case_short("c1_none", damping="none"),
+    "c1_mass": lambda: case_short("c1_mass", damping="mass"),
+    "c1_full": case_full,
+    "c1_np8": case_np8,
+}
+
+if __name__ == "__main__":
+    if not os.path.exists(PSOLVE):
+        sys.exit("build oracle/_ref/psolve first (oracle/build_ref.sh)")
+    for c in (sys.argv[1:] or list(CASES)):
+        CASES[c]()

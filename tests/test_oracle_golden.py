@@ -1,0 +1,159 @@
+"""The oracle (oracle/herc_oracle.c) against the reference's golden vectors.
+
+Pins the CPU restatement before anything is checked against it:
+ * known-answer constants of SURVEY.md s8a (aBase/bBase, float-evaluated
+   mu/lambda/M, K1/K2 entries),
+ * full-field checkpoints written by the real reference binary for the
+   effective and conventional stiffness methods and Rayleigh / mass / no damping,
+ * the station traces the reference ships in examples/simple/expected-out.
+"""
+import numpy as np
+import pytest
+
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+
+def test_setab_known_answers():
+    a, b = ho.setab(5.0, ho.DAMP_RAYLEIGH)
+    assert a == 13.639003892573502
+    assert b == 0.05897899877679408
+    assert ho.setab(5.0, ho.DAMP_NONE) == (0.0, 0.0)
+    am, bm = ho.setab(5.0, ho.DAMP_MASS)
+    assert bm == 0.0 and am > 0
+
+
+def test_K_known_answers():
+    K1, K2 = ho.compute_K()
+    assert np.allclose(np.diag(K1[0, 0]), 4.0, rtol=0, atol=1e-14)
+    assert np.allclose(K1[0, 0][~np.eye(3, dtype=bool)], 0.75, rtol=0, atol=1e-14)
+    assert np.allclose(np.diag(K2[0, 0]), 1.0, rtol=0, atol=1e-14)
+    assert np.allclose(K2[0, 0][~np.eye(3, dtype=bool)], 0.75, rtol=0, atol=1e-14)
+    assert np.allclose(np.diag(K1[0, 7]), -1.0, rtol=0, atol=1e-14)
+    assert np.allclose(K1[0, 7][~np.eye(3, dtype=bool)], -0.375, rtol=0, atol=1e-14)
+    # c1*K1 + c2*K2 is symmetric as a 24x24 matrix
+    A = (1.3 * K1 + 0.7 * K2).transpose(0, 2, 1, 3).reshape(24, 24)
+    assert np.abs(A - A.T).max() < 1e-14
+
+
+def test_solver_init_float_evaluation():
+    p = H.c1_problem()
+    e = p["etable"][100]
+    dt2 = 1e-3 * 1e-3
+    # mu and lambda are evaluated in single precision first (psolve.c:3242-3248)
+    assert e[0] == dt2 * 62.5 * 32398098432.0 / 9
+    assert e[1] == dt2 * 62.5 * 32403800064.0 / 9
+    zeta = 0.0028868359513580799
+    b = zeta * 0.05897899877679408
+    assert e[2] == b * 1e-3 * 62.5 * 32398098432.0 / 9
+    # an interior node collects 8 x M = 8 x 82397464
+    n_int = int(np.argmax(p["ntable"][:, 0]))
+    assert p["ntable"][n_int, 0] == 8 * 82397464.0
+
+
+@pytest.mark.parametrize("case,stiff,damping", [
+    ("c1_short", ho.STIFF_EFFECTIVE, "rayleigh"),
+    ("c1_conv", ho.STIFF_CONVENTIONAL, "rayleigh"),
+    ("c1_none", ho.STIFF_EFFECTIVE, "none"),
+    ("c1_mass", ho.STIFF_EFFECTIVE, "mass"),
+])
+def test_checkpoints_bitwise(case, stiff, damping):
+    """Same loop order as the reference => identical bits, full field."""
+    g = H.load(case)
+    p = H.c1_problem(damping)
+    tm1 = np.zeros((p["N"], 3))
+    tm2 = np.zeros((p["N"], 3))
+    ids, phi = ho.station_weights(H.C1_STATIONS, H.C1_H, H.C1_NX, H.C1_NY, H.C1_NZ,
+                                  p["lnid"], p["elem_ijk"])
+    done = 0
+    caps = []
+    for k, step in enumerate(g["ckpt_steps"]):
+        caps.append(ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done,
+                                  int(step) - done, p["dt"], damping=p["damping"],
+                                  stiff_method=stiff, loaded_lnid=g["loaded_lnid"],
+                                  forces=g["forces"], cap_lnid=ids))
+        done = int(step)
+        # checkpoint = state after the swap at the top of `step` (io_checkpoint.c:98-112)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k])
+        assert np.array_equal(tm2, g["ckpt_tm1"][k])
+    assert np.abs(g["ckpt_tm1"][-1]).max() > 100.0      # the wave is really there
+    # station traces as the reference printed them ("% 8e": 7 significant digits)
+    cap = np.concatenate(caps).reshape(done, len(H.C1_STATIONS), 8, 3)
+    st = np.einsum("sn,tsnd->std", phi, cap)
+    ref = g["stations"][:, :done, 1:]
+    assert np.abs(st - ref).max() <= 6e-7 * np.abs(ref).max()
+
+
+def test_fused_formulation_matches_reference_loops():
+    """Formulation B (one effective product on u1 + beta (u1-u2)) is the same
+    algebra as stiffness + Rayleigh damping loops: agreement ~1e-13."""
+    g = H.load("c1_short")
+    p = H.c1_problem()
+    a1, a2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    ho.solver_run(p["lnid"], p["etable"], p["ntable"], a1, a2, 0, 800, p["dt"], formulation=1,
+                  loaded_lnid=g["loaded_lnid"], forces=g["forces"])
+    assert H.rel_linf(a2, g["ckpt_tm1"][1]) < 1e-11
+    assert H.rel_linf(a1, g["ckpt_tm2"][1]) < 1e-11
+
+
+def test_zero_skip_does_not_change_results():
+    g = H.load("c1_short")
+    p = H.c1_problem()
+    a1, a2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    ho.solver_run(p["lnid"], p["etable"], p["ntable"], a1, a2, 0, 400, p["dt"], zero_skip=False,
+                  loaded_lnid=g["loaded_lnid"], forces=g["forces"])
+    assert H.rel_linf(a2, g["ckpt_tm1"][0]) < 1e-13
+
+
+def test_uniform_mesh_generator_is_octor_order():
+    lnid, node_ijk, elem_ijk, _ = H.c1_mesh()
+    e2, l2, n2 = ho.uniform_mesh(H.C1_NX, H.C1_NY, H.C1_NZ)
+    assert np.array_equal(e2, elem_ijk) and np.array_equal(l2, lnid) and np.array_equal(n2, node_ijk)
+    assert len(node_ijk) == 2601 and len(lnid) == 2048
+
+
+def test_K_matches_reference_dump():
+    """print_matrix_k = yes output of the reference (psolve.c:3183-3225), 3 digits."""
+    import os
+    import re
+    txt = open(os.path.join(H.GOLDEN, "c1_full_stdout_K.txt")).read()
+    K1, K2 = ho.compute_K()
+    for name, K in (("K1", K1), ("K2", K2)):
+        blk = txt[txt.index("Stiffness Matrix " + name):]
+        rows = [l for l in blk.splitlines()[1:] if l.strip()][:24]
+        ref = np.array([[float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", r)] for r in rows])
+        assert ref.shape == (24, 24)
+        mine = K.transpose(0, 2, 1, 3).reshape(24, 24)
+        assert np.abs(mine - ref).max() < 5.1e-3 * np.abs(ref).max()
+
+
+def test_full_run_checkpoints_and_shipped_station_traces():
+    """20 000 steps of examples/simple: bit-identical to the real reference's
+    checkpoints at steps 12 000 / 18 000, and equal to the station traces the
+    reference SHIPS (examples/simple/expected-out/stations) to their printed
+    precision."""
+    g = H.load("c1_full")
+    p = H.c1_problem()
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    ids, phi = ho.station_weights(H.C1_STATIONS, H.C1_H, H.C1_NX, H.C1_NY, H.C1_NZ,
+                                  p["lnid"], p["elem_ijk"])
+    done, caps = 0, []
+    for k, step in enumerate(list(g["ckpt_steps"]) + [20000]):
+        caps.append(ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done,
+                                  int(step) - done, p["dt"], loaded_lnid=g["loaded_lnid"],
+                                  forces=g["forces"], cap_lnid=ids))
+        done = int(step)
+        if k < len(g["ckpt_steps"]):
+            assert np.array_equal(tm1, g["ckpt_tm2"][k])
+            assert np.array_equal(tm2, g["ckpt_tm1"][k])
+    cap = np.concatenate(caps).reshape(20000, 5, 8, 3)
+    st = np.einsum("sn,tsnd->std", phi, cap)
+    exp = g["expected_every20"][:, :, 1:]
+    mine = st[:, ::20, :][:, :exp.shape[1], :]
+    scale = np.abs(exp).max()
+    assert scale > 1000.0
+    assert np.abs(mine - exp).max() <= 6e-7 * scale
+    head = g["expected_head"][:, :, 1:]
+    assert np.abs(st[:, :head.shape[1], :] - head).max() <= 6e-7 * np.abs(head).max()
+    # and the real reference binary reproduced its own shipped traces when the fixture was made
+    assert float(g["max_abs_run_vs_expected"]) < 1e-3
