@@ -1,0 +1,216 @@
+"""ctypes binding of include/hq_solver.h (the stub a Python host would use).
+
+Fails loudly when the native library is missing or no gfx950 device is present:
+there is no fallback implementation.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
+
+HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
+
+EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
+           "hq_comm_unique_id", "hq_comm_init", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
+           "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
+           "hq_run_timed", "hq_dominant_kernel"]
+
+
+class HqError(RuntimeError):
+    pass
+
+
+class _Messenger(ctypes.Structure):
+    _fields_ = [("procid", ctypes.c_int32), ("nodecount", ctypes.c_int32),
+                ("mapping", ctypes.c_void_p)]
+
+
+class _Schedule(ctypes.Structure):
+    _fields_ = [("c_count", ctypes.c_int32), ("first_c", ctypes.POINTER(_Messenger)),
+                ("s_count", ctypes.c_int32), ("first_s", ctypes.POINTER(_Messenger))]
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [("lenum", ctypes.c_int32), ("nharbored", ctypes.c_int32), ("ldnnum", ctypes.c_int32),
+                ("lnid", ctypes.c_void_p), ("node_xyz", ctypes.c_void_p),
+                ("dn_ldnid", ctypes.c_void_p), ("dn_ptr", ctypes.c_void_p), ("dn_lanid", ctypes.c_void_p),
+                ("eTable", ctypes.c_void_p), ("nTable", ctypes.c_void_p),
+                ("tm1", ctypes.c_void_p), ("tm2", ctypes.c_void_p),
+                ("an_sched", _Schedule), ("dn_sched", _Schedule),
+                ("deltaT", ctypes.c_double), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class _Info(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int32), ("npatches", ctypes.c_int32),
+                ("patch_pairs", ctypes.c_int64), ("device_bytes", ctypes.c_int64),
+                ("step", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libhq_solver.so; raises HqError if it was not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIBPATH
+    if not os.path.exists(p):
+        raise HqError("native library %s is missing: run `python -m hercules_amd.build` "
+                      "(there is no Python/CPU fallback)" % p)
+    lib = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    lib.hq_last_error.restype = ctypes.c_char_p
+    lib.hq_dominant_kernel.restype = ctypes.c_char_p
+    lib.hq_dominant_kernel.argtypes = [ctypes.c_void_p]
+    for name in EXPORTS:
+        getattr(lib, name)          # AttributeError if the ABI is incomplete
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().hq_device_count())
+
+
+def _check(rc):
+    if rc != 0:
+        raise HqError("hq error %d: %s" % (rc, load_library().hq_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _schedule(sched, keep):
+    """sched = {"c": [(procid, mapping ndarray), ...], "s": [...]} or None."""
+    out = _Schedule()
+    if not sched:
+        return out
+    for key, cnt, first in (("c", "c_count", "first_c"), ("s", "s_count", "first_s")):
+        items = sched.get(key, [])
+        arr = (_Messenger * max(len(items), 1))()
+        for i, (procid, mapping) in enumerate(items):
+            m = np.ascontiguousarray(mapping, np.int32)
+            keep.append(m)
+            arr[i].procid = int(procid)
+            arr[i].nodecount = len(m)
+            arr[i].mapping = m.ctypes.data
+        keep.append(arr)
+        setattr(out, cnt, len(items))
+        setattr(out, first, ctypes.cast(arr, ctypes.POINTER(_Messenger)))
+    return out
+
+
+class Solver:
+    """One device-resident partition (hq_ctx)."""
+
+    def __init__(self, lnid, etable, ntable, dt, tm1=None, tm2=None, node_xyz=None,
+                 dangling=None, an_sched=None, dn_sched=None, rank=0, nranks=1,
+                 variant=HQ_VARIANT_AUTO, device=0):
+        lib = load_library()
+        keep = []
+        lnid = np.ascontiguousarray(lnid, np.int32)
+        etable = np.ascontiguousarray(etable, np.float64)
+        ntable = np.ascontiguousarray(ntable, np.float64)
+        d = _Desc()
+        d.lenum, d.nharbored = lnid.shape[0], ntable.shape[0]
+        d.lnid, d.eTable, d.nTable = _ptr(lnid), _ptr(etable), _ptr(ntable)
+        keep += [lnid, etable, ntable]
+        if node_xyz is not None:
+            node_xyz = np.ascontiguousarray(node_xyz, np.int32)
+            keep.append(node_xyz)
+            d.node_xyz = _ptr(node_xyz)
+        for name, a in (("tm1", tm1), ("tm2", tm2)):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64)
+                keep.append(a)
+                setattr(d, name, _ptr(a))
+        if dangling is not None:
+            ids, ptr, anchors = [np.ascontiguousarray(x, np.int32) for x in dangling]
+            keep += [ids, ptr, anchors]
+            d.ldnnum = len(ids)
+            d.dn_ldnid, d.dn_ptr, d.dn_lanid = _ptr(ids), _ptr(ptr), _ptr(anchors)
+        d.an_sched = _schedule(an_sched, keep)
+        d.dn_sched = _schedule(dn_sched, keep)
+        d.deltaT, d.rank, d.nranks, d.variant = dt, rank, nranks, variant
+        self._h = ctypes.c_void_p()
+        self.N, self.E = d.nharbored, d.lenum
+        _check(lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(self._h)))
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.hq_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def info(self):
+        i = _Info()
+        _check(self._lib.hq_get_info(self._h, ctypes.byref(i)))
+        return {k: getattr(i, k) for k, _ in _Info._fields_}
+
+    def set_source(self, loaded_lnid, forces, step0=0):
+        ids = np.ascontiguousarray(loaded_lnid, np.int32)
+        F = np.ascontiguousarray(forces, np.float64)
+        nsteps = F.shape[0] if len(ids) else 0
+        _check(self._lib.hq_set_source(self._h, ctypes.c_int32(len(ids)), _ptr(ids),
+                                       ctypes.c_int32(step0), ctypes.c_int32(nsteps), _ptr(F)))
+
+    def comm_init(self, id128):
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
+        _check(self._lib.hq_comm_init(self._h, buf))
+
+    def run(self, nsteps):
+        _check(self._lib.hq_run(self._h, ctypes.c_int32(nsteps)))
+
+    def sync(self):
+        _check(self._lib.hq_sync(self._h))
+
+    def run_timed(self, nsteps):
+        tot, ker = ctypes.c_double(), ctypes.c_double()
+        _check(self._lib.hq_run_timed(self._h, ctypes.c_int32(nsteps), ctypes.byref(tot), ctypes.byref(ker)))
+        return tot.value, ker.value
+
+    def dominant_kernel(self):
+        return self._lib.hq_dominant_kernel(self._h).decode()
+
+    def download(self):
+        tm1 = np.empty((self.N, 3))
+        tm2 = np.empty((self.N, 3))
+        _check(self._lib.hq_download(self._h, _ptr(tm1), _ptr(tm2)))
+        return tm1, tm2
+
+    def upload(self, tm1, tm2, step):
+        a = np.ascontiguousarray(tm1, np.float64)
+        b = np.ascontiguousarray(tm2, np.float64)
+        _check(self._lib.hq_upload(self._h, _ptr(a), _ptr(b), ctypes.c_int32(step)))
+
+    def gather(self, lnid):
+        ids = np.ascontiguousarray(np.asarray(lnid).reshape(-1), np.int32)
+        o1 = np.empty((len(ids), 3))
+        o2 = np.empty((len(ids), 3))
+        _check(self._lib.hq_gather(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o1), _ptr(o2)))
+        return o1, o2
+
+    def phase_force(self):
+        _check(self._lib.hq_phase_force(self._h))
+
+    def phase_update(self):
+        _check(self._lib.hq_phase_update(self._h))
+
+    def download_force(self):
+        f = np.empty((self.N, 3))
+        _check(self._lib.hq_download_force(self._h, _ptr(f)))
+        return f
+
+
+def comm_unique_id():
+    buf = (ctypes.c_char * 128)()
+    _check(load_library().hq_comm_unique_id(buf))
+    return bytes(buf)

@@ -1,0 +1,798 @@
+/*
+ * hq_engine.hip -- MI355X (gfx950) engine behind include/hq_solver.h.
+ *
+ * Device-resident restatement of the body of solver_run()
+ * (quake/forward/psolve.c:4265-4319) for one mesh partition:
+ *
+ *   source force      compute_addforce_s               psolve.c:5912-5928
+ *   element force     compute_addforce_effective       stiffness.c:180-237
+ *                   + damping_addforce                 damping.c:29-103   (fused, hq_kernels.h)
+ *   hanging nodes     compute_adjust                   psolve.c:5936-6039
+ *   halo exchange     schedule_senddata                psolve.c:4945-5079 (RCCL send/recv)
+ *   nodal update      solver_compute_displacement      psolve.c:4072-4114
+ *
+ * Two element-kernel variants:
+ *   SCATTER  one thread per element, SoA connectivity, fp64 hardware atomics
+ *            into the nodal force array, separate nodal-update kernel.  Works
+ *            for any mesh/partition (hanging nodes, halo exchange).
+ *   PATCH    owner-computes: the Z-ordered node range is cut into patches; a
+ *            workgroup stages the displacements of its patch (+ one ring of
+ *            neighbours) in LDS, evaluates every element touching the patch,
+ *            accumulates forces of OWNED nodes in LDS and finishes the
+ *            central-difference update in the same kernel.  The force vector
+ *            never exists in HBM.  (see hq_patch.h)
+ *
+ * There is no CPU fallback: without a gfx950 device hq_create() fails with
+ * HQ_ERR_NODEVICE.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/hq_solver.h"
+#include "hq_kernels.h"
+#include "hq_patch.h"
+
+/* ------------------------------------------------------------------------ */
+/* errors                                                                   */
+/* ------------------------------------------------------------------------ */
+
+static thread_local char g_err[512] = "";
+
+static int hq_fail(int code, const char* fmt, const char* a = "", const char* b = "")
+{
+    snprintf(g_err, sizeof g_err, fmt, a, b);
+    return code;
+}
+
+#define HQ_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return hq_fail(HQ_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+extern "C" const char* hq_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------------ */
+/* RCCL, resolved lazily so that single-GPU use never loads it              */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { char internal[128]; } hq_nccl_id;
+typedef void* hq_nccl_comm;
+struct hq_rccl {
+    void* handle;
+    int (*GetUniqueId)(hq_nccl_id*);
+    int (*CommInitRank)(hq_nccl_comm*, int, hq_nccl_id, int);
+    int (*CommDestroy)(hq_nccl_comm);
+    int (*Send)(const void*, size_t, int, int, hq_nccl_comm, hipStream_t);
+    int (*Recv)(void*, size_t, int, int, hq_nccl_comm, hipStream_t);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    const char* (*GetErrorString)(int);
+};
+static hq_rccl g_rccl = {};
+enum { HQ_NCCL_DOUBLE = 8 };   /* ncclFloat64, rccl.h ncclDataType_t */
+
+static int hq_rccl_load(void)
+{
+    if (g_rccl.handle) return HQ_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return hq_fail(HQ_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define HQ_SYM(field, name)                                                     \
+    *(void**)(&g_rccl.field) = dlsym(h, name);                                  \
+    if (!g_rccl.field) return hq_fail(HQ_ERR_COMM, "librccl lacks %s", name);
+    HQ_SYM(GetUniqueId, "ncclGetUniqueId")
+    HQ_SYM(CommInitRank, "ncclCommInitRank")
+    HQ_SYM(CommDestroy, "ncclCommDestroy")
+    HQ_SYM(Send, "ncclSend")
+    HQ_SYM(Recv, "ncclRecv")
+    HQ_SYM(GroupStart, "ncclGroupStart")
+    HQ_SYM(GroupEnd, "ncclGroupEnd")
+    HQ_SYM(GetErrorString, "ncclGetErrorString")
+#undef HQ_SYM
+    g_rccl.handle = h;
+    return HQ_OK;
+}
+
+#define HQ_NCCL(call)                                                                     \
+    do {                                                                                  \
+        int r_ = (call);                                                                  \
+        if (r_ != 0) return hq_fail(HQ_ERR_COMM, "%s: %s", #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+/* ------------------------------------------------------------------------ */
+/* context                                                                  */
+/* ------------------------------------------------------------------------ */
+
+struct hq_dev_messenger {
+    int32_t procid, nodecount;
+    int32_t offset;          /* first record in the packed buffer */
+};
+
+struct hq_dev_schedule {
+    std::vector<hq_dev_messenger> c, s;
+    int32_t* d_cmap = nullptr;   /* concatenated mappings of the c-list */
+    int32_t* d_smap = nullptr;
+    double*  d_cbuf = nullptr;   /* [sum nodecount][3] */
+    double*  d_sbuf = nullptr;
+    int32_t  ctotal = 0, stotal = 0;
+};
+
+struct hq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int32_t E = 0, N = 0, ldnnum = 0;
+    int32_t variant = HQ_VARIANT_SCATTER;
+    int32_t step = 0;
+    int32_t rank = 0, nranks = 1;
+    double dt = 0, dt2 = 0;
+    int64_t bytes = 0;
+
+    /* element data, SoA */
+    int32_t Epad = 0;
+    int32_t* d_lnid = nullptr;      /* [8][Epad] */
+    double* d_c1 = nullptr;
+    double* d_c2 = nullptr;
+    double* d_beta = nullptr;
+    /* node data */
+    double* d_nt = nullptr;         /* [N][7] */
+    double* d_u[3] = { nullptr, nullptr, nullptr };
+    int now = 0, prev = 1, spare = 2;
+    double* d_force = nullptr;
+    /* source window */
+    int32_t nloaded = 0, src_step0 = 0, src_nsteps = 0;
+    int32_t* d_loaded = nullptr;
+    double* d_F = nullptr;
+    /* hanging nodes */
+    int32_t* d_dn_id = nullptr;
+    int32_t* d_dn_ptr = nullptr;
+    int32_t* d_dn_anchor = nullptr;
+    /* halo */
+    hq_dev_schedule an, dn;
+    hq_nccl_comm comm = nullptr;
+    /* patch variant */
+    hq_patch_plan plan;
+    /* timing */
+    std::vector<hipEvent_t> ev;     /* per-launch marks */
+    hipEvent_t ev_span[2] = { nullptr, nullptr };
+    bool timing = false;
+    size_t ev_used = 0;
+};
+
+template <typename T>
+static int hq_dev_alloc(hq_ctx* c, T** p, size_t count)
+{
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) return hq_fail(HQ_ERR_NOMEM, "hipMalloc(%s) failed: %s", "", hipGetErrorString(e));
+    c->bytes += (int64_t)bytes;
+    return HQ_OK;
+}
+
+#define HQ_TRY(x) do { int r_ = (x); if (r_ != HQ_OK) return r_; } while (0)
+
+/* ------------------------------------------------------------------------ */
+/* kernels: scatter variant                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* force[lnid] = F * dt^2 (assignment): compute_addforce_s, psolve.c:5917-5927 */
+__global__ void hq_k_source(int32_t nloaded, const int32_t* __restrict__ loaded,
+                            const double* __restrict__ F, double dt2, double* __restrict__ force)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nloaded * 3) {
+        int i = t / 3, d = t - 3 * i;
+        force[3 * (int64_t)loaded[i] + d] = F[t] * dt2;
+    }
+}
+
+/*
+ * One thread per element; connectivity and coefficients are SoA so a wave
+ * reads them as contiguous 256-/512-byte rows.  Nodal displacements are
+ * gathered from the Z-ordered AoS node arrays (neighbouring elements share
+ * cache lines) and the 24 force components go out as fp64 hardware atomics.
+ */
+__global__ void __launch_bounds__(256)
+hq_k_element_scatter(int32_t E, int32_t Epad, const int32_t* __restrict__ lnid,
+                     const double* __restrict__ c1v, const double* __restrict__ c2v,
+                     const double* __restrict__ betav, const double* __restrict__ u1,
+                     const double* __restrict__ u2, double* __restrict__ force)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const double beta = betav[e];
+    int32_t id[8];
+    double X[8], Y[8], Z[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) id[n] = lnid[(int64_t)n * Epad + e];
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        const double* p1 = u1 + 3 * (int64_t)id[n];
+        const double* p2 = u2 + 3 * (int64_t)id[n];
+        double a0 = p1[0], a1 = p1[1], a2 = p1[2];
+        X[n] = a0 + beta * (a0 - p2[0]);
+        Y[n] = a1 + beta * (a1 - p2[1]);
+        Z[n] = a2 + beta * (a2 - p2[2]);
+    }
+    hq_element_force(X, Y, Z, c1v[e], c2v[e]);
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        double* f = force + 3 * (int64_t)id[n];
+        unsafeAtomicAdd(f + 0, X[n]);
+        unsafeAtomicAdd(f + 1, Y[n]);
+        unsafeAtomicAdd(f + 2, Z[n]);
+    }
+}
+
+/* solver_compute_displacement (psolve.c:4078-4111): one thread per scalar */
+__global__ void __launch_bounds__(256)
+hq_k_update(int64_t n3, const double* __restrict__ nt, const double* __restrict__ u1,
+            double* __restrict__ u2, double* __restrict__ force)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n3) return;
+    int64_t n = t / 3;
+    int d = (int)(t - 3 * n);
+    const double* np = nt + 7 * n;
+    double f = force[t];
+    f += np[1 + d] * u1[t] - np[4 + d] * u2[t];
+    u2[t] = f / np[0];
+    force[t] = 0.0;
+}
+
+/* compute_adjust DISTRIBUTION (psolve.c:5942-5987) */
+__global__ void hq_k_adjust_distribute(int32_t ldnnum, const int32_t* __restrict__ dn_id,
+                                       const int32_t* __restrict__ dn_ptr,
+                                       const int32_t* __restrict__ dn_anchor, double* __restrict__ table)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ldnnum * 3) return;
+    int k = t / 3, d = t - 3 * k;
+    int32_t lo = dn_ptr[k], hi = dn_ptr[k + 1];
+    double part = table[3 * (int64_t)dn_id[k] + d] / (double)(uint32_t)(hi - lo);
+    for (int32_t p = lo; p < hi; p++) unsafeAtomicAdd(&table[3 * (int64_t)dn_anchor[p] + d], part);
+}
+
+/* compute_adjust ASSIGNMENT (psolve.c:5992-6035) */
+__global__ void hq_k_adjust_assign(int32_t ldnnum, const int32_t* __restrict__ dn_id,
+                                   const int32_t* __restrict__ dn_ptr,
+                                   const int32_t* __restrict__ dn_anchor, double* __restrict__ table)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ldnnum * 3) return;
+    int k = t / 3, d = t - 3 * k;
+    int32_t lo = dn_ptr[k], hi = dn_ptr[k + 1];
+    double deps = (double)(uint32_t)(hi - lo);
+    double s = 0.0;
+    for (int32_t p = lo; p < hi; p++) s += table[3 * (int64_t)dn_anchor[p] + d] / deps;
+    table[3 * (int64_t)dn_id[k] + d] = s;
+}
+
+/* schedule_senddata pack (psolve.c:4985-5011) / unpack (:5035-5073) */
+__global__ void hq_k_pack(int32_t count, const int32_t* __restrict__ map,
+                          const double* __restrict__ table, double* __restrict__ out)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    out[t] = table[3 * (int64_t)map[i] + d];
+}
+
+__global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
+                            const double* __restrict__ in, double* __restrict__ table, int add)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    double* p = &table[3 * (int64_t)map[i] + d];
+    *p = add ? (*p + in[t]) : in[t];
+}
+
+__global__ void hq_k_gather(int32_t n, const int32_t* __restrict__ ids,
+                            const double* __restrict__ a, const double* __restrict__ b,
+                            double* __restrict__ oa, double* __restrict__ ob)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    oa[t] = a[3 * (int64_t)ids[i] + d];
+    ob[t] = b[3 * (int64_t)ids[i] + d];
+}
+
+/* ------------------------------------------------------------------------ */
+/* helpers                                                                  */
+/* ------------------------------------------------------------------------ */
+
+static inline unsigned hq_blocks(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* out)
+{
+    auto load = [&](int32_t count, const hq_messenger* list, std::vector<hq_dev_messenger>& v,
+                    int32_t** d_map, double** d_buf, int32_t* total) -> int {
+        std::vector<int32_t> map;
+        for (int32_t i = 0; i < count; i++) {
+            if (list[i].nodecount < 0 || (list[i].nodecount > 0 && !list[i].mapping))
+                return hq_fail(HQ_ERR_ARG, "messenger with bad mapping%s", "");
+            hq_dev_messenger m = { list[i].procid, list[i].nodecount, (int32_t)map.size() };
+            for (int32_t k = 0; k < list[i].nodecount; k++) {
+                int32_t id = list[i].mapping[k];
+                if (id < 0 || id >= c->N) return hq_fail(HQ_ERR_ARG, "messenger node id out of range%s", "");
+                map.push_back(id);
+            }
+            v.push_back(m);
+        }
+        *total = (int32_t)map.size();
+        if (*total) {
+            HQ_TRY(hq_dev_alloc(c, d_map, map.size()));
+            HQ_TRY(hq_dev_alloc(c, d_buf, map.size() * 3));
+            HQ_HIP(hipMemcpy(*d_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+        }
+        return HQ_OK;
+    };
+    HQ_TRY(load(in->c_count, in->first_c, out->c, &out->d_cmap, &out->d_cbuf, &out->ctotal));
+    HQ_TRY(load(in->s_count, in->first_s, out->s, &out->d_smap, &out->d_sbuf, &out->stotal));
+    return HQ_OK;
+}
+
+/*
+ * schedule_senddata (psolve.c:4945-5079) on device buffers.
+ * contribution: pack c-list, send to owners, receive from sharers, table += .
+ * sharing     : pack s-list, send to sharers, receive from owners, table  = .
+ */
+static int hq_exchange(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution)
+{
+    std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
+    std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
+    int32_t* d_smap = contribution ? s->d_cmap : s->d_smap;
+    int32_t* d_rmap = contribution ? s->d_smap : s->d_cmap;
+    double* d_sbuf = contribution ? s->d_cbuf : s->d_sbuf;
+    double* d_rbuf = contribution ? s->d_sbuf : s->d_cbuf;
+    int32_t stotal = contribution ? s->ctotal : s->stotal;
+    if (snd.empty() && rcv.empty()) return HQ_OK;
+    if (!c->comm) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init%s", "");
+    if (stotal)
+        hq_k_pack<<<hq_blocks((int64_t)stotal * 3, 256), 256, 0, c->stream>>>(stotal, d_smap, table, d_sbuf);
+    HQ_NCCL(g_rccl.GroupStart());
+    for (auto& m : rcv)
+        if (m.nodecount)
+            HQ_NCCL(g_rccl.Recv(d_rbuf + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
+                                m.procid, c->comm, c->stream));
+    for (auto& m : snd)
+        if (m.nodecount)
+            HQ_NCCL(g_rccl.Send(d_sbuf + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
+                                m.procid, c->comm, c->stream));
+    HQ_NCCL(g_rccl.GroupEnd());
+    /* one launch per neighbour: a node may receive from several sharers and the
+     * sums stay in a fixed order (the reference walks its messenger list) */
+    for (auto& m : rcv)
+        if (m.nodecount)
+            hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, c->stream>>>(
+                m.nodecount, d_rmap + m.offset, d_rbuf + 3 * (int64_t)m.offset, table, contribution ? 1 : 0);
+    HQ_HIP(hipGetLastError());
+    return HQ_OK;
+}
+
+static void hq_mark(hq_ctx* c)
+{
+    if (c->timing && c->ev_used < c->ev.size()) hipEventRecord(c->ev[c->ev_used++], c->stream);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the step                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static int hq_launch_source(hq_ctx* c)
+{
+    int32_t k = c->step - c->src_step0;
+    if (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
+        hq_k_source<<<hq_blocks(c->nloaded * 3, 64), 64, 0, c->stream>>>(
+            c->nloaded, c->d_loaded, c->d_F + (int64_t)k * c->nloaded * 3, c->dt2, c->d_force);
+    return HQ_OK;
+}
+
+static int hq_launch_element_scatter(hq_ctx* c)
+{
+    hq_mark(c);
+    hq_k_element_scatter<<<hq_blocks(c->E, 256), 256, 0, c->stream>>>(
+        c->E, c->Epad, c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_u[c->now], c->d_u[c->prev], c->d_force);
+    hq_mark(c);
+    return HQ_OK;
+}
+
+static int hq_launch_update(hq_ctx* c)
+{
+    int64_t n3 = (int64_t)c->N * 3;
+    hq_k_update<<<hq_blocks(n3, 256), 256, 0, c->stream>>>(n3, c->d_nt, c->d_u[c->now], c->d_u[c->prev],
+                                                          c->d_force);
+    return HQ_OK;
+}
+
+/* One iteration of the solver_run loop body, psolve.c:4286-4316 */
+static int hq_step_scatter(hq_ctx* c)
+{
+    HQ_TRY(hq_launch_source(c));                                   /* :4288 */
+    HQ_TRY(hq_launch_element_scatter(c));                          /* :4290-4291 */
+    HQ_TRY(hq_exchange(c, &c->dn, c->d_force, true));              /* :4298 */
+    if (c->ldnnum)                                                 /* :4299 */
+        hq_k_adjust_distribute<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
+            c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, c->d_force);
+    HQ_TRY(hq_exchange(c, &c->an, c->d_force, true));              /* :4301 */
+    HQ_TRY(hq_launch_update(c));                                   /* :4305 */
+    double* unew = c->d_u[c->prev];
+    HQ_TRY(hq_exchange(c, &c->an, unew, false));                   /* :4312 */
+    if (c->ldnnum)                                                 /* :4313 */
+        hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
+            c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
+    HQ_TRY(hq_exchange(c, &c->dn, unew, false));                   /* :4315 */
+    std::swap(c->now, c->prev);                                    /* :4271-4273 of the next iteration */
+    c->step++;
+    return HQ_OK;
+}
+
+static int hq_step_patch(hq_ctx* c)
+{
+    int32_t k = c->step - c->src_step0;
+    const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
+                          ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
+    hq_mark(c);
+    hq_patch_launch(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                    c->stream);
+    hq_mark(c);
+    int n = c->now, p = c->prev, s = c->spare;
+    c->now = s; c->prev = n; c->spare = p;
+    c->step++;
+    return HQ_OK;
+}
+
+static int hq_step(hq_ctx* c)
+{
+    return c->variant == HQ_VARIANT_PATCH ? hq_step_patch(c) : hq_step_scatter(c);
+}
+
+/* ------------------------------------------------------------------------ */
+/* C-ABI                                                                    */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int hq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
+{
+    if (!d || !out) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    *out = nullptr;
+    if (d->lenum < 0 || d->nharbored <= 0 || d->ldnnum < 0 || (d->lenum && !d->lnid) || !d->eTable ||
+        !d->nTable)
+        return hq_fail(HQ_ERR_ARG, "inconsistent mesh description%s", "");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return hq_fail(HQ_ERR_NODEVICE, "no HIP device: this engine has no CPU path%s", "");
+    if (device < 0 || device >= ndev) return hq_fail(HQ_ERR_ARG, "device index out of range%s", "");
+    hipDeviceProp_t prop;
+    HQ_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return hq_fail(HQ_ERR_NODEVICE, "device is %s, kernels are built for gfx950 only", prop.gcnArchName);
+    HQ_HIP(hipSetDevice(device));
+
+    hq_ctx* c = new (std::nothrow) hq_ctx();
+    if (!c) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");
+    c->device = device;
+    c->E = d->lenum; c->N = d->nharbored; c->ldnnum = d->ldnnum;
+    c->dt = d->deltaT; c->dt2 = d->deltaT * d->deltaT;
+    c->rank = d->rank; c->nranks = d->nranks > 0 ? d->nranks : 1;
+    int rc = HQ_OK;
+    auto bail = [&](int r) { hq_destroy(c); return r; };
+
+    for (int64_t i = 0; i < (int64_t)c->E * 8; i++)
+        if (d->lnid[i] < 0 || d->lnid[i] >= c->N) return bail(hq_fail(HQ_ERR_ARG, "lnid out of range%s", ""));
+
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(hq_fail(HQ_ERR_DEVICE, "hipStreamCreate failed%s", ""));
+
+    bool has_halo = d->an_sched.c_count || d->an_sched.s_count || d->dn_sched.c_count || d->dn_sched.s_count;
+    int variant = d->variant;
+    if (variant == HQ_VARIANT_AUTO)
+        variant = (has_halo || c->ldnnum) ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
+    if (variant == HQ_VARIANT_PATCH && (has_halo || c->ldnnum))
+        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take halo schedules or hanging nodes yet%s", ""));
+    if (variant != HQ_VARIANT_SCATTER && variant != HQ_VARIANT_PATCH)
+        return bail(hq_fail(HQ_ERR_ARG, "unknown variant%s", ""));
+    c->variant = variant;
+
+    /* node state */
+    size_t n3 = (size_t)c->N * 3;
+    int nbuf = (variant == HQ_VARIANT_PATCH) ? 3 : 2;
+    for (int b = 0; b < nbuf; b++) {
+        if ((rc = hq_dev_alloc(c, &c->d_u[b], n3)) != HQ_OK) return bail(rc);
+        if (hipMemset(c->d_u[b], 0, sizeof(double) * n3) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
+    }
+    if ((rc = hq_dev_alloc(c, &c->d_nt, (size_t)c->N * 7)) != HQ_OK) return bail(rc);
+    if (hipMemcpy(c->d_nt, d->nTable, sizeof(double) * 7 * c->N, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
+    if (d->tm1 && hipMemcpy(c->d_u[c->now], d->tm1, sizeof(double) * n3, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(hq_fail(HQ_ERR_DEVICE, "tm1 upload failed%s", ""));
+    if (d->tm2 && hipMemcpy(c->d_u[c->prev], d->tm2, sizeof(double) * n3, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(hq_fail(HQ_ERR_DEVICE, "tm2 upload failed%s", ""));
+
+    /* element coefficients: (c1, c2, beta = c3/c1) */
+    std::vector<double> c1(c->E), c2(c->E), beta(c->E);
+    for (int64_t e = 0; e < c->E; e++) {
+        const double* ep = d->eTable + 4 * e;
+        c1[e] = ep[0]; c2[e] = ep[1];
+        beta[e] = (ep[0] != 0.0) ? ep[2] / ep[0] : ((ep[1] != 0.0) ? ep[3] / ep[1] : 0.0);
+    }
+
+    if (variant == HQ_VARIANT_SCATTER) {
+        if ((rc = hq_dev_alloc(c, &c->d_force, n3)) != HQ_OK) return bail(rc);
+        hipMemset(c->d_force, 0, sizeof(double) * n3);
+        c->Epad = (c->E + 63) & ~63;
+        std::vector<int32_t> soa((size_t)8 * c->Epad, 0);
+        for (int64_t e = 0; e < c->E; e++)
+            for (int n = 0; n < 8; n++) soa[(size_t)n * c->Epad + e] = d->lnid[8 * e + n];
+        if ((rc = hq_dev_alloc(c, &c->d_lnid, soa.size())) != HQ_OK) return bail(rc);
+        if ((rc = hq_dev_alloc(c, &c->d_c1, (size_t)c->E)) != HQ_OK) return bail(rc);
+        if ((rc = hq_dev_alloc(c, &c->d_c2, (size_t)c->E)) != HQ_OK) return bail(rc);
+        if ((rc = hq_dev_alloc(c, &c->d_beta, (size_t)c->E)) != HQ_OK) return bail(rc);
+        hipMemcpy(c->d_lnid, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice);
+        hipMemcpy(c->d_c1, c1.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
+        hipMemcpy(c->d_c2, c2.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
+        hipMemcpy(c->d_beta, beta.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
+        if (c->ldnnum) {
+            if (!d->dn_ldnid || !d->dn_ptr || !d->dn_lanid) return bail(hq_fail(HQ_ERR_ARG, "dangling-node tables missing%s", ""));
+            int32_t na = d->dn_ptr[c->ldnnum];
+            if ((rc = hq_dev_alloc(c, &c->d_dn_id, (size_t)c->ldnnum)) != HQ_OK) return bail(rc);
+            if ((rc = hq_dev_alloc(c, &c->d_dn_ptr, (size_t)c->ldnnum + 1)) != HQ_OK) return bail(rc);
+            if ((rc = hq_dev_alloc(c, &c->d_dn_anchor, (size_t)na)) != HQ_OK) return bail(rc);
+            hipMemcpy(c->d_dn_id, d->dn_ldnid, sizeof(int32_t) * c->ldnnum, hipMemcpyHostToDevice);
+            hipMemcpy(c->d_dn_ptr, d->dn_ptr, sizeof(int32_t) * (c->ldnnum + 1), hipMemcpyHostToDevice);
+            hipMemcpy(c->d_dn_anchor, d->dn_lanid, sizeof(int32_t) * na, hipMemcpyHostToDevice);
+        }
+        if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
+        if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
+    } else {
+        int64_t pb = 0;
+        rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), &pb);
+        if (rc != 0)
+            return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
+                                hq_patch_error()));
+        c->bytes += pb;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
+    *out = c;
+    return HQ_OK;
+}
+
+extern "C" int hq_destroy(hq_ctx* c)
+{
+    if (!c) return HQ_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.handle) g_rccl.CommDestroy(c->comm);
+    void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt, c->d_u[0], c->d_u[1], c->d_u[2],
+                     c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
+                     c->an.d_cmap, c->an.d_smap, c->an.d_cbuf, c->an.d_sbuf,
+                     c->dn.d_cmap, c->dn.d_smap, c->dn.d_cbuf, c->dn.d_sbuf };
+    for (void* p : ptrs) if (p) hipFree(p);
+    hq_patch_free(&c->plan);
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) if (c->ev_span[k]) hipEventDestroy(c->ev_span[k]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return HQ_OK;
+}
+
+extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
+{
+    if (!c || !info) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    info->variant = c->variant;
+    info->npatches = c->plan.npatches;
+    info->patch_pairs = c->plan.npairs;
+    info->device_bytes = c->bytes;
+    info->step = c->step;
+    info->nranks = c->nranks;
+    return HQ_OK;
+}
+
+extern "C" int hq_comm_unique_id(void* id128)
+{
+    if (!id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_TRY(hq_rccl_load());
+    hq_nccl_id id;
+    HQ_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return HQ_OK;
+}
+
+extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
+{
+    if (!c || !id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (c->comm) return hq_fail(HQ_ERR_STATE, "communicator already initialised%s", "");
+    HQ_TRY(hq_rccl_load());
+    HQ_HIP(hipSetDevice(c->device));
+    hq_nccl_id id;
+    memcpy(&id, id128, sizeof id);
+    HQ_NCCL(g_rccl.CommInitRank(&c->comm, c->nranks, id, c->rank));
+    return HQ_OK;
+}
+
+extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, int32_t step0,
+                             int32_t nsteps, const double* F)
+{
+    if (!c || nloaded < 0 || nsteps < 0 || (nloaded && nsteps && (!loaded || !F)))
+        return hq_fail(HQ_ERR_ARG, "bad source description%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    for (int32_t i = 0; i < nloaded; i++)
+        if (loaded[i] < 0 || loaded[i] >= c->N) return hq_fail(HQ_ERR_ARG, "loaded node id out of range%s", "");
+    if (c->d_loaded) { hipFree(c->d_loaded); c->d_loaded = nullptr; }
+    if (c->d_F) { hipFree(c->d_F); c->d_F = nullptr; }
+    c->nloaded = nloaded; c->src_step0 = step0; c->src_nsteps = nsteps;
+    if (nloaded && nsteps) {
+        HQ_TRY(hq_dev_alloc(c, &c->d_loaded, (size_t)nloaded));
+        HQ_TRY(hq_dev_alloc(c, &c->d_F, (size_t)nloaded * 3 * nsteps));
+        HQ_HIP(hipMemcpy(c->d_loaded, loaded, sizeof(int32_t) * nloaded, hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+    }
+    if (c->variant == HQ_VARIANT_PATCH) {
+        int r = hq_patch_set_source(&c->plan, (nloaded && nsteps) ? nloaded : 0, loaded, &c->bytes);
+        if (r != 0) return hq_fail(HQ_ERR_NOMEM, "source table allocation failed%s", "");
+    }
+    return HQ_OK;
+}
+
+extern "C" int hq_run(hq_ctx* c, int32_t nsteps)
+{
+    if (!c || nsteps < 0) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    for (int32_t s = 0; s < nsteps; s++) HQ_TRY(hq_step(c));
+    HQ_HIP(hipGetLastError());
+    return HQ_OK;
+}
+
+extern "C" int hq_sync(hq_ctx* c)
+{
+    if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    return HQ_OK;
+}
+
+extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double* kernel_ms_avg)
+{
+    if (!c || nsteps <= 0) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    size_t need = 2 * (size_t)nsteps;
+    while (c->ev.size() < need) {
+        hipEvent_t e;
+        HQ_HIP(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    for (int k = 0; k < 2; k++)
+        if (!c->ev_span[k]) HQ_HIP(hipEventCreate(&c->ev_span[k]));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    c->ev_used = 0;
+    HQ_HIP(hipEventRecord(c->ev_span[0], c->stream));
+    c->timing = true;
+    int rc = HQ_OK;
+    for (int32_t s = 0; s < nsteps && rc == HQ_OK; s++) rc = hq_step(c);
+    c->timing = false;
+    hipEventRecord(c->ev_span[1], c->stream);
+    hipError_t he = hipStreamSynchronize(c->stream);
+    double tot = 0, ker = 0;
+    if (rc == HQ_OK && he == hipSuccess) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev_span[0], c->ev_span[1]);
+        tot = ms;
+        for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+            hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            ker += ms;
+        }
+        if (c->ev_used >= 2) ker /= (double)(c->ev_used / 2);
+    }
+    if (rc != HQ_OK) return rc;
+    if (he != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "timed run failed: %s", hipGetErrorString(he));
+    if (total_ms) *total_ms = tot;
+    if (kernel_ms_avg) *kernel_ms_avg = ker;
+    return HQ_OK;
+}
+
+extern "C" const char* hq_dominant_kernel(hq_ctx* c)
+{
+    return (c && c->variant == HQ_VARIANT_PATCH) ? "hq_k_patch_step" : "hq_k_element_scatter";
+}
+
+extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2)
+{
+    if (!c || n < 0 || (n && !lnid)) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    if (n == 0) return HQ_OK;
+    HQ_HIP(hipSetDevice(c->device));
+    for (int32_t i = 0; i < n; i++)
+        if (lnid[i] < 0 || lnid[i] >= c->N) return hq_fail(HQ_ERR_ARG, "node id out of range%s", "");
+    int32_t* d_ids = nullptr;
+    double* d_o = nullptr;
+    HQ_HIP(hipMalloc((void**)&d_ids, sizeof(int32_t) * n));
+    hipError_t e = hipMalloc((void**)&d_o, sizeof(double) * 6 * (size_t)n);
+    if (e != hipSuccess) { hipFree(d_ids); return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", ""); }
+    hipMemcpyAsync(d_ids, lnid, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream);
+    hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->now], c->d_u[c->prev],
+                                                                         d_o, d_o + 3 * (size_t)n);
+    if (o1) hipMemcpyAsync(o1, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (o2) hipMemcpyAsync(o2, d_o + 3 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    e = hipStreamSynchronize(c->stream);
+    hipFree(d_ids);
+    hipFree(d_o);
+    if (e != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "gather failed: %s", hipGetErrorString(e));
+    return HQ_OK;
+}
+
+extern "C" int hq_download(hq_ctx* c, double* tm1, double* tm2)
+{
+    if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    if (tm1) HQ_HIP(hipMemcpy(tm1, c->d_u[c->now], bytes, hipMemcpyDeviceToHost));
+    if (tm2) HQ_HIP(hipMemcpy(tm2, c->d_u[c->prev], bytes, hipMemcpyDeviceToHost));
+    return HQ_OK;
+}
+
+extern "C" int hq_upload(hq_ctx* c, const double* tm1, const double* tm2, int32_t step)
+{
+    if (!c || !tm1 || !tm2) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    HQ_HIP(hipMemcpy(c->d_u[c->now], tm1, bytes, hipMemcpyHostToDevice));
+    HQ_HIP(hipMemcpy(c->d_u[c->prev], tm2, bytes, hipMemcpyHostToDevice));
+    c->step = step;
+    return HQ_OK;
+}
+
+extern "C" int hq_phase_force(hq_ctx* c)
+{
+    if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (c->variant != HQ_VARIANT_SCATTER) return hq_fail(HQ_ERR_STATE, "phases exist in the scatter variant only%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_TRY(hq_launch_source(c));
+    HQ_TRY(hq_launch_element_scatter(c));
+    HQ_HIP(hipGetLastError());
+    return HQ_OK;
+}
+
+extern "C" int hq_phase_update(hq_ctx* c)
+{
+    if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (c->variant != HQ_VARIANT_SCATTER) return hq_fail(HQ_ERR_STATE, "phases exist in the scatter variant only%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_TRY(hq_launch_update(c));
+    std::swap(c->now, c->prev);
+    c->step++;
+    HQ_HIP(hipGetLastError());
+    return HQ_OK;
+}
+
+extern "C" int hq_download_force(hq_ctx* c, double* force)
+{
+    if (!c || !force) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (c->variant != HQ_VARIANT_SCATTER) return hq_fail(HQ_ERR_STATE, "no force array in the patch variant%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hipMemcpy(force, c->d_force, sizeof(double) * 3 * (size_t)c->N, hipMemcpyDeviceToHost));
+    return HQ_OK;
+}

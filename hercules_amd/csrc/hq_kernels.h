@@ -1,0 +1,108 @@
+/*
+ * hq_kernels.h -- device-side arithmetic shared by the gfx950 kernels.
+ *
+ * The element force of Hercules' explicit step, fused:
+ *
+ *     f_e = -(c1 K1 + c2 K2) (u1 + beta (u1 - u2)),      beta = c3/c1 = c4/c2
+ *
+ * i.e. compute_addforce_effective (stiffness.c:180-237) and damping_addforce
+ * (damping.c:29-103) in ONE "effective" product, legal because
+ * c3 = (b/dt) c1 and c4 = (b/dt) c2 (psolve.c:3387-3409).  The product is
+ * evaluated through the reference's factorisation K = A D A^T
+ * (aTransposeU / firstVector / au, stiffness.c:245-424) but organised as a
+ * 3-stage radix-2 butterfly over the node-sign bits (A is the 8-point Walsh
+ * transform of the trilinear hexahedron), 72 + 72 adds instead of 147 + 168.
+ *
+ * Mode index m = bit0:x bit1:y bit2:z.  Reference row r <-> m:
+ * r1(z)=4 r2(y)=2 r3(x)=1 r4(yz)=6 r5(xz)=5 r6(xy)=3 r7(xyz)=7, r0 (rigid)=0.
+ */
+#ifndef HQ_KERNELS_H
+#define HQ_KERNELS_H
+
+#ifdef HQ_KERNEL_MATH_HOST_CHECK   /* tests/test_kernel_math_cpu.py: g++ compiles the arithmetic alone */
+#define __device__
+#define __forceinline__ inline
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+/* forward butterfly: v[n] (n = node, bit d set = far side of axis d) ->
+ * v[m] = sum_n prod_{d in m} sgn_d(n) v[n],  sgn = +1 on the far side. */
+__device__ __forceinline__ void hq_wht_fwd(double v[8])
+{
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (!(i & s)) {
+                double a = v[i], b = v[i | s];
+                v[i] = a + b;
+                v[i | s] = b - a;
+            }
+        }
+    }
+}
+
+/* transposed butterfly: f[n] = sum_m prod_{d in m} sgn_d(n) g[m] */
+__device__ __forceinline__ void hq_wht_inv(double v[8])
+{
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (!(i & s)) {
+                double lo = v[i], hi = v[i | s];
+                v[i] = lo - hi;
+                v[i | s] = lo + hi;
+            }
+        }
+    }
+}
+
+/*
+ * In: X,Y,Z = w[n][0..2] per node.  Out: X,Y,Z = f_e[n][0..2].
+ * c1, c2 as in e_t (psolve.h:196-198).
+ */
+__device__ __forceinline__ void hq_element_force(double X[8], double Y[8], double Z[8],
+                                                 double c1, double c2)
+{
+    /* stiffness.c:216-218 */
+    const double a = -0.5625 * (c2 + 2.0 * c1);
+    const double c = -0.5625 * c2;
+    const double b = -0.5625 * c1;
+    const double third = 1.0 / 3.0;
+    const double b3 = b * third, c3 = c * third, ab3 = (a + b) * third;
+    const double a2b9 = (a + 2.0 * b) * (1.0 / 9.0);
+
+    hq_wht_fwd(X);
+    hq_wht_fwd(Y);
+    hq_wht_fwd(Z);
+
+    /* D: firstVector (stiffness.c:291-319) in mode indices */
+    const double sxy = b * (Y[1] + X[2]);                    /* shear xy */
+    const double sxz = b * (Z[1] + X[4]);                    /* shear xz */
+    const double syz = b * (Z[2] + Y[4]);                    /* shear yz */
+    const double nx = a * X[1] + c * (Y[2] + Z[4]);          /* normal   */
+    const double ny = a * Y[2] + c * (X[1] + Z[4]);
+    const double nz = a * Z[4] + c * (X[1] + Y[2]);
+    const double t = X[6] + Y[5] + Z[3];                     /* twist    */
+    const double gx6 = b3 * (t + X[6]);
+    const double gy5 = b3 * (t + Y[5]);
+    const double gz3 = b3 * (t + Z[3]);
+    const double gx5 = ab3 * X[5] + c3 * Y[6];
+    const double gx3 = ab3 * X[3] + c3 * Z[6];
+    const double gy6 = ab3 * Y[6] + c3 * X[5];
+    const double gy3 = ab3 * Y[3] + c3 * Z[5];
+    const double gz6 = ab3 * Z[6] + c3 * X[3];
+    const double gz5 = ab3 * Z[5] + c3 * Y[3];
+
+    X[0] = 0.0; X[1] = nx;  X[2] = sxy; X[3] = gx3; X[4] = sxz; X[5] = gx5; X[6] = gx6; X[7] = a2b9 * X[7];
+    Y[0] = 0.0; Y[1] = sxy; Y[2] = ny;  Y[3] = gy3; Y[4] = syz; Y[5] = gy5; Y[6] = gy6; Y[7] = a2b9 * Y[7];
+    Z[0] = 0.0; Z[1] = sxz; Z[2] = syz; Z[3] = gz3; Z[4] = nz;  Z[5] = gz5; Z[6] = gz6; Z[7] = a2b9 * Z[7];
+
+    hq_wht_inv(X);
+    hq_wht_inv(Y);
+    hq_wht_inv(Z);
+}
+
+#endif /* HQ_KERNELS_H */

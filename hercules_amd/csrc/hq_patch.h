@@ -1,0 +1,455 @@
+/*
+ * hq_patch.h -- "owner computes" fused step for gfx950.
+ *
+ * The reference accumulates element forces into a nodal force array
+ * (stiffness.c:228-235, damping.c:88-98) and then sweeps the nodes
+ * (solver_compute_displacement, psolve.c:4078-4111).  On the GPU that costs a
+ * read-modify-write of `force` per element plus a read and a zeroing write per
+ * node.  Here the Z-ordered node range (octor sorts nodes with
+ * octor_zcompare, octor.c:6166) is cut into PATCHES of consecutive nodes that
+ * fill one aligned octree cube.  One workgroup per patch
+ *   1. stages u(t), u(t-dt) of the patch's nodes and of the one ring of
+ *      neighbour ("halo") nodes its elements reach into LDS,
+ *   2. evaluates EVERY element that touches an owned node (an element on a
+ *      patch boundary is evaluated by each patch it touches), accumulating
+ *      the forces of owned nodes in LDS with ds_add_f64,
+ *   3. adds the source force and finishes the central-difference update for
+ *      the owned nodes, writing u(t+dt) to a third buffer.
+ * The force vector never reaches HBM and there is one launch per step.
+ *
+ * Host side (hq_patch_build): cube-aligned cuts from the node coordinates,
+ * per-patch element lists, 16-bit patch-local connectivity, halo lists.
+ */
+#ifndef HQ_PATCH_H
+#define HQ_PATCH_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "hq_kernels.h"
+
+#define HQ_PATCH_THREADS 256
+#define HQ_PATCH_PMAX    768      /* owned nodes per patch (9*9*9 = 729 fits)         */
+#define HQ_PATCH_PMERGE  512      /* small neighbouring cubes are merged up to this   */
+#define HQ_PATCH_NLMAX   1024     /* owned + halo nodes staged in LDS (10*10*10 fits) */
+
+struct hq_patch_desc {
+    int32_t base;        /* first owned node (global id)          */
+    int32_t nown;        /* owned nodes: [base, base + nown)       */
+    int32_t nhalo;       /* halo nodes, local ids nown..nown+nhalo */
+    int32_t npairs;      /* elements evaluated by this patch       */
+    int64_t pair_off;    /* into pidx / pc1 / pc2 / pbeta          */
+    int64_t halo_off;    /* into halo_ids                          */
+};
+
+struct hq_patch_host {
+    std::vector<hq_patch_desc> desc;
+    std::vector<uint16_t> pidx;      /* [npairs][8] patch-local node ids */
+    std::vector<int32_t>  pelem;     /* [npairs] element id (host only)  */
+    std::vector<int32_t>  halo;      /* concatenated halo node ids        */
+};
+
+struct hq_patch_plan {
+    int32_t npatches = 0;
+    int64_t npairs = 0;
+    int64_t nhalo = 0;
+    hq_patch_desc* d_desc = nullptr;
+    uint4*   d_pidx = nullptr;
+    double*  d_pc1 = nullptr;
+    double*  d_pc2 = nullptr;
+    double*  d_pbeta = nullptr;
+    int32_t* d_halo = nullptr;
+    /* source entries grouped by patch (built by hq_patch_set_source) */
+    int32_t* d_src_ptr = nullptr;    /* [npatches + 1]                    */
+    int32_t* d_src_ent = nullptr;    /* [n][2] = {local node, loaded idx} */
+    std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
+    std::vector<int32_t> patch_nown;
+};
+
+static thread_local std::string g_patch_err;
+static const char* hq_patch_error(void) { return g_patch_err.c_str(); }
+
+/* ------------------------------------------------------------------------ */
+/* planner (host)                                                           */
+/* ------------------------------------------------------------------------ */
+
+static inline uint64_t hq_spread3(uint64_t v)
+{
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x1f00000000ffffULL;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+    v = (v | (v << 8))  & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4))  & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2))  & 0x1249249249249249ULL;
+    return v;
+}
+
+/*
+ * Cut [0,N) into runs of consecutive nodes.  With coordinates (node_t.x/y/z,
+ * octor.h:133-147) the cuts follow aligned octree cubes holding at most PMAX
+ * nodes; without them (or if the numbering is not Z-ordered) fixed runs.
+ */
+static void hq_patch_cuts(int64_t N, const int32_t* xyz, std::vector<int32_t>& cuts)
+{
+    cuts.clear();
+    auto fixed = [&]() {
+        cuts.clear();
+        for (int64_t i = 0; i < N; i += HQ_PATCH_PMERGE) cuts.push_back((int32_t)i);
+        cuts.push_back((int32_t)N);
+    };
+    if (!xyz) { fixed(); return; }
+
+    uint32_t orall = 0;
+    int32_t maxc[3] = { 0, 0, 0 };
+    for (int64_t n = 0; n < N; n++)
+        for (int d = 0; d < 3; d++) {
+            int32_t v = xyz[3 * n + d];
+            if (v < 0) { fixed(); return; }
+            orall |= (uint32_t)v;
+            maxc[d] = std::max(maxc[d], v);
+        }
+    int m = orall ? __builtin_ctz(orall) : 0;          /* common edge granularity 2^m ticks */
+    std::vector<uint64_t> key((size_t)N);
+    for (int64_t n = 0; n < N; n++) {
+        uint64_t q[3];
+        for (int d = 0; d < 3; d++) {
+            /* far-boundary nodes sort one tick inwards (octor.c:6100-6106) */
+            int32_t v = xyz[3 * n + d];
+            if (v == maxc[d] && v > 0) v -= 1;
+            q[d] = (uint64_t)(v >> m);
+            if (q[d] >> 21) { fixed(); return; }
+        }
+        key[n] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
+        if (n && key[n] < key[n - 1]) { fixed(); return; }     /* not Z-ordered */
+    }
+
+    std::vector<std::pair<int32_t, int32_t>> runs;              /* candidate patches */
+    struct item { int64_t lo, hi; int s; };
+    std::vector<item> stack;
+    stack.push_back({ 0, N, 21 });
+    while (!stack.empty()) {
+        item it = stack.back();
+        stack.pop_back();
+        if (it.hi - it.lo <= HQ_PATCH_PMAX) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
+        if (it.s == 0) {
+            for (int64_t i = it.lo; i < it.hi; i += HQ_PATCH_PMERGE)
+                runs.push_back({ (int32_t)i, (int32_t)std::min<int64_t>(i + HQ_PATCH_PMERGE, it.hi) });
+            continue;
+        }
+        int sh = 3 * (it.s - 1);
+        std::vector<item> kids;
+        int64_t i = it.lo;
+        while (i < it.hi) {
+            uint64_t cid = key[i] >> sh;
+            int64_t j = std::upper_bound(key.begin() + i, key.begin() + it.hi, cid,
+                                         [sh](uint64_t c, uint64_t k) { return c < (k >> sh); }) - key.begin();
+            kids.push_back({ i, j, it.s - 1 });
+            i = j;
+        }
+        for (auto k = kids.rbegin(); k != kids.rend(); ++k) stack.push_back(*k);   /* keep Z order */
+    }
+    std::sort(runs.begin(), runs.end());
+    /* merge small neighbours (coarse octree regions) */
+    cuts.push_back(0);
+    int32_t cur = 0;
+    for (auto& r : runs) {
+        int32_t n = r.second - r.first;
+        if (cur > 0 && cur + n > HQ_PATCH_PMERGE) { cuts.push_back(r.first); cur = 0; }
+        cur += n;
+    }
+    cuts.push_back((int32_t)N);
+}
+
+/*
+ * Pair lists and local numbering for the node runs `cuts`.  A run whose halo
+ * does not fit LDS is halved and the build repeated.
+ */
+static int hq_patch_plan_host(int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
+                              hq_patch_host* H)
+{
+    std::vector<int32_t> cuts;
+    hq_patch_cuts(N, xyz, cuts);
+
+    for (int attempt = 0; attempt < 12; attempt++) {
+        int32_t P = (int32_t)cuts.size() - 1;
+        std::vector<int32_t> patch_of((size_t)N);
+        for (int32_t p = 0; p < P; p++)
+            for (int32_t n = cuts[p]; n < cuts[p + 1]; n++) patch_of[n] = p;
+
+        /* count (patch, element) pairs */
+        std::vector<int64_t> off((size_t)P + 1, 0);
+        auto patches_of_elem = [&](int64_t e, int32_t out[8]) {
+            int k = 0;
+            for (int c = 0; c < 8; c++) {
+                int32_t p = patch_of[lnid[8 * e + c]];
+                bool seen = false;
+                for (int t = 0; t < k; t++) seen |= (out[t] == p);
+                if (!seen) out[k++] = p;
+            }
+            return k;
+        };
+        for (int64_t e = 0; e < E; e++) {
+            int32_t ps[8];
+            int k = patches_of_elem(e, ps);
+            for (int t = 0; t < k; t++) off[ps[t] + 1]++;
+        }
+        for (int32_t p = 0; p < P; p++) off[p + 1] += off[p];
+        int64_t npairs = off[P];
+        H->pelem.assign((size_t)npairs, 0);
+        {
+            std::vector<int64_t> fill(off.begin(), off.end() - 1);
+            for (int64_t e = 0; e < E; e++) {
+                int32_t ps[8];
+                int k = patches_of_elem(e, ps);
+                for (int t = 0; t < k; t++) H->pelem[(size_t)fill[ps[t]]++] = (int32_t)e;
+            }
+        }
+
+        /* halo lists */
+        std::vector<int64_t> hoff((size_t)P + 1, 0);
+        std::vector<std::vector<int32_t>> halos((size_t)P);
+        std::vector<char> bad((size_t)P, 0);
+        bool any_bad = false;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int32_t p = 0; p < P; p++) {
+            int32_t base = cuts[p], nown = cuts[p + 1] - cuts[p];
+            std::vector<int32_t>& h = halos[p];
+            h.clear();
+            for (int64_t q = off[p]; q < off[p + 1]; q++) {
+                const int32_t* id = lnid + 8 * (int64_t)H->pelem[(size_t)q];
+                for (int c = 0; c < 8; c++)
+                    if (id[c] < base || id[c] >= base + nown) h.push_back(id[c]);
+            }
+            std::sort(h.begin(), h.end());
+            h.erase(std::unique(h.begin(), h.end()), h.end());
+            if (nown + (int64_t)h.size() > HQ_PATCH_NLMAX || nown > HQ_PATCH_PMAX ||
+                off[p + 1] - off[p] > 0x7fffffff)
+                bad[p] = 1;
+        }
+        for (int32_t p = 0; p < P; p++) any_bad |= (bad[p] != 0);
+        if (any_bad) {
+            std::vector<int32_t> nc;
+            for (int32_t p = 0; p < P; p++) {
+                nc.push_back(cuts[p]);
+                if (bad[p]) {
+                    int32_t n = cuts[p + 1] - cuts[p];
+                    if (n < 2) { g_patch_err = "a single node reaches more neighbours than LDS can stage"; return -1; }
+                    nc.push_back(cuts[p] + n / 2);
+                }
+            }
+            nc.push_back((int32_t)N);
+            cuts.swap(nc);
+            continue;
+        }
+
+        for (int32_t p = 0; p < P; p++) hoff[p + 1] = hoff[p] + (int64_t)halos[p].size();
+        H->halo.assign((size_t)hoff[P], 0);
+        H->desc.assign((size_t)P, hq_patch_desc());
+        H->pidx.assign((size_t)npairs * 8, 0);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int32_t p = 0; p < P; p++) {
+            hq_patch_desc& D = H->desc[p];
+            D.base = cuts[p];
+            D.nown = cuts[p + 1] - cuts[p];
+            D.nhalo = (int32_t)halos[p].size();
+            D.npairs = (int32_t)(off[p + 1] - off[p]);
+            D.pair_off = off[p];
+            D.halo_off = hoff[p];
+            std::copy(halos[p].begin(), halos[p].end(), H->halo.begin() + hoff[p]);
+            const std::vector<int32_t>& h = halos[p];
+            for (int64_t q = off[p]; q < off[p + 1]; q++) {
+                const int32_t* id = lnid + 8 * (int64_t)H->pelem[(size_t)q];
+                for (int c = 0; c < 8; c++) {
+                    int32_t l;
+                    if (id[c] >= D.base && id[c] < D.base + D.nown) l = id[c] - D.base;
+                    else l = D.nown + (int32_t)(std::lower_bound(h.begin(), h.end(), id[c]) - h.begin());
+                    H->pidx[(size_t)q * 8 + c] = (uint16_t)l;
+                }
+            }
+        }
+        return 0;
+    }
+    g_patch_err = "patch refinement did not converge";
+    return -1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* kernel                                                                   */
+/* ------------------------------------------------------------------------ */
+
+__global__ void __launch_bounds__(HQ_PATCH_THREADS)
+hq_k_patch_step(int32_t npatches, int32_t per_xcd, const hq_patch_desc* __restrict__ desc,
+                const uint4* __restrict__ pidx, const double* __restrict__ pc1,
+                const double* __restrict__ pc2, const double* __restrict__ pbeta,
+                const int32_t* __restrict__ halo, const double* __restrict__ u1g,
+                const double* __restrict__ u2g, double* __restrict__ ung,
+                const double* __restrict__ nt, const int32_t* __restrict__ src_ptr,
+                const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2)
+{
+    __shared__ double s_u1[HQ_PATCH_NLMAX * 3];
+    __shared__ double s_u2[HQ_PATCH_NLMAX * 3];
+    __shared__ double s_f[HQ_PATCH_PMAX * 3];
+
+    /* workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD a
+     * contiguous run of Z-ordered patches so halo reads hit its own L2 */
+    const int p = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (p >= npatches) return;
+    const hq_patch_desc D = desc[p];
+    const int tid = threadIdx.x;
+    const int own3 = D.nown * 3;
+
+    {   /* owned nodes: one contiguous run of doubles */
+        const double* g1 = u1g + 3 * (int64_t)D.base;
+        const double* g2 = u2g + 3 * (int64_t)D.base;
+        for (int i = tid; i < own3; i += HQ_PATCH_THREADS) {
+            s_u1[i] = g1[i];
+            s_u2[i] = g2[i];
+            s_f[i] = 0.0;
+        }
+        const int32_t* hl = halo + D.halo_off;
+        for (int i = tid; i < D.nhalo * 3; i += HQ_PATCH_THREADS) {
+            int h = i / 3, d = i - 3 * h;
+            int64_t g = 3 * (int64_t)hl[h] + d;
+            s_u1[own3 + i] = u1g[g];
+            s_u2[own3 + i] = u2g[g];
+        }
+    }
+    __syncthreads();
+
+    for (int q = tid; q < D.npairs; q += HQ_PATCH_THREADS) {
+        const int64_t g = D.pair_off + q;
+        const uint4 raw = pidx[g];
+        const double beta = pbeta[g];
+        int l[8];
+        l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
+        l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
+        l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
+        l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
+        double X[8], Y[8], Z[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const double* a = &s_u1[3 * l[n]];
+            const double* b = &s_u2[3 * l[n]];
+            double a0 = a[0], a1 = a[1], a2 = a[2];
+            X[n] = a0 + beta * (a0 - b[0]);
+            Y[n] = a1 + beta * (a1 - b[1]);
+            Z[n] = a2 + beta * (a2 - b[2]);
+        }
+        hq_element_force(X, Y, Z, pc1[g], pc2[g]);
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            if (l[n] < D.nown) {
+                atomicAdd(&s_f[3 * l[n] + 0], X[n]);
+                atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
+                atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
+            }
+        }
+    }
+    if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
+        for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += HQ_PATCH_THREADS) {
+            int ln = src_ent[2 * k], li = src_ent[2 * k + 1];
+            for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * ln + d], F[3 * li + d] * dt2);
+        }
+    }
+    __syncthreads();
+
+    {   /* solver_compute_displacement, psolve.c:4078-4106 */
+        const double* np0 = nt + 7 * (int64_t)D.base;
+        double* out = ung + 3 * (int64_t)D.base;
+        for (int i = tid; i < own3; i += HQ_PATCH_THREADS) {
+            int n = i / 3, d = i - 3 * n;
+            const double* np = np0 + 7 * n;
+            double f = s_f[i] + (np[1 + d] * s_u1[i] - np[4 + d] * s_u2[i]);
+            out[i] = f / np[0];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* device plan                                                              */
+/* ------------------------------------------------------------------------ */
+
+static void hq_patch_free(hq_patch_plan* P)
+{
+    void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent };
+    for (void* p : ptrs) if (p) hipFree(p);
+    *P = hq_patch_plan();
+}
+
+static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
+                          const double* c1, const double* c2, const double* beta, int64_t* bytes)
+{
+    hq_patch_host H;
+    if (hq_patch_plan_host(E, N, lnid, xyz, &H) != 0) return -1 /* HQ_ERR_ARG */;
+    P->npatches = (int32_t)H.desc.size();
+    P->npairs = (int64_t)H.pelem.size();
+    P->nhalo = (int64_t)H.halo.size();
+    std::vector<double> v((size_t)P->npairs);
+    size_t np = (size_t)P->npairs ? (size_t)P->npairs : 1, nh = H.halo.size() ? H.halo.size() : 1;
+#define HQ_PA(ptr, bytes_)                                                                   \
+    if (hipMalloc((void**)&(ptr), (bytes_)) != hipSuccess) { g_patch_err = "hipMalloc failed"; hq_patch_free(P); return -2; } \
+    *bytes += (int64_t)(bytes_);
+    HQ_PA(P->d_desc, sizeof(hq_patch_desc) * H.desc.size())
+    HQ_PA(P->d_pidx, 16 * np)
+    HQ_PA(P->d_pc1, 8 * np)
+    HQ_PA(P->d_pc2, 8 * np)
+    HQ_PA(P->d_pbeta, 8 * np)
+    HQ_PA(P->d_halo, 4 * nh)
+#undef HQ_PA
+    hipMemcpy(P->d_desc, H.desc.data(), sizeof(hq_patch_desc) * H.desc.size(), hipMemcpyHostToDevice);
+    hipMemcpy(P->d_pidx, H.pidx.data(), 16 * (size_t)P->npairs, hipMemcpyHostToDevice);
+    hipMemcpy(P->d_halo, H.halo.data(), 4 * H.halo.size(), hipMemcpyHostToDevice);
+    const double* src[3] = { c1, c2, beta };
+    double* dst[3] = { P->d_pc1, P->d_pc2, P->d_pbeta };
+    for (int k = 0; k < 3; k++) {
+        for (int64_t q = 0; q < P->npairs; q++) v[(size_t)q] = src[k][H.pelem[(size_t)q]];
+        hipMemcpy(dst[k], v.data(), 8 * (size_t)P->npairs, hipMemcpyHostToDevice);
+    }
+    P->patch_base.resize(H.desc.size());
+    P->patch_nown.resize(H.desc.size());
+    for (size_t p = 0; p < H.desc.size(); p++) { P->patch_base[p] = H.desc[p].base; P->patch_nown[p] = H.desc[p].nown; }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+/* group the loaded nodes (Global.theNodesLoadedList, psolve.c:5917-5918) by owning patch */
+static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t* loaded, int64_t* bytes)
+{
+    if (P->d_src_ptr) { hipFree(P->d_src_ptr); P->d_src_ptr = nullptr; }
+    if (P->d_src_ent) { hipFree(P->d_src_ent); P->d_src_ent = nullptr; }
+    if (nloaded <= 0) return 0;
+    std::vector<int32_t> ptr((size_t)P->npatches + 1, 0), owner((size_t)nloaded);
+    for (int32_t i = 0; i < nloaded; i++) {
+        int32_t p = (int32_t)(std::upper_bound(P->patch_base.begin(), P->patch_base.end(), loaded[i]) -
+                              P->patch_base.begin()) - 1;
+        owner[i] = p;
+        ptr[p + 1]++;
+    }
+    for (int32_t p = 0; p < P->npatches; p++) ptr[p + 1] += ptr[p];
+    std::vector<int32_t> ent((size_t)nloaded * 2), fill(ptr.begin(), ptr.end() - 1);
+    for (int32_t i = 0; i < nloaded; i++) {
+        int32_t k = fill[owner[i]]++;
+        ent[2 * k] = loaded[i] - P->patch_base[owner[i]];
+        ent[2 * k + 1] = i;
+    }
+    if (hipMalloc((void**)&P->d_src_ptr, 4 * ptr.size()) != hipSuccess) return -2;
+    if (hipMalloc((void**)&P->d_src_ent, 4 * ent.size()) != hipSuccess) return -2;
+    *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
+    hipMemcpy(P->d_src_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice);
+    hipMemcpy(P->d_src_ent, ent.data(), 4 * ent.size(), hipMemcpyHostToDevice);
+    return 0;
+}
+
+static void hq_patch_launch(const hq_patch_plan* P, const double* u1, const double* u2, double* un,
+                            const double* nt, const double* F, double dt2, hipStream_t stream)
+{
+    int per_xcd = (P->npatches + 7) / 8;
+    hq_k_patch_step<<<per_xcd * 8, HQ_PATCH_THREADS, 0, stream>>>(
+        P->npatches, per_xcd, P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt,
+        P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2);
+}
+
+#endif /* HQ_PATCH_H */

@@ -1,0 +1,203 @@
+/*
+ * hq_solver.h -- C-ABI of the MI355X (gfx950) explicit time-stepping engine.
+ *
+ * Drop-in boundary for the hot path of CMU-Quake/hercules quake/forward
+ * (SURVEY.md s8b).  The reference has no plugin registry: the seam is a set
+ * of C functions called from solver_run() (psolve.c:4241-4324) that work on
+ * the caller-owned plain arrays of mesh_t (octor.h:166-179) and mysolver_t
+ * (psolve.h:295-312).  Each entry point below names the reference function(s)
+ * it replaces.  Plain pointers and sizes only; no HIP, torch or C++ types.
+ *
+ * Ownership : the caller owns every host buffer it passes; the context owns
+ *             all device memory, streams and events.
+ * Errors    : every call returns HQ_OK (0) or a negative hq_status; nothing
+ *             aborts the process (the reference MPI_Abort()s, util.h:128).
+ * Threading : one context per GPU / mesh partition; calls on one context must
+ *             not overlap.  hq_run() only enqueues work; hq_sync(), hq_gather(),
+ *             hq_download() wait for it.
+ */
+#ifndef HQ_SOLVER_H
+#define HQ_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQ_API __attribute__((visibility("default")))
+
+typedef struct hq_ctx hq_ctx;
+
+typedef enum {
+    HQ_OK            =  0,
+    HQ_ERR_ARG       = -1,   /* bad argument / inconsistent description     */
+    HQ_ERR_NOMEM     = -2,   /* host or device allocation failed            */
+    HQ_ERR_DEVICE    = -3,   /* HIP runtime error (see hq_last_error)       */
+    HQ_ERR_NODEVICE  = -4,   /* no gfx950 device / kernel image not loadable */
+    HQ_ERR_COMM      = -5,   /* RCCL error                                  */
+    HQ_ERR_STATE     = -6    /* call not valid in the context's state       */
+} hq_status;
+
+/* Element-kernel variants (hq_desc.variant). */
+enum {
+    HQ_VARIANT_AUTO    = 0,  /* fused patch kernel when the mesh allows it   */
+    HQ_VARIANT_SCATTER = 1,  /* element kernel + fp64 atomics, node kernel   */
+    HQ_VARIANT_PATCH   = 2   /* owner-computes patches, one fused kernel     */
+};
+
+/*
+ * One neighbour's shared-node list: messenger_t (psolve.h:230-249).
+ * `mapping` holds local node ids in the order both sides agreed on
+ * (ascending global id in the reference, psolve.c:4704-4863).
+ */
+typedef struct {
+    int32_t        procid;
+    int32_t        nodecount;
+    const int32_t* mapping;
+} hq_messenger;
+
+/*
+ * One communication schedule: schedule_t (psolve.h:255-274).
+ * c-list: ranks that OWN nodes I harbor -- I send them force contributions and
+ *         receive displacements from them.
+ * s-list: ranks that harbor nodes I OWN -- the reverse.
+ */
+typedef struct {
+    int32_t             c_count;
+    const hq_messenger* first_c;
+    int32_t             s_count;
+    const hq_messenger* first_s;
+} hq_schedule;
+
+/*
+ * Everything solver_run() reads, as plain arrays.
+ */
+typedef struct {
+    /* mesh_t */
+    int32_t        lenum;        /* elements on this partition               */
+    int32_t        nharbored;    /* nodes harbored (owned + shared copies)   */
+    int32_t        ldnnum;       /* dangling (hanging) nodes owned           */
+    const int32_t* lnid;         /* [lenum][8]  elem_t.lnid (octor.h:110-115) */
+    const int32_t* node_xyz;     /* [nharbored][3] node_t.x,y,z in ticks (octor.h:133-147); optional
+                                    (NULL): only used to place patch cuts on octree cubes */
+    /* dnodeTable (octor.h:153-158) as CSR: node dn_ldnid[k] hangs on
+     * anchors dn_lanid[dn_ptr[k] .. dn_ptr[k+1])  (deps = 2 or 4)            */
+    const int32_t* dn_ldnid;
+    const int32_t* dn_ptr;
+    const int32_t* dn_lanid;
+    /* mysolver_t */
+    const double*  eTable;       /* [lenum][4]      e_t  c1..c4 (psolve.h:196-198) */
+    const double*  nTable;       /* [nharbored][7]  n_t  (psolve.h:210-214)   */
+    const double*  tm1;          /* [nharbored][3]  u(t)      or NULL = 0     */
+    const double*  tm2;          /* [nharbored][3]  u(t-dt)   or NULL = 0     */
+    hq_schedule    an_sched;     /* anchored-node schedule  (mysolver_t.an_sched) */
+    hq_schedule    dn_sched;     /* dangling-node schedule  (mysolver_t.dn_sched) */
+    /* Param */
+    double         deltaT;       /* Param.theDeltaT (source force = F * dt^2) */
+    int32_t        rank, nranks; /* Global.myID, Global.theGroupSize          */
+    int32_t        variant;      /* HQ_VARIANT_*                              */
+    int32_t        reserved;
+} hq_desc;
+
+typedef struct {
+    int32_t variant;             /* variant actually built                    */
+    int32_t npatches;            /* patch variant: number of patches          */
+    int64_t patch_pairs;         /* patch variant: sum of per-patch elements  */
+    int64_t device_bytes;        /* device memory owned by the context        */
+    int32_t step;                /* next step to be executed                  */
+    int32_t nranks;
+} hq_info;
+
+/* Number of gfx950 devices visible (0 if none / no HIP runtime). */
+HQ_API int hq_device_count(void);
+
+/* Text of the last error on this thread ("" if none). */
+HQ_API const char* hq_last_error(void);
+
+/*
+ * Build the device-resident solver state.
+ * Replaces: the calloc()s of solver_init (psolve.c:3317-3325) and
+ * stiffness_init (stiffness.c:101-105); consumes the eTable/nTable that
+ * solver_init computed (psolve.c:3360-3473) and the schedules of
+ * schedule_build (psolve.c:4704-4863).
+ */
+HQ_API int hq_create(const hq_desc* desc, int device, hq_ctx** out);
+
+/* solver_delete (psolve.c:3627-3649). */
+HQ_API int hq_destroy(hq_ctx* ctx);
+
+HQ_API int hq_get_info(hq_ctx* ctx, hq_info* info);
+
+/*
+ * Multi-GPU: one RCCL communicator over the ranks that hold the partitions.
+ * Rank 0 obtains a 128-byte id, the host code broadcasts it (MPI_Bcast in the
+ * reference's world), every rank calls hq_comm_init.
+ * Replaces: solver_run_init_comm / schedule_prepare (psolve.c:3785-3808).
+ */
+HQ_API int hq_comm_unique_id(void* id128);
+HQ_API int hq_comm_init(hq_ctx* ctx, const void* id128);
+
+/*
+ * Source forces for steps [step0, step0+nsteps): F[nsteps][nloaded][3], the
+ * payload of force_process.<rank> (quakesource.c:2453-2466).
+ * Replaces: read_myForces (psolve.c:3651-3667) + compute_addforce_s (:5912-5928).
+ * Steps outside the window apply no source.
+ */
+HQ_API int hq_set_source(hq_ctx* ctx, int32_t nloaded, const int32_t* loaded_lnid,
+                         int32_t step0, int32_t nsteps, const double* F);
+
+/*
+ * Enqueue `nsteps` iterations of the solver_run loop body (psolve.c:4265-4319):
+ * tm1/tm2 swap, source force, stiffness + Rayleigh damping force
+ * (compute_addforce_effective stiffness.c:180-237 + damping_addforce
+ * damping.c:29-103), force contribution exchange and hanging-node
+ * distribution (psolve.c:4298-4301), nodal update (solver_compute_displacement
+ * psolve.c:4072-4114), displacement sharing and hanging-node assignment
+ * (psolve.c:4312-4315).  Asynchronous.
+ */
+HQ_API int hq_run(hq_ctx* ctx, int32_t nsteps);
+
+/* Wait for all enqueued work. */
+HQ_API int hq_sync(hq_ctx* ctx);
+
+/*
+ * State as the NEXT loop iteration sees it after its swap -- what stations,
+ * planes and checkpoints read (psolve.c:4271-4280): tm1 = u(step*dt),
+ * tm2 = u((step-1)*dt).  Either output may be NULL.
+ * hq_gather replaces the tm1[] reads of interpolate_station_displacements
+ * (psolve.c:6679-6710) / planes; hq_download those of checkpoint_write
+ * (io_checkpoint.c:98-112) and the 4D output (output.c:1265).
+ */
+HQ_API int hq_gather(hq_ctx* ctx, int32_t n, const int32_t* lnid, double* tm1_out, double* tm2_out);
+HQ_API int hq_download(hq_ctx* ctx, double* tm1, double* tm2);
+/* checkpoint_read (io_checkpoint.c:134-236): overwrite the fields, set the step. */
+HQ_API int hq_upload(hq_ctx* ctx, const double* tm1, const double* tm2, int32_t step);
+
+/*
+ * Single phases, for per-function parity tests against the reference loops
+ * (scatter variant only; the patch variant fuses them):
+ *   hq_phase_force : force += stiffness + damping element forces of the
+ *                    current (tm1,tm2), after the swap and the source force
+ *   hq_phase_update: solver_compute_displacement + zeroing of force
+ *   hq_download_force: copy the force accumulator [nharbored][3]
+ */
+HQ_API int hq_phase_force(hq_ctx* ctx);
+HQ_API int hq_phase_update(hq_ctx* ctx);
+HQ_API int hq_download_force(hq_ctx* ctx, double* force);
+
+/*
+ * Timed run for bench.py: enqueues nsteps like hq_run between two HIP events
+ * on the context's compute stream and additionally brackets every launch of
+ * the dominant kernel with events.  Returns wall ms for the whole batch and
+ * the average ms per launch of the dominant kernel.
+ */
+HQ_API int hq_run_timed(hq_ctx* ctx, int32_t nsteps, double* total_ms, double* kernel_ms_avg);
+
+/* Name of the dominant kernel as it appears in rocprofv3 kernel traces. */
+HQ_API const char* hq_dominant_kernel(hq_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQ_SOLVER_H */

@@ -1,0 +1,191 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the
+reference's own golden checkpoints.  Tolerance: <= 1e-9 relative L-inf on nodal
+displacement (fp64; the GPU sums element forces in a different order), the bar
+SURVEY.md s8c sets."""
+import numpy as np
+import pytest
+
+import hercules_amd as ha
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+VARIANTS = [ha.HQ_VARIANT_SCATTER, ha.HQ_VARIANT_PATCH]
+
+
+def _ticks(node_ijk, edge=1 << 26):
+    return (np.asarray(node_ijk, np.int64) * edge).astype(np.int32)
+
+
+def _box(nx, ny, nz, h=62.5, dt=1e-3, freq=5.0, damping=ho.DAMP_RAYLEIGH, vp=6000.0, vs=3464.0, rho=2700.0):
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:] = (h, vp, vs, rho)
+    face = ho.face_bits(elem_ijk, nx, ny, nz)
+    et, nt = ho.solver_init(lnid, edata, face, len(node_ijk), dt, freq, damping=damping)
+    return lnid, node_ijk, elem_ijk, et, nt
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case,damping", [("c1_short", "rayleigh"), ("c1_none", "none"), ("c1_mass", "mass")])
+def test_c1_against_reference_checkpoints(variant, case, damping):
+    """examples/simple driven by the reference's own force file; compared with the
+    checkpoints the REAL reference wrote at steps 400 and 800."""
+    g = H.load(case)
+    p = H.c1_problem(damping)
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], node_xyz=_ticks(p["node_ijk"]), variant=variant)
+    assert s.info()["variant"] == variant
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL
+        assert H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_c1_full_run_stations(variant):
+    """20 000 steps; stations gathered every step window; against the traces the
+    reference ships (printed to 7 digits) and its checkpoints at 12 000 / 18 000."""
+    g = H.load("c1_full")
+    p = H.c1_problem()
+    ids, phi = ho.station_weights(H.C1_STATIONS, H.C1_H, H.C1_NX, H.C1_NY, H.C1_NZ, p["lnid"], p["elem_ijk"])
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], node_xyz=_ticks(p["node_ijk"]), variant=variant)
+    s.set_source(g["loaded_lnid"], g["forces"])
+    exp = g["expected_every20"]
+    scale = np.abs(exp[:, :, 1:]).max()
+    ck = {int(st): k for k, st in enumerate(g["ckpt_steps"])}
+    for i in range(exp.shape[1]):
+        step = 20 * i
+        if step:
+            s.run(20)
+        if step in ck:
+            tm1, tm2 = s.download()
+            assert H.rel_linf(tm1, g["ckpt_tm1"][ck[step]]) < TOL
+            assert H.rel_linf(tm2, g["ckpt_tm2"][ck[step]]) < TOL
+        u, _ = s.gather(ids)
+        st = np.einsum("sn,snd->sd", phi, u.reshape(len(phi), 8, 3))
+        assert np.abs(st - exp[:, i, 1:]).max() <= 6e-7 * scale, step
+    s.close()
+
+
+def test_phase_force_and_update_match_reference_loops():
+    """hq_phase_force == compute_addforce_effective + damping_addforce;
+    hq_phase_update == solver_compute_displacement, on random fields."""
+    lnid, node_ijk, elem_ijk, et, nt = _box(12, 10, 6)
+    N = len(node_ijk)
+    rng = np.random.default_rng(12345)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-5
+    K1, K2 = ho.compute_K()
+    f = np.zeros((N, 3))
+    ho.lib().ho_addforce_effective(ho.ctypes.c_int64(len(lnid)), ho._p(lnid), ho._p(et), ho._p(u1), ho._p(f), 1)
+    ho.lib().ho_damping_addforce(ho.ctypes.c_int64(len(lnid)), ho._p(lnid), ho._p(et), ho._p(u1), ho._p(u2),
+                                 ho._p(K1), ho._p(K2), ho._p(f), 1)
+    s = ha.Solver(lnid, et, nt, 1e-3, tm1=u1, tm2=u2, variant=ha.HQ_VARIANT_SCATTER)
+    s.phase_force()
+    fg = s.download_force()
+    assert H.rel_linf(fg, f) < 1e-12
+    # update
+    new = u2.copy()
+    fo = f.copy()
+    ho.lib().ho_compute_displacement(ho.ctypes.c_int64(N), ho._p(nt), ho._p(u1), ho._p(new), ho._p(fo), None)
+    s.phase_update()
+    tm1, tm2 = s.download()           # post-swap view: tm1 = newest
+    assert H.rel_linf(tm1, new) < 1e-12
+    assert np.array_equal(tm2, u1)
+    assert np.all(s.download_force() == 0.0)
+    s.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(32, 32, 16), (20, 12, 9), (1, 1, 1), (3, 1, 2)])
+def test_random_field_steps_against_oracle(variant, shape):
+    """Seeded random start (SURVEY s8d stress input), ragged and tiny boxes, 12 steps."""
+    nx, ny, nz = shape
+    lnid, node_ijk, elem_ijk, et, nt = _box(nx, ny, nz, h=10.0, dt=2e-4)
+    N = len(node_ijk)
+    rng = np.random.default_rng(12345)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    o1, o2 = u2.copy(), u1.copy()      # oracle arrays are pre-swap
+    ho.solver_run(lnid, et, nt, o1, o2, 0, 12, 2e-4)
+    s = ha.Solver(lnid, et, nt, 2e-4, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk, 1 << 20), variant=variant)
+    s.run(12)
+    tm1, tm2 = s.download()
+    assert H.rel_linf(tm1, o2) < TOL
+    assert H.rel_linf(tm2, o1) < TOL
+    s.close()
+
+
+def test_patch_without_coordinates_and_heterogeneous_material():
+    """Patch cuts fall back to fixed runs when no coordinates are given; material
+    varies per element (layered Vs, a soft pocket that trips the Vp/Vs cap)."""
+    nx, ny, nz = 24, 16, 12
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    z = elem_ijk[:, 2]
+    edata[:, 0] = 25.0
+    edata[:, 2] = 800.0 + 150.0 * z
+    edata[:, 1] = 1.9 * edata[:, 2]
+    edata[:, 3] = 2000.0 + 30.0 * z
+    soft = (elem_ijk[:, 0] < 4) & (z < 3)
+    edata[soft, 2] = 300.0
+    edata[soft, 1] = 1500.0            # Vp/Vs = 5 > threshold 3
+    face = ho.face_bits(elem_ijk, nx, ny, nz)
+    et, nt = ho.solver_init(lnid, edata, face, len(node_ijk), 1e-3, 2.0)
+    N = len(node_ijk)
+    rng = np.random.default_rng(7)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1.copy()
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(lnid, et, nt, o1, o2, 0, 10, 1e-3)
+    for variant, xyz in ((ha.HQ_VARIANT_PATCH, None), (ha.HQ_VARIANT_SCATTER, None)):
+        s = ha.Solver(lnid, et, nt, 1e-3, tm1=u1, tm2=u2, node_xyz=xyz, variant=variant)
+        s.run(10)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2) < TOL
+        s.close()
+
+
+def test_hanging_node_adjust_and_roundtrip():
+    """compute_adjust (DISTRIBUTION / ASSIGNMENT) with a synthetic dangling table,
+    hq_upload/hq_download/hq_gather round trips."""
+    lnid, node_ijk, elem_ijk, et, nt = _box(6, 6, 4, h=10.0, dt=2e-4)
+    N = len(node_ijk)
+    rng = np.random.default_rng(3)
+    dn_ids = np.array([5, 17, 33, 60], np.int32)
+    dn_ptr = np.array([0, 2, 6, 8, 12], np.int32)
+    anchors = rng.choice(np.setdiff1d(np.arange(N), dn_ids), 12, replace=False).astype(np.int32)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    s = ha.Solver(lnid, et, nt, 2e-4, tm1=u1, tm2=u2, dangling=(dn_ids, dn_ptr, anchors),
+                  variant=ha.HQ_VARIANT_SCATTER)
+    s.run(5)
+    tm1, tm2 = s.download()
+    # oracle: same loop with compute_adjust around the update (psolve.c:4299, 4313)
+    L = ho.lib()
+    a, b = u1.copy(), u2.copy()        # post-swap view
+    f = np.zeros((N, 3))
+    K1, K2 = ho.compute_K()
+    for _ in range(5):
+        L.ho_addforce_effective(ho.ctypes.c_int64(len(lnid)), ho._p(lnid), ho._p(et), ho._p(a), ho._p(f), 1)
+        L.ho_damping_addforce(ho.ctypes.c_int64(len(lnid)), ho._p(lnid), ho._p(et), ho._p(a), ho._p(b),
+                              ho._p(K1), ho._p(K2), ho._p(f), 1)
+        L.ho_compute_adjust(ho._p(f), 3, 0, len(dn_ids), ho._p(dn_ids), ho._p(dn_ptr), ho._p(anchors))
+        L.ho_compute_displacement(ho.ctypes.c_int64(N), ho._p(nt), ho._p(a), ho._p(b), ho._p(f), None)
+        L.ho_compute_adjust(ho._p(b), 3, 1, len(dn_ids), ho._p(dn_ids), ho._p(dn_ptr), ho._p(anchors))
+        a, b = b, a
+    assert H.rel_linf(tm1, a) < TOL
+    assert H.rel_linf(tm2, b) < TOL
+    g1, g2 = s.gather(np.array([0, 7, N - 1]))
+    assert np.array_equal(g1, tm1[[0, 7, N - 1]]) and np.array_equal(g2, tm2[[0, 7, N - 1]])
+    s.upload(u1, u2, 0)
+    x1, x2 = s.download()
+    assert np.array_equal(x1, u1) and np.array_equal(x2, u2)
+    s.close()
