@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- element-updates/s of the explicit time-stepping hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1]
+
+One "step" = one iteration of the solver_run loop body (psolve.c:4265-4319) over
+the whole mesh: source force, stiffness + Rayleigh damping element force, nodal
+central-difference update (and the halo exchange when N > 1).
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 64 M-element
+uniform box 512 x 512 x 256, homogeneous half-space Vp 6000 / Vs 3464 / rho 2700,
+Rayleigh damping, Lysmer dashpots on five faces, point double-couple source,
+started from a seeded random displacement field so every element is active.
+N > 1 partitions the SAME mesh along the octor block decomposition (strong
+scaling) and exchanges interface-node forces / displacements with RCCL.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per element-update (fp64, uniform mesh)
+BYTES_PER_ELEMENT_UPDATE = 336.0
+BYTES_ELEMENT_PHASE = 160.0          # lnid 32 + coefficients 32 + tm1,tm2 48 + force RMW 48
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+WORKLOADS = {
+    # name: (nx, ny, nz, h, dt, freq)
+    "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0),
+    "c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
+    "c1": (16, 16, 8, 62.5, 1.0e-3, 5.0),
+    "m1": (128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0),
+}
+WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
+                  "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
+                  "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64"}
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle's reference-formulation loops (effective stiffness + the 8x8
+    conventional damping loop + nodal update) on the host cores: one independent
+    64x64x32 partition per core, seeded random field (all elements active)."""
+    from oracle import herc_oracle as ho
+    ho.lib()
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    nx, ny, nz, h, dt, freq = 64, 64, 32, 1000.0 / 128, 3.6e-4, 50.0
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:] = (h, 6000.0, 3464.0, 2700.0)
+    et, nt = ho.solver_init(lnid, edata, ho.face_bits(elem_ijk, nx, ny, nz), len(node_ijk), dt, freq)
+    K = ho.compute_K()
+    E, N = len(lnid), len(node_ijk)
+    rng = np.random.default_rng(12345)
+    base1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    base2 = base1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+
+    def timed(formulation, steps):
+        state = [(base1.copy(), base2.copy()) for _ in range(cores)]
+
+        def work(i):
+            ho.solver_run(lnid, et, nt, state[i][0], state[i][1], 0, steps, dt, formulation=formulation, K=K)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    t1 = timed(0, 1)                                   # calibrate
+    steps = int(max(2, min(200, seconds_target / max(t1, 1e-3))))
+    tref = timed(0, steps)
+    tf1 = timed(1, 2)
+    fsteps = int(max(2, min(400, 3.0 / max(tf1 / 2, 1e-3))))
+    tfused = timed(1, fsteps)
+    return {
+        "value": cores * E * steps / tref,
+        "unit": "element-updates/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d independent %dx%dx%d partitions (one per core), %d steps, reference formulation "
+                  "(effective stiffness + conventional Rayleigh damping loop + nodal update), "
+                  "random field, zero-skip on but no quiescent element" % (cores, nx, ny, nz, steps),
+        "per_core": E * steps / tref,
+        "fused_formulation_value": cores * E * fsteps / tfused,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("HQ_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", default="auto", choices=["auto", "scatter", "patch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    # CPU baseline first: it uses threads only and must not overlap the GPU timing.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    import hercules_amd as ha
+    from hercules_amd import host as hhost
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
+    t_setup = time.perf_counter()
+    box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
+    variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+    N = box.info["nharbored"]
+    # seeded random start: identical on every rank for shared nodes
+    # because it is a function of the global node coordinates
+    ijk = box.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    u1 = np.empty((N, 3))
+    for d in range(3):
+        x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
+        u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+    u2 = u1 * (1.0 - 1e-3)
+    solver = box.create_solver(variant=variant, device=local_rank, tm1=u1, tm2=u2)
+    del u1, u2, ijk, gid
+    if world > 1:
+        idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(idbuf, src=0)
+        solver.comm_init(idbuf[0])
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+    total_steps = args.warmup + args.steps
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt,
+                        source_window=max(total_steps, 1))
+    if len(loaded):
+        solver.set_source(loaded, box.source_table(rp, 0, total_steps), 0)
+    info = solver.info()
+    setup_s = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    solver.run(args.warmup)
+    solver.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    total_ms, kernel_ms = solver.run_timed(args.steps)     # enqueues K steps, HIP events, syncs
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    tm1, _ = solver.gather(np.arange(min(N, 64), dtype=np.int32))
+    finite = bool(np.isfinite(tm1).all())
+
+    if rank == 0:
+        E_total = box.info["total_elements"]
+        E_local = box.info["lenum"]
+        value = E_total * args.steps / elapsed
+        is_patch = info["variant"] == ha.HQ_VARIANT_PATCH
+        bytes_per_launch = (BYTES_PER_ELEMENT_UPDATE if is_patch else BYTES_ELEMENT_PHASE) * E_local
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                key = "%s_%s" % (args.workload, "patch" if is_patch else "scatter")
+                if world == 1 and key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "element-updates/sec (whole node) + achieved HBM GB/s, 64M-elem box",
+            "value": value,
+            "unit": "element-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": WORKLOAD_NAMES[args.workload], "elements": int(E_total),
+                       "nodes": int(box.info["total_nodes"]), "partition": "octor block x%d" % world,
+                       "kernel_variant": "patch" if is_patch else "scatter",
+                       "patches": int(info["npatches"]), "patch_elements": int(info["patch_pairs"]),
+                       "setup_s": round(setup_s, 1), "finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": solver.dominant_kernel(), "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "whole_step_GBs": BYTES_PER_ELEMENT_UPDATE * value / 1e9},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    solver.close()
+    box.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,699 @@
+/*
+ * hq_host.c -- C host side of the MI355X engine (include/hq_host.h).
+ *
+ * Builds, without the octree mesher or the etree database, exactly the arrays
+ * the reference's solver_run() works on for a uniformly refined, horizontally
+ * layered box, for one partition of `nranks`:
+ *
+ *   - elements in octree pre-order = Z-order (octor.c:6444-6470), block
+ *     partition of the Z-ordered element list (octor.c:740-746, 4939-4944);
+ *   - harbored nodes in Z-order of their far-boundary-adjusted coordinates
+ *     (octor.c:6100-6106, 6166); owner = rank whose element interval contains
+ *     the adjusted node (octor.c:5466-5475);
+ *   - eTable (psolve.c:3387-3409) and nTable (psolve.c:3436-3471) with the
+ *     reference's single-precision material arithmetic (edata_t is float);
+ *   - an_sched messenger lists (psolve.c:4704-4863).
+ *
+ * nTable is evaluated node-by-node (each node gathers its <= 8 elements in
+ * Z-order, the order the reference's element loop reaches them) so the build
+ * parallelises over nodes, and every harbored copy holds the complete sums: no
+ * initial mass exchange (psolve.c:3498-3507) is needed.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "hq_host.h"
+
+#define HQH_PI 3.14159265358979323846
+
+struct hqh_box {
+    hqh_box_params p;
+    int ax, ay, az;                 /* log2 of nx, ny, nz */
+    uint64_t zmask;                 /* Z-value bits that in-domain elements can set */
+    int64_t Eg, Ng;                 /* whole box */
+    int64_t elo, ehi;               /* my element interval */
+    int32_t lenum, nharbored, nowned;
+    int32_t* lnid;                  /* [lenum][8] */
+    int32_t* node_ijk;              /* [nharbored][3] */
+    int32_t* node_xyz;              /* [nharbored][3] ticks */
+    int32_t* owner;                 /* [nharbored] */
+    int32_t* loc;                   /* [Ng] global grid index -> local id or -1 */
+    double* etable;                 /* [lenum][4] */
+    double* ntable;                 /* [nharbored][7] */
+    /* per-depth-index element constants */
+    float *k_vp, *k_vs, *k_rho;
+    double *k_c1, *k_c2, *k_c3, *k_c4, *k_a, *k_M;
+    /* schedule */
+    int32_t nc, ns;
+    hq_messenger *mc, *ms;
+    int32_t *cmap, *smap;
+    int64_t shared_nodes;
+    float* layer_store;
+};
+
+/* ------------------------------------------------------------------------ */
+/* bit helpers                                                              */
+/* ------------------------------------------------------------------------ */
+
+static uint64_t spread3(uint64_t v)
+{
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x1f00000000ffffULL;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+    v = (v | (v << 8))  & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4))  & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2))  & 0x1249249249249249ULL;
+    return v;
+}
+
+static uint32_t compact3(uint64_t v)
+{
+    v &= 0x1249249249249249ULL;
+    v = (v | (v >> 2))  & 0x10c30c30c30c30c3ULL;
+    v = (v | (v >> 4))  & 0x100f00f00f00f00fULL;
+    v = (v | (v >> 8))  & 0x1f0000ff0000ffULL;
+    v = (v | (v >> 16)) & 0x1f00000000ffffULL;
+    v = (v | (v >> 32)) & 0x1fffffULL;
+    return (uint32_t)v;
+}
+
+static uint64_t zvalue(uint32_t x, uint32_t y, uint32_t z)
+{
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+
+/* software pext / pdep over the (sparse) element mask */
+static uint64_t bits_extract(uint64_t v, uint64_t mask)
+{
+    uint64_t r = 0;
+    int k = 0;
+    for (uint64_t m = mask; m; m &= m - 1, k++)
+        if (v & (m & -m)) r |= 1ULL << k;
+    return r;
+}
+
+static uint64_t bits_deposit(uint64_t v, uint64_t mask)
+{
+    uint64_t r = 0;
+    int k = 0;
+    for (uint64_t m = mask; m; m &= m - 1, k++)
+        if (v & (1ULL << k)) r |= (m & -m);
+    return r;
+}
+
+static int ilog2_exact(int32_t n)
+{
+    int b = 0;
+    if (n <= 0 || (n & (n - 1))) return -1;
+    while ((1 << b) < n) b++;
+    return b;
+}
+
+/* index of element (i,j,k) in the Z-ordered list of in-domain elements */
+static int64_t elem_index(const hqh_box* b, int32_t i, int32_t j, int32_t k)
+{
+    return (int64_t)bits_extract(zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k), b->zmask);
+}
+
+/* BLOCK_OWNER, octor.c:741-746 */
+static int32_t rank_of_elem(const hqh_box* b, int64_t idx)
+{
+    return (int32_t)((((idx + 1) * b->p.nranks) - 1) / b->Eg);
+}
+
+static int64_t grid_index(const hqh_box* b, int32_t i, int32_t j, int32_t k)
+{
+    return ((int64_t)k * (b->p.ny + 1) + j) * (b->p.nx + 1) + i;
+}
+
+static uint64_t node_key(const hqh_box* b, int32_t i, int32_t j, int32_t k)
+{
+    uint32_t dx = (i == b->p.nx) ? (uint32_t)(2 * i - 1) : (uint32_t)(2 * i);
+    uint32_t dy = (j == b->p.ny) ? (uint32_t)(2 * j - 1) : (uint32_t)(2 * j);
+    uint32_t dz = (k == b->p.nz) ? (uint32_t)(2 * k - 1) : (uint32_t)(2 * k);
+    return zvalue(dx, dy, dz);
+}
+
+/* LSD radix sort of 64-bit keys, 11-bit digits, `bits` significant bits */
+static int radix_sort_u64(uint64_t* a, int64_t n, int bits)
+{
+    uint64_t* t = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    if (!t) return -1;
+    uint64_t* src = a;
+    uint64_t* dst = t;
+    for (int sh = 0; sh < bits; sh += 11) {
+        int64_t cnt[2049];
+        memset(cnt, 0, sizeof cnt);
+        for (int64_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 2047) + 1]++;
+        for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 2047]++] = src[i];
+        uint64_t* s = src; src = dst; dst = s;
+    }
+    if (src != a) memcpy(a, src, sizeof(uint64_t) * (size_t)n);
+    free(t);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* physics set-up                                                           */
+/* ------------------------------------------------------------------------ */
+
+/* compute_setab, psolve.c:5813-5876 */
+static void rayleigh_base(double freq, int damping, double* aBase, double* bBase)
+{
+    *aBase = 0.0;
+    *bBase = 0.0;
+    if (damping == HQH_DAMP_RAYLEIGH) {
+        double w1 = 2 * HQH_PI * freq * .2, w2 = 2 * HQH_PI * freq * 1;
+        double l1 = log(w1), l2 = log(w2);
+        double s1 = w1 * w1, s2 = w2 * w2;
+        double q1 = w1 * w1 * w1, q2 = w2 * w2 * w2;
+        double den = (q1 - q2 + 3 * s2 * w1 - 3 * s1 * w2);
+        double num = w1 * w2 * (-2 * s1 * l2 + 2 * s1 * l1 - 2 * w1 * w2 * l2 + 2 * w1 * w2 * l1
+                                + 3 * s2 - 3 * s1 - 2 * s2 * l2 + 2 * s2 * l1);
+        *aBase = num / den;
+        num = 3 * (2 * w1 * w2 * l2 - 2 * w1 * w2 * l1 + s1 - s2);
+        *bBase = num / den;
+    } else if (damping == HQH_DAMP_MASS) {
+        double w1 = 2 * HQH_PI * freq * .1, w2 = 2 * HQH_PI * freq * 8;
+        *aBase = 1.3 * (2 * w2 * w1 * log(w2 / w1)) / (w2 - w1);
+    }
+}
+
+/*
+ * Element constants for depth index k (material depends on depth only):
+ * mu_and_lambda (psolve.c:3236-3272) + psolve.c:3387-3409, 3436-3437.
+ */
+static int depth_constants(hqh_box* b)
+{
+    const hqh_box_params* p = &b->p;
+    double aBase, bBase;
+    rayleigh_base(p->freq, p->damping, &aBase, &bBase);
+    double dt = p->deltaT, dt2 = dt * dt;
+    float h = (float)p->h;
+    for (int32_t k = 0; k < p->nz; k++) {
+        double zc = (k + 0.5) * p->h;
+        int L = 0;
+        for (int l = 0; l < p->nlayers; l++)
+            if (p->layer_ztop[l] <= zc) L = l;
+        float Vp = p->layer_vp[L], Vs = p->layer_vs[L], rho = p->layer_rho[L];
+        double mu = rho * Vs * Vs;
+        double lambda;
+        if (Vp > (Vs * p->threshold_vpvs))
+            lambda = rho * Vs * Vs * p->threshold_vpvs * p->threshold_vpvs - 2 * mu;
+        else
+            lambda = rho * Vp * Vp - 2 * mu;
+        if (lambda < 0) {
+            if (Vs < 500) Vp = 2.45 * Vs;
+            else if (Vs < 1200) Vp = 2 * Vs;
+            else Vp = 1.87 * Vs;
+            lambda = rho * Vp * Vp;
+        }
+        if (lambda < 0) return -1;
+        double zeta = 10 / Vs;
+        if (zeta > p->threshold_damping) zeta = p->threshold_damping;
+        double a = zeta * aBase, bb = zeta * bBase;
+        b->k_vp[k] = Vp; b->k_vs[k] = Vs; b->k_rho[k] = rho;
+        b->k_c1[k] = dt2 * h * mu / 9;
+        b->k_c2[k] = dt2 * h * lambda / 9;
+        b->k_c3[k] = bb * dt * h * mu / 9;
+        b->k_c4[k] = bb * dt * h * lambda / 9;
+        b->k_a[k] = a;
+        double mass = rho * h * h * h;
+        b->k_M[k] = mass / 8;
+    }
+    return 0;
+}
+
+/*
+ * Lysmer dashpot of the corner `corner` (bit d = far side of axis d) of an
+ * element at (ei,ej,ek), per axis: compute_setflag + theIDBoundaryMatrix +
+ * compute_setboundary (psolve.c:5629-5804).  An absorbing face normal to axis
+ * d acts on the corner if the element touches that domain face and the corner
+ * lies on it; with -DHALFSPACE the z = 0 face is free (:5762-5764).
+ * Returns 0 if the element is interior (flag 13).
+ */
+static int corner_dashpot(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek, int corner, double out[3])
+{
+    const hqh_box_params* p = &b->p;
+    int e[3] = { ei, ej, ek }, n[3] = { p->nx, p->ny, p->nz };
+    int touches = 0, bits = 0;
+    for (int d = 0; d < 3; d++) {
+        int near = (e[d] == 0), far = (e[d] == n[d] - 1);
+        /* compute_setflag tests the far face after the near one, so an element that is
+         * both (one element thick) is classed "far" (psolve.c:5636-5648) */
+        if (near || far) touches = 1;
+        int cls = far ? 2 : (near ? 0 : 1);
+        if (d == 2 && p->halfspace && cls == 0) cls = 1;
+        int cfar = (corner >> d) & 1;
+        if ((cls == 0 && !cfar) || (cls == 2 && cfar)) bits |= 1 << d;
+    }
+    out[0] = out[1] = out[2] = 0.0;
+    if (!touches) return 0;
+    float size = (float)p->h, Vp = b->k_vp[ek], Vs = b->k_vs[ek], rho = b->k_rho[ek];
+    double scale = rho * (size / 2) * (size / 2);
+    int nf = (bits & 1) + ((bits >> 1) & 1) + ((bits >> 2) & 1);
+    for (int d = 0; d < 3; d++) {
+        if (nf == 3) out[d] = (Vp + 2 * Vs) * scale;
+        else if (nf == 2) out[d] = (Vs + ((bits & (1 << d)) ? Vp : Vs)) * scale;
+        else if (nf == 1) out[d] = ((bits & (1 << d)) ? Vp : Vs) * scale;
+    }
+    return 1;
+}
+
+/* n_t of node (i,j,k): psolve.c:3440-3471 summed over its elements in Z-order */
+static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, double np[7])
+{
+    const hqh_box_params* p = &b->p;
+    int64_t idx[8];
+    int32_t ee[8][3];
+    int cn[8], cnt = 0;
+    for (int c = 0; c < 8; c++) {
+        int32_t ei = i - 1 + (c & 1), ej = j - 1 + ((c >> 1) & 1), ek = k - 1 + ((c >> 2) & 1);
+        if (ei < 0 || ej < 0 || ek < 0 || ei >= p->nx || ej >= p->ny || ek >= p->nz) continue;
+        int64_t id = elem_index(b, ei, ej, ek);
+        int pos = cnt++;
+        while (pos > 0 && idx[pos - 1] > id) {
+            idx[pos] = idx[pos - 1]; cn[pos] = cn[pos - 1];
+            memcpy(ee[pos], ee[pos - 1], sizeof ee[0]);
+            pos--;
+        }
+        idx[pos] = id;
+        ee[pos][0] = ei; ee[pos][1] = ej; ee[pos][2] = ek;
+        /* this node is corner (1-di, 1-dj, 1-dk) of that element */
+        cn[pos] = (1 - (c & 1)) | ((1 - ((c >> 1) & 1)) << 1) | ((1 - ((c >> 2) & 1)) << 2);
+    }
+    double dt = p->deltaT;
+    for (int t = 0; t < 7; t++) np[t] = 0.0;
+    for (int q = 0; q < cnt; q++) {
+        int32_t ek = ee[q][2];
+        double M = b->k_M[ek], a = b->k_a[ek], dash[3];
+        int bnd = corner_dashpot(b, ee[q][0], ee[q][1], ek, cn[q], dash);
+        np[0] += M;
+        for (int ax = 0; ax < 3; ax++) {
+            np[4 + ax] -= (dt * a * M);
+            np[1 + ax] -= (dt * a * M);
+            if (bnd) {
+                np[4 + ax] -= (dt * dash[ax]);
+                np[1 + ax] -= (dt * dash[ax]);
+            }
+            np[4 + ax] += M;
+            np[1 + ax] += (M * 2);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* box                                                                      */
+/* ------------------------------------------------------------------------ */
+
+void hqh_box_destroy(hqh_box* b)
+{
+    if (!b) return;
+    free(b->lnid); free(b->node_ijk); free(b->node_xyz); free(b->owner); free(b->loc);
+    free(b->etable); free(b->ntable);
+    free(b->k_vp); free(b->k_vs); free(b->k_rho);
+    free(b->k_c1); free(b->k_c2); free(b->k_c3); free(b->k_c4); free(b->k_a); free(b->k_M);
+    free(b->mc); free(b->ms); free(b->cmap); free(b->smap);
+    free(b->layer_store);
+    free(b);
+}
+
+static int build_schedule(hqh_box* b);
+
+int hqh_box_create(const hqh_box_params* p, hqh_box** out)
+{
+    if (!p || !out) return HQ_ERR_ARG;
+    *out = NULL;
+    int ax = ilog2_exact(p->nx), ay = ilog2_exact(p->ny), az = ilog2_exact(p->nz);
+    if (ax < 0 || ay < 0 || az < 0 || ax > 10 || ay > 10 || az > 10) return HQ_ERR_ARG;
+    if (p->nlayers < 1 || !p->layer_ztop || !p->layer_vp || !p->layer_vs || !p->layer_rho) return HQ_ERR_ARG;
+    if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    hqh_box* b = (hqh_box*)calloc(1, sizeof(hqh_box));
+    if (!b) return HQ_ERR_NOMEM;
+    b->p = *p;
+    /* private copy of the layer tables */
+    size_t nl = (size_t)p->nlayers;
+    b->layer_store = (float*)malloc(nl * (3 * sizeof(float) + sizeof(double)));
+    if (!b->layer_store) { hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    {
+        double* zt = (double*)b->layer_store;
+        float* f = (float*)(zt + nl);
+        memcpy(zt, p->layer_ztop, nl * sizeof(double));
+        memcpy(f, p->layer_vp, nl * sizeof(float));
+        memcpy(f + nl, p->layer_vs, nl * sizeof(float));
+        memcpy(f + 2 * nl, p->layer_rho, nl * sizeof(float));
+        b->p.layer_ztop = zt; b->p.layer_vp = f; b->p.layer_vs = f + nl; b->p.layer_rho = f + 2 * nl;
+    }
+    b->ax = ax; b->ay = ay; b->az = az;
+    b->zmask = zvalue((uint32_t)p->nx - 1, (uint32_t)p->ny - 1, (uint32_t)p->nz - 1);
+    b->Eg = (int64_t)p->nx * p->ny * p->nz;
+    b->Ng = (int64_t)(p->nx + 1) * (p->ny + 1) * (p->nz + 1);
+    if (b->Eg < p->nranks) { hqh_box_destroy(b); return HQ_ERR_ARG; }
+    b->elo = (int64_t)p->rank * b->Eg / p->nranks;                       /* BLOCK_LOW  */
+    b->ehi = (int64_t)(p->rank + 1) * b->Eg / p->nranks;                 /* BLOCK_HIGH + 1 */
+    if (b->ehi - b->elo > 0x7fffffff / 8) { hqh_box_destroy(b); return HQ_ERR_ARG; }
+    b->lenum = (int32_t)(b->ehi - b->elo);
+
+    size_t nz = (size_t)p->nz;
+    b->k_vp = (float*)malloc(nz * sizeof(float)); b->k_vs = (float*)malloc(nz * sizeof(float));
+    b->k_rho = (float*)malloc(nz * sizeof(float));
+    b->k_c1 = (double*)malloc(nz * 8); b->k_c2 = (double*)malloc(nz * 8); b->k_c3 = (double*)malloc(nz * 8);
+    b->k_c4 = (double*)malloc(nz * 8); b->k_a = (double*)malloc(nz * 8); b->k_M = (double*)malloc(nz * 8);
+    if (!b->k_vp || !b->k_vs || !b->k_rho || !b->k_c1 || !b->k_c2 || !b->k_c3 || !b->k_c4 || !b->k_a || !b->k_M) {
+        hqh_box_destroy(b); return HQ_ERR_NOMEM;
+    }
+    if (depth_constants(b) != 0) { hqh_box_destroy(b); return HQ_ERR_ARG; }
+
+    /* harbored nodes: corners of my elements, marked on the global node grid */
+    b->loc = (int32_t*)malloc(sizeof(int32_t) * (size_t)b->Ng);
+    if (!b->loc) { hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    memset(b->loc, 0xff, sizeof(int32_t) * (size_t)b->Ng);
+    int64_t nh = 0;
+    if (p->nranks == 1) {
+        nh = b->Ng;
+    } else {
+        uint64_t z = bits_deposit((uint64_t)b->elo, b->zmask);
+        for (int64_t e = b->elo; e < b->ehi; e++) {
+            int32_t i = (int32_t)compact3(z), j = (int32_t)compact3(z >> 1), k = (int32_t)compact3(z >> 2);
+            for (int c = 0; c < 8; c++) {
+                int64_t g = grid_index(b, i + (c & 1), j + ((c >> 1) & 1), k + ((c >> 2) & 1));
+                if (b->loc[g] < 0) { b->loc[g] = 0; nh++; }
+            }
+            z = ((z | ~b->zmask) + 1) & b->zmask;          /* next in-domain Z-value */
+        }
+    }
+    if (nh > 0x7fffffff / 8) { hqh_box_destroy(b); return HQ_ERR_ARG; }
+    b->nharbored = (int32_t)nh;
+    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)nh);
+    if (!keys) { hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    {
+        int64_t t = 0;
+        for (int32_t k = 0; k <= p->nz; k++)
+            for (int32_t j = 0; j <= p->ny; j++)
+                for (int32_t i = 0; i <= p->nx; i++)
+                    if (p->nranks == 1 || b->loc[grid_index(b, i, j, k)] == 0) keys[t++] = node_key(b, i, j, k);
+    }
+    int kbits = 3 * ((ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az)) + 2);
+    if (radix_sort_u64(keys, nh, kbits) != 0) { free(keys); hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+
+    b->node_ijk = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)nh);
+    b->node_xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)nh);
+    b->owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)nh);
+    b->ntable = (double*)malloc(sizeof(double) * 7 * (size_t)nh);
+    b->lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)(b->lenum ? b->lenum : 1));
+    b->etable = (double*)malloc(sizeof(double) * 4 * (size_t)(b->lenum ? b->lenum : 1));
+    if (!b->node_ijk || !b->node_xyz || !b->owner || !b->ntable || !b->lnid || !b->etable) {
+        free(keys); hqh_box_destroy(b); return HQ_ERR_NOMEM;
+    }
+    /* tick coordinates as octor would give them: root edge 2^30 ticks over the longest axis */
+    int amax = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    int32_t edge_ticks = (int32_t)1 << (30 - amax);
+    int32_t nown = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nown)
+    for (int64_t n = 0; n < nh; n++) {
+        uint32_t d[3] = { compact3(keys[n]), compact3(keys[n] >> 1), compact3(keys[n] >> 2) };
+        int32_t lim[3] = { p->nx, p->ny, p->nz }, c[3];
+        for (int q = 0; q < 3; q++) c[q] = (d[q] & 1) ? lim[q] : (int32_t)(d[q] >> 1);
+        for (int q = 0; q < 3; q++) {
+            b->node_ijk[3 * n + q] = c[q];
+            b->node_xyz[3 * n + q] = c[q] * edge_ticks;
+        }
+        b->loc[grid_index(b, c[0], c[1], c[2])] = (int32_t)n;
+        int32_t oi = c[0] < p->nx ? c[0] : p->nx - 1, oj = c[1] < p->ny ? c[1] : p->ny - 1,
+                ok = c[2] < p->nz ? c[2] : p->nz - 1;
+        b->owner[n] = rank_of_elem(b, elem_index(b, oi, oj, ok));
+        if (b->owner[n] == p->rank) nown++;
+        node_constants(b, c[0], c[1], c[2], &b->ntable[7 * n]);
+    }
+    b->nowned = nown;
+    free(keys);
+
+    /* elements */
+#pragma omp parallel
+    {
+        int tid = 0, nt = 1;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+        nt = omp_get_num_threads();
+#endif
+        int64_t lo = b->elo + (int64_t)b->lenum * tid / nt, hi = b->elo + (int64_t)b->lenum * (tid + 1) / nt;
+        uint64_t z = bits_deposit((uint64_t)lo, b->zmask);
+        for (int64_t e = lo; e < hi; e++) {
+            int32_t i = (int32_t)compact3(z), j = (int32_t)compact3(z >> 1), k = (int32_t)compact3(z >> 2);
+            int64_t le = e - b->elo;
+            for (int c = 0; c < 8; c++)
+                b->lnid[8 * le + c] = b->loc[grid_index(b, i + (c & 1), j + ((c >> 1) & 1), k + ((c >> 2) & 1))];
+            double* ep = &b->etable[4 * le];
+            ep[0] = b->k_c1[k]; ep[1] = b->k_c2[k]; ep[2] = b->k_c3[k]; ep[3] = b->k_c4[k];
+            z = ((z | ~b->zmask) + 1) & b->zmask;
+        }
+    }
+    int rc = build_schedule(b);
+    if (rc != HQ_OK) { hqh_box_destroy(b); return rc; }
+    *out = b;
+    return HQ_OK;
+}
+
+/* schedule_build, psolve.c:4704-4863 (anchored nodes only: uniform meshes have no hanging nodes) */
+static int build_schedule(hqh_box* b)
+{
+    const hqh_box_params* p = &b->p;
+    int P = p->nranks, me = p->rank;
+    if (P == 1) return HQ_OK;
+    int64_t* ccount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+    int64_t* scount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+    if (!ccount || !scount) { free(ccount); free(scount); return HQ_ERR_NOMEM; }
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t *cfill = NULL, *sfill = NULL;
+        if (pass == 1) {
+            cfill = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+            sfill = (int64_t*)calloc((size_t)P, sizeof(int64_t));
+            int64_t ct = 0, st = 0;
+            for (int r = 0; r < P; r++) { ct += ccount[r]; st += scount[r]; b->nc += ccount[r] > 0; b->ns += scount[r] > 0; }
+            b->cmap = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ct ? ct : 1));
+            b->smap = (int32_t*)malloc(sizeof(int32_t) * (size_t)(st ? st : 1));
+            b->mc = (hq_messenger*)calloc((size_t)(b->nc ? b->nc : 1), sizeof(hq_messenger));
+            b->ms = (hq_messenger*)calloc((size_t)(b->ns ? b->ns : 1), sizeof(hq_messenger));
+            if (!cfill || !sfill || !b->cmap || !b->smap || !b->mc || !b->ms) {
+                free(cfill); free(sfill); free(ccount); free(scount); return HQ_ERR_NOMEM;
+            }
+            int64_t co = 0, so = 0;
+            int ic = 0, is = 0;
+            for (int r = 0; r < P; r++) {            /* messengers in ascending rank order */
+                if (ccount[r]) { b->mc[ic].procid = r; b->mc[ic].nodecount = (int32_t)ccount[r]; b->mc[ic].mapping = b->cmap + co; cfill[r] = co; co += ccount[r]; ic++; }
+                if (scount[r]) { b->ms[is].procid = r; b->ms[is].nodecount = (int32_t)scount[r]; b->ms[is].mapping = b->smap + so; sfill[r] = so; so += scount[r]; is++; }
+            }
+        }
+        for (int32_t n = 0; n < b->nharbored; n++) {
+            int32_t i = b->node_ijk[3 * n], j = b->node_ijk[3 * n + 1], k = b->node_ijk[3 * n + 2];
+            if (b->owner[n] != me) {
+                if (pass == 0) { ccount[b->owner[n]]++; b->shared_nodes++; }
+                else b->cmap[cfill[b->owner[n]]++] = n;
+                continue;
+            }
+            int sh[8], nsh = 0;
+            for (int c = 0; c < 8; c++) {
+                int32_t ei = i - 1 + (c & 1), ej = j - 1 + ((c >> 1) & 1), ek = k - 1 + ((c >> 2) & 1);
+                if (ei < 0 || ej < 0 || ek < 0 || ei >= p->nx || ej >= p->ny || ek >= p->nz) continue;
+                int r = rank_of_elem(b, elem_index(b, ei, ej, ek));
+                if (r == me) continue;
+                int seen = 0;
+                for (int t = 0; t < nsh; t++) seen |= (sh[t] == r);
+                if (!seen) sh[nsh++] = r;
+            }
+            if (pass == 0 && nsh) b->shared_nodes++;
+            for (int t = 0; t < nsh; t++) {
+                if (pass == 0) scount[sh[t]]++;
+                else b->smap[sfill[sh[t]]++] = n;
+            }
+        }
+        free(cfill); free(sfill);
+    }
+    free(ccount); free(scount);
+    return HQ_OK;
+}
+
+int hqh_box_get_info(const hqh_box* b, hqh_box_info* info)
+{
+    if (!b || !info) return HQ_ERR_ARG;
+    info->total_elements = b->Eg; info->total_nodes = b->Ng;
+    info->lenum = b->lenum; info->nharbored = b->nharbored; info->nowned = b->nowned;
+    int nb = 0;
+    for (int r = 0; r < b->p.nranks; r++) {
+        int hit = 0;
+        for (int i = 0; i < b->nc; i++) hit |= (b->mc[i].procid == r);
+        for (int i = 0; i < b->ns; i++) hit |= (b->ms[i].procid == r);
+        nb += hit;
+    }
+    info->nneighbors = nb;
+    info->shared_nodes = b->shared_nodes;
+    return HQ_OK;
+}
+
+int hqh_box_desc(const hqh_box* b, hq_desc* d)
+{
+    if (!b || !d) return HQ_ERR_ARG;
+    memset(d, 0, sizeof *d);
+    d->lenum = b->lenum; d->nharbored = b->nharbored; d->ldnnum = 0;
+    d->lnid = b->lnid; d->node_xyz = b->node_xyz;
+    d->eTable = b->etable; d->nTable = b->ntable;
+    d->an_sched.c_count = b->nc; d->an_sched.first_c = b->mc;
+    d->an_sched.s_count = b->ns; d->an_sched.first_s = b->ms;
+    d->deltaT = b->p.deltaT; d->rank = b->p.rank; d->nranks = b->p.nranks;
+    d->variant = HQ_VARIANT_AUTO;
+    return HQ_OK;
+}
+
+const int32_t* hqh_box_lnid(const hqh_box* b) { return b ? b->lnid : NULL; }
+const int32_t* hqh_box_node_ijk(const hqh_box* b) { return b ? b->node_ijk : NULL; }
+const double* hqh_box_etable(const hqh_box* b) { return b ? b->etable : NULL; }
+const double* hqh_box_ntable(const hqh_box* b) { return b ? b->ntable : NULL; }
+const int32_t* hqh_box_owner(const hqh_box* b) { return b ? b->owner : NULL; }
+
+/* ------------------------------------------------------------------------ */
+/* source and stations                                                      */
+/* ------------------------------------------------------------------------ */
+
+static int locate(const hqh_box* b, double x, double y, double z, int32_t e[3], double off[3])
+{
+    double c[3] = { x, y, z };
+    int32_t n[3] = { b->p.nx, b->p.ny, b->p.nz };
+    for (int d = 0; d < 3; d++) {
+        if (c[d] < 0 || c[d] > n[d] * b->p.h) return -1;
+        e[d] = (int32_t)floor(c[d] / b->p.h);
+        if (e[d] >= n[d]) e[d] = n[d] - 1;
+        off[d] = c[d] - (e[d] + 0.5) * b->p.h;         /* offset from the element centre */
+    }
+    return 0;
+}
+
+static int local_element(const hqh_box* b, const int32_t e[3], int32_t lnid[8])
+{
+    int64_t idx = elem_index(b, e[0], e[1], e[2]);
+    if (idx < b->elo || idx >= b->ehi) return 0;
+    memcpy(lnid, &b->lnid[8 * (idx - b->elo)], sizeof(int32_t) * 8);
+    return 1;
+}
+
+int hqh_point_source(const hqh_box* b, double x, double y, double z, double strike, double dip, double rake,
+                     int32_t* nloaded, int32_t lnid[8], double pattern[24])
+{
+    if (!b || !nloaded || !lnid || !pattern) return HQ_ERR_ARG;
+    int32_t e[3];
+    double off[3];
+    if (locate(b, x, y, z, e, off) != 0) return HQ_ERR_ARG;
+    *nloaded = local_element(b, e, lnid) ? 8 : 0;
+    double s = strike / 180.0 * HQH_PI, d = dip / 180.0 * HQH_PI, r = rake / 180.0 * HQH_PI;
+    /* fault normal and slip vectors, moment tensor n t^T + t n^T (quakesource.c:445-458) */
+    double nv[3] = { -sin(s) * sin(d), cos(s) * sin(d), -cos(d) };
+    double tv[3] = { cos(r) * sin(HQH_PI / 2 - s) + sin(r) * sin(s) * cos(d),
+                     cos(r) * sin(s) - sin(r) * cos(s) * cos(d), -sin(r) * sin(d) };
+    double h = b->p.h, h3 = h * h * h;
+    for (int n = 0; n < 8; n++) {
+        double sg[3] = { (n & 1) ? 1.0 : -1.0, (n & 2) ? 1.0 : -1.0, (n & 4) ? 1.0 : -1.0 };
+        double w[3] = { h + 2 * sg[0] * off[0], h + 2 * sg[1] * off[1], h + 2 * sg[2] * off[2] };
+        /* gradient of the trilinear shape function of corner n at the source point */
+        double g[3] = { (2 * sg[0]) * w[1] * w[2] / (8 * h3), (2 * sg[1]) * w[2] * w[0] / (8 * h3),
+                        (2 * sg[2]) * w[0] * w[1] / (8 * h3) };
+        for (int a = 0; a < 3; a++) {
+            double f = 0.0;
+            for (int c = 0; c < 3; c++) f += (nv[a] * tv[c] + nv[c] * tv[a]) * g[c];
+            pattern[3 * n + a] = f;
+        }
+    }
+    return HQ_OK;
+}
+
+int hqh_stations(const hqh_box* b, int32_t n, const double* xyz, int32_t* ids, double* phi, int32_t* mine)
+{
+    if (!b || n < 0 || (n && (!xyz || !ids || !phi || !mine))) return HQ_ERR_ARG;
+    for (int32_t s = 0; s < n; s++) {
+        int32_t e[3];
+        double off[3];
+        if (locate(b, xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2], e, off) != 0) return HQ_ERR_ARG;
+        mine[s] = local_element(b, e, &ids[8 * s]);
+        double lc[3] = { 2 * off[0] / b->p.h, 2 * off[1] / b->p.h, 2 * off[2] / b->p.h };
+        for (int c = 0; c < 8; c++)
+            phi[8 * s + c] = (1 + ((c & 1) ? 1 : -1) * lc[0]) * (1 + ((c & 2) ? 1 : -1) * lc[1]) *
+                             (1 + ((c & 4) ? 1 : -1) * lc[2]) / 8;
+    }
+    return HQ_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* solver_run                                                               */
+/* ------------------------------------------------------------------------ */
+
+void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F)
+{
+    for (int32_t s = 0; s < nsteps; s++) {
+        double t = (step0 + s) * dt;
+        double g = (rp->rise_time > 0 && t < rp->rise_time) ? 0.5 * (1.0 - cos(HQH_PI * t / rp->rise_time)) : 1.0;
+        for (int32_t i = 0; i < rp->nloaded * 3; i++)
+            F[(int64_t)s * rp->nloaded * 3 + i] = rp->moment * g * rp->pattern[i];
+    }
+}
+
+/*
+ * solver_run, psolve.c:4241-4324.  Per step the reference does: swap, outputs
+ * (stations read tm1), read source forces, physics + communication.  Here the
+ * force table is uploaded one window at a time and the steps between two
+ * output steps are enqueued back to back.
+ */
+int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int32_t step0, int32_t nsteps)
+{
+    if (!ctx || !b || !rp || nsteps < 0) return HQ_ERR_ARG;
+    int32_t win = rp->source_window > 0 ? rp->source_window : 256;
+    double* F = NULL;
+    double *u = NULL, *disp = NULL;
+    if (rp->nloaded > 0) {
+        F = (double*)malloc(sizeof(double) * 3 * (size_t)rp->nloaded * (size_t)win);
+        if (!F) return HQ_ERR_NOMEM;
+    }
+    if (rp->nstations > 0 && rp->station_rate > 0 && rp->station_fn) {
+        u = (double*)malloc(sizeof(double) * 24 * (size_t)rp->nstations);
+        disp = (double*)malloc(sizeof(double) * 3 * (size_t)rp->nstations);
+        if (!u || !disp) { free(F); free(u); free(disp); return HQ_ERR_NOMEM; }
+    }
+    int rc = HQ_OK;
+    int32_t step = step0, end = step0 + nsteps, win_end = step0;
+    while (step < end && rc == HQ_OK) {
+        if (u && step % rp->station_rate == 0) {                 /* solver_output_stations, :4280 */
+            rc = hq_gather(ctx, rp->nstations * 8, rp->station_ids, u, NULL);
+            if (rc != HQ_OK) break;
+            for (int32_t s = 0; s < rp->nstations; s++)
+                for (int d = 0; d < 3; d++) {
+                    double acc = 0.0;
+                    for (int c = 0; c < 8; c++) acc += rp->station_phi[8 * s + c] * u[(8 * s + c) * 3 + d];
+                    disp[3 * s + d] = acc;
+                }
+            rp->station_fn(rp->station_user, step, rp->nstations, disp);
+        }
+        if (F && step >= win_end) {                              /* solver_read_source_forces, :4282 */
+            int32_t n = end - step < win ? end - step : win;
+            hqh_source_table(rp, b->p.deltaT, step, n, F);
+            rc = hq_set_source(ctx, rp->nloaded, rp->loaded_lnid, step, n, F);
+            if (rc != HQ_OK) break;
+            win_end = step + n;
+        }
+        int32_t next = end;
+        if (F && win_end < next) next = win_end;
+        if (u) {
+            int32_t ns = (step / rp->station_rate + 1) * rp->station_rate;
+            if (ns < next) next = ns;
+        }
+        rc = hq_run(ctx, next - step);
+        step = next;
+    }
+    if (rc == HQ_OK) rc = hq_sync(ctx);
+    free(F); free(u); free(disp);
+    return rc;
+}

@@ -1,0 +1,206 @@
+"""ctypes binding of include/hq_host.h (C host side: uniform layered boxes,
+point source, stations, solver_run)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "csrc", "libhq_host.so")
+
+DAMPING = {"none": 0, "rayleigh": 1, "mass": 2}
+EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_desc", "hqh_box_lnid",
+           "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner",
+           "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table"]
+
+
+class _BoxParams(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nz", ctypes.c_int32),
+                ("h", ctypes.c_double), ("nlayers", ctypes.c_int32),
+                ("layer_ztop", ctypes.c_void_p), ("layer_vp", ctypes.c_void_p),
+                ("layer_vs", ctypes.c_void_p), ("layer_rho", ctypes.c_void_p),
+                ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
+                ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+
+
+class _BoxInfo(ctypes.Structure):
+    _fields_ = [("total_elements", ctypes.c_int64), ("total_nodes", ctypes.c_int64),
+                ("lenum", ctypes.c_int32), ("nharbored", ctypes.c_int32), ("nowned", ctypes.c_int32),
+                ("nneighbors", ctypes.c_int32), ("shared_nodes", ctypes.c_int64)]
+
+
+STATION_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                              ctypes.POINTER(ctypes.c_double))
+
+
+class _RunParams(ctypes.Structure):
+    _fields_ = [("nloaded", ctypes.c_int32), ("loaded_lnid", ctypes.c_void_p),
+                ("pattern", ctypes.c_void_p), ("moment", ctypes.c_double),
+                ("rise_time", ctypes.c_double), ("source_window", ctypes.c_int32),
+                ("nstations", ctypes.c_int32), ("station_ids", ctypes.c_void_p),
+                ("station_phi", ctypes.c_void_p), ("station_rate", ctypes.c_int32),
+                ("station_fn", STATION_FN), ("station_user", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        capi.load_library()                      # libhq_solver.so first (RTLD_GLOBAL)
+        if not os.path.exists(_LIBPATH):
+            raise capi.HqError("native library %s is missing: run `python -m hercules_amd.build`" % _LIBPATH)
+        lib = ctypes.CDLL(_LIBPATH)
+        for n in ("hqh_box_lnid", "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner"):
+            getattr(lib, n).restype = ctypes.c_void_p
+            getattr(lib, n).argtypes = [ctypes.c_void_p]
+        lib.hqh_box_destroy.restype = None
+        lib.hqh_box_destroy.argtypes = [ctypes.c_void_p]
+        lib.hqh_source_table.restype = None
+        _lib = lib
+    return _lib
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class Box:
+    """One partition of a uniform layered box (hqh_box)."""
+
+    def __init__(self, nx, ny, nz, h, dt, freq, vp=6000.0, vs=3464.0, rho=2700.0, layers=None,
+                 damping="rayleigh", threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True,
+                 rank=0, nranks=1):
+        lib = load_library()
+        if layers is None:
+            layers = [(0.0, vp, vs, rho)]
+        zt = np.array([l[0] for l in layers], np.float64)
+        lvp = np.array([l[1] for l in layers], np.float32)
+        lvs = np.array([l[2] for l in layers], np.float32)
+        lrho = np.array([l[3] for l in layers], np.float32)
+        p = _BoxParams(nx, ny, nz, h, len(layers), zt.ctypes.data, lvp.ctypes.data, lvs.ctypes.data,
+                       lrho.ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
+                       int(halfspace), rank, nranks)
+        self._h = ctypes.c_void_p()
+        rc = lib.hqh_box_create(ctypes.byref(p), ctypes.byref(self._h))
+        if rc != 0:
+            raise capi.HqError("hqh_box_create failed: %d" % rc)
+        self._lib = lib
+        self.nx, self.ny, self.nz, self.h, self.dt = nx, ny, nz, h, dt
+        self.rank, self.nranks = rank, nranks
+        i = _BoxInfo()
+        lib.hqh_box_get_info(self._h, ctypes.byref(i))
+        self.info = {k: getattr(i, k) for k, _ in _BoxInfo._fields_}
+        E, N = i.lenum, i.nharbored
+        self.lnid = _view(lib.hqh_box_lnid(self._h), (E, 8), np.int32)
+        self.node_ijk = _view(lib.hqh_box_node_ijk(self._h), (N, 3), np.int32)
+        self.etable = _view(lib.hqh_box_etable(self._h), (E, 4), np.float64)
+        self.ntable = _view(lib.hqh_box_ntable(self._h), (N, 7), np.float64)
+        self.owner = _view(lib.hqh_box_owner(self._h), (N,), np.int32)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            for k in ("lnid", "node_ijk", "etable", "ntable", "owner"):
+                setattr(self, k, None)
+            self._lib.hqh_box_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def schedule(self):
+        """an_sched as {"c": [(procid, mapping)], "s": [...]} (copies)."""
+        d = capi._Desc()
+        self._lib.hqh_box_desc(self._h, ctypes.byref(d))
+        out = {}
+        for key, cnt, first in (("c", d.an_sched.c_count, d.an_sched.first_c),
+                                ("s", d.an_sched.s_count, d.an_sched.first_s)):
+            out[key] = [(first[i].procid,
+                         _view(first[i].mapping, (first[i].nodecount,), np.int32).copy()) for i in range(cnt)]
+        return out
+
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
+        """hq_create on the arrays the C host side built (no copies through Python)."""
+        d = capi._Desc()
+        rc = self._lib.hqh_box_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_box_desc failed: %d" % rc)
+        d.variant = variant
+        keep = []
+        for name, a in (("tm1", tm1), ("tm2", tm2)):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64)
+                keep.append(a)
+                setattr(d, name, a.ctypes.data)
+        s = capi.Solver.__new__(capi.Solver)
+        s._lib = capi.load_library()
+        s._h = ctypes.c_void_p()
+        s.N, s.E = d.nharbored, d.lenum
+        capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        return s
+
+    def point_source(self, x, y, z, strike=0.0, dip=90.0, rake=0.0):
+        n = ctypes.c_int32()
+        ids = np.zeros(8, np.int32)
+        pat = np.zeros((8, 3))
+        rc = self._lib.hqh_point_source(self._h, ctypes.c_double(x), ctypes.c_double(y), ctypes.c_double(z),
+                                        ctypes.c_double(strike), ctypes.c_double(dip), ctypes.c_double(rake),
+                                        ctypes.byref(n), ids.ctypes.data_as(ctypes.c_void_p),
+                                        pat.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise capi.HqError("hqh_point_source failed: %d" % rc)
+        return (ids, pat) if n.value == 8 else (ids[:0], pat[:0])
+
+    def stations(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        n = len(xyz)
+        ids = np.zeros((n, 8), np.int32)
+        phi = np.zeros((n, 8))
+        mine = np.zeros(n, np.int32)
+        rc = self._lib.hqh_stations(self._h, ctypes.c_int32(n), xyz.ctypes.data_as(ctypes.c_void_p),
+                                    ids.ctypes.data_as(ctypes.c_void_p), phi.ctypes.data_as(ctypes.c_void_p),
+                                    mine.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise capi.HqError("hqh_stations failed: %d" % rc)
+        return ids, phi, mine
+
+    def run_params(self, loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
+                   station_ids=None, station_phi=None, station_rate=0, station_fn=None):
+        rp = _RunParams()
+        keep = []
+        if loaded is not None and len(loaded):
+            l = np.ascontiguousarray(loaded, np.int32)
+            pt = np.ascontiguousarray(pattern, np.float64)
+            keep += [l, pt]
+            rp.nloaded, rp.loaded_lnid, rp.pattern = len(l), l.ctypes.data, pt.ctypes.data
+        rp.moment, rp.rise_time, rp.source_window = moment, rise_time, source_window
+        if station_ids is not None and len(station_ids) and station_fn is not None:
+            si = np.ascontiguousarray(station_ids, np.int32)
+            sp = np.ascontiguousarray(station_phi, np.float64)
+            n = len(si)
+
+            def _cb(user, step, ns, disp):
+                station_fn(step, np.ctypeslib.as_array(disp, (ns, 3)).copy())
+            cb = STATION_FN(_cb)
+            keep += [si, sp, cb]
+            rp.nstations, rp.station_ids, rp.station_phi = n, si.ctypes.data, sp.ctypes.data
+            rp.station_rate, rp.station_fn = station_rate, cb
+        rp._keep = keep
+        return rp
+
+    def source_table(self, rp, step0, nsteps):
+        F = np.zeros((nsteps, rp.nloaded, 3))
+        self._lib.hqh_source_table(ctypes.byref(rp), ctypes.c_double(self.dt), ctypes.c_int32(step0),
+                                   ctypes.c_int32(nsteps), F.ctypes.data_as(ctypes.c_void_p))
+        return F
+
+    def solver_run(self, solver, rp, step0, nsteps):
+        capi._check(self._lib.hqh_solver_run(solver._h, self._h, ctypes.byref(rp), ctypes.c_int32(step0),
+                                             ctypes.c_int32(nsteps)))

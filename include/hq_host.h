@@ -1,0 +1,124 @@
+/*
+ * hq_host.h -- C host side above include/hq_solver.h.
+ *
+ * Mirrors, for uniformly refined boxes, the host code that surrounds the hot
+ * path in CMU-Quake/hercules quake/forward (the reference is C, so the host
+ * side is C too):
+ *
+ *   hqh_box_create    mesh_generate + octor_extractmesh for a uniform box
+ *                     (psolve.c:1920-2176, octor.c:5268-6650: elements in octree
+ *                     pre-order, nodes in Z-order, block partition
+ *                     octor.c:4939-4944, node ownership :5466-5475),
+ *                     solver_init (psolve.c:3280-3510: eTable, nTable with
+ *                     Rayleigh/mass damping and Lysmer dashpots) and
+ *                     schedule_build (psolve.c:4704-4863)
+ *   hqh_point_source  source_initnodalforce (quakesource.c:420-476) for one
+ *                     double-couple point source
+ *   hqh_stations      compute_csi_eta_dzeta (psolve.c:6378-6440)
+ *   hqh_solver_run    solver_run (psolve.c:4241-4324): source window, step loop,
+ *                     station output cadence, on an hq_ctx
+ *
+ * The octree mesher, etree/CVM database, slip-function source generator and
+ * the I/O planes stay in the reference (out of scope).
+ */
+#ifndef HQ_HOST_H
+#define HQ_HOST_H
+
+#include <stdint.h>
+
+#include "hq_solver.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hqh_box hqh_box;
+
+enum { HQH_DAMP_NONE = 0, HQH_DAMP_RAYLEIGH = 1, HQH_DAMP_MASS = 2 };
+
+typedef struct {
+    int32_t       nx, ny, nz;        /* elements per axis; powers of two           */
+    double        h;                 /* element edge, metres (edata_t.edgesize)    */
+    int32_t       nlayers;           /* >= 1 horizontal layers                     */
+    const double* layer_ztop;        /* [nlayers] top depth of each layer, [0]=0   */
+    const float*  layer_vp;          /* [nlayers] edata_t.Vp                       */
+    const float*  layer_vs;          /* [nlayers] edata_t.Vs                       */
+    const float*  layer_rho;         /* [nlayers] edata_t.rho                      */
+    double        deltaT;            /* Param.theDeltaT                            */
+    double        freq;              /* Param.theFreq (simulation_wave_max_freq_hz)*/
+    int32_t       damping;           /* HQH_DAMP_* (type_of_damping)               */
+    double        threshold_damping; /* the_threshold_damping                      */
+    double        threshold_vpvs;    /* the_threshold_Vp_over_Vs                   */
+    int32_t       halfspace;         /* 1: z = 0 is a free surface (-DHALFSPACE)   */
+    int32_t       rank, nranks;      /* this partition / number of partitions      */
+} hqh_box_params;
+
+typedef struct {
+    int64_t total_elements, total_nodes;   /* whole box                            */
+    int32_t lenum, nharbored, nowned;      /* this partition                       */
+    int32_t nneighbors;                    /* ranks I exchange with                */
+    int64_t shared_nodes;                  /* harbored nodes someone else owns or shares */
+} hqh_box_info;
+
+HQ_API int  hqh_box_create(const hqh_box_params* p, hqh_box** out);
+HQ_API void hqh_box_destroy(hqh_box* box);
+HQ_API int  hqh_box_get_info(const hqh_box* box, hqh_box_info* info);
+
+/* Fill an hq_desc with pointers into arrays owned by `box` (valid until
+ * hqh_box_destroy).  variant/tm1/tm2 are left for the caller. */
+HQ_API int  hqh_box_desc(const hqh_box* box, hq_desc* desc);
+
+/* Read-only views for tests: lnid [lenum][8], node_ijk [nharbored][3] (element
+ * units), eTable [lenum][4], nTable [nharbored][7], owner [nharbored]. */
+HQ_API const int32_t* hqh_box_lnid(const hqh_box* box);
+HQ_API const int32_t* hqh_box_node_ijk(const hqh_box* box);
+HQ_API const double*  hqh_box_etable(const hqh_box* box);
+HQ_API const double*  hqh_box_ntable(const hqh_box* box);
+HQ_API const int32_t* hqh_box_owner(const hqh_box* box);
+
+/*
+ * Double-couple point source at (x,y,z) metres: finds the containing element
+ * and returns the 8 equivalent nodal force vectors for unit moment
+ * (source_initnodalforce).  *nloaded is 8 if the element is on this partition,
+ * else 0 (each rank loads only its own elements' nodes, quakesource.c).
+ */
+HQ_API int hqh_point_source(const hqh_box* box, double x, double y, double z, double strike_deg,
+                            double dip_deg, double rake_deg, int32_t* nloaded, int32_t lnid[8],
+                            double pattern[24]);
+
+/* Stations: containing element and trilinear weights; mine[s] = 1 if the
+ * element is local.  ids [n][8], phi [n][8]. */
+HQ_API int hqh_stations(const hqh_box* box, int32_t n, const double* xyz, int32_t* ids, double* phi,
+                        int32_t* mine);
+
+/* Called at every station print step with interpolated displacements [n][3]. */
+typedef void (*hqh_station_fn)(void* user, int32_t step, int32_t n, const double* disp);
+
+typedef struct {
+    /* source: F(step) = moment * ramp(step*dt) * pattern */
+    int32_t nloaded;
+    const int32_t* loaded_lnid;
+    const double*  pattern;          /* [nloaded][3] nodal force for unit moment  */
+    double         moment;           /* N m                                        */
+    double         rise_time;        /* s; smooth ramp 0.5 (1 - cos(pi t / T))      */
+    int32_t        source_window;    /* steps of force table uploaded at a time    */
+    /* stations */
+    int32_t nstations;
+    const int32_t* station_ids;      /* [n][8] */
+    const double*  station_phi;      /* [n][8] */
+    int32_t        station_rate;     /* output_stations_print_rate; 0 = never      */
+    hqh_station_fn station_fn;
+    void*          station_user;
+} hqh_run_params;
+
+/* solver_run: steps [step0, step0 + nsteps) on `ctx`. */
+HQ_API int hqh_solver_run(hq_ctx* ctx, const hqh_box* box, const hqh_run_params* rp,
+                          int32_t step0, int32_t nsteps);
+
+/* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
+HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQ_HOST_H */
