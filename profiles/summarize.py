@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Digest rocprofv3 CSV output of profiles/run_profiles.sh into one JSON:
+per-kernel launch counts / average durations (kernel trace) and per-kernel
+average counter values per launch (PMC passes).  FETCH_SIZE is doubled as
+MI355X_MICROARCH.md (s HBM) prescribes for gfx950 wide streaming reads;
+FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, suffix):
+    return sorted(glob.glob(os.path.join(root, "**", "*" + suffix), recursive=True))
+
+
+def kernel_trace(root):
+    out = defaultdict(lambda: [0, 0.0])
+    for f in find(root, "kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            name = r.get("Kernel_Name", "")
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            out[name][0] += 1
+            out[name][1] += dur
+    return {k: {"launches": v[0], "avg_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items()}
+
+
+def counters(root):
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in find(root, "counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            a = acc[r.get("Kernel_Name", "")][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {k: {c: v[1] / v[0] for c, v in d.items()} for k, d in acc.items()}
+
+
+def short(name):
+    return name.split("(")[0]
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    res = {"tag": tag, "kernels": {}}
+    kt = kernel_trace(os.path.join(root, "trace"))
+    for k, v in kt.items():
+        res["kernels"][short(k)] = dict(v)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_tcc"):
+        for k, d in counters(os.path.join(root, sub)).items():
+            res["kernels"].setdefault(short(k), {}).setdefault("pmc_avg_per_launch", {}).update(d)
+    for k, v in res["kernels"].items():
+        p = v.get("pmc_avg_per_launch", {})
+        if "FETCH_SIZE" in p or "WRITE_SIZE" in p:
+            fetch = p.get("FETCH_SIZE", 0.0) * 1024 * 2.0      # KiB -> B, x2 gfx950 correction
+            write = p.get("WRITE_SIZE", 0.0) * 1024
+            v["hbm_bytes_per_launch"] = fetch + write
+            v["hbm_read_bytes_corrected"] = fetch
+            v["hbm_write_bytes"] = write
+        if "TCC_HIT_sum" in p and (p["TCC_HIT_sum"] + p.get("TCC_MISS_sum", 0)) > 0:
+            v["l2_hit_rate"] = p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"])
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
