@@ -32,10 +32,37 @@
 
 #include "hq_kernels.h"
 
-#define HQ_PATCH_THREADS 256
-#define HQ_PATCH_PMAX    768      /* owned nodes per patch (9*9*9 = 729 fits)         */
-#define HQ_PATCH_PMERGE  512      /* small neighbouring cubes are merged up to this   */
-#define HQ_PATCH_NLMAX   1024     /* owned + halo nodes staged in LDS (10*10*10 fits) */
+#define HQ_PATCH_MAX_THREADS 512
+
+/* Tuning knobs (environment overrides HQ_PATCH_THREADS / _PMAX / _PMERGE / _NLMAX are
+ * read once per plan; defaults from the sweeps in profiles/). */
+struct hq_patch_cfg {
+    int threads = 512;    /* workgroup size                                          */
+    int pmax    = 768;    /* owned nodes per patch (9*9*9 = 729 fits)                */
+    int pmerge  = 512;    /* small neighbouring cubes are merged up to this          */
+    int nlmax   = 1024;   /* owned + halo nodes staged in LDS (10*10*10 fits)        */
+};
+
+static hq_patch_cfg hq_patch_cfg_from_env(void)
+{
+    hq_patch_cfg c;
+    auto geti = [](const char* n, int def) { const char* v = getenv(n); return (v && *v) ? atoi(v) : def; };
+    c.threads = geti("HQ_PATCH_THREADS", c.threads);
+    c.pmax = geti("HQ_PATCH_PMAX", c.pmax);
+    c.pmerge = geti("HQ_PATCH_PMERGE", c.pmerge);
+    c.nlmax = geti("HQ_PATCH_NLMAX", c.nlmax);
+    if (c.threads < 64) c.threads = 64;
+    if (c.threads > HQ_PATCH_MAX_THREADS) c.threads = HQ_PATCH_MAX_THREADS;
+    c.threads &= ~63;
+    if (c.pmax < 8) c.pmax = 8;
+    if (c.pmerge > c.pmax) c.pmerge = c.pmax;
+    if (c.pmerge < 1) c.pmerge = 1;
+    if (c.nlmax < c.pmax + 8) c.nlmax = c.pmax + 8;
+    if (c.nlmax > 0xffff) c.nlmax = 0xffff;
+    /* LDS: (6 nlmax + 3 pmax) doubles must fit 160 KiB */
+    while ((6 * (size_t)c.nlmax + 3 * (size_t)c.pmax) * 8 > 160 * 1024) c.nlmax -= 8;
+    return c;
+}
 
 struct hq_patch_desc {
     int32_t base;        /* first owned node (global id)          */
@@ -54,6 +81,7 @@ struct hq_patch_host {
 };
 
 struct hq_patch_plan {
+    hq_patch_cfg cfg;
     int32_t npatches = 0;
     int64_t npairs = 0;
     int64_t nhalo = 0;
@@ -93,12 +121,12 @@ static inline uint64_t hq_spread3(uint64_t v)
  * octor.h:133-147) the cuts follow aligned octree cubes holding at most PMAX
  * nodes; without them (or if the numbering is not Z-ordered) fixed runs.
  */
-static void hq_patch_cuts(int64_t N, const int32_t* xyz, std::vector<int32_t>& cuts)
+static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz, std::vector<int32_t>& cuts)
 {
     cuts.clear();
     auto fixed = [&]() {
         cuts.clear();
-        for (int64_t i = 0; i < N; i += HQ_PATCH_PMERGE) cuts.push_back((int32_t)i);
+        for (int64_t i = 0; i < N; i += cfg.pmerge) cuts.push_back((int32_t)i);
         cuts.push_back((int32_t)N);
     };
     if (!xyz) { fixed(); return; }
@@ -134,10 +162,10 @@ static void hq_patch_cuts(int64_t N, const int32_t* xyz, std::vector<int32_t>& c
     while (!stack.empty()) {
         item it = stack.back();
         stack.pop_back();
-        if (it.hi - it.lo <= HQ_PATCH_PMAX) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
+        if (it.hi - it.lo <= cfg.pmax) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
         if (it.s == 0) {
-            for (int64_t i = it.lo; i < it.hi; i += HQ_PATCH_PMERGE)
-                runs.push_back({ (int32_t)i, (int32_t)std::min<int64_t>(i + HQ_PATCH_PMERGE, it.hi) });
+            for (int64_t i = it.lo; i < it.hi; i += cfg.pmerge)
+                runs.push_back({ (int32_t)i, (int32_t)std::min<int64_t>(i + cfg.pmerge, it.hi) });
             continue;
         }
         int sh = 3 * (it.s - 1);
@@ -158,7 +186,7 @@ static void hq_patch_cuts(int64_t N, const int32_t* xyz, std::vector<int32_t>& c
     int32_t cur = 0;
     for (auto& r : runs) {
         int32_t n = r.second - r.first;
-        if (cur > 0 && cur + n > HQ_PATCH_PMERGE) { cuts.push_back(r.first); cur = 0; }
+        if (cur > 0 && cur + n > cfg.pmerge) { cuts.push_back(r.first); cur = 0; }
         cur += n;
     }
     cuts.push_back((int32_t)N);
@@ -168,11 +196,11 @@ static void hq_patch_cuts(int64_t N, const int32_t* xyz, std::vector<int32_t>& c
  * Pair lists and local numbering for the node runs `cuts`.  A run whose halo
  * does not fit LDS is halved and the build repeated.
  */
-static int hq_patch_plan_host(int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
-                              hq_patch_host* H)
+static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, const int32_t* lnid,
+                              const int32_t* xyz, hq_patch_host* H)
 {
     std::vector<int32_t> cuts;
-    hq_patch_cuts(N, xyz, cuts);
+    hq_patch_cuts(cfg, N, xyz, cuts);
 
     for (int attempt = 0; attempt < 12; attempt++) {
         int32_t P = (int32_t)cuts.size() - 1;
@@ -226,7 +254,7 @@ static int hq_patch_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             }
             std::sort(h.begin(), h.end());
             h.erase(std::unique(h.begin(), h.end()), h.end());
-            if (nown + (int64_t)h.size() > HQ_PATCH_NLMAX || nown > HQ_PATCH_PMAX ||
+            if (nown + (int64_t)h.size() > cfg.nlmax || nown > cfg.pmax ||
                 off[p + 1] - off[p] > 0x7fffffff)
                 bad[p] = 1;
         }
@@ -281,8 +309,33 @@ static int hq_patch_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
 /* kernel                                                                   */
 /* ------------------------------------------------------------------------ */
 
-__global__ void __launch_bounds__(HQ_PATCH_THREADS)
-hq_k_patch_step(int32_t npatches, int32_t per_xcd, const hq_patch_desc* __restrict__ desc,
+struct hq_pair_data {
+    uint4 raw;
+    double beta, c1, c2;
+};
+
+__device__ __forceinline__ hq_pair_data hq_pair_load(const uint4* __restrict__ pidx, const double* __restrict__ pc1,
+                                                     const double* __restrict__ pc2,
+                                                     const double* __restrict__ pbeta, int64_t g)
+{
+    hq_pair_data d;
+    d.raw = pidx[g];
+    d.beta = pbeta[g];
+    d.c1 = pc1[g];
+    d.c2 = pc2[g];
+    return d;
+}
+
+/*
+ * LDS: s_u1[3 nlmax] | s_u2[3 nlmax] | s_f[3 pmax]   (doubles, node-major AoS)
+ *
+ * Every global load whose address does not depend on LDS contents is issued as
+ * early as possible (pair data of the first round before the staging barrier,
+ * the next round's before the current round's arithmetic, the nodal constants
+ * before the element loop) so the few waves a CU holds keep requests in flight.
+ */
+__global__ void __launch_bounds__(HQ_PATCH_MAX_THREADS, 4)
+hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
@@ -290,40 +343,61 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const hq_patch_desc* __restri
                 const double* __restrict__ nt, const int32_t* __restrict__ src_ptr,
                 const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2)
 {
-    __shared__ double s_u1[HQ_PATCH_NLMAX * 3];
-    __shared__ double s_u2[HQ_PATCH_NLMAX * 3];
-    __shared__ double s_f[HQ_PATCH_PMAX * 3];
+    extern __shared__ __align__(16) double s_mem[];
+    double* __restrict__ s_u1 = s_mem;
+    double* __restrict__ s_u2 = s_mem + 3 * nlmax;
+    double* __restrict__ s_f = s_mem + 6 * nlmax;
 
     /* workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD a
      * contiguous run of Z-ordered patches so halo reads hit its own L2 */
     const int p = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (p >= npatches) return;
     const hq_patch_desc D = desc[p];
-    const int tid = threadIdx.x;
-    const int own3 = D.nown * 3;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
 
-    {   /* owned nodes: one contiguous run of doubles */
+    hq_pair_data cur;
+    if (tid < D.npairs) cur = hq_pair_load(pidx, pc1, pc2, pbeta, D.pair_off + tid);
+
+    {   /* stage: owned nodes are one contiguous run of doubles, halo nodes a gather */
         const double* g1 = u1g + 3 * (int64_t)D.base;
         const double* g2 = u2g + 3 * (int64_t)D.base;
-        for (int i = tid; i < own3; i += HQ_PATCH_THREADS) {
-            s_u1[i] = g1[i];
-            s_u2[i] = g2[i];
-            s_f[i] = 0.0;
-        }
         const int32_t* hl = halo + D.halo_off;
-        for (int i = tid; i < D.nhalo * 3; i += HQ_PATCH_THREADS) {
-            int h = i / 3, d = i - 3 * h;
-            int64_t g = 3 * (int64_t)hl[h] + d;
-            s_u1[own3 + i] = u1g[g];
-            s_u2[own3 + i] = u2g[g];
+        for (int i0 = 0; i0 < own3 || i0 < halo3; i0 += 4 * T) {
+            double a1[4], a2[4], b1[4], b2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int i = i0 + k * T + tid;
+                if (i < own3) { a1[k] = g1[i]; a2[k] = g2[i]; }
+                if (i < halo3) {
+                    int h = i / 3, d = i - 3 * h;
+                    int64_t g = 3 * (int64_t)hl[h] + d;
+                    b1[k] = u1g[g]; b2[k] = u2g[g];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int i = i0 + k * T + tid;
+                if (i < own3) { s_u1[i] = a1[k]; s_u2[i] = a2[k]; s_f[i] = 0.0; }
+                if (i < halo3) { s_u1[own3 + i] = b1[k]; s_u2[own3 + i] = b2[k]; }
+            }
         }
     }
     __syncthreads();
 
-    for (int q = tid; q < D.npairs; q += HQ_PATCH_THREADS) {
-        const int64_t g = D.pair_off + q;
-        const uint4 raw = pidx[g];
-        const double beta = pbeta[g];
+    /* nodal constants of "my" node for the update below */
+    double np[7];
+    if (tid < D.nown) {
+        const double* q = nt + 7 * ((int64_t)D.base + tid);
+#pragma unroll
+        for (int k = 0; k < 7; k++) np[k] = q[k];
+    }
+
+    for (int q = tid; q < D.npairs; q += T) {
+        hq_pair_data nxt;
+        if (q + T < D.npairs) nxt = hq_pair_load(pidx, pc1, pc2, pbeta, D.pair_off + q + T);
+        const uint4 raw = cur.raw;
+        const double beta = cur.beta;
         int l[8];
         l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
         l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
@@ -339,7 +413,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const hq_patch_desc* __restri
             Y[n] = a1 + beta * (a1 - b[1]);
             Z[n] = a2 + beta * (a2 - b[2]);
         }
-        hq_element_force(X, Y, Z, pc1[g], pc2[g]);
+        hq_element_force(X, Y, Z, cur.c1, cur.c2);
 #pragma unroll
         for (int n = 0; n < 8; n++) {
             if (l[n] < D.nown) {
@@ -348,23 +422,28 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const hq_patch_desc* __restri
                 atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
             }
         }
+        cur = nxt;
     }
     if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
-        for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += HQ_PATCH_THREADS) {
+        for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += T) {
             int ln = src_ent[2 * k], li = src_ent[2 * k + 1];
             for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * ln + d], F[3 * li + d] * dt2);
         }
     }
     __syncthreads();
 
-    {   /* solver_compute_displacement, psolve.c:4078-4106 */
-        const double* np0 = nt + 7 * (int64_t)D.base;
-        double* out = ung + 3 * (int64_t)D.base;
-        for (int i = tid; i < own3; i += HQ_PATCH_THREADS) {
-            int n = i / 3, d = i - 3 * n;
-            const double* np = np0 + 7 * n;
-            double f = s_f[i] + (np[1 + d] * s_u1[i] - np[4 + d] * s_u2[i]);
-            out[i] = f / np[0];
+    /* solver_compute_displacement, psolve.c:4078-4106: one thread per owned node */
+    for (int n = tid; n < D.nown; n += T) {
+        if (n != tid) {
+            const double* q = nt + 7 * ((int64_t)D.base + n);
+#pragma unroll
+            for (int k = 0; k < 7; k++) np[k] = q[k];
+        }
+        double* out = ung + 3 * ((int64_t)D.base + n);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
+            out[d] = f / np[0];
         }
     }
 }
@@ -384,7 +463,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                           const double* c1, const double* c2, const double* beta, int64_t* bytes)
 {
     hq_patch_host H;
-    if (hq_patch_plan_host(E, N, lnid, xyz, &H) != 0) return -1 /* HQ_ERR_ARG */;
+    P->cfg = hq_patch_cfg_from_env();
+    if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, &H) != 0) return -1 /* HQ_ERR_ARG */;
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
@@ -447,8 +527,9 @@ static void hq_patch_launch(const hq_patch_plan* P, const double* u1, const doub
                             const double* nt, const double* F, double dt2, hipStream_t stream)
 {
     int per_xcd = (P->npatches + 7) / 8;
-    hq_k_patch_step<<<per_xcd * 8, HQ_PATCH_THREADS, 0, stream>>>(
-        P->npatches, per_xcd, P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt,
+    size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)P->cfg.pmax) * sizeof(double);
+    hq_k_patch_step<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
+        P->npatches, per_xcd, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt,
         P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2);
 }
 
