@@ -14,7 +14,7 @@ _LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
-           "hq_comm_unique_id", "hq_comm_init", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
+           "hq_comm_unique_id", "hq_comm_init", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel"]
 
@@ -214,3 +214,16 @@ def comm_unique_id():
     buf = (ctypes.c_char * 128)()
     _check(load_library().hq_comm_unique_id(buf))
     return bytes(buf)
+
+
+def group_link(solvers):
+    """hq_group_link: solvers[i] must hold rank i of len(solvers)."""
+    arr = (ctypes.c_void_p * len(solvers))(*[s._h for s in solvers])
+    _check(load_library().hq_group_link(arr, ctypes.c_int32(len(solvers))))
+
+
+def group_run(solvers, nsteps):
+    arr = (ctypes.c_void_p * len(solvers))(*[s._h for s in solvers])
+    _check(load_library().hq_group_run(arr, ctypes.c_int32(len(solvers)), ctypes.c_int32(nsteps)))
+    for s in solvers:
+        s.sync()

@@ -118,11 +118,15 @@ struct hq_dev_messenger {
 };
 
 struct hq_dev_schedule {
-    std::vector<hq_dev_messenger> c, s;
-    int32_t* d_cmap = nullptr;   /* concatenated mappings of the c-list */
+    std::vector<hq_dev_messenger> c, s;   /* c: owners of nodes I harbor; s: sharers of nodes I own */
+    int32_t* d_cmap = nullptr;   /* node ids, concatenated c-list mappings           */
     int32_t* d_smap = nullptr;
-    double*  d_cbuf = nullptr;   /* [sum nodecount][3] */
-    double*  d_sbuf = nullptr;
+    int32_t* d_cmap_f = nullptr; /* the same entries as indices into the force table */
+    int32_t* d_smap_f = nullptr; /* (scatter: node ids again; patch: interface slots) */
+    double*  d_c_out = nullptr;  /* contribution send   [ctotal][3]                   */
+    double*  d_c_in = nullptr;   /* sharing      recv   [ctotal][3]                   */
+    double*  d_s_out = nullptr;  /* sharing      send   [stotal][3]                   */
+    double*  d_s_in = nullptr;   /* contribution recv   [stotal][3]                   */
     int32_t  ctotal = 0, stotal = 0;
 };
 
@@ -158,6 +162,14 @@ struct hq_ctx {
     /* halo */
     hq_dev_schedule an, dn;
     hq_nccl_comm comm = nullptr;
+    std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
+    bool group_owner = false;
+    hipEvent_t ev_sent = nullptr;
+    /* patch variant: nodes on the partition interface */
+    int32_t nI = 0, nOI = 0;
+    double* d_iforce = nullptr;       /* [nI][3] partial / summed force of interface nodes */
+    int32_t* d_oi_node = nullptr;     /* [nOI] interface nodes I own                        */
+    int32_t* d_oi_slot = nullptr;
     /* patch variant */
     hq_patch_plan plan;
     /* timing */
@@ -316,11 +328,13 @@ static inline unsigned hq_blocks(int64_t n, int bs) { return (unsigned)((n + bs 
 static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* out)
 {
     auto load = [&](int32_t count, const hq_messenger* list, std::vector<hq_dev_messenger>& v,
-                    int32_t** d_map, double** d_buf, int32_t* total) -> int {
+                    int32_t** d_map, double** d_out, double** d_in, int32_t* total) -> int {
         std::vector<int32_t> map;
         for (int32_t i = 0; i < count; i++) {
             if (list[i].nodecount < 0 || (list[i].nodecount > 0 && !list[i].mapping))
                 return hq_fail(HQ_ERR_ARG, "messenger with bad mapping%s", "");
+            if (list[i].procid < 0 || list[i].procid >= c->nranks || list[i].procid == c->rank)
+                return hq_fail(HQ_ERR_ARG, "messenger with bad procid%s", "");
             hq_dev_messenger m = { list[i].procid, list[i].nodecount, (int32_t)map.size() };
             for (int32_t k = 0; k < list[i].nodecount; k++) {
                 int32_t id = list[i].mapping[k];
@@ -332,50 +346,93 @@ static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* 
         *total = (int32_t)map.size();
         if (*total) {
             HQ_TRY(hq_dev_alloc(c, d_map, map.size()));
-            HQ_TRY(hq_dev_alloc(c, d_buf, map.size() * 3));
+            HQ_TRY(hq_dev_alloc(c, d_out, map.size() * 3));
+            HQ_TRY(hq_dev_alloc(c, d_in, map.size() * 3));
             HQ_HIP(hipMemcpy(*d_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
         }
         return HQ_OK;
     };
-    HQ_TRY(load(in->c_count, in->first_c, out->c, &out->d_cmap, &out->d_cbuf, &out->ctotal));
-    HQ_TRY(load(in->s_count, in->first_s, out->s, &out->d_smap, &out->d_sbuf, &out->stotal));
+    HQ_TRY(load(in->c_count, in->first_c, out->c, &out->d_cmap, &out->d_c_out, &out->d_c_in, &out->ctotal));
+    HQ_TRY(load(in->s_count, in->first_s, out->s, &out->d_smap, &out->d_s_out, &out->d_s_in, &out->stotal));
+    out->d_cmap_f = out->d_cmap;
+    out->d_smap_f = out->d_smap;
     return HQ_OK;
 }
 
+static hq_dev_schedule* hq_peer_schedule(hq_ctx* peer, hq_ctx* me, hq_dev_schedule* mine)
+{
+    return (mine == &me->an) ? &peer->an : &peer->dn;
+}
+
 /*
- * schedule_senddata (psolve.c:4945-5079) on device buffers.
- * contribution: pack c-list, send to owners, receive from sharers, table += .
- * sharing     : pack s-list, send to sharers, receive from owners, table  = .
+ * schedule_senddata (psolve.c:4945-5079) on device buffers, in two halves so that
+ * several in-process partitions can be stepped in lockstep:
+ *   send half : pack (psolve.c:4985-5011) and hand the records to the transport
+ *   recv half : wait for the neighbours' records, unpack (:5035-5073)
+ * contribution: c-list out (to owners),  s-list in, table[...] += record
+ * sharing     : s-list out (to sharers), c-list in, table[...]  = record
+ * Transport: RCCL grouped send/recv over xGMI (hq_comm_init) or device-to-device
+ * copies between contexts of one process (hq_group_link).
  */
-static int hq_exchange(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution)
+static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool contribution, bool force_table)
 {
     std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
     std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
-    int32_t* d_smap = contribution ? s->d_cmap : s->d_smap;
-    int32_t* d_rmap = contribution ? s->d_smap : s->d_cmap;
-    double* d_sbuf = contribution ? s->d_cbuf : s->d_sbuf;
-    double* d_rbuf = contribution ? s->d_sbuf : s->d_cbuf;
-    int32_t stotal = contribution ? s->ctotal : s->stotal;
     if (snd.empty() && rcv.empty()) return HQ_OK;
-    if (!c->comm) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init%s", "");
-    if (stotal)
-        hq_k_pack<<<hq_blocks((int64_t)stotal * 3, 256), 256, 0, c->stream>>>(stotal, d_smap, table, d_sbuf);
-    HQ_NCCL(g_rccl.GroupStart());
-    for (auto& m : rcv)
-        if (m.nodecount)
-            HQ_NCCL(g_rccl.Recv(d_rbuf + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
-                                m.procid, c->comm, c->stream));
-    for (auto& m : snd)
-        if (m.nodecount)
-            HQ_NCCL(g_rccl.Send(d_sbuf + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
-                                m.procid, c->comm, c->stream));
-    HQ_NCCL(g_rccl.GroupEnd());
+    const int32_t* d_map = contribution ? (force_table ? s->d_cmap_f : s->d_cmap)
+                                        : (force_table ? s->d_smap_f : s->d_smap);
+    double* d_out = contribution ? s->d_c_out : s->d_s_out;
+    double* d_in = contribution ? s->d_s_in : s->d_c_in;
+    int32_t total = contribution ? s->ctotal : s->stotal;
+    if (!c->comm && !c->group) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init or hq_group_link%s", "");
+    if (total)
+        hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, c->stream>>>(total, d_map, table, d_out);
+    if (c->group) {
+        for (auto& m : snd) {
+            if (!m.nodecount) continue;
+            hq_ctx* peer = (*c->group)[m.procid];
+            hq_dev_schedule* ps = hq_peer_schedule(peer, c, s);
+            std::vector<hq_dev_messenger>& prcv = contribution ? ps->s : ps->c;
+            double* p_in = contribution ? ps->d_s_in : ps->d_c_in;
+            const hq_dev_messenger* pm = nullptr;
+            for (auto& q : prcv) if (q.procid == c->rank) pm = &q;
+            if (!pm || pm->nodecount != m.nodecount)
+                return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
+            HQ_HIP(hipMemcpyAsync(p_in + 3 * (int64_t)pm->offset, d_out + 3 * (int64_t)m.offset,
+                                  sizeof(double) * 3 * (size_t)m.nodecount, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HQ_HIP(hipEventRecord(c->ev_sent, c->stream));
+    } else {
+        HQ_NCCL(g_rccl.GroupStart());
+        for (auto& m : rcv)
+            if (m.nodecount)
+                HQ_NCCL(g_rccl.Recv(d_in + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
+                                    m.procid, c->comm, c->stream));
+        for (auto& m : snd)
+            if (m.nodecount)
+                HQ_NCCL(g_rccl.Send(d_out + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
+                                    m.procid, c->comm, c->stream));
+        HQ_NCCL(g_rccl.GroupEnd());
+    }
+    return HQ_OK;
+}
+
+static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution, bool force_table)
+{
+    std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
+    if (rcv.empty()) return HQ_OK;
+    const int32_t* d_map = contribution ? (force_table ? s->d_smap_f : s->d_smap)
+                                        : (force_table ? s->d_cmap_f : s->d_cmap);
+    double* d_in = contribution ? s->d_s_in : s->d_c_in;
+    if (c->group)
+        for (auto& m : rcv)
+            if (m.nodecount) HQ_HIP(hipStreamWaitEvent(c->stream, (*c->group)[m.procid]->ev_sent, 0));
     /* one launch per neighbour: a node may receive from several sharers and the
      * sums stay in a fixed order (the reference walks its messenger list) */
     for (auto& m : rcv)
         if (m.nodecount)
             hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, c->stream>>>(
-                m.nodecount, d_rmap + m.offset, d_rbuf + 3 * (int64_t)m.offset, table, contribution ? 1 : 0);
+                m.nodecount, d_map + m.offset, d_in + 3 * (int64_t)m.offset, table, contribution ? 1 : 0);
     HQ_HIP(hipGetLastError());
     return HQ_OK;
 }
@@ -415,51 +472,147 @@ static int hq_launch_update(hq_ctx* c)
     return HQ_OK;
 }
 
-/* One iteration of the solver_run loop body, psolve.c:4286-4316 */
-static int hq_step_scatter(hq_ctx* c)
+/* update of the interface nodes this rank owns, from the summed interface force */
+__global__ void hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
+                                      const double* __restrict__ iforce, const double* __restrict__ nt,
+                                      const double* __restrict__ u1, const double* __restrict__ u2,
+                                      double* __restrict__ un)
 {
-    HQ_TRY(hq_launch_source(c));                                   /* :4288 */
-    HQ_TRY(hq_launch_element_scatter(c));                          /* :4290-4291 */
-    HQ_TRY(hq_exchange(c, &c->dn, c->d_force, true));              /* :4298 */
-    if (c->ldnnum)                                                 /* :4299 */
-        hq_k_adjust_distribute<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
-            c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, c->d_force);
-    HQ_TRY(hq_exchange(c, &c->an, c->d_force, true));              /* :4301 */
-    HQ_TRY(hq_launch_update(c));                                   /* :4305 */
-    double* unew = c->d_u[c->prev];
-    HQ_TRY(hq_exchange(c, &c->an, unew, false));                   /* :4312 */
-    if (c->ldnnum)                                                 /* :4313 */
-        hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
-            c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
-    HQ_TRY(hq_exchange(c, &c->dn, unew, false));                   /* :4315 */
-    std::swap(c->now, c->prev);                                    /* :4271-4273 of the next iteration */
-    c->step++;
-    return HQ_OK;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    int64_t g = node[i];
+    const double* np = nt + 7 * g;
+    double f = iforce[3 * (int64_t)slot[i] + d] + (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
+    un[3 * g + d] = f / np[0];
 }
 
-static int hq_step_patch(hq_ctx* c)
+/*
+ * One iteration of the solver_run loop body (psolve.c:4286-4316) as NPHASE
+ * phases; a phase never waits for a neighbour's data that the neighbour has
+ * not been asked to send in an earlier phase, so in-process groups enqueue
+ * phase k for every member before phase k+1.
+ */
+enum { HQ_NPHASE = 9 };
+
+static int hq_phase(hq_ctx* c, int ph)
 {
-    int32_t k = c->step - c->src_step0;
-    const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
-                          ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
-    hq_mark(c);
-    hq_patch_launch(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
-                    c->stream);
-    hq_mark(c);
-    int n = c->now, p = c->prev, s = c->spare;
-    c->now = s; c->prev = n; c->spare = p;
-    c->step++;
+    const bool patch = (c->variant == HQ_VARIANT_PATCH);
+    double* ftab = patch ? c->d_iforce : c->d_force;
+    double* unew = patch ? c->d_u[c->spare] : c->d_u[c->prev];
+    switch (ph) {
+    case 0:
+        if (patch) {
+            int32_t k = c->step - c->src_step0;
+            const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
+                                  ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
+            hq_mark(c);
+            hq_patch_launch(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                            c->d_iforce, c->stream);
+            hq_mark(c);
+        } else {
+            HQ_TRY(hq_launch_source(c));                                   /* :4288 */
+            HQ_TRY(hq_launch_element_scatter(c));                          /* :4290-4291 */
+        }
+        return HQ_OK;
+    case 1: return patch ? HQ_OK : hq_xchg_send(c, &c->dn, ftab, true, true);       /* :4298 */
+    case 2:
+        if (patch) return HQ_OK;
+        HQ_TRY(hq_xchg_recv(c, &c->dn, ftab, true, true));
+        if (c->ldnnum)                                                     /* :4299 */
+            hq_k_adjust_distribute<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
+                c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, c->d_force);
+        return HQ_OK;
+    case 3: return hq_xchg_send(c, &c->an, ftab, true, true);                        /* :4301 */
+    case 4:
+        HQ_TRY(hq_xchg_recv(c, &c->an, ftab, true, true));
+        if (patch) {
+            if (c->nOI)
+                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, c->stream>>>(
+                    c->nOI, c->d_oi_node, c->d_oi_slot, c->d_iforce, c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew);
+        } else {
+            HQ_TRY(hq_launch_update(c));                                   /* :4305 */
+        }
+        return HQ_OK;
+    case 5: return hq_xchg_send(c, &c->an, unew, false, false);                      /* :4312 */
+    case 6:
+        HQ_TRY(hq_xchg_recv(c, &c->an, unew, false, false));
+        if (!patch && c->ldnnum)                                           /* :4313 */
+            hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
+                c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
+        return HQ_OK;
+    case 7: return patch ? HQ_OK : hq_xchg_send(c, &c->dn, unew, false, false);     /* :4315 */
+    case 8:
+        if (!patch) HQ_TRY(hq_xchg_recv(c, &c->dn, unew, false, false));
+        if (patch) {
+            int n = c->now, p = c->prev, sp = c->spare;
+            c->now = sp; c->prev = n; c->spare = p;
+        } else {
+            std::swap(c->now, c->prev);                                    /* :4271-4273 of the next iteration */
+        }
+        c->step++;
+        return HQ_OK;
+    }
     return HQ_OK;
 }
 
 static int hq_step(hq_ctx* c)
 {
-    return c->variant == HQ_VARIANT_PATCH ? hq_step_patch(c) : hq_step_scatter(c);
+    for (int ph = 0; ph < HQ_NPHASE; ph++) HQ_TRY(hq_phase(c, ph));
+    return HQ_OK;
 }
 
 /* ------------------------------------------------------------------------ */
 /* C-ABI                                                                    */
 /* ------------------------------------------------------------------------ */
+
+/*
+ * Patch variant on a partition: nodes named in the anchored-node schedule form
+ * the "interface".  The patch kernel stores their partial force in a compact
+ * table (one slot per interface node) instead of trusting its own update; the
+ * contribution exchange adds the neighbours' partials to the owner's slot, the
+ * owner updates the node (hq_k_interface_update) and shares the result.
+ */
+static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
+{
+    if (c->an.ctotal == 0 && c->an.stotal == 0) return HQ_OK;
+    std::vector<int32_t> slot((size_t)c->N, -1), cs, ss, oin, ois;
+    int32_t nI = 0;
+    auto slots_of = [&](int32_t count, const hq_messenger* list, std::vector<int32_t>& out, bool owned) {
+        for (int32_t i = 0; i < count; i++)
+            for (int32_t k = 0; k < list[i].nodecount; k++) {
+                int32_t n = list[i].mapping[k];
+                if (slot[n] < 0) {
+                    slot[n] = nI++;
+                    if (owned) { oin.push_back(n); ois.push_back(slot[n]); }
+                }
+                out.push_back(slot[n]);
+            }
+    };
+    slots_of(d->an_sched.s_count, d->an_sched.first_s, ss, true);
+    slots_of(d->an_sched.c_count, d->an_sched.first_c, cs, false);
+    c->nI = nI;
+    c->nOI = (int32_t)oin.size();
+    HQ_TRY(hq_dev_alloc(c, &c->d_iforce, (size_t)nI * 3));
+    HQ_HIP(hipMemset(c->d_iforce, 0, sizeof(double) * 3 * (size_t)nI));
+    if (!cs.empty()) {
+        HQ_TRY(hq_dev_alloc(c, &c->an.d_cmap_f, cs.size()));
+        HQ_HIP(hipMemcpy(c->an.d_cmap_f, cs.data(), 4 * cs.size(), hipMemcpyHostToDevice));
+    }
+    if (!ss.empty()) {
+        HQ_TRY(hq_dev_alloc(c, &c->an.d_smap_f, ss.size()));
+        HQ_HIP(hipMemcpy(c->an.d_smap_f, ss.data(), 4 * ss.size(), hipMemcpyHostToDevice));
+    }
+    if (c->nOI) {
+        HQ_TRY(hq_dev_alloc(c, &c->d_oi_node, oin.size()));
+        HQ_TRY(hq_dev_alloc(c, &c->d_oi_slot, ois.size()));
+        HQ_HIP(hipMemcpy(c->d_oi_node, oin.data(), 4 * oin.size(), hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(c->d_oi_slot, ois.data(), 4 * ois.size(), hipMemcpyHostToDevice));
+    }
+    if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
+        return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
+    return HQ_OK;
+}
 
 extern "C" int hq_device_count(void)
 {
@@ -505,12 +658,13 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "hipStreamCreate failed%s", ""));
 
-    bool has_halo = d->an_sched.c_count || d->an_sched.s_count || d->dn_sched.c_count || d->dn_sched.s_count;
+    bool has_dn = d->dn_sched.c_count || d->dn_sched.s_count || c->ldnnum;
     int variant = d->variant;
-    if (variant == HQ_VARIANT_AUTO)
-        variant = (has_halo || c->ldnnum) ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
-    if (variant == HQ_VARIANT_PATCH && (has_halo || c->ldnnum))
-        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take halo schedules or hanging nodes yet%s", ""));
+    if (variant == HQ_VARIANT_AUTO) variant = has_dn ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
+    if (variant == HQ_VARIANT_PATCH && has_dn)
+        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take hanging nodes (use the scatter variant)%s", ""));
+    if (hipEventCreateWithFlags(&c->ev_sent, hipEventDisableTiming) != hipSuccess)
+        return bail(hq_fail(HQ_ERR_DEVICE, "hipEventCreate failed%s", ""));
     if (variant != HQ_VARIANT_SCATTER && variant != HQ_VARIANT_PATCH)
         return bail(hq_fail(HQ_ERR_ARG, "unknown variant%s", ""));
     c->variant = variant;
@@ -572,6 +726,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));
         c->bytes += pb;
+        if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
+        if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
     *out = c;
@@ -586,9 +742,20 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->comm && g_rccl.handle) g_rccl.CommDestroy(c->comm);
     void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt, c->d_u[0], c->d_u[1], c->d_u[2],
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
-                     c->an.d_cmap, c->an.d_smap, c->an.d_cbuf, c->an.d_sbuf,
-                     c->dn.d_cmap, c->dn.d_smap, c->dn.d_cbuf, c->dn.d_sbuf };
+                     c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
+                     c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot };
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->an.d_cmap_f && c->an.d_cmap_f != c->an.d_cmap) hipFree(c->an.d_cmap_f);
+    if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
+    if (c->ev_sent) hipEventDestroy(c->ev_sent);
+    if (c->group) {
+        /* unlink: the last member to go frees the table */
+        std::vector<hq_ctx*>* g = c->group;
+        bool any = false;
+        for (auto& m : *g) { if (m == c) m = nullptr; any |= (m != nullptr); }
+        if (!any) delete g;
+    }
     hq_patch_free(&c->plan);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (int k = 0; k < 2; k++) if (c->ev_span[k]) hipEventDestroy(c->ev_span[k]);
@@ -631,6 +798,36 @@ extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
     return HQ_OK;
 }
 
+extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
+{
+    if (!ctxs || n < 1) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    for (int32_t i = 0; i < n; i++) {
+        if (!ctxs[i] || ctxs[i]->rank != i || ctxs[i]->nranks != n)
+            return hq_fail(HQ_ERR_ARG, "group member %s must be the context of rank i of n", "i");
+        if (ctxs[i]->group || ctxs[i]->comm) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    }
+    std::vector<hq_ctx*>* g = new (std::nothrow) std::vector<hq_ctx*>(ctxs, ctxs + n);
+    if (!g) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");
+    for (int32_t i = 0; i < n; i++) ctxs[i]->group = g;
+    return HQ_OK;
+}
+
+extern "C" int hq_group_run(hq_ctx** ctxs, int32_t n, int32_t nsteps)
+{
+    if (!ctxs || n < 1 || nsteps < 0) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    for (int32_t i = 0; i < n; i++)
+        if (!ctxs[i] || !ctxs[i]->group || (*ctxs[i]->group)[i] != ctxs[i])
+            return hq_fail(HQ_ERR_STATE, "contexts are not linked (hq_group_link)%s", "");
+    for (int32_t s = 0; s < nsteps; s++)
+        for (int ph = 0; ph < HQ_NPHASE; ph++)
+            for (int32_t i = 0; i < n; i++) {
+                HQ_HIP(hipSetDevice(ctxs[i]->device));
+                HQ_TRY(hq_phase(ctxs[i], ph));
+            }
+    HQ_HIP(hipGetLastError());
+    return HQ_OK;
+}
+
 extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, int32_t step0,
                              int32_t nsteps, const double* F)
 {
@@ -659,6 +856,8 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
 extern "C" int hq_run(hq_ctx* c, int32_t nsteps)
 {
     if (!c || nsteps < 0) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    if (c->group && c->group->size() > 1)
+        return hq_fail(HQ_ERR_STATE, "linked contexts are stepped with hq_group_run%s", "");
     HQ_HIP(hipSetDevice(c->device));
     for (int32_t s = 0; s < nsteps; s++) HQ_TRY(hq_step(c));
     HQ_HIP(hipGetLastError());

@@ -94,6 +94,9 @@ struct hq_patch_plan {
     /* source entries grouped by patch (built by hq_patch_set_source) */
     int32_t* d_src_ptr = nullptr;    /* [npatches + 1]                    */
     int32_t* d_src_ent = nullptr;    /* [n][2] = {local node, loaded idx} */
+    /* partition-interface nodes grouped by owning patch (hq_patch_set_interface) */
+    int32_t* d_if_ptr = nullptr;     /* [npatches + 1]                    */
+    int32_t* d_if_ent = nullptr;     /* [n][2] = {local node, slot}       */
     std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
     std::vector<int32_t> patch_nown;
 };
@@ -341,7 +344,9 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch
                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
                 const double* __restrict__ u2g, double* __restrict__ ung,
                 const double* __restrict__ nt, const int32_t* __restrict__ src_ptr,
-                const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2)
+                const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
+                const int32_t* __restrict__ if_ptr, const int32_t* __restrict__ if_ent,
+                double* __restrict__ iforce)
 {
     extern __shared__ __align__(16) double s_mem[];
     double* __restrict__ s_u1 = s_mem;
@@ -446,6 +451,13 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch
             out[d] = f / np[0];
         }
     }
+    if (if_ptr) {   /* partition interface: hand the partial force to the exchange (psolve.c:4301) */
+        for (int k = if_ptr[p] + tid; k < if_ptr[p + 1]; k += T) {
+            int ln = if_ent[2 * k];
+            double* o = iforce + 3 * (int64_t)if_ent[2 * k + 1];
+            o[0] = s_f[3 * ln]; o[1] = s_f[3 * ln + 1]; o[2] = s_f[3 * ln + 2];
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -454,7 +466,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch
 
 static void hq_patch_free(hq_patch_plan* P)
 {
-    void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent };
+    void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
+                     P->d_if_ptr, P->d_if_ent };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
@@ -523,14 +536,34 @@ static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t*
     return 0;
 }
 
+/* slot[n] >= 0 for nodes on the partition interface */
+static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t* bytes)
+{
+    std::vector<int32_t> ptr((size_t)P->npatches + 1, 0), ent;
+    for (int32_t p = 0; p < P->npatches; p++) {
+        for (int32_t n = 0; n < P->patch_nown[p]; n++) {
+            int32_t sl = slot[P->patch_base[p] + n];
+            if (sl >= 0) { ent.push_back(n); ent.push_back(sl); }
+        }
+        ptr[p + 1] = (int32_t)(ent.size() / 2);
+    }
+    if (ent.empty()) return 0;
+    if (hipMalloc((void**)&P->d_if_ptr, 4 * ptr.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+    if (hipMalloc((void**)&P->d_if_ent, 4 * ent.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+    *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
+    hipMemcpy(P->d_if_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice);
+    hipMemcpy(P->d_if_ent, ent.data(), 4 * ent.size(), hipMemcpyHostToDevice);
+    return 0;
+}
+
 static void hq_patch_launch(const hq_patch_plan* P, const double* u1, const double* u2, double* un,
-                            const double* nt, const double* F, double dt2, hipStream_t stream)
+                            const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
     int per_xcd = (P->npatches + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)P->cfg.pmax) * sizeof(double);
     hq_k_patch_step<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
         P->npatches, per_xcd, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt,
-        P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2);
+        P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce);
 }
 
 #endif /* HQ_PATCH_H */

@@ -139,6 +139,16 @@ HQ_API int hq_comm_unique_id(void* id128);
 HQ_API int hq_comm_init(hq_ctx* ctx, const void* id128);
 
 /*
+ * In-process transport for hosts that drive several partitions from ONE process
+ * (and for tests on a single GPU): ctxs[i] must be the context of rank i of n.
+ * The halo records then travel by device-to-device copies ordered with HIP
+ * events; hq_group_run enqueues `nsteps` steps for all members in lockstep
+ * (hq_run on a linked context is not allowed to run alone).
+ */
+HQ_API int hq_group_link(hq_ctx** ctxs, int32_t n);
+HQ_API int hq_group_run(hq_ctx** ctxs, int32_t n, int32_t nsteps);
+
+/*
  * Source forces for steps [step0, step0+nsteps): F[nsteps][nloaded][3], the
  * payload of force_process.<rank> (quakesource.c:2453-2466).
  * Replaces: read_myForces (psolve.c:3651-3667) + compute_addforce_s (:5912-5928).

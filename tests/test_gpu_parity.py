@@ -189,3 +189,55 @@ def test_hanging_node_adjust_and_roundtrip():
     x1, x2 = s.download()
     assert np.array_equal(x1, u1) and np.array_equal(x2, u2)
     s.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_partitioned_box_matches_single_partition(variant, nranks):
+    """The same box cut into octor-style block partitions (C host side), all
+    partitions stepped in one process on one GPU with the in-process halo
+    transport: every harbored copy must agree with the oracle's single-rank run."""
+    from hercules_amd import capi, host
+    nx, ny, nz, h, dt, freq = 32, 16, 16, 20.0, 4e-4, 20.0
+    nsteps = 25
+    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=nranks) for r in range(nranks)]
+    # oracle, one rank
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:] = (h, 6000.0, 3464.0, 2700.0)
+    et, nt = ho.solver_init(lnid, edata, ho.face_bits(elem_ijk, nx, ny, nz), len(node_ijk), dt, freq)
+    N = len(node_ijk)
+    rng = np.random.default_rng(99)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    gidx = {tuple(v): i for i, v in enumerate(node_ijk.tolist())}
+    # a point source in the middle: only the rank holding the element loads it
+    src = [b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0) for b in boxes]
+    owner_rank = [r for r in range(nranks) if len(src[r][0])]
+    assert len(owner_rank) == 1
+    rp = boxes[owner_rank[0]].run_params(loaded=src[owner_rank[0]][0], pattern=src[owner_rank[0]][1],
+                                         moment=1e13, rise_time=10 * dt)
+    F = boxes[owner_rank[0]].source_table(rp, 0, nsteps)
+    loaded_global = [gidx[tuple(boxes[owner_rank[0]].node_ijk[i])] for i in src[owner_rank[0]][0]]
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(lnid, et, nt, o1, o2, 0, nsteps, dt, loaded_lnid=np.array(loaded_global, np.int32), forces=F)
+    solvers = []
+    maps = []
+    for r, b in enumerate(boxes):
+        m = np.array([gidx[tuple(v)] for v in b.node_ijk.tolist()])
+        maps.append(m)
+        s = b.create_solver(variant=variant, tm1=u1[m], tm2=u2[m])
+        assert s.info()["variant"] == variant
+        if r == owner_rank[0]:
+            s.set_source(src[r][0], F)
+        solvers.append(s)
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for r, s in enumerate(solvers):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[maps[r]]) < TOL, (r, "tm1")
+        assert H.rel_linf(tm2, o1[maps[r]]) < TOL, (r, "tm2")
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()
