@@ -126,7 +126,8 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()      # (several ranks per GPU only in dry runs)
+    torch.cuda.set_device(device)
 
     nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
@@ -142,7 +143,7 @@ def main():
         x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
         u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
     u2 = u1 * (1.0 - 1e-3)
-    solver = box.create_solver(variant=variant, device=local_rank, tm1=u1, tm2=u2)
+    solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2)
     del u1, u2, ijk, gid
     if world > 1:
         idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]

@@ -165,6 +165,11 @@ struct hq_ctx {
     std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
     bool group_owner = false;
     hipEvent_t ev_sent = nullptr;
+    /* patch variant with an interface: the exchange chain runs on its own stream
+     * beside the interior patches */
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_shared = nullptr;
+    bool overlap = false;
     /* patch variant: nodes on the partition interface */
     int32_t nI = 0, nOI = 0;
     double* d_iforce = nullptr;       /* [nI][3] partial / summed force of interface nodes */
@@ -376,6 +381,7 @@ static hq_dev_schedule* hq_peer_schedule(hq_ctx* peer, hq_ctx* me, hq_dev_schedu
  */
 static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool contribution, bool force_table)
 {
+    hipStream_t xs = c->overlap ? c->cstream : c->stream;
     std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
     std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
     if (snd.empty() && rcv.empty()) return HQ_OK;
@@ -386,7 +392,7 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     int32_t total = contribution ? s->ctotal : s->stotal;
     if (!c->comm && !c->group) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init or hq_group_link%s", "");
     if (total)
-        hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, c->stream>>>(total, d_map, table, d_out);
+        hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_out);
     if (c->group) {
         for (auto& m : snd) {
             if (!m.nodecount) continue;
@@ -399,19 +405,19 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
             if (!pm || pm->nodecount != m.nodecount)
                 return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
             HQ_HIP(hipMemcpyAsync(p_in + 3 * (int64_t)pm->offset, d_out + 3 * (int64_t)m.offset,
-                                  sizeof(double) * 3 * (size_t)m.nodecount, hipMemcpyDeviceToDevice, c->stream));
+                                  sizeof(double) * 3 * (size_t)m.nodecount, hipMemcpyDeviceToDevice, xs));
         }
-        HQ_HIP(hipEventRecord(c->ev_sent, c->stream));
+        HQ_HIP(hipEventRecord(c->ev_sent, xs));
     } else {
         HQ_NCCL(g_rccl.GroupStart());
         for (auto& m : rcv)
             if (m.nodecount)
                 HQ_NCCL(g_rccl.Recv(d_in + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
-                                    m.procid, c->comm, c->stream));
+                                    m.procid, c->comm, xs));
         for (auto& m : snd)
             if (m.nodecount)
                 HQ_NCCL(g_rccl.Send(d_out + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
-                                    m.procid, c->comm, c->stream));
+                                    m.procid, c->comm, xs));
         HQ_NCCL(g_rccl.GroupEnd());
     }
     return HQ_OK;
@@ -419,6 +425,7 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
 
 static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution, bool force_table)
 {
+    hipStream_t xs = c->overlap ? c->cstream : c->stream;
     std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
     if (rcv.empty()) return HQ_OK;
     const int32_t* d_map = contribution ? (force_table ? s->d_smap_f : s->d_smap)
@@ -426,15 +433,26 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     double* d_in = contribution ? s->d_s_in : s->d_c_in;
     if (c->group)
         for (auto& m : rcv)
-            if (m.nodecount) HQ_HIP(hipStreamWaitEvent(c->stream, (*c->group)[m.procid]->ev_sent, 0));
+            if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
     /* one launch per neighbour: a node may receive from several sharers and the
      * sums stay in a fixed order (the reference walks its messenger list) */
     for (auto& m : rcv)
         if (m.nodecount)
-            hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, c->stream>>>(
+            hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, xs>>>(
                 m.nodecount, d_map + m.offset, d_in + 3 * (int64_t)m.offset, table, contribution ? 1 : 0);
     HQ_HIP(hipGetLastError());
     return HQ_OK;
+}
+
+/* wait for everything enqueued on the context's streams */
+static hipError_t hq_quiesce(hq_ctx* c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->cstream) {
+        hipError_t e2 = hipStreamSynchronize(c->cstream);
+        if (e == hipSuccess) e = e2;
+    }
+    return e;
 }
 
 static void hq_mark(hq_ctx* c)
@@ -506,9 +524,17 @@ static int hq_phase(hq_ctx* c, int ph)
             int32_t k = c->step - c->src_step0;
             const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
                                   ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
+            int32_t nb = c->plan.nb, np = c->plan.npatches;
+            if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             hq_mark(c);
-            hq_patch_launch(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+            hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                             c->d_iforce, c->stream);
+            if (c->overlap) {
+                HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
+                HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+            }
+            hq_patch_launch(&c->plan, nb, np - nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
+                            c->dt2, c->d_iforce, c->stream);
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -528,7 +554,7 @@ static int hq_phase(hq_ctx* c, int ph)
         HQ_TRY(hq_xchg_recv(c, &c->an, ftab, true, true));
         if (patch) {
             if (c->nOI)
-                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, c->stream>>>(
+                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, c->overlap ? c->cstream : c->stream>>>(
                     c->nOI, c->d_oi_node, c->d_oi_slot, c->d_iforce, c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew);
         } else {
             HQ_TRY(hq_launch_update(c));                                   /* :4305 */
@@ -545,6 +571,7 @@ static int hq_phase(hq_ctx* c, int ph)
     case 8:
         if (!patch) HQ_TRY(hq_xchg_recv(c, &c->dn, unew, false, false));
         if (patch) {
+            if (c->overlap) HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));
             int n = c->now, p = c->prev, sp = c->spare;
             c->now = sp; c->prev = n; c->spare = p;
         } else {
@@ -611,6 +638,13 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
+    if (!getenv("HQ_NO_OVERLAP")) {
+        HQ_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+        HQ_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
+        HQ_HIP(hipEventCreateWithFlags(&c->ev_shared, hipEventDisableTiming));
+        HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));
+        c->overlap = true;
+    }
     return HQ_OK;
 }
 
@@ -738,7 +772,7 @@ extern "C" int hq_destroy(hq_ctx* c)
 {
     if (!c) return HQ_OK;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) hq_quiesce(c);
     if (c->comm && g_rccl.handle) g_rccl.CommDestroy(c->comm);
     void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt, c->d_u[0], c->d_u[1], c->d_u[2],
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
@@ -749,6 +783,9 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->an.d_cmap_f && c->an.d_cmap_f != c->an.d_cmap) hipFree(c->an.d_cmap_f);
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
+    if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
+    if (c->ev_shared) hipEventDestroy(c->ev_shared);
     if (c->group) {
         /* unlink: the last member to go frees the table */
         std::vector<hq_ctx*>* g = c->group;
@@ -834,7 +871,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
     if (!c || nloaded < 0 || nsteps < 0 || (nloaded && nsteps && (!loaded || !F)))
         return hq_fail(HQ_ERR_ARG, "bad source description%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     for (int32_t i = 0; i < nloaded; i++)
         if (loaded[i] < 0 || loaded[i] >= c->N) return hq_fail(HQ_ERR_ARG, "loaded node id out of range%s", "");
     if (c->d_loaded) { hipFree(c->d_loaded); c->d_loaded = nullptr; }
@@ -868,7 +905,7 @@ extern "C" int hq_sync(hq_ctx* c)
 {
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     return HQ_OK;
 }
 
@@ -884,15 +921,16 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
     }
     for (int k = 0; k < 2; k++)
         if (!c->ev_span[k]) HQ_HIP(hipEventCreate(&c->ev_span[k]));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     c->ev_used = 0;
     HQ_HIP(hipEventRecord(c->ev_span[0], c->stream));
     c->timing = true;
     int rc = HQ_OK;
     for (int32_t s = 0; s < nsteps && rc == HQ_OK; s++) rc = hq_step(c);
     c->timing = false;
+    if (c->overlap) hipStreamWaitEvent(c->stream, c->ev_shared, 0);
     hipEventRecord(c->ev_span[1], c->stream);
-    hipError_t he = hipStreamSynchronize(c->stream);
+    hipError_t he = hq_quiesce(c);
     double tot = 0, ker = 0;
     if (rc == HQ_OK && he == hipSuccess) {
         float ms = 0;
@@ -921,6 +959,7 @@ extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, 
     if (!c || n < 0 || (n && !lnid)) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     if (n == 0) return HQ_OK;
     HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hq_quiesce(c));
     for (int32_t i = 0; i < n; i++)
         if (lnid[i] < 0 || lnid[i] >= c->N) return hq_fail(HQ_ERR_ARG, "node id out of range%s", "");
     int32_t* d_ids = nullptr;
@@ -933,7 +972,7 @@ extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, 
                                                                          d_o, d_o + 3 * (size_t)n);
     if (o1) hipMemcpyAsync(o1, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
     if (o2) hipMemcpyAsync(o2, d_o + 3 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
-    e = hipStreamSynchronize(c->stream);
+    e = hq_quiesce(c);
     hipFree(d_ids);
     hipFree(d_o);
     if (e != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "gather failed: %s", hipGetErrorString(e));
@@ -944,7 +983,7 @@ extern "C" int hq_download(hq_ctx* c, double* tm1, double* tm2)
 {
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     size_t bytes = sizeof(double) * 3 * (size_t)c->N;
     if (tm1) HQ_HIP(hipMemcpy(tm1, c->d_u[c->now], bytes, hipMemcpyDeviceToHost));
     if (tm2) HQ_HIP(hipMemcpy(tm2, c->d_u[c->prev], bytes, hipMemcpyDeviceToHost));
@@ -955,7 +994,7 @@ extern "C" int hq_upload(hq_ctx* c, const double* tm1, const double* tm2, int32_
 {
     if (!c || !tm1 || !tm2) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     size_t bytes = sizeof(double) * 3 * (size_t)c->N;
     HQ_HIP(hipMemcpy(c->d_u[c->now], tm1, bytes, hipMemcpyHostToDevice));
     HQ_HIP(hipMemcpy(c->d_u[c->prev], tm2, bytes, hipMemcpyHostToDevice));
@@ -991,7 +1030,7 @@ extern "C" int hq_download_force(hq_ctx* c, double* force)
     if (!c || !force) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     if (c->variant != HQ_VARIANT_SCATTER) return hq_fail(HQ_ERR_STATE, "no force array in the patch variant%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    HQ_HIP(hipStreamSynchronize(c->stream));
+    HQ_HIP(hq_quiesce(c));
     HQ_HIP(hipMemcpy(force, c->d_force, sizeof(double) * 3 * (size_t)c->N, hipMemcpyDeviceToHost));
     return HQ_OK;
 }

@@ -97,6 +97,8 @@ struct hq_patch_plan {
     /* partition-interface nodes grouped by owning patch (hq_patch_set_interface) */
     int32_t* d_if_ptr = nullptr;     /* [npatches + 1]                    */
     int32_t* d_if_ent = nullptr;     /* [n][2] = {local node, slot}       */
+    int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
+    int32_t  nb = 0;
     std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
     std::vector<int32_t> patch_nown;
 };
@@ -338,7 +340,8 @@ __device__ __forceinline__ hq_pair_data hq_pair_load(const uint4* __restrict__ p
  * before the element loop) so the few waves a CU holds keep requests in flight.
  */
 __global__ void __launch_bounds__(HQ_PATCH_MAX_THREADS, 4)
-hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch_desc* __restrict__ desc,
+hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
+                const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
@@ -355,8 +358,9 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch
 
     /* workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD a
      * contiguous run of Z-ordered patches so halo reads hit its own L2 */
-    const int p = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (p >= npatches) return;
+    const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (slot >= npatches) return;
+    const int p = order ? order[slot] : slot;
     const hq_patch_desc D = desc[p];
     const int tid = threadIdx.x, T = blockDim.x;
     const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
@@ -467,7 +471,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, int32_t nlmax, const hq_patch
 static void hq_patch_free(hq_patch_plan* P)
 {
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent };
+                     P->d_if_ptr, P->d_if_ent, P->d_order };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
@@ -548,6 +552,16 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
         ptr[p + 1] = (int32_t)(ent.size() / 2);
     }
     if (ent.empty()) return 0;
+    {   /* launch order: patches owning interface nodes first, so their partial forces can
+         * travel while the rest of the partition is still being computed */
+        std::vector<int32_t> order;
+        for (int32_t p = 0; p < P->npatches; p++) if (ptr[p + 1] > ptr[p]) order.push_back(p);
+        P->nb = (int32_t)order.size();
+        for (int32_t p = 0; p < P->npatches; p++) if (ptr[p + 1] == ptr[p]) order.push_back(p);
+        if (hipMalloc((void**)&P->d_order, 4 * order.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+        *bytes += (int64_t)(4 * order.size());
+        hipMemcpy(P->d_order, order.data(), 4 * order.size(), hipMemcpyHostToDevice);
+    }
     if (hipMalloc((void**)&P->d_if_ptr, 4 * ptr.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     if (hipMalloc((void**)&P->d_if_ent, 4 * ent.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
@@ -556,14 +570,18 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
     return 0;
 }
 
-static void hq_patch_launch(const hq_patch_plan* P, const double* u1, const double* u2, double* un,
-                            const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
+/* launch patches order[first .. first+count) (order == identity when there is no interface) */
+static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const double* u1,
+                            const double* u2, double* un, const double* nt, const double* F, double dt2,
+                            double* iforce, hipStream_t stream)
 {
-    int per_xcd = (P->npatches + 7) / 8;
+    if (count <= 0) return;
+    int per_xcd = (count + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)P->cfg.pmax) * sizeof(double);
     hq_k_patch_step<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
-        P->npatches, per_xcd, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt,
-        P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce);
+        count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
+        P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_src_ptr, P->d_src_ent,
+        (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce);
 }
 
 #endif /* HQ_PATCH_H */
