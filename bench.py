@@ -95,6 +95,35 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def inproc_diagnostic(args):
+    import hercules_amd as ha
+    from hercules_amd import capi, host as hhost
+    nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
+    P = args.inproc_parts
+    variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+    boxes, solvers = [], []
+    for r in range(P):
+        b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P)
+        ijk = b.node_ijk.astype(np.int64)
+        gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+        u1 = np.empty((len(gid), 3))
+        for d in range(3):
+            x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
+            u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+        solvers.append(b.create_solver(variant=variant, tm1=u1, tm2=u1 * (1.0 - 1e-3)))
+        boxes.append(b)
+    capi.group_link(solvers)
+    capi.group_run(solvers, args.warmup)
+    t0 = time.perf_counter()
+    capi.group_run(solvers, args.steps)
+    el = time.perf_counter() - t0
+    E = boxes[0].info["total_elements"]
+    print(json.dumps({"diagnostic": "in-process partitions on one GPU", "parts": P, "workload": args.workload,
+                      "value": E * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                      "shared_nodes": [b.info["shared_nodes"] for b in boxes],
+                      "neighbors": [b.info["nneighbors"] for b in boxes]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +132,12 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("HQ_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="auto", choices=["auto", "scatter", "patch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inproc-parts", type=int, default=0,
+                    help="diagnostic: P block partitions stepped in ONE process on ONE GPU with the "
+                         "in-process halo transport (measures the cost of partitioning, not xGMI)")
     args = ap.parse_args()
+    if args.inproc_parts > 1:
+        return inproc_diagnostic(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

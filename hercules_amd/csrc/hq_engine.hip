@@ -175,6 +175,8 @@ struct hq_ctx {
     double* d_iforce = nullptr;       /* [nI][3] partial / summed force of interface nodes */
     int32_t* d_oi_node = nullptr;     /* [nOI] interface nodes I own                        */
     int32_t* d_oi_slot = nullptr;
+    int32_t* d_oi_ptr = nullptr;      /* [nOI+1] CSR: records of an.d_s_in to add, in       */
+    int32_t* d_oi_pos = nullptr;      /*         messenger order (fixed summation order)    */
     /* patch variant */
     hq_patch_plan plan;
     /* timing */
@@ -434,12 +436,19 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     if (c->group)
         for (auto& m : rcv)
             if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
-    /* one launch per neighbour: a node may receive from several sharers and the
-     * sums stay in a fixed order (the reference walks its messenger list) */
-    for (auto& m : rcv)
-        if (m.nodecount)
-            hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, xs>>>(
-                m.nodecount, d_map + m.offset, d_in + 3 * (int64_t)m.offset, table, contribution ? 1 : 0);
+    if (!contribution) {
+        /* sharing: every non-owned node has exactly one owner, one launch covers all records */
+        int32_t total = s->ctotal;
+        if (total)
+            hq_k_unpack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, d_in, table, 0);
+    } else {
+        /* contribution: one launch per neighbour: a node may receive from several sharers and
+         * the sums stay in a fixed order (the reference walks its messenger list) */
+        for (auto& m : rcv)
+            if (m.nodecount)
+                hq_k_unpack<<<hq_blocks((int64_t)m.nodecount * 3, 256), 256, 0, xs>>>(
+                    m.nodecount, d_map + m.offset, d_in + 3 * (int64_t)m.offset, table, 1);
+    }
     HQ_HIP(hipGetLastError());
     return HQ_OK;
 }
@@ -490,18 +499,25 @@ static int hq_launch_update(hq_ctx* c)
     return HQ_OK;
 }
 
-/* update of the interface nodes this rank owns, from the summed interface force */
+/*
+ * Interface nodes this rank owns: own partial force + the sharers' records
+ * (the "+=" unpack of schedule_senddata, psolve.c:5035-5073, in messenger order)
+ * + solver_compute_displacement, in one kernel.
+ */
 __global__ void hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
-                                      const double* __restrict__ iforce, const double* __restrict__ nt,
-                                      const double* __restrict__ u1, const double* __restrict__ u2,
-                                      double* __restrict__ un)
+                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos,
+                                      const double* __restrict__ iforce, const double* __restrict__ rec,
+                                      const double* __restrict__ nt, const double* __restrict__ u1,
+                                      const double* __restrict__ u2, double* __restrict__ un)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 3) return;
     int i = t / 3, d = t - 3 * i;
     int64_t g = node[i];
     const double* np = nt + 7 * g;
-    double f = iforce[3 * (int64_t)slot[i] + d] + (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
+    double f = iforce[3 * (int64_t)slot[i] + d];
+    for (int32_t k = ptr[i]; k < ptr[i + 1]; k++) f += rec[3 * (int64_t)pos[k] + d];
+    f += (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
     un[3 * g + d] = f / np[0];
 }
 
@@ -551,12 +567,17 @@ static int hq_phase(hq_ctx* c, int ph)
         return HQ_OK;
     case 3: return hq_xchg_send(c, &c->an, ftab, true, true);                        /* :4301 */
     case 4:
-        HQ_TRY(hq_xchg_recv(c, &c->an, ftab, true, true));
         if (patch) {
+            hipStream_t xs = c->overlap ? c->cstream : c->stream;
+            if (c->group)
+                for (auto& m : c->an.s)
+                    if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
             if (c->nOI)
-                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, c->overlap ? c->cstream : c->stream>>>(
-                    c->nOI, c->d_oi_node, c->d_oi_slot, c->d_iforce, c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew);
+                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
+                    c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
+                    c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew);
         } else {
+            HQ_TRY(hq_xchg_recv(c, &c->an, ftab, true, true));
             HQ_TRY(hq_launch_update(c));                                   /* :4305 */
         }
         return HQ_OK;
@@ -631,10 +652,21 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         HQ_HIP(hipMemcpy(c->an.d_smap_f, ss.data(), 4 * ss.size(), hipMemcpyHostToDevice));
     }
     if (c->nOI) {
+        /* records of the contribution receive buffer per owned interface node, messenger order */
+        std::vector<int32_t> oi_index((size_t)nI, -1), ptr((size_t)c->nOI + 1, 0), pos(ss.size());
+        for (int32_t i = 0; i < c->nOI; i++) oi_index[ois[i]] = i;
+        for (size_t r = 0; r < ss.size(); r++) ptr[oi_index[ss[r]] + 1]++;
+        for (int32_t i = 0; i < c->nOI; i++) ptr[i + 1] += ptr[i];
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (size_t r = 0; r < ss.size(); r++) pos[fill[oi_index[ss[r]]]++] = (int32_t)r;
         HQ_TRY(hq_dev_alloc(c, &c->d_oi_node, oin.size()));
         HQ_TRY(hq_dev_alloc(c, &c->d_oi_slot, ois.size()));
+        HQ_TRY(hq_dev_alloc(c, &c->d_oi_ptr, ptr.size()));
+        HQ_TRY(hq_dev_alloc(c, &c->d_oi_pos, pos.size()));
         HQ_HIP(hipMemcpy(c->d_oi_node, oin.data(), 4 * oin.size(), hipMemcpyHostToDevice));
         HQ_HIP(hipMemcpy(c->d_oi_slot, ois.data(), 4 * ois.size(), hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(c->d_oi_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice));
+        HQ_HIP(hipMemcpy(c->d_oi_pos, pos.data(), 4 * pos.size(), hipMemcpyHostToDevice));
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
@@ -778,7 +810,7 @@ extern "C" int hq_destroy(hq_ctx* c)
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
-                     c->d_iforce, c->d_oi_node, c->d_oi_slot };
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos };
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->an.d_cmap_f && c->an.d_cmap_f != c->an.d_cmap) hipFree(c->an.d_cmap_f);
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
