@@ -1,0 +1,149 @@
+"""Host logic of the product's C side (hercules_amd/csrc/hq_host.c), no GPU:
+mesh order, solver_init constants, block partition, node ownership, schedules,
+point source and stations -- against the oracle and the reference's own
+8-rank run (tests/golden/c1_np8.npz)."""
+import numpy as np
+import pytest
+
+from hercules_amd import host
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+
+def _oracle_box(nx, ny, nz, h, dt, freq, layers=None, damping=ho.DAMP_RAYLEIGH):
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:, 0] = h
+    if layers is None:
+        edata[:, 1:] = (6000.0, 3464.0, 2700.0)
+    else:
+        zc = (elem_ijk[:, 2] + 0.5) * h
+        for ztop, vp, vs, rho in layers:
+            m = zc >= ztop
+            edata[m, 1], edata[m, 2], edata[m, 3] = vp, vs, rho
+    et, nt = ho.solver_init(lnid, edata, ho.face_bits(elem_ijk, nx, ny, nz), len(node_ijk), dt, freq, damping=damping)
+    return elem_ijk, lnid, node_ijk, et, nt
+
+
+@pytest.mark.parametrize("shape,layers,damping", [
+    ((16, 16, 8), None, "rayleigh"),
+    ((8, 32, 4), [(0.0, 1500.0, 300.0, 1800.0), (50.0, 3000.0, 1400.0, 2200.0), (120.0, 6000.0, 3464.0, 2700.0)], "rayleigh"),
+    ((16, 8, 8), None, "mass"),
+    ((4, 4, 2), None, "none"),
+])
+def test_single_partition_equals_oracle_bitwise(shape, layers, damping):
+    nx, ny, nz = shape
+    h, dt, freq = 62.5, 1e-3, 5.0
+    b = host.Box(nx, ny, nz, h, dt, freq, layers=layers, damping=damping)
+    elem_ijk, lnid, node_ijk, et, nt = _oracle_box(nx, ny, nz, h, dt, freq, layers, ho.DAMPING_BY_NAME[damping])
+    assert np.array_equal(b.lnid, lnid)
+    assert np.array_equal(b.node_ijk, node_ijk)
+    assert np.array_equal(b.etable, et)          # float-evaluated mu/lambda/zeta reproduced (psolve.c:3242-3409)
+    assert np.array_equal(b.ntable, nt)          # gather form == the reference's scatter loop, same order
+    assert b.info["nowned"] == b.info["nharbored"] == len(node_ijk)
+    b.close()
+
+
+def test_partitions_match_reference_8_rank_run():
+    """Elements per rank and the per-rank harbored-node ORDER are octor's: the
+    reference's own 8-rank checkpoints line up with our local numbering."""
+    g = H.load("c1_np8")
+    p = H.c1_problem()
+    gidx = {tuple(v): i for i, v in enumerate(p["node_ijk"].tolist())}
+    edge = 1 << 26
+    # single-rank oracle state at the checkpoint steps
+    g1 = H.load("c1_short")
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    states = {}
+    for step in g["ckpt_steps"]:
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g1["loaded_lnid"], forces=g1["forces"])
+        done = int(step)
+        states[done] = (tm1.copy(), tm2.copy())
+    for r in range(8):
+        b = host.Box(16, 16, 8, 62.5, 1e-3, 5.0, rank=r, nranks=8)
+        ref_elems = g["elem_ticks_%d" % r]
+        assert b.info["lenum"] == len(ref_elems) == 256
+        mine = (b.node_ijk[b.lnid].astype(np.int64) * edge)
+        assert np.array_equal(mine, ref_elems.astype(np.int64))
+        m = np.array([gidx[tuple(v)] for v in b.node_ijk.tolist()])
+        for step in g["ckpt_steps"]:
+            ref_tm2 = g["ckpt%d_tm2_%d" % (int(step), r)][:len(m)]
+            ref_tm1 = g["ckpt%d_tm1_%d" % (int(step), r)][:len(m)]
+            o1, o2 = states[int(step)]
+            scale = np.abs(o2).max()
+            # 1-rank vs 8-rank reference runs differ by rounding only
+            assert np.abs(ref_tm1 - o2[m]).max() <= 1e-12 * scale
+            assert np.abs(ref_tm2 - o1[m]).max() <= 1e-12 * scale
+        b.close()
+
+
+@pytest.mark.parametrize("shape,nranks", [((16, 16, 8), 8), ((32, 16, 16), 2), ((8, 8, 8), 5), ((16, 8, 4), 3)])
+def test_ownership_and_schedules_are_consistent(shape, nranks):
+    nx, ny, nz = shape
+    boxes = [host.Box(nx, ny, nz, 10.0, 1e-4, 50.0, rank=r, nranks=nranks) for r in range(nranks)]
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    E = len(lnid)
+    gkey = lambda ijk: (ijk[:, 2].astype(np.int64) * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    owner_global = np.full(len(node_ijk), -1)
+    gid_of = {int(k): i for i, k in enumerate(gkey(node_ijk))}
+    off = 0
+    for r, b in enumerate(boxes):
+        lo, hi = r * E // nranks, (r + 1) * E // nranks            # BLOCK_LOW / BLOCK_HIGH (octor.c:4939-4944)
+        assert b.info["lenum"] == hi - lo
+        assert np.array_equal(b.node_ijk[b.lnid], node_ijk[lnid[lo:hi]])
+        ids = np.array([gid_of[int(k)] for k in gkey(b.node_ijk)])
+        assert np.all(np.diff(ids) > 0)                             # local order == global Z-order
+        for n, o in zip(ids, b.owner):
+            assert owner_global[n] in (-1, o)
+            owner_global[n] = o
+        off += hi - lo
+    assert np.all(owner_global >= 0)
+    # owner = rank of the element whose lower-left corner is the (clamped) node (octor.c:5466-5475)
+    eidx = {tuple(v): i for i, v in enumerate(elem_ijk.tolist())}
+    for n, ijk in enumerate(node_ijk):
+        e = eidx[(min(ijk[0], nx - 1), min(ijk[1], ny - 1), min(ijk[2], nz - 1))]
+        assert owner_global[n] == ((e + 1) * nranks - 1) // E
+    # schedules: my c-list to q mirrors q's s-list to me, node for node
+    sched = [b.schedule() for b in boxes]
+    for r in range(nranks):
+        for q, mapping in sched[r]["c"]:
+            other = dict(sched[q]["s"])
+            assert r in other and len(other[r]) == len(mapping)
+            a = gkey(boxes[r].node_ijk[mapping])
+            c = gkey(boxes[q].node_ijk[other[r]])
+            assert np.array_equal(a, c)
+            assert np.all(boxes[r].owner[mapping] == q)
+        for q, mapping in sched[r]["s"]:
+            assert np.all(boxes[r].owner[mapping] == r)
+            assert r in dict(sched[q]["c"])
+    # every non-owned harbored node is in exactly one c-list
+    for r, b in enumerate(boxes):
+        listed = np.concatenate([m for _, m in sched[r]["c"]]) if sched[r]["c"] else np.zeros(0, int)
+        assert sorted(listed.tolist()) == np.nonzero(b.owner != r)[0].tolist()
+    for b in boxes:
+        b.close()
+
+
+def test_point_source_matches_reference_force_file():
+    """source_initnodalforce: same loaded nodes and the same nodal pattern as the
+    reference's force_process.0 (up to the scalar time function)."""
+    g = H.load("c1_short")
+    b = host.Box(16, 16, 8, 62.5, 1e-3, 5.0)
+    ids, pat = b.point_source(500.0, 500.0, 100.0, 0.0, 90.0, 0.0)
+    assert np.array_equal(ids, g["loaded_lnid"])
+    F = g["forces"][100]
+    s = F[np.unravel_index(np.abs(F).argmax(), F.shape)] / pat[np.unravel_index(np.abs(F).argmax(), F.shape)]
+    assert np.abs(F - s * pat).max() <= 1e-12 * np.abs(F).max()
+    b.close()
+
+
+def test_stations_match_oracle_weights():
+    b = host.Box(16, 16, 8, 62.5, 1e-3, 5.0)
+    pts = H.C1_STATIONS + [(33.0, 977.0, 412.5), (1000.0, 1000.0, 500.0)]
+    ids, phi, mine = b.stations(pts)
+    oi, op = ho.station_weights(pts, 62.5, 16, 16, 8, b.lnid, ho.uniform_mesh(16, 16, 8)[0])
+    assert np.array_equal(ids, oi) and np.allclose(phi, op, rtol=0, atol=1e-15) and mine.all()
+    assert np.allclose(phi.sum(axis=1), 1.0)
+    b.close()
