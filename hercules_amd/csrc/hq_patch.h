@@ -71,7 +71,10 @@ struct hq_patch_desc {
     int32_t npairs;      /* elements evaluated by this patch       */
     int64_t pair_off;    /* into pidx / pc1 / pc2 / pbeta          */
     int64_t halo_off;    /* into halo_ids                          */
+    int32_t flags;       /* HQ_PATCH_ISO: every owned node has axis-independent n_t */
+    int32_t pad;
 };
+#define HQ_PATCH_ISO 1
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -91,6 +94,7 @@ struct hq_patch_plan {
     double*  d_pc2 = nullptr;
     double*  d_pbeta = nullptr;
     int32_t* d_halo = nullptr;
+    double*  d_nt3 = nullptr;        /* [N][3] {mass_simple, mass2_minusaM, mass_minusaM} for ISO patches */
     /* source entries grouped by patch (built by hq_patch_set_source) */
     int32_t* d_src_ptr = nullptr;    /* [npatches + 1]                    */
     int32_t* d_src_ent = nullptr;    /* [n][2] = {local node, loaded idx} */
@@ -160,30 +164,28 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
         if (n && key[n] < key[n - 1]) { fixed(); return; }     /* not Z-ordered */
     }
 
-    std::vector<std::pair<int32_t, int32_t>> runs;              /* candidate patches */
-    struct item { int64_t lo, hi; int s; };
+    /* k-d style descent over the bits of the Z-value (z, y, x of the coarsest level first):
+     * a run of nodes sharing a key prefix is an axis-aligned box; split it at the next bit
+     * until it holds at most pmax nodes.  8x8x8 -> 8x8x4 -> 8x4x4 -> 4x4x4 ... */
+    std::vector<std::pair<int32_t, int32_t>> runs;
+    struct item { int64_t lo, hi; int bit; };
     std::vector<item> stack;
-    stack.push_back({ 0, N, 21 });
+    stack.push_back({ 0, N, 63 });
     while (!stack.empty()) {
         item it = stack.back();
         stack.pop_back();
         if (it.hi - it.lo <= cfg.pmax) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
-        if (it.s == 0) {
+        if (it.bit <= 0) {
             for (int64_t i = it.lo; i < it.hi; i += cfg.pmerge)
                 runs.push_back({ (int32_t)i, (int32_t)std::min<int64_t>(i + cfg.pmerge, it.hi) });
             continue;
         }
-        int sh = 3 * (it.s - 1);
-        std::vector<item> kids;
-        int64_t i = it.lo;
-        while (i < it.hi) {
-            uint64_t cid = key[i] >> sh;
-            int64_t j = std::upper_bound(key.begin() + i, key.begin() + it.hi, cid,
-                                         [sh](uint64_t c, uint64_t k) { return c < (k >> sh); }) - key.begin();
-            kids.push_back({ i, j, it.s - 1 });
-            i = j;
-        }
-        for (auto k = kids.rbegin(); k != kids.rend(); ++k) stack.push_back(*k);   /* keep Z order */
+        int sh = it.bit - 1;
+        /* first node whose bit `sh` is set (keys are sorted and share the bits above) */
+        int64_t mid = std::partition_point(key.begin() + it.lo, key.begin() + it.hi,
+                                           [sh](uint64_t k) { return ((k >> sh) & 1) == 0; }) - key.begin();
+        if (mid < it.hi) stack.push_back({ mid, it.hi, sh });
+        if (mid > it.lo) stack.push_back({ it.lo, mid, sh });
     }
     std::sort(runs.begin(), runs.end());
     /* merge small neighbours (coarse octree regions) */
@@ -319,15 +321,28 @@ struct hq_pair_data {
     double beta, c1, c2;
 };
 
+typedef unsigned int hq_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T hq_ld(const T* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+template <bool NT>
 __device__ __forceinline__ hq_pair_data hq_pair_load(const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                                                      const double* __restrict__ pc2,
                                                      const double* __restrict__ pbeta, int64_t g)
 {
     hq_pair_data d;
-    d.raw = pidx[g];
-    d.beta = pbeta[g];
-    d.c1 = pc1[g];
-    d.c2 = pc2[g];
+    /* streamed once per step: non-temporal, so that the node data the neighbouring
+     * patches re-read keeps its place in the XCD's L2 */
+    hq_u32x4 r = hq_ld<NT>(reinterpret_cast<const hq_u32x4*>(pidx) + g);
+    d.raw.x = r.x; d.raw.y = r.y; d.raw.z = r.z; d.raw.w = r.w;
+    d.beta = hq_ld<NT>(&pbeta[g]);
+    d.c1 = hq_ld<NT>(&pc1[g]);
+    d.c2 = hq_ld<NT>(&pc2[g]);
     return d;
 }
 
@@ -339,6 +354,12 @@ __device__ __forceinline__ hq_pair_data hq_pair_load(const uint4* __restrict__ p
  * the next round's before the current round's arithmetic, the nodal constants
  * before the element loop) so the few waves a CU holds keep requests in flight.
  */
+/* DIAG != 0 only in -DHQ_PATCH_PROFILING builds (results are wrong): 1 = skip the element
+ * loop, 2 = skip the staging loads, 3 = skip the nodal update, 4 = skip the LDS atomics,
+ * 5 = conflict-free LDS gathers.  Measured on the 64M box (ms/step): full 3.09, (1) 1.78,
+ * (2) 2.14, (3) 2.85, (4) 3.00, (5) 2.83 -- the memory phases alone run at the HBM rate,
+ * the element loop adds ~1.3 ms that two workgroups per CU do not overlap (round 2 work). */
+template <bool NT, int DIAG>
 __global__ void __launch_bounds__(HQ_PATCH_MAX_THREADS, 4)
 hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
                 const hq_patch_desc* __restrict__ desc,
@@ -346,7 +367,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
                 const double* __restrict__ u2g, double* __restrict__ ung,
-                const double* __restrict__ nt, const int32_t* __restrict__ src_ptr,
+                const double* __restrict__ nt, const double* __restrict__ nt3,
+                const int32_t* __restrict__ src_ptr,
                 const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
                 const int32_t* __restrict__ if_ptr, const int32_t* __restrict__ if_ent,
                 double* __restrict__ iforce)
@@ -366,7 +388,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
 
     hq_pair_data cur;
-    if (tid < D.npairs) cur = hq_pair_load(pidx, pc1, pc2, pbeta, D.pair_off + tid);
+    if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + tid);
 
     {   /* stage: owned nodes are one contiguous run of doubles, halo nodes a gather */
         const double* g1 = u1g + 3 * (int64_t)D.base;
@@ -377,10 +399,11 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int i = i0 + k * T + tid;
+                if (DIAG == 2) { a1[k] = a2[k] = b1[k] = b2[k] = 1e-3 * i; continue; }
                 if (i < own3) { a1[k] = g1[i]; a2[k] = g2[i]; }
                 if (i < halo3) {
                     int h = i / 3, d = i - 3 * h;
-                    int64_t g = 3 * (int64_t)hl[h] + d;
+                    int64_t g = 3 * (int64_t)hq_ld<NT>(&hl[h]) + d;
                     b1[k] = u1g[g]; b2[k] = u2g[g];
                 }
             }
@@ -394,17 +417,28 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     }
     __syncthreads();
 
-    /* nodal constants of "my" node for the update below */
+    /* nodal constants of "my" node for the update below: n_t (psolve.h:210-214), or its
+     * 3-double form where no dashpot makes the axes differ */
+    const bool iso = (D.flags & HQ_PATCH_ISO) != 0;
     double np[7];
     if (tid < D.nown) {
-        const double* q = nt + 7 * ((int64_t)D.base + tid);
+        if (iso) {
+            const double* q = nt3 + 3 * ((int64_t)D.base + tid);
+            np[0] = hq_ld<NT>(q);
+            np[1] = hq_ld<NT>(q + 1);
+            np[4] = hq_ld<NT>(q + 2);
+            np[2] = np[3] = np[1];
+            np[5] = np[6] = np[4];
+        } else {
+            const double* q = nt + 7 * ((int64_t)D.base + tid);
 #pragma unroll
-        for (int k = 0; k < 7; k++) np[k] = q[k];
+            for (int k = 0; k < 7; k++) np[k] = hq_ld<NT>(q + k);
+        }
     }
 
-    for (int q = tid; q < D.npairs; q += T) {
+    for (int q = tid; q < (DIAG == 1 ? 0 : D.npairs); q += T) {
         hq_pair_data nxt;
-        if (q + T < D.npairs) nxt = hq_pair_load(pidx, pc1, pc2, pbeta, D.pair_off + q + T);
+        if (q + T < D.npairs) nxt = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + q + T);
         const uint4 raw = cur.raw;
         const double beta = cur.beta;
         int l[8];
@@ -415,8 +449,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         double X[8], Y[8], Z[8];
 #pragma unroll
         for (int n = 0; n < 8; n++) {
-            const double* a = &s_u1[3 * l[n]];
-            const double* b = &s_u2[3 * l[n]];
+            const double* a = &s_u1[3 * (DIAG == 5 ? (tid & 7) : l[n])];
+            const double* b = &s_u2[3 * (DIAG == 5 ? (tid & 7) : l[n])];
             double a0 = a[0], a1 = a[1], a2 = a[2];
             X[n] = a0 + beta * (a0 - b[0]);
             Y[n] = a1 + beta * (a1 - b[1]);
@@ -425,6 +459,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         hq_element_force(X, Y, Z, cur.c1, cur.c2);
 #pragma unroll
         for (int n = 0; n < 8; n++) {
+            if (DIAG == 4) { if (X[n] + Y[n] + Z[n] == 1.2345e-300) s_f[n] = 1.0; continue; }
             if (l[n] < D.nown) {
                 atomicAdd(&s_f[3 * l[n] + 0], X[n]);
                 atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
@@ -442,17 +477,25 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     __syncthreads();
 
     /* solver_compute_displacement, psolve.c:4078-4106: one thread per owned node */
-    for (int n = tid; n < D.nown; n += T) {
+    for (int n = tid; n < (DIAG == 3 ? (tid == 0 ? 1 : 0) : D.nown); n += T) {
         if (n != tid) {
-            const double* q = nt + 7 * ((int64_t)D.base + n);
+            if (iso) {
+                const double* q = nt3 + 3 * ((int64_t)D.base + n);
+                np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
+                np[2] = np[3] = np[1];
+                np[5] = np[6] = np[4];
+            } else {
+                const double* q = nt + 7 * ((int64_t)D.base + n);
 #pragma unroll
-            for (int k = 0; k < 7; k++) np[k] = q[k];
+                for (int k = 0; k < 7; k++) np[k] = q[k];
+            }
         }
         double* out = ung + 3 * ((int64_t)D.base + n);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
-            out[d] = f / np[0];
+            if (NT) __builtin_nontemporal_store(f / np[0], out + d);
+            else out[d] = f / np[0];
         }
     }
     if (if_ptr) {   /* partition interface: hand the partial force to the exchange (psolve.c:4301) */
@@ -471,17 +514,34 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 static void hq_patch_free(hq_patch_plan* P)
 {
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3 };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
 
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
-                          const double* c1, const double* c2, const double* beta, int64_t* bytes)
+                          const double* c1, const double* c2, const double* beta, const double* ntab,
+                          int64_t* bytes)
 {
     hq_patch_host H;
     P->cfg = hq_patch_cfg_from_env();
     if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, &H) != 0) return -1 /* HQ_ERR_ARG */;
+    /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
+     * for every owned node, i.e. no dashpot touches the patch */
+    std::vector<double> nt3((size_t)N * 3);
+    for (int64_t n = 0; n < N; n++) {
+        nt3[3 * n] = ntab[7 * n]; nt3[3 * n + 1] = ntab[7 * n + 1]; nt3[3 * n + 2] = ntab[7 * n + 4];
+    }
+    const bool use_iso = !getenv("HQ_PATCH_NO_ISO");
+    for (auto& D : H.desc) {
+        bool iso = use_iso;
+        for (int32_t n = D.base; n < D.base + D.nown && iso; n++) {
+            const double* q = ntab + 7 * (int64_t)n;
+            iso = (q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]);
+        }
+        D.flags = iso ? HQ_PATCH_ISO : 0;
+        D.pad = 0;
+    }
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
@@ -496,7 +556,9 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     HQ_PA(P->d_pc2, 8 * np)
     HQ_PA(P->d_pbeta, 8 * np)
     HQ_PA(P->d_halo, 4 * nh)
+    HQ_PA(P->d_nt3, 8 * nt3.size())
 #undef HQ_PA
+    hipMemcpy(P->d_nt3, nt3.data(), 8 * nt3.size(), hipMemcpyHostToDevice);
     hipMemcpy(P->d_desc, H.desc.data(), sizeof(hq_patch_desc) * H.desc.size(), hipMemcpyHostToDevice);
     hipMemcpy(P->d_pidx, H.pidx.data(), 16 * (size_t)P->npairs, hipMemcpyHostToDevice);
     hipMemcpy(P->d_halo, H.halo.data(), 4 * H.halo.size(), hipMemcpyHostToDevice);
@@ -578,9 +640,19 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (count <= 0) return;
     int per_xcd = (count + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)P->cfg.pmax) * sizeof(double);
-    hq_k_patch_step<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
+    static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
+    auto kern = nt_hint ? hq_k_patch_step<true, 0> : hq_k_patch_step<false, 0>;
+#ifdef HQ_PATCH_PROFILING   /* ablation builds for profiles/: results are WRONG by construction */
+    static const int diag = getenv("HQ_PATCH_DIAG") ? atoi(getenv("HQ_PATCH_DIAG")) : 0;
+    if (diag == 1) kern = hq_k_patch_step<false, 1>;
+    if (diag == 2) kern = hq_k_patch_step<false, 2>;
+    if (diag == 3) kern = hq_k_patch_step<false, 3>;
+    if (diag == 4) kern = hq_k_patch_step<false, 4>;
+    if (diag == 5) kern = hq_k_patch_step<false, 5>;
+#endif
+    kern<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
         count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
-        P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_src_ptr, P->d_src_ent,
+        P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
         (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce);
 }
 

@@ -1,0 +1,111 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties
+(the oracle cannot finish 8M / 64M elements in seconds):
+
+* the two independent kernel paths (atomic scatter vs fused patches) agree;
+* the step is linear in (tm1, tm2, source): step(a u + b v) = a step(u) + b step(v);
+* a quiescent field stays exactly zero; all values stay finite;
+* at 1M elements the oracle itself is still affordable for a few steps.
+All through the C-ABI, meshes built by the C host side."""
+import numpy as np
+import pytest
+
+import hercules_amd as ha
+from hercules_amd import host
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(box, seed, amp=1e-3):
+    ijk = box.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (box.ny + 1) + ijk[:, 1]) * (box.nx + 1) + ijk[:, 0]
+    u = np.empty((len(gid), 3))
+    for d in range(3):
+        x = (gid * 3 + d + seed) * np.int64(2654435761) % np.int64(2 ** 31)
+        u[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * amp
+    return u
+
+
+def _run(box, variant, u1, u2, nsteps, src=None):
+    s = box.create_solver(variant=variant, tm1=u1, tm2=u2)
+    if src is not None:
+        s.set_source(src[0], src[1])
+    s.run(nsteps)
+    out = s.download()
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_fullsize_variants_agree_and_step_is_linear(wl):
+    nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
+                               "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    assert box.info["total_elements"] == {"c2": 8388608, "c3": 67108864}[wl]
+    nsteps = 4
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=3 * dt)
+    F = box.source_table(rp, 0, nsteps)
+    u = _field(box, 12345)
+    v = _field(box, 777, 2e-3)
+    a, b = 0.75, -1.5
+    pu = _run(box, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps, (loaded, F))
+    su = _run(box, ha.HQ_VARIANT_SCATTER, u, 0.999 * u, nsteps, (loaded, F))
+    scale = np.abs(pu[0]).max()
+    assert np.isfinite(pu[0]).all() and scale > 0
+    assert np.abs(pu[0] - su[0]).max() <= 1e-11 * scale          # two independent kernel paths
+    assert np.abs(pu[1] - su[1]).max() <= 1e-11 * scale
+    del su
+    pv = _run(box, ha.HQ_VARIANT_PATCH, v, 1.001 * v, nsteps, (loaded, 2.0 * F))
+    w1 = a * u + b * v
+    w2 = a * 0.999 * u + b * 1.001 * v
+    pw = _run(box, ha.HQ_VARIANT_PATCH, w1, w2, nsteps, (loaded, (a + 2.0 * b) * F))
+    lin = a * pu[0] + b * pv[0]
+    assert np.abs(pw[0] - lin).max() <= 1e-11 * np.abs(lin).max()
+    z = _run(box, ha.HQ_VARIANT_PATCH, np.zeros_like(u), np.zeros_like(u), nsteps)
+    assert not z[0].any() and not z[1].any()
+    box.close()
+
+
+def test_one_million_elements_against_oracle():
+    nx, ny, nz, h, dt, freq = 128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    u = _field(box, 4242)
+    nsteps = 3
+    o1, o2 = (0.999 * u).copy(), u.copy()                            # oracle arrays are pre-swap
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, dt)
+    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
+        tm1, tm2 = _run(box, variant, u, 0.999 * u, nsteps)
+        assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    box.close()
+
+
+def test_host_solver_run_with_stations():
+    """hqh_solver_run (the C mirror of solver_run): source windows, station
+    cadence and interpolation, against the oracle driven the same way."""
+    nx, ny, nz, h, dt, freq = 16, 16, 8, 62.5, 1e-3, 5.0
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    loaded, pattern = box.point_source(500.0, 500.0, 100.0, 0.0, 90.0, 0.0)
+    ids, phi, mine = box.stations(H.C1_STATIONS)
+    got = {}
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e15, rise_time=0.05, source_window=37,
+                        station_ids=ids, station_phi=phi, station_rate=5,
+                        station_fn=lambda step, disp: got.__setitem__(step, disp))
+    nsteps = 200
+    s = box.create_solver()
+    box.solver_run(s, rp, 0, nsteps)
+    F = box.source_table(rp, 0, nsteps)
+    o1, o2 = np.zeros((box.info["nharbored"], 3)), np.zeros((box.info["nharbored"], 3))
+    cap = ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, dt,
+                        loaded_lnid=loaded, forces=F, cap_lnid=ids)
+    st = np.einsum("sn,tsnd->tsd", phi, cap.reshape(nsteps, len(phi), 8, 3))
+    assert sorted(got) == list(range(0, nsteps, 5))
+    scale = np.abs(st).max()
+    for step, disp in got.items():
+        assert np.abs(disp - st[step]).max() <= 1e-9 * scale
+    tm1, tm2 = s.download()
+    assert H.rel_linf(tm1, o2) < 1e-9
+    s.close()
+    box.close()
