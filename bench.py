@@ -45,13 +45,25 @@ WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-coupl
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64"}
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(seconds_target=12.0):
     """The oracle's reference-formulation loops (effective stiffness + the 8x8
     conventional damping loop + nodal update) on the host cores: one independent
     64x64x32 partition per core, seeded random field (all elements active)."""
     from oracle import herc_oracle as ho
     ho.lib()
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = usable_cores()
     nx, ny, nz, h, dt, freq = 64, 64, 32, 1000.0 / 128, 3.6e-4, 50.0
     elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
     edata = np.empty((len(lnid), 4), np.float32)
@@ -144,6 +156,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+
+    # torchrun pins OMP_NUM_THREADS=1; the C host side builds the partition with OpenMP
+    os.environ["OMP_NUM_THREADS"] = str(max(1, usable_cores() // max(world, 1)))
 
     # CPU baseline first: it uses threads only and must not overlap the GPU timing.
     cpu = None

@@ -671,7 +671,11 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
     if (!getenv("HQ_NO_OVERLAP")) {
-        HQ_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+        /* the exchange chain is short and latency-bound: let its kernels (and RCCL's) get CUs ahead
+         * of the thousands of interior patch workgroups queued on the compute stream */
+        int prio_lo = 0, prio_hi = 0;
+        HQ_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HQ_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio_hi));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_shared, hipEventDisableTiming));
         HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));

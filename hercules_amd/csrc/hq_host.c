@@ -632,6 +632,127 @@ int hqh_stations(const hqh_box* b, int32_t n, const double* xyz, int32_t* ids, d
 /* solver_run                                                               */
 /* ------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------ */
+/* reference file formats                                                   */
+/* ------------------------------------------------------------------------ */
+
+int hqh_forcefile_info(const char* path, int32_t* nloaded, int32_t* nsteps, int32_t* lnid, int32_t lnid_cap)
+{
+    if (!path || !nloaded || !nsteps) return HQ_ERR_ARG;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return HQ_ERR_ARG;
+    int32_t n = 0;
+    int rc = HQ_OK;
+    if (fread(&n, sizeof n, 1, fp) != 1 || n < 0) rc = HQ_ERR_ARG;
+    if (rc == HQ_OK && lnid) {
+        if (lnid_cap < n || (n && fread(lnid, sizeof(int32_t), (size_t)n, fp) != (size_t)n)) rc = HQ_ERR_ARG;
+    }
+    if (rc == HQ_OK) {
+        fseeko(fp, 0, SEEK_END);
+        off_t payload = ftello(fp) - (off_t)sizeof(int32_t) * (1 + (off_t)n);
+        *nloaded = n;
+        *nsteps = n ? (int32_t)(payload / ((off_t)n * 24)) : 0;
+    }
+    fclose(fp);
+    return rc;
+}
+
+int hqh_forcefile_read(const char* path, int32_t step0, int32_t nsteps, double* F)
+{
+    if (!path || step0 < 0 || nsteps < 0 || (nsteps && !F)) return HQ_ERR_ARG;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return HQ_ERR_ARG;
+    int32_t n = 0;
+    if (fread(&n, sizeof n, 1, fp) != 1 || n < 0) { fclose(fp); return HQ_ERR_ARG; }
+    /* read_myForces, psolve.c:3657-3664 */
+    off_t where = (off_t)sizeof(int32_t) + (off_t)n * sizeof(int32_t) + (off_t)n * step0 * sizeof(double) * 3;
+    size_t want = (size_t)n * 3 * (size_t)nsteps, got = 0;
+    if (fseeko(fp, where, SEEK_SET) == 0) got = fread(F, sizeof(double), want, fp);
+    for (size_t i = got; i < want; i++) F[i] = 0.0;
+    fclose(fp);
+    return HQ_OK;
+}
+
+int hqh_forcefile_write(const char* path, int32_t nloaded, const int32_t* lnid, int32_t nsteps, const double* F)
+{
+    if (!path || nloaded < 0 || nsteps < 0 || (nloaded && !lnid) || (nloaded && nsteps && !F)) return HQ_ERR_ARG;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return HQ_ERR_ARG;
+    size_t ok = fwrite(&nloaded, sizeof nloaded, 1, fp);
+    if (nloaded) ok += fwrite(lnid, sizeof(int32_t), (size_t)nloaded, fp) == (size_t)nloaded;
+    size_t cnt = (size_t)nloaded * 3 * (size_t)nsteps;
+    if (cnt) ok += fwrite(F, sizeof(double), cnt, fp) == cnt;
+    int bad = fclose(fp) != 0 || ok != (size_t)(1 + (nloaded ? 1 : 0) + (cnt ? 1 : 0));
+    return bad ? HQ_ERR_ARG : HQ_OK;
+}
+
+int hqh_checkpoint_write(hq_ctx* ctx, const char* path, int32_t step, int32_t rank, int32_t nranks,
+                         int32_t nharbored, int32_t nharboredmax)
+{
+    if (!ctx || !path || rank < 0 || rank >= nranks || nharbored < 0 || nharbored > nharboredmax) return HQ_ERR_ARG;
+    size_t n3 = (size_t)nharbored * 3;
+    double* tm1 = (double*)malloc(sizeof(double) * (n3 ? n3 : 1));
+    double* tm2 = (double*)malloc(sizeof(double) * (n3 ? n3 : 1));
+    if (!tm1 || !tm2) { free(tm1); free(tm2); return HQ_ERR_NOMEM; }
+    int rc = hq_download(ctx, tm1, tm2);
+    FILE* fp = NULL;
+    if (rc == HQ_OK && rank == 0) {                       /* io_checkpoint.c:63-74 */
+        fp = fopen(path, "wb");
+        int hdr[3] = { nranks, step, nharboredmax };
+        if (!fp || fwrite(hdr, sizeof(int), 3, fp) != 3) rc = HQ_ERR_ARG;
+        if (fp) fclose(fp);
+    }
+    if (rc == HQ_OK) {
+        fp = fopen(path, "rb+");
+        if (!fp) rc = HQ_ERR_ARG;
+    }
+    if (rc == HQ_OK) {                                    /* io_checkpoint.c:93-118: older field first */
+        off_t off = (off_t)(3 * sizeof(int)) + (off_t)2 * rank * nharboredmax * 24;
+        if (fseeko(fp, off, SEEK_SET) != 0 || fwrite(tm2, 24, (size_t)nharbored, fp) != (size_t)nharbored) rc = HQ_ERR_ARG;
+        off += (off_t)nharbored * 24;
+        if (rc == HQ_OK && (fseeko(fp, off, SEEK_SET) != 0 || fwrite(tm1, 24, (size_t)nharbored, fp) != (size_t)nharbored))
+            rc = HQ_ERR_ARG;
+        if (fclose(fp) != 0) rc = HQ_ERR_ARG;
+    }
+    free(tm1); free(tm2);
+    return rc;
+}
+
+int hqh_checkpoint_read(hq_ctx* ctx, const char* path, int32_t rank, int32_t nranks, int32_t nharbored,
+                        int32_t* step)
+{
+    if (!ctx || !path || rank < 0 || rank >= nranks || nharbored < 0) return HQ_ERR_ARG;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return HQ_ERR_ARG;
+    int hdr[3];
+    if (fread(hdr, sizeof(int), 3, fp) != 3 || hdr[0] != nranks || nharbored > hdr[2]) { fclose(fp); return HQ_ERR_ARG; }
+    size_t n3 = (size_t)nharbored * 3;
+    double* older = (double*)malloc(sizeof(double) * (n3 ? n3 : 1));
+    double* newer = (double*)malloc(sizeof(double) * (n3 ? n3 : 1));
+    int rc = (older && newer) ? HQ_OK : HQ_ERR_NOMEM;
+    if (rc == HQ_OK) {                                    /* io_checkpoint.c:205-222 */
+        off_t off = (off_t)(3 * sizeof(int)) + (off_t)2 * rank * hdr[2] * 24;
+        if (fseeko(fp, off, SEEK_SET) != 0 || fread(older, 24, (size_t)nharbored, fp) != (size_t)nharbored) rc = HQ_ERR_ARG;
+        off += (off_t)nharbored * 24;
+        if (rc == HQ_OK && (fseeko(fp, off, SEEK_SET) != 0 || fread(newer, 24, (size_t)nharbored, fp) != (size_t)nharbored))
+            rc = HQ_ERR_ARG;
+    }
+    fclose(fp);
+    /* the reference loads the older field into tm1 and swaps at the top of the loop
+     * (psolve.c:4271-4273); the engine takes the post-swap view directly */
+    if (rc == HQ_OK) rc = hq_upload(ctx, newer, older, hdr[1]);
+    if (rc == HQ_OK && step) *step = hdr[1];
+    free(older); free(newer);
+    return rc;
+}
+
+int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3])
+{
+    if (!buf || cap < 64 || !disp) return HQ_ERR_ARG;
+    snprintf(buf, (size_t)cap, "\n%10.6f % 8e % 8e % 8e", time, disp[0], disp[1], disp[2]);
+    return HQ_OK;
+}
+
 void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F)
 {
     for (int32_t s = 0; s < nsteps; s++) {
@@ -679,7 +800,12 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
         }
         if (F && step >= win_end) {                              /* solver_read_source_forces, :4282 */
             int32_t n = end - step < win ? end - step : win;
-            hqh_source_table(rp, b->p.deltaT, step, n, F);
+            if (rp->force_file) {
+                rc = hqh_forcefile_read(rp->force_file, step, n, F);
+                if (rc != HQ_OK) break;
+            } else {
+                hqh_source_table(rp, b->p.deltaT, step, n, F);
+            }
             rc = hq_set_source(ctx, rp->nloaded, rp->loaded_lnid, step, n, F);
             if (rc != HQ_OK) break;
             win_end = step + n;

@@ -13,7 +13,9 @@ _LIBPATH = os.path.join(_HERE, "csrc", "libhq_host.so")
 DAMPING = {"none": 0, "rayleigh": 1, "mass": 2}
 EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_desc", "hqh_box_lnid",
            "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner",
-           "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table"]
+           "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
+           "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
+           "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format"]
 
 
 class _BoxParams(ctypes.Structure):
@@ -37,7 +39,7 @@ STATION_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32, ctypes.c_in
 
 
 class _RunParams(ctypes.Structure):
-    _fields_ = [("nloaded", ctypes.c_int32), ("loaded_lnid", ctypes.c_void_p),
+    _fields_ = [("force_file", ctypes.c_char_p), ("nloaded", ctypes.c_int32), ("loaded_lnid", ctypes.c_void_p),
                 ("pattern", ctypes.c_void_p), ("moment", ctypes.c_double),
                 ("rise_time", ctypes.c_double), ("source_window", ctypes.c_int32),
                 ("nstations", ctypes.c_int32), ("station_ids", ctypes.c_void_p),
@@ -172,10 +174,15 @@ class Box:
         return ids, phi, mine
 
     def run_params(self, loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
-                   station_ids=None, station_phi=None, station_rate=0, station_fn=None):
+                   station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None):
         rp = _RunParams()
         keep = []
-        if loaded is not None and len(loaded):
+        if force_file is not None:
+            rp.force_file = os.fsencode(force_file)
+            l = np.ascontiguousarray(loaded, np.int32)
+            keep.append(l)
+            rp.nloaded, rp.loaded_lnid = len(l), l.ctypes.data
+        elif loaded is not None and len(loaded):
             l = np.ascontiguousarray(loaded, np.int32)
             pt = np.ascontiguousarray(pattern, np.float64)
             keep += [l, pt]
@@ -204,3 +211,59 @@ class Box:
     def solver_run(self, solver, rp, step0, nsteps):
         capi._check(self._lib.hqh_solver_run(solver._h, self._h, ctypes.byref(rp), ctypes.c_int32(step0),
                                              ctypes.c_int32(nsteps)))
+
+
+def forcefile_info(path):
+    lib = load_library()
+    n, ns = ctypes.c_int32(), ctypes.c_int32()
+    rc = lib.hqh_forcefile_info(os.fsencode(path), ctypes.byref(n), ctypes.byref(ns), None, 0)
+    if rc != 0:
+        raise capi.HqError("hqh_forcefile_info failed: %d" % rc)
+    ids = np.zeros(n.value, np.int32)
+    lib.hqh_forcefile_info(os.fsencode(path), ctypes.byref(n), ctypes.byref(ns),
+                           ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(n.value))
+    return ids, ns.value
+
+
+def forcefile_read(path, nloaded, step0, nsteps):
+    F = np.empty((nsteps, nloaded, 3))
+    rc = load_library().hqh_forcefile_read(os.fsencode(path), ctypes.c_int32(step0), ctypes.c_int32(nsteps),
+                                           F.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise capi.HqError("hqh_forcefile_read failed: %d" % rc)
+    return F
+
+
+def forcefile_write(path, lnid, F):
+    ids = np.ascontiguousarray(lnid, np.int32)
+    F = np.ascontiguousarray(F, np.float64)
+    rc = load_library().hqh_forcefile_write(os.fsencode(path), ctypes.c_int32(len(ids)),
+                                            ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(F.shape[0]),
+                                            F.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise capi.HqError("hqh_forcefile_write failed: %d" % rc)
+
+
+def checkpoint_write(solver, path, step, rank=0, nranks=1, nharboredmax=None):
+    nh = solver.N
+    rc = load_library().hqh_checkpoint_write(solver._h, os.fsencode(path), ctypes.c_int32(step), ctypes.c_int32(rank),
+                                             ctypes.c_int32(nranks), ctypes.c_int32(nh),
+                                             ctypes.c_int32(nh if nharboredmax is None else nharboredmax))
+    if rc != 0:
+        raise capi.HqError("hqh_checkpoint_write failed: %d" % rc)
+
+
+def checkpoint_read(solver, path, rank=0, nranks=1):
+    step = ctypes.c_int32()
+    rc = load_library().hqh_checkpoint_read(solver._h, os.fsencode(path), ctypes.c_int32(rank), ctypes.c_int32(nranks),
+                                            ctypes.c_int32(solver.N), ctypes.byref(step))
+    if rc != 0:
+        raise capi.HqError("hqh_checkpoint_read failed: %d" % rc)
+    return step.value
+
+
+def station_format(time, disp):
+    buf = ctypes.create_string_buffer(128)
+    d = np.ascontiguousarray(disp, np.float64)
+    load_library().hqh_station_format(buf, 128, ctypes.c_double(time), d.ctypes.data_as(ctypes.c_void_p))
+    return buf.value.decode()

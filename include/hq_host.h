@@ -95,7 +95,9 @@ HQ_API int hqh_stations(const hqh_box* box, int32_t n, const double* xyz, int32_
 typedef void (*hqh_station_fn)(void* user, int32_t step, int32_t n, const double* disp);
 
 typedef struct {
-    /* source: F(step) = moment * ramp(step*dt) * pattern */
+    /* source: a reference force file (force_file != NULL: nloaded/loaded_lnid must match its
+     * header) or the synthetic F(step) = moment * ramp(step*dt) * pattern */
+    const char* force_file;
     int32_t nloaded;
     const int32_t* loaded_lnid;
     const double*  pattern;          /* [nloaded][3] nodal force for unit moment  */
@@ -114,6 +116,36 @@ typedef struct {
 /* solver_run: steps [step0, step0 + nsteps) on `ctx`. */
 HQ_API int hqh_solver_run(hq_ctx* ctx, const hqh_box* box, const hqh_run_params* rp,
                           int32_t step0, int32_t nsteps);
+
+/*
+ * Files in the reference's formats, so runs can be exchanged with psolve.
+ *
+ * force_process.<rank> (written by quakesource.c:2453-2466, read per step by
+ * read_myForces psolve.c:3651-3667): int32 n; int32 lnid[n]; double F[steps][n][3].
+ *   hqh_forcefile_info : n and the number of steps in the file; lnid (may be NULL) gets n ids
+ *   hqh_forcefile_read : F for steps [step0, step0+nsteps); steps past the end read as 0
+ *   hqh_forcefile_write: create such a file
+ */
+HQ_API int hqh_forcefile_info(const char* path, int32_t* nloaded, int32_t* nsteps, int32_t* lnid, int32_t lnid_cap);
+HQ_API int hqh_forcefile_read(const char* path, int32_t step0, int32_t nsteps, double* F);
+HQ_API int hqh_forcefile_write(const char* path, int32_t nloaded, const int32_t* lnid, int32_t nsteps, const double* F);
+
+/*
+ * checkpoint.out{0,1} / checkpoint.in (io_checkpoint.c:29-236): header
+ * {groupsize, step, nharboredmax} ints; rank r's stripe at 12 + 2 r nharboredmax 24:
+ * u((step-1) dt) then u(step dt), nharbored fvector_t each.
+ *   hqh_checkpoint_write: rank 0 must have been called (creates the file) before the
+ *                         others write their stripes (the reference barriers there);
+ *   hqh_checkpoint_read : verifies the rank count, loads this rank's stripe into the
+ *                         context and sets its step; returns the step in *step.
+ */
+HQ_API int hqh_checkpoint_write(hq_ctx* ctx, const char* path, int32_t step, int32_t rank, int32_t nranks,
+                                int32_t nharbored, int32_t nharboredmax);
+HQ_API int hqh_checkpoint_read(hq_ctx* ctx, const char* path, int32_t rank, int32_t nranks,
+                               int32_t nharbored, int32_t* step);
+
+/* One station line in the reference's text format (psolve.c:6727-6731). */
+HQ_API int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3]);
 
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);

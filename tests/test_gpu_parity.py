@@ -241,3 +241,39 @@ def test_partitioned_box_matches_single_partition(variant, nranks):
         s.close()
     for b in boxes:
         b.close()
+
+
+def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
+    """A checkpoint file and a force file laid out as the reference writes them
+    (io_checkpoint.c:63-118, quakesource.c:2453-2466), built from the reference's own
+    data: restart at step 400, march to 800 through the C host's solver_run, land on
+    the reference's step-800 checkpoint; then write our checkpoint and re-read it."""
+    from hercules_amd import host
+    g = H.load("c1_short")
+    p = H.c1_problem()
+    N = p["N"]
+    ck = tmp_path / "checkpoint.in"
+    ck.write_bytes(np.array([1, 400, N], "<i4").tobytes() + g["ckpt_tm2"][0].astype("<f8").tobytes()
+                   + g["ckpt_tm1"][0].astype("<f8").tobytes())
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    box = host.Box(H.C1_NX, H.C1_NY, H.C1_NZ, H.C1_H, 1e-3, 5.0)
+    s = box.create_solver()
+    assert host.checkpoint_read(s, str(ck)) == 400
+    assert s.info()["step"] == 400
+    ids, nsteps = host.forcefile_info(str(ff))
+    rp = box.run_params(loaded=ids, force_file=str(ff), source_window=64)
+    box.solver_run(s, rp, 400, 400)
+    tm1, tm2 = s.download()
+    assert H.rel_linf(tm1, g["ckpt_tm1"][1]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][1]) < TOL
+    out = tmp_path / "checkpoint.out0"
+    host.checkpoint_write(s, str(out), 800)
+    b = out.read_bytes()
+    assert list(np.frombuffer(b[:12], "<i4")) == [1, 800, N] and len(b) == 12 + 2 * N * 24
+    assert np.array_equal(np.frombuffer(b[12:12 + N * 24], "<f8").reshape(N, 3), tm2)
+    assert np.array_equal(np.frombuffer(b[12 + N * 24:], "<f8").reshape(N, 3), tm1)
+    s2 = box.create_solver(variant=ha.HQ_VARIANT_SCATTER)
+    assert host.checkpoint_read(s2, str(out)) == 800
+    x1, x2 = s2.download()
+    assert np.array_equal(x1, tm1) and np.array_equal(x2, tm2)
+    s.close(); s2.close(); box.close()

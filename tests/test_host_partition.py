@@ -147,3 +147,27 @@ def test_stations_match_oracle_weights():
     assert np.array_equal(ids, oi) and np.allclose(phi, op, rtol=0, atol=1e-15) and mine.all()
     assert np.allclose(phi.sum(axis=1), 1.0)
     b.close()
+
+
+def test_force_file_format_roundtrip(tmp_path):
+    """force_process.<rank> layout (quakesource.c:2453-2466): a file assembled from the
+    reference's payload reads back exactly; windows past the end read as zero."""
+    g = H.load("c1_short")
+    ids, F = g["loaded_lnid"], g["forces"]
+    raw = np.int32(len(ids)).tobytes() + ids.astype("<i4").tobytes() + F.astype("<f8").tobytes()
+    ref = tmp_path / "force_process.0"
+    ref.write_bytes(raw)
+    got_ids, nsteps = host.forcefile_info(str(ref))
+    assert np.array_equal(got_ids, ids) and nsteps == F.shape[0]
+    assert np.array_equal(host.forcefile_read(str(ref), len(ids), 0, nsteps), F)
+    w = host.forcefile_read(str(ref), len(ids), nsteps - 3, 8)
+    assert np.array_equal(w[:3], F[-3:]) and not w[3:].any()
+    mine = tmp_path / "mine"
+    host.forcefile_write(str(mine), ids, F)
+    assert mine.read_bytes() == raw
+
+
+def test_station_line_format_matches_reference_text():
+    """psolve.c:6729-6731 prints "\\n%10.6f % 8e % 8e % 8e"."""
+    line = host.station_format(0.002, [-1.234661e-02, -1.234661e-02, 7.560121e-19])
+    assert line == "\n  0.002000 -1.234661e-02 -1.234661e-02  7.560121e-19"
