@@ -39,5 +39,7 @@ $CC $CFLAGS $DEFS $INC -c "$REF/quake/cvm/cvm.c" -o "$OUT/obj/cvm.o"   & objs="$
 wait
 ar rcs "$OUT/obj/libetree.a" $eobjs
 $CC -o "$OUT/psolve" $objs "$OUT/obj/libetree.a" -L"$MPI/lib" -Wl,-rpath,"$MPI/lib" -lmpi -lm
+# fixture helper: a layered CVM database writer on top of the reference's etree + cvm libraries
+$CC $CFLAGS $INC -o "$OUT/make_cvm" "$HERE/make_cvm.c" "$OUT/obj/cvm.o" "$OUT/obj/libetree.a" -lm
 rm -rf "$OUT/obj"
-echo "build_ref: built $OUT/psolve"
+echo "build_ref: built $OUT/psolve $OUT/make_cvm"

@@ -646,12 +646,13 @@ HO_API void ho_compute_adjust(double* table, int32_t items, int32_t how, int32_t
 }
 
 /* ------------------------------------------------------------------------ */
-/* solver_run: one rank, no hanging nodes                                   */
+/* solver_run: one rank                                                     */
 /* ------------------------------------------------------------------------ */
 
 /*
  * March `nsteps` steps starting at `step0`, solver_run psolve.c:4241-4324:
- * swap tm1/tm2, [capture], source, stiffness, damping, update.
+ * swap tm1/tm2, [capture], source, stiffness, damping, [hanging-node force
+ * distribution], update, [hanging-node displacement assignment].
  *
  * formulation: 0 = reference (stiff_method + conventional damping loop),
  *              1 = fused (formulation B).
@@ -670,7 +671,8 @@ HO_API void ho_solver_run(int64_t E, int64_t N, const int32_t* lnid, const doubl
                           int formulation, int zero_skip, int32_t nloaded,
                           const int32_t* loaded_lnid, const double* forces,
                           int32_t nforce_steps, int32_t cap_n, const int32_t* cap_lnid,
-                          double* cap_out)
+                          double* cap_out, int32_t ldnnum, const int32_t* dn_id,
+                          const int32_t* dn_ptr, const int32_t* dn_anchor)
 {
     double dt2 = dt * dt;
     double *p1 = tm1, *p2 = tm2;
@@ -691,7 +693,11 @@ HO_API void ho_solver_run(int64_t E, int64_t N, const int32_t* lnid, const doubl
             if (damping == HO_DAMP_RAYLEIGH || damping == HO_DAMP_MASS)   /* psolve.c:3991 */
                 ho_damping_addforce(E, lnid, etable, p1, p2, K1, K2, force, zero_skip);
         }
+        if (ldnnum > 0)                                     /* solver_adjust_forces, psolve.c:4299 */
+            ho_compute_adjust(force, 3, 0, ldnnum, dn_id, dn_ptr, dn_anchor);
         ho_compute_displacement(N, ntable, p1, p2, force, NULL);
+        if (ldnnum > 0)                                     /* solver_adjust_displacement, :4313 */
+            ho_compute_adjust(p2, 3, 1, ldnnum, dn_id, dn_ptr, dn_anchor);
     }
     if (p1 != tm1) {            /* odd number of swaps: put the roles back into the caller's arrays */
         size_t bytes = sizeof(double) * 3 * (size_t)N;

@@ -105,7 +105,7 @@ def solver_init(lnid, edata, face, N, dt, freq, damping=DAMP_RAYLEIGH, thr_dampi
 
 def solver_run(lnid, etable, ntable, tm1, tm2, step0, nsteps, dt, damping=DAMP_RAYLEIGH,
                stiff_method=STIFF_EFFECTIVE, formulation=0, zero_skip=True, loaded_lnid=None,
-               forces=None, cap_lnid=None, K=None):
+               forces=None, cap_lnid=None, K=None, dangling=None):
     """March in place; returns captured tm1 rows [nsteps, cap_n, 3] (or None)."""
     lnid = _c(lnid, np.int32)
     E = lnid.shape[0]
@@ -126,13 +126,93 @@ def solver_run(lnid, etable, ntable, tm1, tm2, step0, nsteps, dt, damping=DAMP_R
         cl = _c(np.asarray(cap_lnid).reshape(-1), np.int32)
         cn = len(cl)
         cap = np.zeros((nsteps, cn, 3))
+    if dangling is None:
+        nd, di, dp, da = 0, None, None, None
+    else:
+        di, dp, da = [_c(x, np.int32) for x in dangling]
+        nd = len(di)
     lib().ho_solver_run(ctypes.c_int64(E), ctypes.c_int64(N), _p(lnid), _p(etable), _p(ntable),
                         _p(K1), _p(K2), _p(tm1), _p(tm2), _p(force), ctypes.c_int32(step0),
                         ctypes.c_int32(nsteps), ctypes.c_double(dt), ctypes.c_int(damping),
                         ctypes.c_int(stiff_method), ctypes.c_int(formulation),
                         ctypes.c_int(int(zero_skip)), ctypes.c_int32(nl), _p(ll), _p(F),
-                        ctypes.c_int32(nfs), ctypes.c_int32(cn), _p(cl), _p(cap))
+                        ctypes.c_int32(nfs), ctypes.c_int32(cn), _p(cl), _p(cap),
+                        ctypes.c_int32(nd), _p(di), _p(dp), _p(da))
     return cap
+
+
+def compute_adjust(table, how, dangling):
+    """compute_adjust (psolve.c:5936-6039) in place; how 0 = DISTRIBUTION, 1 = ASSIGNMENT."""
+    di, dp, da = [_c(x, np.int32) for x in dangling]
+    assert table.dtype == np.float64 and table.flags.c_contiguous
+    lib().ho_compute_adjust(_p(table), ctypes.c_int32(table.shape[1]), ctypes.c_int32(how),
+                            ctypes.c_int32(len(di)), _p(di), _p(dp), _p(da))
+
+
+def octree_mesh_from_elem_ticks(elem_ticks, far_ticks):
+    """Rebuild octor's tables from the reference's flat element dump for meshes with
+    several refinement levels (no buildings):
+      nodes   : unique vertices in Z-order of the far-boundary-adjusted coordinates
+                (octor.c:6100-6106, 6166)
+      dangling: node_setproperty (octor.c:3280-3860) by touch count / boundary position /
+                alignment to the next coarser grid; anchors as dnode correlation lists them
+                (octor.c:6493-6612, prepended => reversed order)
+    -> dict(lnid, node_q, elem_q, elem_size, emin, face, dangling=(ids, ptr, anchors))
+    where *_q are coordinates in units of the smallest edge."""
+    t = np.asarray(elem_ticks, np.int64)
+    edge = t[:, 1, 0] - t[:, 0, 0]
+    emin = int(edge.min())
+    assert np.all(t % emin == 0)
+    q = t // emin
+    size = (edge // emin).astype(np.int64)
+    nq = [int(f // emin) for f in far_ticks]
+    flat = q.reshape(-1, 3)
+    uniq, inv = np.unique(flat, axis=0, return_inverse=True)
+    key_c = [np.where(uniq[:, d] == nq[d], 2 * nq[d] - 1, 2 * uniq[:, d]) for d in range(3)]
+    order = np.argsort(zvalue(key_c[0], key_c[1], key_c[2]), kind="stable")
+    rank = np.empty(len(uniq), np.int64)
+    rank[order] = np.arange(len(uniq))
+    lnid = rank[inv.reshape(-1)].reshape(-1, 8).astype(np.int32)
+    node_q = uniq[order]
+    N = len(node_q)
+    ll = q[:, 0, :]
+    face = ((ll[:, 0] == 0) * 1 | (ll[:, 1] == 0) * 2 | (ll[:, 2] == 0) * 4 |
+            (ll[:, 0] + size == nq[0]) * 8 | (ll[:, 1] + size == nq[1]) * 16 |
+            (ll[:, 2] + size == nq[2]) * 32).astype(np.uint8)
+    touches = np.bincount(lnid.reshape(-1), minlength=N)
+    small = np.full(N, np.iinfo(np.int64).max)
+    np.minimum.at(small, lnid.reshape(-1), np.repeat(size, 8))     # vertex->level: smallest toucher
+    where = sum(((node_q[:, d] == 0) | (node_q[:, d] == nq[d])).astype(int) for d in range(3))
+    index = {tuple(v): i for i, v in enumerate(node_q.tolist())}
+    ids, ptr, anchors = [], [0], []
+    for n in range(N):
+        tc, wh, s = int(touches[n]), int(where[n]), int(small[n])
+        if tc == 8 or (tc == 4 and wh == 1) or (tc == 2 and wh == 2) or (tc == 1 and wh == 3):
+            continue                                             # anchored
+        mods = [int(node_q[n, d] % (2 * s) != 0) for d in range(3)]
+        nm = sum(mods)
+        ok = (tc == 6 and wh == 0 and nm == 1) or (tc == 4 and wh == 0 and nm in (1, 2)) or \
+             (tc == 2 and wh in (0, 1) and nm == 1)
+        if not ok:
+            raise ValueError("node %d: touches %d where %d mods %s is not a legal octor vertex" % (n, tc, wh, mods))
+        pts = []
+        if nm == 1:                                              # X/Y/ZEDGE: -s then +s
+            d = mods.index(1)
+            for sg in (-s, s):
+                p = node_q[n].copy(); p[d] += sg; pts.append(tuple(p))
+        else:                                                    # face: the two in-plane axes, low axis fastest
+            a, b = [d for d in range(3) if mods[d]]
+            for dep in range(4):
+                p = node_q[n].copy()
+                p[a] += s if (dep & 1) else -s
+                p[b] += s if (dep & 2) else -s
+                pts.append(tuple(p))
+        ids.append(n)
+        anchors += [index[p] for p in reversed(pts)]             # the list is built by prepending
+        ptr.append(len(anchors))
+    return dict(lnid=lnid, node_q=node_q.astype(np.int32), elem_q=ll.astype(np.int32),
+                elem_size=size.astype(np.int32), emin=emin, face=face,
+                dangling=(np.array(ids, np.int32), np.array(ptr, np.int32), np.array(anchors, np.int32)))
 
 
 # ---------------------------------------------------------------------------

@@ -61,7 +61,7 @@ use_infinite_qk = no
 
 
 def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
-                  nranks=1, printk="no", freq=None, dt=None):
+                  nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None):
     """Run the reference in a scratch dir; return (dir, stdout)."""
     run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
     src = os.path.join(REF, "examples", "simple")
@@ -70,6 +70,11 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
     for root, dirs, files in os.walk(run):
         for n in dirs + files:
             os.chmod(os.path.join(root, n), 0o755)
+    if cvm_args is not None:
+        # layered material database written with the reference's own etree/cvm libraries
+        os.remove(os.path.join(run, "simple_case.e"))
+        subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "make_cvm"),
+                               os.path.join(run, "simple_case.e")] + [str(a) for a in cvm_args])
     for d in ("checkpoints", "planes", "srctmp", "stations", "matlab"):
         os.makedirs(os.path.join(run, "out", d))
     text = open(os.path.join(run, "in", "physics.in")).read() + \
@@ -82,6 +87,8 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
     text = setkey(text, "simulation_end_time_sec", end_time)
     text = setkey(text, "checkpointing_rate", ckpt_rate)
     text = setkey(text, "type_of_damping", damping)
+    if vscut is not None:
+        text = setkey(text, "simulation_shear_velocity_min", vscut)
     if freq is not None:
         text = setkey(text, "simulation_wave_max_freq_hz", freq)
     if dt is not None:
@@ -237,6 +244,32 @@ def case_np8():
     print("c1_np8 ok")
 
 
+def case_two_level():
+    """Soft top layer (2 octant layers = 125 m, Vs 1732) over the stiff half-space: the
+    reference's Vs rule refines the top one level deeper -> 2:1 interface with hanging nodes."""
+    run, out = run_reference("c5_two_level", "1.0", 400, cvm_args=[2, 3000, 1732, 2200, 6000, 3464, 2700],
+                             vscut=500)
+    ids, F = read_forces(run)
+    elem_ticks, mat = read_mesh(run)
+    ck = {}
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", f))
+        ck[step] = blocks[0]
+    st = read_stations(run)
+    counts = {k: int(re.search(k + r":\s+(\d+)", out).group(1))
+              for k in ("Total elements", "Total nodes", "Total dangling nodes")}
+    np.savez_compressed(os.path.join(HERE, "c5_two_level.npz"),
+                        elem_ticks=elem_ticks, mat_vs_vp_rho=mat, loaded_lnid=ids, forces=F,
+                        ckpt_steps=np.array(sorted(ck)),
+                        ckpt_tm2=np.stack([ck[s][0] for s in sorted(ck)]),
+                        ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
+                        stations=st, dt=1e-3, end_time=1.0, freq=5.0,
+                        total_elements=counts["Total elements"], total_nodes=counts["Total nodes"],
+                        total_dangling=counts["Total dangling nodes"])
+    shutil.rmtree(run)
+    print("c5_two_level ok", counts, sorted(ck))
+
+
 CASES = {
     "c1_short": lambda: case_short("c1_short"),
     "c1_conv": lambda: case_short("c1_conv", stiffness="conventional"),
@@ -244,6 +277,7 @@ CASES = {
     "c1_mass": lambda: case_short("c1_mass", damping="mass"),
     "c1_full": case_full,
     "c1_np8": case_np8,
+    "c5_two_level": case_two_level,
 }
 
 if __name__ == "__main__":

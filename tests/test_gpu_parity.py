@@ -277,3 +277,22 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     x1, x2 = s2.download()
     assert np.array_equal(x1, tm1) and np.array_equal(x2, tm2)
     s.close(); s2.close(); box.close()
+
+
+def test_two_level_mesh_with_hanging_nodes_against_reference():
+    """Scatter kernels + compute_adjust kernels on the reference's own two-level mesh
+    (800 hanging nodes), against the checkpoints the real reference wrote."""
+    p = H.c5_problem()
+    g = p["golden"]
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"],
+                  node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32))
+    assert s.info()["variant"] == ha.HQ_VARIANT_SCATTER            # AUTO picks it for hanging nodes
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL
+        assert H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()

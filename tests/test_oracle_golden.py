@@ -157,3 +157,29 @@ def test_full_run_checkpoints_and_shipped_station_traces():
     assert np.abs(st[:, :head.shape[1], :] - head).max() <= 6e-7 * np.abs(head).max()
     # and the real reference binary reproduced its own shipped traces when the fixture was made
     assert float(g["max_abs_run_vs_expected"]) < 1e-3
+
+
+def test_two_level_mesh_with_hanging_nodes_bitwise():
+    """SURVEY s8 a13 / config 5 in miniature: the REAL reference meshed a soft layer one
+    level deeper (5632 elements, 7179 nodes, 800 dangling nodes).  Mixed-level element
+    order, node order, node_setproperty classification, anchor lists, the mass
+    distribution at init and compute_adjust every step: bit-identical checkpoints."""
+    p = H.c5_problem()
+    g = p["golden"]
+    assert p["E"] == int(g["total_elements"]) == 5632
+    assert p["N"] == int(g["total_nodes"]) == 7179
+    ids, ptr, anchors = p["dangling"]
+    assert len(ids) == int(g["total_dangling"]) == 800
+    deps = np.diff(ptr)
+    assert set(deps.tolist()) == {2, 4} and (deps == 4).sum() == 16 * 16
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"], dangling=p["dangling"])
+        done = int(step)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k])
+        assert np.array_equal(tm2, g["ckpt_tm1"][k])
+    # a hanging node sits at the mean of its anchors after every step (psolve.c:5992-6035)
+    k = 17
+    assert np.allclose(tm2[ids[k]], tm2[anchors[ptr[k]:ptr[k + 1]]].mean(axis=0), rtol=1e-13, atol=0)
