@@ -584,7 +584,7 @@ static int hq_phase(hq_ctx* c, int ph)
     case 5: return hq_xchg_send(c, &c->an, unew, false, false);                      /* :4312 */
     case 6:
         HQ_TRY(hq_xchg_recv(c, &c->an, unew, false, false));
-        if (!patch && c->ldnnum)                                           /* :4313 */
+        if (c->ldnnum)                                                     /* :4313 */
             hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
                 c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
         return HQ_OK;
@@ -670,7 +670,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
-    if (!getenv("HQ_NO_OVERLAP")) {
+    if (!getenv("HQ_NO_OVERLAP") && c->ldnnum == 0) {
         /* the exchange chain is short and latency-bound: let its kernels (and RCCL's) get CUs ahead
          * of the thousands of interior patch workgroups queued on the compute stream */
         int prio_lo = 0, prio_hi = 0;
@@ -728,11 +728,21 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "hipStreamCreate failed%s", ""));
 
-    bool has_dn = d->dn_sched.c_count || d->dn_sched.s_count || c->ldnnum;
+    /* hanging nodes shared between ranks (dn_sched) need the reference's two extra exchanges:
+     * scatter variant only */
+    bool has_dn_sched = d->dn_sched.c_count || d->dn_sched.s_count;
     int variant = d->variant;
-    if (variant == HQ_VARIANT_AUTO) variant = has_dn ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
-    if (variant == HQ_VARIANT_PATCH && has_dn)
-        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take hanging nodes (use the scatter variant)%s", ""));
+    if (variant == HQ_VARIANT_AUTO) variant = has_dn_sched ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
+    if (variant == HQ_VARIANT_PATCH && has_dn_sched)
+        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take hanging nodes shared between ranks%s", ""));
+    if (c->ldnnum && (!d->dn_ldnid || !d->dn_ptr || !d->dn_lanid))
+        return bail(hq_fail(HQ_ERR_ARG, "dangling-node tables missing%s", ""));
+    for (int32_t k = 0; k < c->ldnnum; k++) {
+        if (d->dn_ldnid[k] < 0 || d->dn_ldnid[k] >= c->N || d->dn_ptr[k + 1] <= d->dn_ptr[k])
+            return bail(hq_fail(HQ_ERR_ARG, "bad dangling-node table%s", ""));
+        for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++)
+            if (d->dn_lanid[a] < 0 || d->dn_lanid[a] >= c->N) return bail(hq_fail(HQ_ERR_ARG, "bad anchor id%s", ""));
+    }
     if (hipEventCreateWithFlags(&c->ev_sent, hipEventDisableTiming) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "hipEventCreate failed%s", ""));
     if (variant != HQ_VARIANT_SCATTER && variant != HQ_VARIANT_PATCH)
@@ -753,6 +763,16 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         return bail(hq_fail(HQ_ERR_DEVICE, "tm1 upload failed%s", ""));
     if (d->tm2 && hipMemcpy(c->d_u[c->prev], d->tm2, sizeof(double) * n3, hipMemcpyHostToDevice) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "tm2 upload failed%s", ""));
+
+    if (c->ldnnum) {
+        int32_t na = d->dn_ptr[c->ldnnum];
+        if ((rc = hq_dev_alloc(c, &c->d_dn_id, (size_t)c->ldnnum)) != HQ_OK) return bail(rc);
+        if ((rc = hq_dev_alloc(c, &c->d_dn_ptr, (size_t)c->ldnnum + 1)) != HQ_OK) return bail(rc);
+        if ((rc = hq_dev_alloc(c, &c->d_dn_anchor, (size_t)na)) != HQ_OK) return bail(rc);
+        hipMemcpy(c->d_dn_id, d->dn_ldnid, sizeof(int32_t) * c->ldnnum, hipMemcpyHostToDevice);
+        hipMemcpy(c->d_dn_ptr, d->dn_ptr, sizeof(int32_t) * (c->ldnnum + 1), hipMemcpyHostToDevice);
+        hipMemcpy(c->d_dn_anchor, d->dn_lanid, sizeof(int32_t) * na, hipMemcpyHostToDevice);
+    }
 
     /* element coefficients: (c1, c2, beta = c3/c1) */
     std::vector<double> c1(c->E), c2(c->E), beta(c->E);
@@ -777,21 +797,14 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         hipMemcpy(c->d_c1, c1.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
         hipMemcpy(c->d_c2, c2.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
         hipMemcpy(c->d_beta, beta.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
-        if (c->ldnnum) {
-            if (!d->dn_ldnid || !d->dn_ptr || !d->dn_lanid) return bail(hq_fail(HQ_ERR_ARG, "dangling-node tables missing%s", ""));
-            int32_t na = d->dn_ptr[c->ldnnum];
-            if ((rc = hq_dev_alloc(c, &c->d_dn_id, (size_t)c->ldnnum)) != HQ_OK) return bail(rc);
-            if ((rc = hq_dev_alloc(c, &c->d_dn_ptr, (size_t)c->ldnnum + 1)) != HQ_OK) return bail(rc);
-            if ((rc = hq_dev_alloc(c, &c->d_dn_anchor, (size_t)na)) != HQ_OK) return bail(rc);
-            hipMemcpy(c->d_dn_id, d->dn_ldnid, sizeof(int32_t) * c->ldnnum, hipMemcpyHostToDevice);
-            hipMemcpy(c->d_dn_ptr, d->dn_ptr, sizeof(int32_t) * (c->ldnnum + 1), hipMemcpyHostToDevice);
-            hipMemcpy(c->d_dn_anchor, d->dn_lanid, sizeof(int32_t) * na, hipMemcpyHostToDevice);
-        }
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
     } else {
         int64_t pb = 0;
-        rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, &pb);
+        hq_dangling dn;
+        dn.n = c->ldnnum; dn.id = d->dn_ldnid; dn.ptr = d->dn_ptr; dn.anchor = d->dn_lanid;
+        rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
+                            dn, &pb);
         if (rc != 0)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));

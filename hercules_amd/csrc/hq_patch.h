@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,8 @@ struct hq_patch_cfg {
     int pmax    = 768;    /* owned nodes per patch (9*9*9 = 729 fits)                */
     int pmerge  = 512;    /* small neighbouring cubes are merged up to this          */
     int nlmax   = 1024;   /* owned + halo nodes staged in LDS (10*10*10 fits)        */
+    int vmax    = 0;      /* extra force accumulators for hanging nodes whose anchors */
+                          /* the patch owns (set by the planner when the mesh has any) */
 };
 
 static hq_patch_cfg hq_patch_cfg_from_env(void)
@@ -59,8 +62,9 @@ static hq_patch_cfg hq_patch_cfg_from_env(void)
     if (c.pmerge < 1) c.pmerge = 1;
     if (c.nlmax < c.pmax + 8) c.nlmax = c.pmax + 8;
     if (c.nlmax > 0xffff) c.nlmax = 0xffff;
-    /* LDS: (6 nlmax + 3 pmax) doubles must fit 160 KiB */
-    while ((6 * (size_t)c.nlmax + 3 * (size_t)c.pmax) * 8 > 160 * 1024) c.nlmax -= 8;
+    c.vmax = geti("HQ_PATCH_VMAX", c.vmax);
+    /* LDS: (6 nlmax + 3 (pmax + vmax)) doubles must fit 160 KiB */
+    while ((6 * (size_t)c.nlmax + 3 * (size_t)(c.pmax + c.vmax)) * 8 > 160 * 1024) c.nlmax -= 8;
     return c;
 }
 
@@ -72,7 +76,8 @@ struct hq_patch_desc {
     int64_t pair_off;    /* into pidx / pc1 / pc2 / pbeta          */
     int64_t halo_off;    /* into halo_ids                          */
     int32_t flags;       /* HQ_PATCH_ISO: every owned node has axis-independent n_t */
-    int32_t pad;
+    int32_t nacc;        /* local nodes with a force accumulator: owned + the first   */
+                         /* (nacc - nown) halo nodes = hanging nodes on owned anchors */
 };
 #define HQ_PATCH_ISO 1
 
@@ -81,6 +86,16 @@ struct hq_patch_host {
     std::vector<uint16_t> pidx;      /* [npairs][8] patch-local node ids */
     std::vector<int32_t>  pelem;     /* [npairs] element id (host only)  */
     std::vector<int32_t>  halo;      /* concatenated halo node ids        */
+    std::vector<int32_t>  ds_ptr;    /* [P+1] hanging-node distribution entries per patch */
+    std::vector<int32_t>  ds_ent;    /* [n][3] = {src local, dst local (owned anchor), deps} */
+};
+
+/* dnodeTable (octor.h:153-158) as CSR */
+struct hq_dangling {
+    int32_t n = 0;
+    const int32_t* id = nullptr;
+    const int32_t* ptr = nullptr;
+    const int32_t* anchor = nullptr;
 };
 
 struct hq_patch_plan {
@@ -103,6 +118,11 @@ struct hq_patch_plan {
     int32_t* d_if_ent = nullptr;     /* [n][2] = {local node, slot}       */
     int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
     int32_t  nb = 0;
+    int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
+    int32_t* d_ds_ent = nullptr;
+    std::vector<int32_t> h_halo;     /* host copies kept only for meshes with hanging nodes */
+    std::vector<int64_t> h_halo_off;
+    std::vector<int32_t> h_nvirt;
     std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
     std::vector<int32_t> patch_nown;
 };
@@ -204,10 +224,19 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
  * does not fit LDS is halved and the build repeated.
  */
 static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, const int32_t* lnid,
-                              const int32_t* xyz, hq_patch_host* H)
+                              const int32_t* xyz, const hq_dangling& dn, hq_patch_host* H)
 {
     std::vector<int32_t> cuts;
     hq_patch_cuts(cfg, N, xyz, cuts);
+    /* hanging nodes: dn_of[n] = index into the dangling table or -1 */
+    std::vector<int32_t> dn_of;
+    if (dn.n > 0) {
+        dn_of.assign((size_t)N, -1);
+        for (int32_t k = 0; k < dn.n; k++) dn_of[dn.id[k]] = k;
+        for (int32_t k = 0; k < dn.n; k++)
+            for (int32_t a = dn.ptr[k]; a < dn.ptr[k + 1]; a++)
+                if (dn_of[dn.anchor[a]] >= 0) { g_patch_err = "an anchor is itself a hanging node"; return -1; }
+    }
 
     for (int attempt = 0; attempt < 12; attempt++) {
         int32_t P = (int32_t)cuts.size() - 1;
@@ -217,18 +246,25 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
 
         /* count (patch, element) pairs */
         std::vector<int64_t> off((size_t)P + 1, 0);
-        auto patches_of_elem = [&](int64_t e, int32_t out[8]) {
+        /* patches that must evaluate element e: the owners of its nodes and, for a hanging
+         * node, the owners of its anchors (they need its complete force, psolve.c:5942-5987) */
+        auto patches_of_elem = [&](int64_t e, int32_t out[40]) {
             int k = 0;
-            for (int c = 0; c < 8; c++) {
-                int32_t p = patch_of[lnid[8 * e + c]];
+            auto add = [&](int32_t p) {
                 bool seen = false;
                 for (int t = 0; t < k; t++) seen |= (out[t] == p);
                 if (!seen) out[k++] = p;
+            };
+            for (int c = 0; c < 8; c++) {
+                int32_t n = lnid[8 * e + c];
+                add(patch_of[n]);
+                if (dn.n > 0 && dn_of[n] >= 0)
+                    for (int32_t a = dn.ptr[dn_of[n]]; a < dn.ptr[dn_of[n] + 1]; a++) add(patch_of[dn.anchor[a]]);
             }
             return k;
         };
         for (int64_t e = 0; e < E; e++) {
-            int32_t ps[8];
+            int32_t ps[40];
             int k = patches_of_elem(e, ps);
             for (int t = 0; t < k; t++) off[ps[t] + 1]++;
         }
@@ -238,7 +274,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         {
             std::vector<int64_t> fill(off.begin(), off.end() - 1);
             for (int64_t e = 0; e < E; e++) {
-                int32_t ps[8];
+                int32_t ps[40];
                 int k = patches_of_elem(e, ps);
                 for (int t = 0; t < k; t++) H->pelem[(size_t)fill[ps[t]]++] = (int32_t)e;
             }
@@ -247,6 +283,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         /* halo lists */
         std::vector<int64_t> hoff((size_t)P + 1, 0);
         std::vector<std::vector<int32_t>> halos((size_t)P);
+        std::vector<int32_t> nvirt((size_t)P, 0);
         std::vector<char> bad((size_t)P, 0);
         bool any_bad = false;
 #pragma omp parallel for schedule(dynamic, 64)
@@ -261,7 +298,19 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             }
             std::sort(h.begin(), h.end());
             h.erase(std::unique(h.begin(), h.end()), h.end());
-            if (nown + (int64_t)h.size() > cfg.nlmax || nown > cfg.pmax ||
+            if (dn.n > 0) {
+                /* halo order: first the hanging nodes that hang on an anchor this patch owns
+                 * ("virtual" accumulators), then the rest; both ascending */
+                auto hangs_here = [&](int32_t n) {
+                    if (dn_of[n] < 0) return false;
+                    for (int32_t a = dn.ptr[dn_of[n]]; a < dn.ptr[dn_of[n] + 1]; a++)
+                        if (dn.anchor[a] >= base && dn.anchor[a] < base + nown) return true;
+                    return false;
+                };
+                auto mid = std::stable_partition(h.begin(), h.end(), hangs_here);
+                nvirt[p] = (int32_t)(mid - h.begin());
+            }
+            if (nown + (int64_t)h.size() > cfg.nlmax || nown > cfg.pmax || nvirt[p] > cfg.vmax ||
                 off[p + 1] - off[p] > 0x7fffffff)
                 bad[p] = 1;
         }
@@ -294,16 +343,42 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             D.npairs = (int32_t)(off[p + 1] - off[p]);
             D.pair_off = off[p];
             D.halo_off = hoff[p];
+            D.nacc = D.nown + nvirt[p];
             std::copy(halos[p].begin(), halos[p].end(), H->halo.begin() + hoff[p]);
             const std::vector<int32_t>& h = halos[p];
+            const int32_t nv = nvirt[p];
+            auto local_of = [&](int32_t g) -> int32_t {
+                if (g >= D.base && g < D.base + D.nown) return g - D.base;
+                auto v = std::lower_bound(h.begin(), h.begin() + nv, g);
+                if (v != h.begin() + nv && *v == g) return D.nown + (int32_t)(v - h.begin());
+                return D.nown + (int32_t)(std::lower_bound(h.begin() + nv, h.end(), g) - h.begin());
+            };
             for (int64_t q = off[p]; q < off[p + 1]; q++) {
                 const int32_t* id = lnid + 8 * (int64_t)H->pelem[(size_t)q];
-                for (int c = 0; c < 8; c++) {
-                    int32_t l;
-                    if (id[c] >= D.base && id[c] < D.base + D.nown) l = id[c] - D.base;
-                    else l = D.nown + (int32_t)(std::lower_bound(h.begin(), h.end(), id[c]) - h.begin());
-                    H->pidx[(size_t)q * 8 + c] = (uint16_t)l;
+                for (int c = 0; c < 8; c++) H->pidx[(size_t)q * 8 + c] = (uint16_t)local_of(id[c]);
+            }
+        }
+        if (dn.n > 0) {
+            /* distribution entries, hanging nodes in table order (the reference's loop order) */
+            std::vector<std::vector<int32_t>> ent((size_t)P);
+            for (int32_t k = 0; k < dn.n; k++) {
+                int32_t deps = dn.ptr[k + 1] - dn.ptr[k];
+                for (int32_t a = dn.ptr[k]; a < dn.ptr[k + 1]; a++) {
+                    int32_t p = patch_of[dn.anchor[a]];
+                    const hq_patch_desc& D = H->desc[p];
+                    const std::vector<int32_t>& h = halos[p];
+                    int32_t g = dn.id[k], src;
+                    if (g >= D.base && g < D.base + D.nown) src = g - D.base;
+                    else src = D.nown + (int32_t)(std::lower_bound(h.begin(), h.begin() + nvirt[p], g) - h.begin());
+                    ent[p].push_back(src);
+                    ent[p].push_back(dn.anchor[a] - D.base);
+                    ent[p].push_back(deps);
                 }
+            }
+            H->ds_ptr.assign((size_t)P + 1, 0);
+            for (int32_t p = 0; p < P; p++) {
+                H->ds_ptr[p + 1] = H->ds_ptr[p] + (int32_t)(ent[p].size() / 3);
+                H->ds_ent.insert(H->ds_ent.end(), ent[p].begin(), ent[p].end());
             }
         }
         return 0;
@@ -371,7 +446,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 const int32_t* __restrict__ src_ptr,
                 const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
                 const int32_t* __restrict__ if_ptr, const int32_t* __restrict__ if_ent,
-                double* __restrict__ iforce)
+                double* __restrict__ iforce, const int32_t* __restrict__ ds_ptr,
+                const int32_t* __restrict__ ds_ent)
 {
     extern __shared__ __align__(16) double s_mem[];
     double* __restrict__ s_u1 = s_mem;
@@ -386,6 +462,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     const hq_patch_desc D = desc[p];
     const int tid = threadIdx.x, T = blockDim.x;
     const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
+    for (int i = own3 + tid; i < 3 * D.nacc; i += T) s_f[i] = 0.0;   /* hanging nodes on owned anchors */
 
     hq_pair_data cur;
     if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + tid);
@@ -460,7 +537,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
         for (int n = 0; n < 8; n++) {
             if (DIAG == 4) { if (X[n] + Y[n] + Z[n] == 1.2345e-300) s_f[n] = 1.0; continue; }
-            if (l[n] < D.nown) {
+            if (l[n] < D.nacc) {
                 atomicAdd(&s_f[3 * l[n] + 0], X[n]);
                 atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
                 atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
@@ -472,6 +549,14 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += T) {
             int ln = src_ent[2 * k], li = src_ent[2 * k + 1];
             for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * ln + d], F[3 * li + d] * dt2);
+        }
+    }
+    if (ds_ptr && ds_ptr[p + 1] > ds_ptr[p]) {       /* compute_adjust DISTRIBUTION, psolve.c:5942-5987 */
+        __syncthreads();
+        for (int k = ds_ptr[p] + tid; k < ds_ptr[p + 1]; k += T) {
+            const int src = ds_ent[3 * k], dst = ds_ent[3 * k + 1];
+            const double deps = (double)(unsigned)ds_ent[3 * k + 2];
+            for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
         }
     }
     __syncthreads();
@@ -514,18 +599,22 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 static void hq_patch_free(hq_patch_plan* P)
 {
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3 };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
 
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
                           const double* c1, const double* c2, const double* beta, const double* ntab,
-                          int64_t* bytes)
+                          const hq_dangling& dn, int64_t* bytes)
 {
     hq_patch_host H;
     P->cfg = hq_patch_cfg_from_env();
-    if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, &H) != 0) return -1 /* HQ_ERR_ARG */;
+    if (dn.n > 0 && P->cfg.vmax == 0) {
+        P->cfg.vmax = 384;
+        while ((6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * 8 > 160 * 1024) P->cfg.nlmax -= 8;
+    }
+    if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, &H) != 0) return -1 /* HQ_ERR_ARG */;
     /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
      * for every owned node, i.e. no dashpot touches the patch */
     std::vector<double> nt3((size_t)N * 3);
@@ -540,7 +629,6 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             iso = (q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]);
         }
         D.flags = iso ? HQ_PATCH_ISO : 0;
-        D.pad = 0;
     }
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
@@ -557,6 +645,19 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     HQ_PA(P->d_pbeta, 8 * np)
     HQ_PA(P->d_halo, 4 * nh)
     HQ_PA(P->d_nt3, 8 * nt3.size())
+    if (dn.n > 0) {
+        HQ_PA(P->d_ds_ptr, 4 * H.ds_ptr.size())
+        HQ_PA(P->d_ds_ent, 4 * (H.ds_ent.size() ? H.ds_ent.size() : 1))
+        hipMemcpy(P->d_ds_ptr, H.ds_ptr.data(), 4 * H.ds_ptr.size(), hipMemcpyHostToDevice);
+        hipMemcpy(P->d_ds_ent, H.ds_ent.data(), 4 * H.ds_ent.size(), hipMemcpyHostToDevice);
+        P->h_halo = H.halo;
+        P->h_halo_off.resize(H.desc.size());
+        P->h_nvirt.resize(H.desc.size());
+        for (size_t p = 0; p < H.desc.size(); p++) {
+            P->h_halo_off[p] = H.desc[p].halo_off;
+            P->h_nvirt[p] = H.desc[p].nacc - H.desc[p].nown;
+        }
+    }
 #undef HQ_PA
     hipMemcpy(P->d_nt3, nt3.data(), 8 * nt3.size(), hipMemcpyHostToDevice);
     hipMemcpy(P->d_desc, H.desc.data(), sizeof(hq_patch_desc) * H.desc.size(), hipMemcpyHostToDevice);
@@ -580,20 +681,25 @@ static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t*
     if (P->d_src_ptr) { hipFree(P->d_src_ptr); P->d_src_ptr = nullptr; }
     if (P->d_src_ent) { hipFree(P->d_src_ent); P->d_src_ent = nullptr; }
     if (nloaded <= 0) return 0;
-    std::vector<int32_t> ptr((size_t)P->npatches + 1, 0), owner((size_t)nloaded);
+    /* (patch, local accumulator, loaded index): the owning patch, plus every patch that keeps a
+     * "virtual" accumulator of a loaded hanging node (its force is distributed to their anchors) */
+    std::vector<std::array<int32_t, 3>> rec;
     for (int32_t i = 0; i < nloaded; i++) {
         int32_t p = (int32_t)(std::upper_bound(P->patch_base.begin(), P->patch_base.end(), loaded[i]) -
                               P->patch_base.begin()) - 1;
-        owner[i] = p;
-        ptr[p + 1]++;
+        rec.push_back({ p, loaded[i] - P->patch_base[p], i });
+        for (size_t q = 0; q < P->h_nvirt.size(); q++) {
+            const int32_t* v = P->h_halo.data() + P->h_halo_off[q];
+            const int32_t* hit = std::lower_bound(v, v + P->h_nvirt[q], loaded[i]);
+            if (hit != v + P->h_nvirt[q] && *hit == loaded[i])
+                rec.push_back({ (int32_t)q, P->patch_nown[q] + (int32_t)(hit - v), i });
+        }
     }
+    std::sort(rec.begin(), rec.end());
+    std::vector<int32_t> ptr((size_t)P->npatches + 1, 0), ent(rec.size() * 2);
+    for (auto& r : rec) ptr[r[0] + 1]++;
     for (int32_t p = 0; p < P->npatches; p++) ptr[p + 1] += ptr[p];
-    std::vector<int32_t> ent((size_t)nloaded * 2), fill(ptr.begin(), ptr.end() - 1);
-    for (int32_t i = 0; i < nloaded; i++) {
-        int32_t k = fill[owner[i]]++;
-        ent[2 * k] = loaded[i] - P->patch_base[owner[i]];
-        ent[2 * k + 1] = i;
-    }
+    for (size_t k = 0; k < rec.size(); k++) { ent[2 * k] = rec[k][1]; ent[2 * k + 1] = rec[k][2]; }
     if (hipMalloc((void**)&P->d_src_ptr, 4 * ptr.size()) != hipSuccess) return -2;
     if (hipMalloc((void**)&P->d_src_ent, 4 * ent.size()) != hipSuccess) return -2;
     *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
@@ -639,7 +745,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
 {
     if (count <= 0) return;
     int per_xcd = (count + 7) / 8;
-    size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)P->cfg.pmax) * sizeof(double);
+    size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double);
     static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
     auto kern = nt_hint ? hq_k_patch_step<true, 0> : hq_k_patch_step<false, 0>;
 #ifdef HQ_PATCH_PROFILING   /* ablation builds for profiles/: results are WRONG by construction */
@@ -653,7 +759,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     kern<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
         count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
         P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
-        (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce);
+        (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent);
 }
 
 #endif /* HQ_PATCH_H */

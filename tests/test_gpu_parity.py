@@ -279,14 +279,17 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     s.close(); s2.close(); box.close()
 
 
-def test_two_level_mesh_with_hanging_nodes_against_reference():
-    """Scatter kernels + compute_adjust kernels on the reference's own two-level mesh
-    (800 hanging nodes), against the checkpoints the real reference wrote."""
+@pytest.mark.parametrize("variant", VARIANTS + [ha.HQ_VARIANT_AUTO])
+def test_two_level_mesh_with_hanging_nodes_against_reference(variant):
+    """compute_adjust on the reference's own two-level mesh (800 hanging nodes): scatter
+    kernels + adjust kernels, and the patch kernel (hanging-node forces accumulated by the
+    patches that own their anchors, assignment kernel after), against the checkpoints the
+    real reference wrote."""
     p = H.c5_problem()
     g = p["golden"]
-    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"],
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"], variant=variant,
                   node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32))
-    assert s.info()["variant"] == ha.HQ_VARIANT_SCATTER            # AUTO picks it for hanging nodes
+    assert s.info()["variant"] == (ha.HQ_VARIANT_PATCH if variant == ha.HQ_VARIANT_AUTO else variant)
     s.set_source(g["loaded_lnid"], g["forces"])
     done = 0
     for k, step in enumerate(g["ckpt_steps"]):
