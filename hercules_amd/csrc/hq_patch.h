@@ -601,9 +601,15 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
  * so the memory system stays busy during the element loop (the non-pipelined kernel moves
  * no bytes while both resident workgroups compute).  T = 256 threads: 2 waves per SIMD,
  * 256 registers per lane to hold the in-flight patch.
+ *
+ * EXPERIMENT (opt-in, HQ_PATCH_PIPE=1), parity-green but 6 % slower than hq_k_patch_step on
+ * the 64M box: vmcnt retires in order, so the first use of a younger load (the next round's
+ * pair data) waits for the whole in-flight patch.  AHEAD = false (only descriptor + halo ids
+ * one patch ahead, 512 threads) spills 79 VGPRs at the 128-register budget and is not
+ * instantiated.  Kept as the starting point for a loader-wave design.
  */
-template <int T, int KO, int KH>
-__global__ void __launch_bounds__(T, 2)
+template <int T, int KO, int KH, bool AHEAD, int WPS>
+__global__ void __launch_bounds__(T, WPS)
 hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
                 const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
@@ -662,7 +668,7 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     }
 
     HQ_PIPE_IDS(D)
-    HQ_PIPE_ISSUE(D)
+    if (AHEAD) HQ_PIPE_ISSUE(D)
     int slot_n = slot + W;
     bool has_n = slot_n < end;
     int pn = 0;
@@ -670,11 +676,17 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     if (has_n) {
         pn = order ? order[slot_n] : slot_n;
         Dn = desc[pn];
-        HQ_PIPE_IDS(Dn)
+        if (AHEAD) HQ_PIPE_IDS(Dn)
     }
 
     for (;;) {
         const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
+        if (!AHEAD) {
+            /* the ids of this patch's halo arrived during the previous patch: one latency
+             * (the data itself) instead of three (descriptor -> ids -> data) */
+            HQ_PIPE_ISSUE(D)
+            if (has_n) HQ_PIPE_IDS(Dn)
+        }
         /* registers -> LDS */
 #pragma unroll
         for (int k = 0; k < KO; k++) {
@@ -695,11 +707,11 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         bool has_nn = has_n && slot_nn < end;
         int pnn = 0;
         hq_patch_desc Dnn = Dn;
-        if (has_n) HQ_PIPE_ISSUE(Dn)
+        if (AHEAD && has_n) HQ_PIPE_ISSUE(Dn)
         if (has_nn) {
             pnn = order ? order[slot_nn] : slot_nn;
             Dnn = desc[pnn];
-            HQ_PIPE_IDS(Dnn)
+            if (AHEAD) HQ_PIPE_IDS(Dnn)
         }
 
         const bool iso = (D.flags & HQ_PATCH_ISO) != 0;
@@ -960,11 +972,10 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
     /* persistent pipelined form: needs every patch to fit its per-thread staging registers */
     static const int pipe = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 0;
-    if (pipe && 3 * P->max_nown <= 256 * 9 && 3 * P->max_nhalo <= 256 * 6) {
-        int wgs = pipe > 1 ? pipe : 2;                      /* workgroups per CU */
-        int grid = 256 * wgs;
+    if (pipe == 1 && 3 * P->max_nown <= 256 * 9 && 3 * P->max_nhalo <= 256 * 6) {
+        int grid = 256 * 2;
         while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
-        hq_k_patch_pipe<256, 9, 6><<<grid, 256, lds, stream>>>(
+        hq_k_patch_pipe<256, 9, 6, true, 2><<<grid, 256, lds, stream>>>(
             count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
             P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
             (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent);
