@@ -50,8 +50,26 @@ def build_host(force=False):
     return HOST_LIB
 
 
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "hq_psolve_mini")
+
+
+def build_example(force=False):
+    """The all-C host program (examples/hq_psolve_mini.c) on the two libraries."""
+    src = os.path.join(ROOT, "examples", "hq_psolve_mini.c")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(EXAMPLE_BIN, [src, SOLVER_LIB, HOST_LIB]):
+        cmd = ["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"), "-o", EXAMPLE_BIN, src,
+               "-L", CSRC, "-lhq_host", "-lhq_solver", "-Wl,-rpath,$ORIGIN/../hercules_amd/csrc",
+               "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+        subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 def build(force=False):
-    return build_solver(force), build_host(force)
+    out = build_solver(force), build_host(force)
+    build_example(force)
+    return out
 
 
 if __name__ == "__main__":

@@ -109,3 +109,78 @@ def test_host_solver_run_with_stations():
     assert H.rel_linf(tm1, o2) < 1e-9
     s.close()
     box.close()
+
+
+def test_all_c_host_program(tmp_path):
+    """examples/hq_psolve_mini.c: a host written entirely in C on the two C-ABI libraries
+    (mesh + solver_init, point source, stations, solver_run, checkpoint) -- its station
+    files and checkpoint against the oracle driven the same way."""
+    import os
+    import subprocess
+    from hercules_amd import build as hbuild
+    exe = hbuild.build_example()
+    nx, ny, nz, h, dt, freq, nsteps = 16, 16, 8, 62.5, 1e-3, 5.0, 300
+    out = subprocess.run([exe, str(nx), str(ny), str(nz), str(h), str(dt), str(freq), str(nsteps), str(tmp_path)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert out.returncode == 0, out.stdout
+    assert "Total elements: 2048" in out.stdout and "steps run: %d" % nsteps in out.stdout
+    # the same problem through the oracle
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    L, Lz = nx * h, nz * h
+    loaded, pattern = box.point_source(L / 2, L / 2, Lz / 5, 0.0, 90.0, 0.0)
+    pts = [(L / 2, L / 2, 0.0), (0.6 * L, 0.6 * L, 0.0), (0.75 * L, 0.75 * L, Lz / 4)]
+    ids, phi, _ = box.stations(pts)
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e15, rise_time=40 * dt)
+    F = box.source_table(rp, 0, nsteps)
+    N = box.info["nharbored"]
+    o1, o2 = np.zeros((N, 3)), np.zeros((N, 3))
+    cap = ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, dt,
+                        loaded_lnid=loaded, forces=F, cap_lnid=ids)
+    st = np.einsum("sn,tsnd->tsd", phi, cap.reshape(nsteps, 3, 8, 3))
+    scale = np.abs(st).max()
+    for s in range(3):
+        rows = [l.split() for l in open(os.path.join(str(tmp_path), "station.%d" % s)).read().splitlines()[1:]]
+        got = np.array([[float(v) for v in r] for r in rows])
+        assert len(got) == nsteps // 10
+        assert np.allclose(got[:, 0], np.arange(0, nsteps, 10) * dt, atol=1e-9)
+        assert np.abs(got[:, 1:] - st[::10, s, :]).max() <= 6e-7 * scale     # "% 8e" text precision
+    b = open(os.path.join(str(tmp_path), "checkpoint.out0"), "rb").read()
+    assert list(np.frombuffer(b[:12], "<i4")) == [1, nsteps, N]
+    tm2 = np.frombuffer(b[12:12 + N * 24], "<f8").reshape(N, 3)
+    tm1 = np.frombuffer(b[12 + N * 24:], "<f8").reshape(N, 3)
+    assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    box.close()
+
+
+def test_eight_partitions_of_the_8m_box_match_one_partition():
+    """BASELINE config 4 in miniature on one GPU: the 8M box cut 8 ways (octor blocks),
+    stepped with the in-process transport and the comm/compute overlap, against the
+    single-partition run."""
+    from hercules_amd import capi
+    nx, ny, nz, h, dt, freq = 256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0
+    nsteps = 4
+    one = host.Box(nx, ny, nz, h, dt, freq)
+    u = _field(one, 31337)
+    ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    gid_one = (one.node_ijk[:, 2].astype(np.int64) * (ny + 1) + one.node_ijk[:, 1]) * (nx + 1) + one.node_ijk[:, 0]
+    lut = np.empty(gid_one.max() + 1, np.int64)
+    lut[gid_one] = np.arange(len(gid_one))
+    one.close()
+    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8) for r in range(8)]
+    solvers, maps = [], []
+    for b in boxes:
+        g = (b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]
+        m = lut[g]
+        maps.append(m)
+        solvers.append(b.create_solver(tm1=u[m], tm2=0.999 * u[m]))
+        assert solvers[-1].info()["variant"] == ha.HQ_VARIANT_PATCH
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    scale = np.abs(ref1).max()
+    for s, m in zip(solvers, maps):
+        tm1, tm2 = s.download()
+        assert np.abs(tm1 - ref1[m]).max() <= 1e-11 * scale
+        assert np.abs(tm2 - ref2[m]).max() <= 1e-11 * scale
+        s.close()
+    for b in boxes:
+        b.close()
