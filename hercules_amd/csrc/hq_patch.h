@@ -602,13 +602,14 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
  * no bytes while both resident workgroups compute).  T = 256 threads: 2 waves per SIMD,
  * 256 registers per lane to hold the in-flight patch.
  *
- * EXPERIMENT (opt-in, HQ_PATCH_PIPE=1), parity-green but 6 % slower than hq_k_patch_step on
- * the 64M box: vmcnt retires in order, so the first use of a younger load (the next round's
- * pair data) waits for the whole in-flight patch.  AHEAD = false (only descriptor + halo ids
- * one patch ahead, 512 threads) spills 79 VGPRs at the 128-register budget and is not
- * instantiated.  Kept as the starting point for a loader-wave design.
+ * EXPERIMENT (opt-in, HQ_PATCH_PIPE=1), parity-green but 12 % slower than hq_k_patch_step on
+ * the 64M box (3.49 vs 3.11 ms): the in-flight patch costs 256 registers per lane = 8 waves
+ * per CU, and at 2 waves per SIMD the element loop loses more than the overlap gains.
+ * AHEAD = false (only descriptor + halo ids one patch ahead, 512 threads) spills 79 VGPRs at
+ * the 128-register budget and is not instantiated.  Kept as the starting point for a
+ * loader-wave design (2 loader + 6 compute waves per 512-thread workgroup).
  */
-template <int T, int KO, int KH, bool AHEAD, int WPS>
+template <int T, int KO, int KH, bool AHEAD, int WPS, int NR>
 __global__ void __launch_bounds__(T, WPS)
 hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
                 const hq_patch_desc* __restrict__ desc,
@@ -702,19 +703,14 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         hq_pair_data mine = cur;
         __syncthreads();
 
-        /* put the next patch in flight, then the ids of the one after it */
-        int slot_nn = slot_n + W;
-        bool has_nn = has_n && slot_nn < end;
-        int pnn = 0;
-        hq_patch_desc Dnn = Dn;
-        if (AHEAD && has_n) HQ_PIPE_ISSUE(Dn)
-        if (has_nn) {
-            pnn = order ? order[slot_nn] : slot_nn;
-            Dnn = desc[pnn];
-            if (AHEAD) HQ_PIPE_IDS(Dnn)
-        }
-
+        /* vmcnt retires in order: everything THIS patch still needs from memory (pair data of
+         * the later rounds, nodal constants) is requested first, the next patch's staging loads
+         * last, so no wait inside the element loop is ordered behind them */
         const bool iso = (D.flags & HQ_PATCH_ISO) != 0;
+        hq_pair_data pr[NR - 1];
+#pragma unroll
+        for (int r = 1; r < NR; r++)
+            if (r * T + tid < D.npairs) pr[r - 1] = hq_pair_load<false>(pidx, pc1, pc2, pbeta, D.pair_off + r * T + tid);
         double np[7];
         if (tid < D.nown) {
             if (iso) {
@@ -728,10 +724,52 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 for (int k = 0; k < 7; k++) np[k] = q[k];
             }
         }
+        int slot_nn = slot_n + W;
+        bool has_nn = has_n && slot_nn < end;
+        int pnn = 0;
+        hq_patch_desc Dnn = Dn;
+        if (AHEAD && has_n) HQ_PIPE_ISSUE(Dn)
+        if (has_nn) {
+            pnn = order ? order[slot_nn] : slot_nn;
+            Dnn = desc[pnn];
+            if (AHEAD) HQ_PIPE_IDS(Dnn)
+        }
 
-        for (int q = tid; q < D.npairs; q += T) {
-            hq_pair_data nxt;
-            if (q + T < D.npairs) nxt = hq_pair_load<false>(pidx, pc1, pc2, pbeta, D.pair_off + q + T);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int q = r * T + tid;
+            if (r > 0) mine = pr[r - 1];
+            if (q < D.npairs) {
+                const uint4 raw = mine.raw;
+                const double beta = mine.beta;
+                int l[8];
+                l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
+                l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
+                l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
+                l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
+                double X[8], Y[8], Z[8];
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const double* a = &s_u1[3 * l[n]];
+                    const double* b = &s_u2[3 * l[n]];
+                    double a0 = a[0], a1_ = a[1], a2_ = a[2];
+                    X[n] = a0 + beta * (a0 - b[0]);
+                    Y[n] = a1_ + beta * (a1_ - b[1]);
+                    Z[n] = a2_ + beta * (a2_ - b[2]);
+                }
+                hq_element_force(X, Y, Z, mine.c1, mine.c2);
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    if (l[n] < D.nacc) {
+                        atomicAdd(&s_f[3 * l[n] + 0], X[n]);
+                        atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
+                        atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
+                    }
+                }
+            }
+        }
+        for (int q = NR * T + tid; q < D.npairs; q += T) {       /* patches with unusually many elements */
+            mine = hq_pair_load<false>(pidx, pc1, pc2, pbeta, D.pair_off + q);
             const uint4 raw = mine.raw;
             const double beta = mine.beta;
             int l[8];
@@ -740,7 +778,6 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
             l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
             l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
             double X[8], Y[8], Z[8];
-#pragma unroll
             for (int n = 0; n < 8; n++) {
                 const double* a = &s_u1[3 * l[n]];
                 const double* b = &s_u2[3 * l[n]];
@@ -750,7 +787,6 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 Z[n] = a2_ + beta * (a2_ - b[2]);
             }
             hq_element_force(X, Y, Z, mine.c1, mine.c2);
-#pragma unroll
             for (int n = 0; n < 8; n++) {
                 if (l[n] < D.nacc) {
                     atomicAdd(&s_f[3 * l[n] + 0], X[n]);
@@ -758,7 +794,6 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                     atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
                 }
             }
-            mine = nxt;
         }
         if (F) {
             for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += T) {
@@ -975,7 +1010,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (pipe == 1 && 3 * P->max_nown <= 256 * 9 && 3 * P->max_nhalo <= 256 * 6) {
         int grid = 256 * 2;
         while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
-        hq_k_patch_pipe<256, 9, 6, true, 2><<<grid, 256, lds, stream>>>(
+        hq_k_patch_pipe<256, 9, 6, true, 2, 3><<<grid, 256, lds, stream>>>(
             count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
             P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
             (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent);
