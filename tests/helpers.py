@@ -61,3 +61,35 @@ def c5_problem():
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
                 N=N, E=E, dt=1e-3, emin=m["emin"], golden=g)
+
+
+def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), hard=(6000.0, 3464.0, 2700.0),
+                   h_fine=31.25, dt=1e-3, freq=5.0):
+    """A layered box meshed on two octree levels, in octor's conventions: the top
+    nz_fine layers of fine elements (nx x ny, edge h) over nz_coarse layers of elements of
+    edge 2h -- the shape the reference's mesher produced for tests/golden/c5_two_level
+    (where this construction is pinned bit-for-bit).  nx, ny, nz_fine even.
+    -> dict like c5_problem()."""
+    assert nx % 2 == 0 and ny % 2 == 0 and nz_fine % 2 == 0
+    corners = np.array([[(c >> 0) & 1, (c >> 1) & 1, (c >> 2) & 1] for c in range(8)], np.int64)
+    fi, fj, fk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz_fine), indexing="ij")
+    fine_ll = np.stack([fi.ravel(), fj.ravel(), fk.ravel()], 1).astype(np.int64)
+    ci, cj, ck = np.meshgrid(np.arange(nx // 2), np.arange(ny // 2), np.arange(nz_coarse), indexing="ij")
+    coarse_ll = np.stack([2 * ci.ravel(), 2 * cj.ravel(), nz_fine + 2 * ck.ravel()], 1).astype(np.int64)
+    ll = np.concatenate([fine_ll, coarse_ll])
+    size = np.concatenate([np.ones(len(fine_ll), np.int64), 2 * np.ones(len(coarse_ll), np.int64)])
+    order = np.argsort(ho.zvalue(ll[:, 0], ll[:, 1], ll[:, 2]), kind="stable")   # octree pre-order
+    ll, size = ll[order], size[order]
+    ticks = ll[:, None, :] + corners[None, :, :] * size[:, None, None]
+    far = (nx, ny, nz_fine + 2 * nz_coarse)
+    m = ho.octree_mesh_from_elem_ticks(ticks, far)
+    E, N = len(m["lnid"]), len(m["node_q"])
+    edata = np.empty((E, 4), np.float32)
+    edata[:, 0] = (h_fine * m["elem_size"]).astype(np.float32)
+    is_fine = m["elem_size"] == 1
+    for col, (a, b) in enumerate(zip(soft, hard)):
+        edata[:, 1 + col] = np.where(is_fine, a, b)
+    etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, dt, freq)
+    ho.compute_adjust(ntable, 0, m["dangling"])
+    return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
+                N=N, E=E, dt=dt, emin=1)

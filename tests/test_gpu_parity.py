@@ -299,3 +299,27 @@ def test_two_level_mesh_with_hanging_nodes_against_reference(variant):
         assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL
         assert H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
     s.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(64, 64, 8, 12), (128, 96, 16, 20)])
+def test_larger_two_level_meshes_against_oracle(variant, shape):
+    """Hanging nodes at non-trivial size (up to ~0.3M elements, 12k dangling nodes): patch
+    cuts across the refinement interface, extra accumulators, in-LDS distribution."""
+    nx, ny, nzf, nzc = shape
+    p = H.two_level_mesh(nx, ny, nzf, nzc, h_fine=10.0, dt=2e-4, freq=20.0)
+    N = p["N"]
+    rng = np.random.default_rng(2024)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    ho.compute_adjust(u1, 1, p["dangling"])            # a consistent state: hanging = mean of anchors
+    ho.compute_adjust(u2, 1, p["dangling"])
+    nsteps = 6
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(p["lnid"], p["etable"], p["ntable"], o1, o2, 0, nsteps, p["dt"], dangling=p["dangling"])
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], tm1=u1, tm2=u2, dangling=p["dangling"],
+                  node_xyz=p["node_q"], variant=variant)
+    s.run(nsteps)
+    tm1, tm2 = s.download()
+    assert H.rel_linf(tm1, o2) < TOL and H.rel_linf(tm2, o1) < TOL
+    s.close()

@@ -183,3 +183,14 @@ def test_two_level_mesh_with_hanging_nodes_bitwise():
     # a hanging node sits at the mean of its anchors after every step (psolve.c:5992-6035)
     k = 17
     assert np.allclose(tm2[ids[k]], tm2[anchors[ptr[k]:ptr[k + 1]]].mean(axis=0), rtol=1e-13, atol=0)
+
+
+def test_two_level_generator_reproduces_the_reference_mesh():
+    """tests/helpers.two_level_mesh (used for larger hanging-node cases) rebuilds exactly
+    the mesh, tables and constants the reference produced for c5_two_level."""
+    ref = H.c5_problem()
+    mine = H.two_level_mesh(32, 32, 4, 6)
+    assert np.array_equal(mine["lnid"], ref["lnid"])
+    assert np.array_equal(mine["etable"], ref["etable"]) and np.array_equal(mine["ntable"], ref["ntable"])
+    for a, b in zip(mine["dangling"], ref["dangling"]):
+        assert np.array_equal(a, b)
