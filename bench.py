@@ -39,10 +39,14 @@ WORKLOADS = {
     "c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
     "c1": (16, 16, 8, 62.5, 1.0e-3, 5.0),
     "m1": (128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0),
+    # two-level octree box (hanging nodes): nx, ny, nz_fine, h_fine, dt, freq  (+ 96 coarse layers)
+    "o1": (512, 512, 64, 1000.0 / 512, 9.0e-5, 200.0),
 }
+OCT_COARSE_LAYERS = {"o1": 96}
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
-                  "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64"}
+                  "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
+                  "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)"}
 
 
 def usable_cores():
@@ -205,8 +209,16 @@ def main():
 
     nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
-    box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
+    octree = args.workload in OCT_COARSE_LAYERS
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+    if octree:
+        if world != 1:
+            raise SystemExit("the two-level workload is single-partition")
+        box = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq)
+        box.info = {"nharbored": box.N, "total_elements": box.E, "lenum": box.E, "total_nodes": box.N}
+        box.node_ijk = box.node_xyz
+    else:
+        box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
     N = box.info["nharbored"]
     # seeded random start: identical on every rank for shared nodes
     # because it is a function of the global node coordinates
@@ -217,6 +229,12 @@ def main():
         x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
         u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
     u2 = u1 * (1.0 - 1e-3)
+    if octree:                                   # hanging nodes start at the mean of their anchors
+        ids, ptr, anc = box.dangling
+        for a in (u1, u2):
+            cnt = np.diff(ptr)
+            sums = np.add.reduceat(a[anc], ptr[:-1], axis=0)
+            a[ids] = sums / cnt[:, None]
     solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2)
     del u1, u2, ijk, gid
     if world > 1:
@@ -224,12 +242,13 @@ def main():
         dist.broadcast_object_list(idbuf, src=0)
         solver.comm_init(idbuf[0])
     L = nx * h
-    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
     total_steps = args.warmup + args.steps
-    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt,
-                        source_window=max(total_steps, 1))
-    if len(loaded):
-        solver.set_source(loaded, box.source_table(rp, 0, total_steps), 0)
+    if not octree:
+        loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+        rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt,
+                            source_window=max(total_steps, 1))
+        if len(loaded):
+            solver.set_source(loaded, box.source_table(rp, 0, total_steps), 0)
     info = solver.info()
     setup_s = time.perf_counter() - t_setup
 

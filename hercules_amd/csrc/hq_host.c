@@ -823,3 +823,232 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
     free(F); free(u); free(disp);
     return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* two-level layered box (hanging nodes)                                    */
+/* ------------------------------------------------------------------------ */
+
+struct hqh_octbox {
+    hqh_octbox_params p;
+    int64_t E, N;
+    int32_t ldnnum;
+    int32_t *lnid, *node_xyz, *dn_id, *dn_ptr, *dn_anchor;
+    double *etable, *ntable;
+};
+
+void hqh_octbox_destroy(hqh_octbox* b)
+{
+    if (!b) return;
+    free(b->lnid); free(b->node_xyz); free(b->dn_id); free(b->dn_ptr); free(b->dn_anchor);
+    free(b->etable); free(b->ntable);
+    free(b);
+}
+
+/* Lysmer dashpot of one element corner from the element's six face bits
+ * (compute_setflag + theIDBoundaryMatrix + compute_setboundary, psolve.c:5629-5804) */
+static int face_dashpot(int face, int corner, int halfspace, float size, float Vp, float Vs, float rho, double out[3])
+{
+    int bits = 0;
+    out[0] = out[1] = out[2] = 0.0;
+    if (!face) return 0;
+    for (int d = 0; d < 3; d++) {
+        int near = (face >> d) & 1, far = (face >> (3 + d)) & 1;
+        int cls = far ? 2 : (near ? 0 : 1);
+        if (d == 2 && halfspace && cls == 0) cls = 1;
+        int cfar = (corner >> d) & 1;
+        if ((cls == 0 && !cfar) || (cls == 2 && cfar)) bits |= 1 << d;
+    }
+    double scale = rho * (size / 2) * (size / 2);
+    int nf = (bits & 1) + ((bits >> 1) & 1) + ((bits >> 2) & 1);
+    for (int d = 0; d < 3; d++) {
+        if (nf == 3) out[d] = (Vp + 2 * Vs) * scale;
+        else if (nf == 2) out[d] = (Vs + ((bits & (1 << d)) ? Vp : Vs)) * scale;
+        else if (nf == 1) out[d] = ((bits & (1 << d)) ? Vp : Vs) * scale;
+    }
+    return 1;
+}
+
+int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
+{
+    if (!p || !out) return HQ_ERR_ARG;
+    *out = NULL;
+    if (p->nx < 2 || p->ny < 2 || p->nz_fine < 2 || p->nz_coarse < 1 || (p->nx & 1) || (p->ny & 1) || (p->nz_fine & 1))
+        return HQ_ERR_ARG;
+    const int32_t nx = p->nx, ny = p->ny, nzf = p->nz_fine, nzt = p->nz_fine + 2 * p->nz_coarse;
+    if (nx > 2047 || ny > 2047 || nzt > 2047 || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
+    if (!b) return HQ_ERR_NOMEM;
+    b->p = *p;
+    int64_t Ef = (int64_t)nx * ny * nzf, Ec = (int64_t)(nx / 2) * (ny / 2) * p->nz_coarse;
+    int64_t E = Ef + Ec;
+    int64_t Nf = (int64_t)(nx + 1) * (ny + 1) * (nzf + 1), Nc = (int64_t)(nx / 2 + 1) * (ny / 2 + 1) * p->nz_coarse;
+    int64_t N = Nf + Nc;
+    if (E > 0x7fffffff / 8 || N > 0x7fffffff / 8) { free(b); return HQ_ERR_ARG; }
+    b->E = E; b->N = N;
+    int64_t G = (int64_t)(nx + 1) * (ny + 1) * (nzt + 1);
+    uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
+    uint64_t* nk = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    int32_t* loc = (int32_t*)malloc(sizeof(int32_t) * (size_t)G);
+    b->lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)E);
+    b->node_xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)N);
+    b->etable = (double*)malloc(sizeof(double) * 4 * (size_t)E);
+    b->ntable = (double*)calloc((size_t)N * 7, sizeof(double));
+    if (!ek || !nk || !loc || !b->lnid || !b->node_xyz || !b->etable || !b->ntable) {
+        free(ek); free(nk); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM;
+    }
+    /* elements: octree pre-order = Z-order of the lower-left corner (fine-edge units) */
+    int64_t t = 0;
+    for (int32_t k = 0; k < nzf; k++)
+        for (int32_t j = 0; j < ny; j++)
+            for (int32_t i = 0; i < nx; i++) ek[t++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    for (int32_t k = nzf; k < nzt; k += 2)
+        for (int32_t j = 0; j < ny; j += 2)
+            for (int32_t i = 0; i < nx; i += 2) ek[t++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    /* nodes: Z-order of the far-boundary-adjusted coordinates (octor.c:6100-6106, 6166) */
+    t = 0;
+    for (int32_t k = 0; k <= nzt; k++) {
+        int step = (k <= nzf) ? 1 : 2;
+        if (k > nzf && ((k - nzf) & 1)) continue;
+        for (int32_t j = 0; j <= ny; j += step)
+            for (int32_t i = 0; i <= nx; i += step) {
+                uint32_t dx = (i == nx) ? (uint32_t)(2 * i - 1) : (uint32_t)(2 * i);
+                uint32_t dy = (j == ny) ? (uint32_t)(2 * j - 1) : (uint32_t)(2 * j);
+                uint32_t dz = (k == nzt) ? (uint32_t)(2 * k - 1) : (uint32_t)(2 * k);
+                nk[t++] = zvalue(dx, dy, dz);
+            }
+    }
+    if (t != N || radix_sort_u64(ek, E, 36) != 0 || radix_sort_u64(nk, N, 36) != 0) {
+        free(ek); free(nk); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM;
+    }
+    memset(loc, 0xff, sizeof(int32_t) * (size_t)G);
+    int32_t ldn = 0;
+    for (int64_t n = 0; n < N; n++) {
+        uint32_t d[3] = { compact3(nk[n]), compact3(nk[n] >> 1), compact3(nk[n] >> 2) };
+        int32_t lim[3] = { nx, ny, nzt }, c[3];
+        for (int q = 0; q < 3; q++) c[q] = (d[q] & 1) ? lim[q] : (int32_t)(d[q] >> 1);
+        for (int q = 0; q < 3; q++) b->node_xyz[3 * n + q] = c[q];
+        loc[((int64_t)c[2] * (ny + 1) + c[1]) * (nx + 1) + c[0]] = (int32_t)n;
+        if (c[2] == nzf && ((c[0] & 1) || (c[1] & 1))) ldn++;       /* fine node that is no coarse vertex */
+    }
+    free(nk);
+    b->ldnnum = ldn;
+    b->dn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ldn ? ldn : 1));
+    b->dn_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ldn + 1));
+    b->dn_anchor = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)(ldn ? ldn : 1));
+    if (!b->dn_id || !b->dn_ptr || !b->dn_anchor) { free(ek); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM; }
+#define HQH_LOC(i, j, k) loc[((int64_t)(k) * (ny + 1) + (j)) * (nx + 1) + (i)]
+    /* dnodeTable in node order; anchors in the order octor's prepending leaves them */
+    {
+        int32_t kdn = 0, na = 0;
+        b->dn_ptr[0] = 0;
+        for (int64_t n = 0; n < N; n++) {
+            const int32_t* c = &b->node_xyz[3 * n];
+            if (c[2] != nzf || !((c[0] & 1) || (c[1] & 1))) continue;
+            b->dn_id[kdn] = (int32_t)n;
+            if ((c[0] & 1) && (c[1] & 1)) {                      /* ZFACE: (+,+) (-,+) (+,-) (-,-) */
+                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1] + 1, nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1] + 1, nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1] - 1, nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1] - 1, nzf);
+            } else if (c[0] & 1) {                               /* XEDGE: +s then -s */
+                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1], nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1], nzf);
+            } else {                                             /* YEDGE */
+                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] + 1, nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] - 1, nzf);
+            }
+            b->dn_ptr[++kdn] = na;
+        }
+    }
+    /* element constants per level (mu_and_lambda + psolve.c:3387-3409, 3436-3437) */
+    double aBase, bBase, dt = p->deltaT, dt2 = dt * dt;
+    rayleigh_base(p->freq, p->damping, &aBase, &bBase);
+    double lc[2][4], la[2], lM[2];
+    float lvp[2], lvs[2] = { p->vs_top, p->vs_bot }, lrho[2] = { p->rho_top, p->rho_bot }, lh[2];
+    lvp[0] = p->vp_top; lvp[1] = p->vp_bot;
+    lh[0] = (float)p->h; lh[1] = (float)(2 * p->h);
+    for (int L = 0; L < 2; L++) {
+        float Vp = lvp[L], Vs = lvs[L], rho = lrho[L], h = lh[L];
+        double mu = rho * Vs * Vs, lambda;
+        if (Vp > (Vs * p->threshold_vpvs)) lambda = rho * Vs * Vs * p->threshold_vpvs * p->threshold_vpvs - 2 * mu;
+        else lambda = rho * Vp * Vp - 2 * mu;
+        if (lambda < 0) {
+            if (Vs < 500) Vp = 2.45 * Vs; else if (Vs < 1200) Vp = 2 * Vs; else Vp = 1.87 * Vs;
+            lambda = rho * Vp * Vp;
+        }
+        if (lambda < 0) { free(ek); free(loc); hqh_octbox_destroy(b); return HQ_ERR_ARG; }
+        lvp[L] = Vp;
+        double zeta = 10 / Vs;
+        if (zeta > p->threshold_damping) zeta = p->threshold_damping;
+        double a = zeta * aBase, bb = zeta * bBase;
+        lc[L][0] = dt2 * h * mu / 9; lc[L][1] = dt2 * h * lambda / 9;
+        lc[L][2] = bb * dt * h * mu / 9; lc[L][3] = bb * dt * h * lambda / 9;
+        la[L] = a;
+        double mass = rho * h * h * h;
+        lM[L] = mass / 8;
+    }
+    /* connectivity, eTable, nTable (the reference's element loop, psolve.c:3360-3473) */
+    for (int64_t e = 0; e < E; e++) {
+        int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+        int L = (k >= nzf) ? 1 : 0, s = L ? 2 : 1;
+        int face = (i == 0) | ((j == 0) << 1) | ((k == 0) << 2) | ((i + s == nx) << 3) | ((j + s == ny) << 4) |
+                   ((k + s == nzt) << 5);
+        for (int q = 0; q < 4; q++) b->etable[4 * e + q] = lc[L][q];
+        double M = lM[L], a = la[L];
+        for (int c = 0; c < 8; c++) {
+            int32_t n = HQH_LOC(i + s * (c & 1), j + s * ((c >> 1) & 1), k + s * ((c >> 2) & 1));
+            b->lnid[8 * e + c] = n;
+            double dash[3];
+            int bnd = face_dashpot(face, c, p->halfspace, lh[L], lvp[L], lvs[L], lrho[L], dash);
+            double* np = &b->ntable[7 * (int64_t)n];
+            np[0] += M;
+            for (int ax = 0; ax < 3; ax++) {
+                np[4 + ax] -= (dt * a * M);
+                np[1 + ax] -= (dt * a * M);
+                if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
+                np[4 + ax] += M;
+                np[1 + ax] += (M * 2);
+            }
+        }
+    }
+#undef HQH_LOC
+    free(ek); free(loc);
+    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors */
+    for (int32_t k = 0; k < b->ldnnum; k++) {
+        double part[7];
+        uint32_t deps = (uint32_t)(b->dn_ptr[k + 1] - b->dn_ptr[k]);
+        for (int q = 0; q < 7; q++) part[q] = b->ntable[7 * (int64_t)b->dn_id[k] + q] / deps;
+        for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
+            for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
+    }
+    *out = b;
+    return HQ_OK;
+}
+
+int hqh_octbox_desc(const hqh_octbox* b, hq_desc* d)
+{
+    if (!b || !d) return HQ_ERR_ARG;
+    memset(d, 0, sizeof *d);
+    d->lenum = (int32_t)b->E; d->nharbored = (int32_t)b->N; d->ldnnum = b->ldnnum;
+    d->lnid = b->lnid; d->node_xyz = b->node_xyz;
+    d->dn_ldnid = b->dn_id; d->dn_ptr = b->dn_ptr; d->dn_lanid = b->dn_anchor;
+    d->eTable = b->etable; d->nTable = b->ntable;
+    d->deltaT = b->p.deltaT; d->rank = 0; d->nranks = 1;
+    d->variant = HQ_VARIANT_AUTO;
+    return HQ_OK;
+}
+
+const void* hqh_octbox_view(const hqh_octbox* b, int32_t which, int64_t* count)
+{
+    if (!b || !count) return NULL;
+    switch (which) {
+    case 0: *count = b->E * 8; return b->lnid;
+    case 1: *count = b->N * 3; return b->node_xyz;
+    case 2: *count = b->ldnnum; return b->dn_id;
+    case 3: *count = (int64_t)b->ldnnum + 1; return b->dn_ptr;
+    case 4: *count = b->dn_ptr[b->ldnnum]; return b->dn_anchor;
+    case 5: *count = b->E * 4; return b->etable;
+    case 6: *count = b->N * 7; return b->ntable;
+    }
+    return NULL;
+}

@@ -15,7 +15,8 @@ EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_des
            "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner",
            "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
-           "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format"]
+           "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format",
+           "hqh_octbox_create", "hqh_octbox_destroy", "hqh_octbox_desc", "hqh_octbox_view"]
 
 
 class _BoxParams(ctypes.Structure):
@@ -211,6 +212,76 @@ class Box:
     def solver_run(self, solver, rp, step0, nsteps):
         capi._check(self._lib.hqh_solver_run(solver._h, self._h, ctypes.byref(rp), ctypes.c_int32(step0),
                                              ctypes.c_int32(nsteps)))
+
+
+class _OctParams(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nz_fine", ctypes.c_int32),
+                ("nz_coarse", ctypes.c_int32), ("h", ctypes.c_double),
+                ("vp_top", ctypes.c_float), ("vs_top", ctypes.c_float), ("rho_top", ctypes.c_float),
+                ("vp_bot", ctypes.c_float), ("vs_bot", ctypes.c_float), ("rho_bot", ctypes.c_float),
+                ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
+                ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
+                ("halfspace", ctypes.c_int32)]
+
+
+class OctBox:
+    """Two-level layered box with hanging nodes (hqh_octbox)."""
+
+    def __init__(self, nx, ny, nz_fine, nz_coarse, h, dt, freq, top=(3000.0, 1732.0, 2200.0),
+                 bottom=(6000.0, 3464.0, 2700.0), damping="rayleigh", threshold_damping=0.05,
+                 threshold_vpvs=3.0, halfspace=True):
+        lib = load_library()
+        lib.hqh_octbox_view.restype = ctypes.c_void_p
+        lib.hqh_octbox_view.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
+        lib.hqh_octbox_destroy.restype = None
+        lib.hqh_octbox_destroy.argtypes = [ctypes.c_void_p]
+        p = _OctParams(nx, ny, nz_fine, nz_coarse, h, top[0], top[1], top[2], bottom[0], bottom[1], bottom[2],
+                       dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace))
+        self._h = ctypes.c_void_p()
+        rc = lib.hqh_octbox_create(ctypes.byref(p), ctypes.byref(self._h))
+        if rc != 0:
+            raise capi.HqError("hqh_octbox_create failed: %d" % rc)
+        self._lib = lib
+        self.dt = dt
+
+        def view(which, dtype, cols):
+            n = ctypes.c_int64()
+            ptr = lib.hqh_octbox_view(self._h, which, ctypes.byref(n))
+            a = _view(ptr, (n.value,), dtype)
+            return a.reshape(-1, cols) if cols > 1 else a
+        self.lnid = view(0, np.int32, 8)
+        self.node_xyz = view(1, np.int32, 3)
+        self.dangling = (view(2, np.int32, 1), view(3, np.int32, 1), view(4, np.int32, 1))
+        self.etable = view(5, np.float64, 4)
+        self.ntable = view(6, np.float64, 7)
+        self.E, self.N, self.ldnnum = len(self.lnid), len(self.node_xyz), len(self.dangling[0])
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lnid = self.node_xyz = self.dangling = self.etable = self.ntable = None
+            self._lib.hqh_octbox_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
+        d = capi._Desc()
+        rc = self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
+        d.variant = variant
+        keep = []
+        for name, a in (("tm1", tm1), ("tm2", tm2)):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64)
+                keep.append(a)
+                setattr(d, name, a.ctypes.data)
+        s = capi.Solver.__new__(capi.Solver)
+        s._lib = capi.load_library()
+        s._h = ctypes.c_void_p()
+        s.N, s.E = d.nharbored, d.lenum
+        capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        return s
 
 
 def forcefile_info(path):

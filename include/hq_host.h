@@ -147,6 +147,37 @@ HQ_API int hqh_checkpoint_read(hq_ctx* ctx, const char* path, int32_t rank, int3
 /* One station line in the reference's text format (psolve.c:6727-6731). */
 HQ_API int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3]);
 
+/*
+ * Two-level layered box: the top nz_fine layers of elements of edge h over nz_coarse
+ * layers of elements of edge 2h -- what the reference's Vs rule (quake_util.c:215-225)
+ * makes of a soft layer over a stiff half-space; a 2:1 interface whose fine nodes that are
+ * not coarse vertices are hanging nodes (octor node_setproperty, octor.c:3280-3860).
+ * One partition.  Produces octor's tables: elements in octree pre-order, nodes in Z-order,
+ * dnodeTable with anchors in octor's list order (octor.c:6493-6612), eTable, and nTable
+ * after the hanging-node mass distribution (psolve.c:3498-3507).
+ */
+typedef struct hqh_octbox hqh_octbox;
+
+typedef struct {
+    int32_t nx, ny;              /* fine elements per horizontal axis (even)            */
+    int32_t nz_fine;             /* fine layers on top (even)                           */
+    int32_t nz_coarse;           /* layers of edge 2h below                             */
+    double  h;                   /* fine edge, metres                                   */
+    float   vp_top, vs_top, rho_top;
+    float   vp_bot, vs_bot, rho_bot;
+    double  deltaT, freq;
+    int32_t damping;
+    double  threshold_damping, threshold_vpvs;
+    int32_t halfspace;
+} hqh_octbox_params;
+
+HQ_API int  hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out);
+HQ_API void hqh_octbox_destroy(hqh_octbox* box);
+HQ_API int  hqh_octbox_desc(const hqh_octbox* box, hq_desc* desc);
+/* views: which = 0 lnid [E][8], 1 node_xyz [N][3] (fine-edge units), 2 dn_ldnid, 3 dn_ptr,
+ * 4 dn_lanid (int32); 5 eTable [E][4], 6 nTable [N][7] (double).  *count = entries. */
+HQ_API const void* hqh_octbox_view(const hqh_octbox* box, int32_t which, int64_t* count);
+
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);
 

@@ -184,3 +184,28 @@ def test_eight_partitions_of_the_8m_box_match_one_partition():
         s.close()
     for b in boxes:
         b.close()
+
+
+def test_large_two_level_box_variants_agree():
+    """A 6M-element two-level octree box from the C host (131k hanging nodes): the fused
+    patch kernel (hanging-node accumulators + in-LDS distribution) against the scatter
+    kernels + compute_adjust kernels, two independent implementations."""
+    ob = host.OctBox(256, 256, 32, 48, 1000.0 / 256, 1.8e-4, 100.0)
+    assert ob.ldnnum == 257 * 257 - 129 * 129
+    rng = np.random.default_rng(5)
+    u1 = rng.uniform(-1, 1, (ob.N, 3)) * 1e-3
+    u2 = u1 * 0.999
+    ho.compute_adjust(u1, 1, ob.dangling)
+    ho.compute_adjust(u2, 1, ob.dangling)
+    res = []
+    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
+        s = ob.create_solver(variant=variant, tm1=u1, tm2=u2)
+        assert s.info()["variant"] == variant
+        s.run(5)
+        res.append(s.download())
+        s.close()
+    scale = np.abs(res[0][0]).max()
+    assert np.isfinite(scale) and scale > 0
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-11 * scale
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-11 * scale
+    ob.close()

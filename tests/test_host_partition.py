@@ -171,3 +171,25 @@ def test_station_line_format_matches_reference_text():
     """psolve.c:6729-6731 prints "\\n%10.6f % 8e % 8e % 8e"."""
     line = host.station_format(0.002, [-1.234661e-02, -1.234661e-02, 7.560121e-19])
     assert line == "\n  0.002000 -1.234661e-02 -1.234661e-02  7.560121e-19"
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 4, 6), (8, 12, 2, 1), (16, 8, 6, 3)])
+def test_two_level_box_of_the_c_host_is_octors(shape):
+    """hqh_octbox_create (C host) against tests/helpers.two_level_mesh, the construction
+    pinned bit-for-bit to the mesh the REAL reference generated (c5_two_level): element
+    order, node order, hanging-node table with anchor order, eTable, nTable incl. the mass
+    distribution -- all bitwise."""
+    nx, ny, nzf, nzc = shape
+    ob = host.OctBox(nx, ny, nzf, nzc, 31.25, 1e-3, 5.0)
+    ref = H.two_level_mesh(nx, ny, nzf, nzc)
+    assert ob.E == ref["E"] and ob.N == ref["N"]
+    assert np.array_equal(ob.lnid, ref["lnid"])
+    assert np.array_equal(ob.node_xyz, ref["node_q"])
+    for a, b in zip(ob.dangling, ref["dangling"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ob.etable, ref["etable"])
+    assert np.array_equal(ob.ntable, ref["ntable"])
+    if shape == (32, 32, 4, 6):
+        real = H.c5_problem()
+        assert np.array_equal(ob.lnid, real["lnid"]) and np.array_equal(ob.ntable, real["ntable"])
+    ob.close()
