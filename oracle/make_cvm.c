@@ -13,6 +13,7 @@
  * soft.
  *
  * usage: make_cvm out.e nsoft Vp_soft Vs_soft rho_soft Vp Vs rho
+ *    or: make_cvm out.e layers n  k0 Vp Vs rho  k1 Vp Vs rho ...   (layer i starts at octant layer k_i)
  */
 #include <fcntl.h>
 #include <stdio.h>
@@ -31,10 +32,25 @@ static unsigned compact3(unsigned long long v, int shift)
 
 int main(int argc, char** argv)
 {
-    if (argc != 9) { fprintf(stderr, "usage: %s out.e nsoft Vp_s Vs_s rho_s Vp Vs rho\n", argv[0]); return 2; }
-    int nsoft = atoi(argv[2]);
-    cvmpayload_t soft = { (float)atof(argv[3]), (float)atof(argv[4]), (float)atof(argv[5]) };
-    cvmpayload_t hard = { (float)atof(argv[6]), (float)atof(argv[7]), (float)atof(argv[8]) };
+    int nlay = 0, kstart[8];
+    cvmpayload_t lay[8];
+    if (argc >= 4 && strcmp(argv[2], "layers") == 0) {
+        nlay = atoi(argv[3]);
+        if (nlay < 1 || nlay > 8 || argc != 4 + 4 * nlay) { fprintf(stderr, "bad layer list\n"); return 2; }
+        for (int l = 0; l < nlay; l++) {
+            kstart[l] = atoi(argv[4 + 4 * l]);
+            lay[l].Vp = (float)atof(argv[5 + 4 * l]); lay[l].Vs = (float)atof(argv[6 + 4 * l]);
+            lay[l].rho = (float)atof(argv[7 + 4 * l]);
+        }
+    } else if (argc == 9) {
+        nlay = 2;
+        kstart[0] = 0; kstart[1] = atoi(argv[2]);
+        lay[0].Vp = (float)atof(argv[3]); lay[0].Vs = (float)atof(argv[4]); lay[0].rho = (float)atof(argv[5]);
+        lay[1].Vp = (float)atof(argv[6]); lay[1].Vs = (float)atof(argv[7]); lay[1].rho = (float)atof(argv[8]);
+    } else {
+        fprintf(stderr, "usage: %s out.e nsoft Vp_s Vs_s rho_s Vp Vs rho | out.e layers n k Vp Vs rho ...\n", argv[0]);
+        return 2;
+    }
     const int level = 4, nx = 16, ny = 16, nz = 8;
     const etree_tick_t edge = (etree_tick_t)1 << (31 - level);
 
@@ -53,7 +69,9 @@ int main(int argc, char** argv)
         a.x = i * edge; a.y = j * edge; a.z = k * edge;
         a.level = level;
         a.type = ETREE_LEAF;
-        if (etree_append(ep, a, (int)k < nsoft ? &soft : &hard) != 0) {
+        int L = 0;
+        for (int l = 0; l < nlay; l++) if ((int)k >= kstart[l]) L = l;
+        if (etree_append(ep, a, &lay[L]) != 0) {
             fprintf(stderr, "append: %s\n", etree_strerror(etree_errno(ep))); return 1;
         }
     }

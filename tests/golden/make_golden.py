@@ -247,8 +247,20 @@ def case_np8():
 def case_two_level():
     """Soft top layer (2 octant layers = 125 m, Vs 1732) over the stiff half-space: the
     reference's Vs rule refines the top one level deeper -> 2:1 interface with hanging nodes."""
-    run, out = run_reference("c5_two_level", "1.0", 400, cvm_args=[2, 3000, 1732, 2200, 6000, 3464, 2700],
-                             vscut=500)
+    _octree_case("c5_two_level", "1.0", 400, [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0)
+
+
+def case_three_level():
+    """Three materials chosen to take every branch of mu_and_lambda / the damping threshold
+    (psolve.c:3236-3272, 3397-3401): a very soft layer (Vp/Vs = 10 > cap 3, zeta capped), a
+    layer with Vp^2 < 2 Vs^2 (negative lambda -> Vp rewritten) and the stiff half-space; at
+    f = 0.25 Hz the Vs rule leaves elements of 62.5, 125 and 250 m: a three-level octree."""
+    _octree_case("c5_three_level", "0.4", 100,
+                 ["layers", 3, 0, 1500, 150, 1800, 2, 2500, 2000, 2300, 4, 6000, 3464, 2700], 100, 0.25)
+
+
+def _octree_case(name, end_time, ckpt_rate, cvm_args, vscut, freq):
+    run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq)
     ids, F = read_forces(run)
     elem_ticks, mat = read_mesh(run)
     ck = {}
@@ -258,16 +270,16 @@ def case_two_level():
     st = read_stations(run)
     counts = {k: int(re.search(k + r":\s+(\d+)", out).group(1))
               for k in ("Total elements", "Total nodes", "Total dangling nodes")}
-    np.savez_compressed(os.path.join(HERE, "c5_two_level.npz"),
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
                         elem_ticks=elem_ticks, mat_vs_vp_rho=mat, loaded_lnid=ids, forces=F,
                         ckpt_steps=np.array(sorted(ck)),
                         ckpt_tm2=np.stack([ck[s][0] for s in sorted(ck)]),
                         ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
-                        stations=st, dt=1e-3, end_time=1.0, freq=5.0,
+                        stations=st, dt=1e-3, end_time=float(end_time), freq=freq,
                         total_elements=counts["Total elements"], total_nodes=counts["Total nodes"],
                         total_dangling=counts["Total dangling nodes"])
     shutil.rmtree(run)
-    print("c5_two_level ok", counts, sorted(ck))
+    print(name, "ok", counts, sorted(ck))
 
 
 CASES = {
@@ -278,6 +290,7 @@ CASES = {
     "c1_full": case_full,
     "c1_np8": case_np8,
     "c5_two_level": case_two_level,
+    "c5_three_level": case_three_level,
 }
 
 if __name__ == "__main__":

@@ -45,11 +45,12 @@ def rel_linf(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300))
 
 
-def c5_problem():
-    """The reference's two-level mesh (soft layer refined one level deeper, 800 hanging
-    nodes) rebuilt from its flat dump, with eTable / nTable as solver_init leaves them
-    (incl. the hanging-node mass distribution, psolve.c:3498-3507)."""
-    g = load("c5_two_level")
+def c5_problem(name="c5_two_level"):
+    """One of the reference's own octree meshes (c5_two_level: soft layer refined one level
+    deeper, 800 hanging nodes; c5_three_level: three element sizes and three materials that
+    take every branch of mu_and_lambda) rebuilt from its flat dump, with eTable / nTable as
+    solver_init leaves them (incl. the hanging-node mass distribution, psolve.c:3498-3507)."""
+    g = load(name)
     m = ho.octree_mesh_from_elem_ticks(g["elem_ticks"], C1_FAR_TICKS)
     E, N = len(m["lnid"]), len(m["node_q"])
     mat = g["mat_vs_vp_rho"]
@@ -57,10 +58,10 @@ def c5_problem():
     edata = np.empty((E, 4), np.float32)
     edata[:, 0] = (tick * m["emin"] * m["elem_size"].astype(np.float64)).astype(np.float32)
     edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
-    etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, 1e-3, 5.0)
+    etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, 1e-3, float(g["freq"]))
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
-                N=N, E=E, dt=1e-3, emin=m["emin"], golden=g)
+                N=N, E=E, dt=1e-3, emin=m["emin"], golden=g, elem_size=m["elem_size"])
 
 
 def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), hard=(6000.0, 3464.0, 2700.0),

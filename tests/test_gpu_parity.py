@@ -279,13 +279,14 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     s.close(); s2.close(); box.close()
 
 
+@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level"])
 @pytest.mark.parametrize("variant", VARIANTS + [ha.HQ_VARIANT_AUTO])
-def test_two_level_mesh_with_hanging_nodes_against_reference(variant):
+def test_two_level_mesh_with_hanging_nodes_against_reference(variant, mesh):
     """compute_adjust on the reference's own two-level mesh (800 hanging nodes): scatter
     kernels + adjust kernels, and the patch kernel (hanging-node forces accumulated by the
     patches that own their anchors, assignment kernel after), against the checkpoints the
-    real reference wrote."""
-    p = H.c5_problem()
+    real reference wrote (also its three-level, three-material mesh)."""
+    p = H.c5_problem(mesh)
     g = p["golden"]
     s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"], variant=variant,
                   node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32))

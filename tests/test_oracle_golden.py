@@ -194,3 +194,24 @@ def test_two_level_generator_reproduces_the_reference_mesh():
     assert np.array_equal(mine["etable"], ref["etable"]) and np.array_equal(mine["ntable"], ref["ntable"])
     for a, b in zip(mine["dangling"], ref["dangling"]):
         assert np.array_equal(a, b)
+
+
+def test_three_level_mesh_all_material_branches_bitwise():
+    """The reference on a three-material model that takes every branch of mu_and_lambda
+    (Vp/Vs cap; negative lambda -> Vp rewritten) and the damping threshold, meshed by its own
+    Vs rule on THREE octree levels (592 elements, 264 hanging nodes): bit-identical."""
+    p = H.c5_problem("c5_three_level")
+    g = p["golden"]
+    assert p["E"] == int(g["total_elements"]) == 592 and p["N"] == int(g["total_nodes"]) == 973
+    assert len(p["dangling"][0]) == int(g["total_dangling"]) == 264
+    assert sorted(set(p["elem_size"].tolist())) == [1, 2, 4]
+    mats = {tuple(m) for m in g["mat_vs_vp_rho"].tolist()}
+    assert (150.0, 1500.0, 1800.0) in mats and (2000.0, 2500.0, 2300.0) in mats
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"], dangling=p["dangling"])
+        done = int(step)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k]) and np.array_equal(tm2, g["ckpt_tm1"][k])
+    assert np.abs(tm2).max() > 10.0
