@@ -267,3 +267,143 @@ def station_weights(points_m, h, nx, ny, nz, lnid, elem_ijk):
         ids.append(lnid[e])
         phis.append(phi)
     return np.array(ids, np.int32), np.array(phis)
+
+
+# ---------------------------------------------------------------------------
+# octor's multi-rank tables for an octree mesh, from the global view
+# ---------------------------------------------------------------------------
+
+def octree_partition(m, nranks, far_q):
+    """Restates what octor_extractmesh leaves on every rank for the mesh `m`
+    (octree_mesh_from_elem_ticks) cut into `nranks` blocks:
+
+      elements : contiguous blocks of the pre-ordered leaves (BLOCK_LOW/HIGH, octor.c:4939-4944)
+      owner    : rank of the leaf that contains the far-boundary-adjusted node (octor.c:5466-5475)
+      harbored : vertices of the rank's elements + the nodes it owns (direct sharing,
+                 octor.c:5516-5793) + the anchors of the hanging nodes it owns (indirect
+                 sharing, node_harboranchored octor.c:3916-4042, :5795-6040); Z-ordered
+      sharers  : ranks that have an owned node as element vertex, or harbor it as an anchor
+      dnodeTable: the hanging nodes the rank OWNS, anchors as local ids
+      an_sched / dn_sched: schedule_build (psolve.c:4704-4863); messengers by ascending rank
+
+    -> list of per-rank dicts."""
+    lnid, node_q, elem_q, size = m["lnid"], m["node_q"], m["elem_q"], m["elem_size"]
+    E, N = len(lnid), len(node_q)
+    dn_ids, dn_ptr, dn_anc = m["dangling"]
+    dn_of = np.full(N, -1)
+    dn_of[dn_ids] = np.arange(len(dn_ids))
+    erank = ((np.arange(E, dtype=np.int64) + 1) * nranks - 1) // E
+    # leaf containing each fine cell
+    cell = np.full((far_q[0], far_q[1], far_q[2]), -1, np.int64)
+    for e in range(E):
+        i, j, k = (int(v) for v in elem_q[e])
+        s = int(size[e])
+        cell[i:i + s, j:j + s, k:k + s] = e
+    adj = np.minimum(node_q, np.array(far_q) - 1)
+    owner = erank[cell[adj[:, 0], adj[:, 1], adj[:, 2]]]
+    verts = [set(lnid[erank == r].reshape(-1).tolist()) for r in range(nranks)]
+    out = []
+    harbored = []
+    for r in range(nranks):
+        h = set(verts[r]) | set(np.nonzero(owner == r)[0].tolist())
+        for k in np.nonzero(owner[dn_ids] == r)[0]:
+            h |= set(dn_anc[dn_ptr[k]:dn_ptr[k + 1]].tolist())
+        harbored.append(h)
+    for r in range(nranks):
+        nodes = np.array(sorted(harbored[r]), np.int64)              # global ids are already Z-ordered
+        loc = {int(g): i for i, g in enumerate(nodes)}
+        e_ids = np.nonzero(erank == r)[0]
+        l_lnid = np.array([[loc[int(g)] for g in lnid[e]] for e in e_ids], np.int32).reshape(-1, 8)
+        own = owner[nodes]
+        # hanging nodes owned here, in local order
+        d_loc, d_ptr, d_anc = [], [0], []
+        for i, g in enumerate(nodes):
+            k = dn_of[g]
+            if k >= 0 and own[i] == r:
+                d_loc.append(i)
+                d_anc += [loc[int(a)] for a in dn_anc[dn_ptr[k]:dn_ptr[k + 1]]]
+                d_ptr.append(len(d_anc))
+        # schedules
+        sched = {"an": {"c": {}, "s": {}}, "dn": {"c": {}, "s": {}}}
+        for i, g in enumerate(nodes):
+            kind = "dn" if dn_of[g] >= 0 else "an"
+            if own[i] != r:
+                sched[kind]["c"].setdefault(int(own[i]), []).append(i)
+            else:
+                for q in range(nranks):
+                    if q != r and int(g) in harbored[q]:
+                        sched[kind]["s"].setdefault(q, []).append(i)
+        pack = lambda d: [(q, np.array(v, np.int32)) for q, v in sorted(d.items())]
+        out.append(dict(rank=r, elems=e_ids, nodes=nodes, owner=own.astype(np.int32), lnid=l_lnid,
+                        dangling=(np.array(d_loc, np.int32), np.array(d_ptr, np.int32), np.array(d_anc, np.int32)),
+                        an_sched={k: pack(v) for k, v in sched["an"].items()},
+                        dn_sched={k: pack(v) for k, v in sched["dn"].items()},
+                        is_dangling=(dn_of[nodes] >= 0)))
+    return out
+
+
+def _exchange_sim(parts, tables, kind, contribution):
+    """schedule_senddata (psolve.c:4945-5079) between in-memory ranks."""
+    msgs = {}
+    for p in parts:
+        for q, mapping in p[kind]["c" if contribution else "s"]:
+            msgs[(p["rank"], q)] = tables[p["rank"]][mapping].copy()
+    for p in parts:
+        for q, mapping in p[kind]["s" if contribution else "c"]:
+            rec = msgs[(q, p["rank"])]
+            if contribution:
+                np.add.at(tables[p["rank"]], mapping, rec)
+            else:
+                tables[p["rank"]][mapping] = rec
+
+
+def multi_rank_init(parts, edata_by_rank, face_by_rank, dt, freq, **kw):
+    """solver_init on every rank incl. the three-stage mass exchange (psolve.c:3498-3507)."""
+    ets, nts = [], []
+    for p, ed, fc in zip(parts, edata_by_rank, face_by_rank):
+        et, nt = solver_init(p["lnid"], ed, fc, len(p["nodes"]), dt, freq, **kw)
+        ets.append(et)
+        nts.append(nt)
+    _exchange_sim(parts, nts, "dn_sched", True)
+    for p, nt in zip(parts, nts):
+        if len(p["dangling"][0]):
+            compute_adjust(nt, 0, p["dangling"])
+    _exchange_sim(parts, nts, "an_sched", True)
+    return ets, nts
+
+
+def multi_rank_run(parts, ets, nts, tm1s, tm2s, step0, nsteps, dt, loaded, forces):
+    """solver_run (psolve.c:4265-4319) for all ranks in lockstep; tm1s/tm2s are the
+    reference's pre-swap arrays per rank, updated in place."""
+    L = lib()
+    K1, K2 = compute_K()
+    c64 = ctypes.c_int64
+    frc = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    a = [t for t in tm1s]
+    b = [t for t in tm2s]
+    for step in range(step0, step0 + nsteps):
+        a, b = b, a                                            # psolve.c:4271-4273
+        for p, et, u1, u2, f, ld, F in zip(parts, ets, a, b, frc, loaded, forces):
+            if len(ld) and step < len(F):
+                L.ho_addforce_source(ctypes.c_int32(len(ld)), _p(_c(ld, np.int32)), _p(np.ascontiguousarray(F[step])),
+                                     ctypes.c_double(dt * dt), _p(f))
+            n_e = len(p["lnid"])
+            L.ho_addforce_effective(c64(n_e), _p(p["lnid"]), _p(et), _p(u1), _p(f), 1)
+            L.ho_damping_addforce(c64(n_e), _p(p["lnid"]), _p(et), _p(u1), _p(u2), _p(K1), _p(K2), _p(f), 1)
+        _exchange_sim(parts, frc, "dn_sched", True)             # :4298
+        for p, f in zip(parts, frc):                            # :4299
+            if len(p["dangling"][0]):
+                compute_adjust(f, 0, p["dangling"])
+        _exchange_sim(parts, frc, "an_sched", True)             # :4301
+        for p, nt, u1, u2, f in zip(parts, nts, a, b, frc):     # :4305
+            L.ho_compute_displacement(c64(len(p["nodes"])), _p(nt), _p(u1), _p(u2), _p(f), None)
+        _exchange_sim(parts, b, "an_sched", False)              # :4312
+        for p, u2 in zip(parts, b):                             # :4313
+            if len(p["dangling"][0]):
+                compute_adjust(u2, 1, p["dangling"])
+        _exchange_sim(parts, b, "dn_sched", False)              # :4315
+    if nsteps % 2:                                              # keep the callers' arrays in their roles
+        for t1, t2 in zip(tm1s, tm2s):
+            tmp = t1.copy()
+            t1[:] = t2
+            t2[:] = tmp

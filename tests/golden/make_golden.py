@@ -259,6 +259,37 @@ def case_three_level():
                  ["layers", 3, 0, 1500, 150, 1800, 2, 2500, 2000, 2300, 4, 6000, 3464, 2700], 100, 0.25)
 
 
+def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq):
+    """The same octree models on `nranks` MPI ranks: per-rank element dumps, force files and
+    checkpoint stripes pin octor's multi-rank tables (block partition, ownership by containing
+    leaf, direct + indirect sharing octor.c:5516-6040, dnodeTable of owned hanging nodes)."""
+    run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq, nranks=nranks)
+    # A rank's stripe holds nharbored (not nharboredmax) records per field, so the raw stripes
+    # are kept and parsed by whoever knows each rank's nharbored (io_checkpoint.c:93-118).
+    ckfiles = {}
+    nmax = 0
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        b = open(os.path.join(run, "out", "checkpoints", f), "rb").read()
+        groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+        ckfiles[step] = [np.frombuffer(b[12 + 2 * r * nmax * 24: 12 + 2 * (r + 1) * nmax * 24], "<f8").copy()
+                         for r in range(groupsize)]
+    arrays = {"nharboredmax": nmax}
+    for r in range(nranks):
+        et, _ = read_mesh(run, r)
+        ids, F = read_forces(run, r)
+        arrays["elem_ticks_%d" % r] = et
+        arrays["loaded_lnid_%d" % r] = ids
+        arrays["forces_%d" % r] = F
+        for s_ in sorted(ckfiles):
+            arrays["ckpt%d_stripe_%d" % (s_, r)] = ckfiles[s_][r]
+    meshstat = open(os.path.join(run, "stat-mesh.txt")).read() if os.path.exists(os.path.join(run, "stat-mesh.txt")) else ""
+    sched = open(os.path.join(run, "stat-sched.txt")).read() if os.path.exists(os.path.join(run, "stat-sched.txt")) else ""
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), ckpt_steps=np.array(sorted(ckfiles)), nranks=nranks,
+                        base=np.array(base), stat_mesh=np.array(meshstat), stat_sched=np.array(sched), **arrays)
+    shutil.rmtree(run)
+    print(name, "ok", sorted(ckfiles))
+
+
 def _octree_case(name, end_time, ckpt_rate, cvm_args, vscut, freq):
     run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq)
     ids, F = read_forces(run)
@@ -291,6 +322,11 @@ CASES = {
     "c1_np8": case_np8,
     "c5_two_level": case_two_level,
     "c5_three_level": case_three_level,
+    "c5_two_level_np8": lambda: case_octree_np("c5_two_level_np8", "c5_two_level", 8, "0.5", 200,
+                                               [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
+    "c5_three_level_np5": lambda: case_octree_np("c5_three_level_np5", "c5_three_level", 5, "0.4", 100,
+                                                 ["layers", 3, 0, 1500, 150, 1800, 2, 2500, 2000, 2300, 4, 6000, 3464, 2700],
+                                                 100, 0.25),
 }
 
 if __name__ == "__main__":

@@ -94,3 +94,32 @@ def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), ha
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
                 N=N, E=E, dt=dt, emin=1)
+
+
+def c5_np8_problem():
+    """The reference's two-level octree mesh on 8 MPI ranks: octor's per-rank tables restated
+    from the global view (ho.octree_partition), per-rank eTable / nTable after the mass
+    exchange, the reference's per-rank force files and checkpoint stripes."""
+    g = load("c5_two_level_np8")
+    base = load("c5_two_level")
+    m = ho.octree_mesh_from_elem_ticks(base["elem_ticks"], C1_FAR_TICKS)
+    far_q = [f // m["emin"] for f in C1_FAR_TICKS]
+    parts = ho.octree_partition(m, 8, far_q)
+    mat = base["mat_vs_vp_rho"]
+    tick = 1000.0 / 2 ** 30
+    E = len(m["lnid"])
+    edata = np.empty((E, 4), np.float32)
+    edata[:, 0] = (tick * m["emin"] * m["elem_size"].astype(np.float64)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    eds = [np.ascontiguousarray(edata[p["elems"]]) for p in parts]
+    fcs = [np.ascontiguousarray(m["face"][p["elems"]]) for p in parts]
+    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, 5.0)
+    return dict(golden=g, base=base, mesh=m, parts=parts, ets=ets, nts=nts, dt=1e-3,
+                loaded=[g["loaded_lnid_%d" % r] for r in range(8)],
+                forces=[g["forces_%d" % r] for r in range(8)])
+
+
+def np8_stripe(g, step, rank, n):
+    """(tm2, tm1) of one rank from its raw checkpoint stripe (io_checkpoint.c:93-118)."""
+    s = g["ckpt%d_stripe_%d" % (int(step), rank)]
+    return s[:3 * n].reshape(n, 3), s[3 * n:6 * n].reshape(n, 3)

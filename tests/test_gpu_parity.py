@@ -324,3 +324,33 @@ def test_larger_two_level_meshes_against_oracle(variant, shape):
     tm1, tm2 = s.download()
     assert H.rel_linf(tm1, o2) < TOL and H.rel_linf(tm2, o1) < TOL
     s.close()
+
+
+def test_octree_mesh_on_eight_partitions_against_reference():
+    """The reference's 8-rank run of its two-level mesh: hanging nodes shared between
+    ranks (dn_sched), anchors harbored indirectly, the four exchanges of a step and both
+    compute_adjust passes -- eight contexts stepped in one process on one GPU against the
+    reference's per-rank checkpoint stripes."""
+    from hercules_amd import capi
+    pr = H.c5_np8_problem()
+    g, parts = pr["golden"], pr["parts"]
+    solvers = []
+    for p in parts:
+        r = p["rank"]
+        s = ha.Solver(p["lnid"], pr["ets"][r], pr["nts"][r], pr["dt"], dangling=p["dangling"],
+                      an_sched=p["an_sched"], dn_sched=p["dn_sched"], rank=r, nranks=8)
+        if len(pr["loaded"][r]):
+            s.set_source(pr["loaded"][r], pr["forces"][r])
+        solvers.append(s)
+    capi.group_link(solvers)
+    done = 0
+    for step in g["ckpt_steps"]:
+        capi.group_run(solvers, int(step) - done)
+        done = int(step)
+        for p, s in zip(parts, solvers):
+            ref2, ref1 = H.np8_stripe(g, step, p["rank"], len(p["nodes"]))
+            tm1, tm2 = s.download()
+            scale = max(np.abs(ref1).max(), 1.0)
+            assert np.abs(tm1 - ref1).max() <= TOL * scale and np.abs(tm2 - ref2).max() <= TOL * scale
+    for s in solvers:
+        s.close()
