@@ -177,6 +177,8 @@ struct hq_ctx {
     int32_t* d_oi_slot = nullptr;
     int32_t* d_oi_ptr = nullptr;      /* [nOI+1] CSR: records of an.d_s_in to add, in       */
     int32_t* d_oi_pos = nullptr;      /*         messenger order (fixed summation order)    */
+    int32_t  nSD = 0;                 /* distribution entries of owned hanging nodes that    */
+    int32_t* d_sd_ent = nullptr;      /* other ranks share: [nSD][3] {src slot, dst slot, deps} */
     /* patch variant */
     hq_patch_plan plan;
     /* timing */
@@ -499,6 +501,17 @@ static int hq_launch_update(hq_ctx* c)
     return HQ_OK;
 }
 
+/* compute_adjust DISTRIBUTION (psolve.c:5942-5987) for owned hanging nodes that other ranks share,
+ * on the interface force table, after their contribution exchange */
+__global__ void hq_k_iface_distribute(int32_t n, const int32_t* __restrict__ ent, double* __restrict__ iforce)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    double part = iforce[3 * (int64_t)ent[3 * i] + d] / (double)(uint32_t)ent[3 * i + 2];
+    unsafeAtomicAdd(&iforce[3 * (int64_t)ent[3 * i + 1] + d], part);
+}
+
 /*
  * Interface nodes this rank owns: own partial force + the sharers' records
  * (the "+=" unpack of schedule_senddata, psolve.c:5035-5073, in messenger order)
@@ -557,13 +570,18 @@ static int hq_phase(hq_ctx* c, int ph)
             HQ_TRY(hq_launch_element_scatter(c));                          /* :4290-4291 */
         }
         return HQ_OK;
-    case 1: return patch ? HQ_OK : hq_xchg_send(c, &c->dn, ftab, true, true);       /* :4298 */
+    case 1: return hq_xchg_send(c, &c->dn, ftab, true, true);                        /* :4298 */
     case 2:
-        if (patch) return HQ_OK;
         HQ_TRY(hq_xchg_recv(c, &c->dn, ftab, true, true));
-        if (c->ldnnum)                                                     /* :4299 */
+        if (patch) {
+            /* hanging nodes nobody shares were distributed inside the patches; the shared ones here */
+            if (c->nSD)
+                hq_k_iface_distribute<<<hq_blocks(c->nSD * 3, 256), 256, 0, c->overlap ? c->cstream : c->stream>>>(
+                    c->nSD, c->d_sd_ent, c->d_iforce);
+        } else if (c->ldnnum) {                                            /* :4299 */
             hq_k_adjust_distribute<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
                 c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, c->d_force);
+        }
         return HQ_OK;
     case 3: return hq_xchg_send(c, &c->an, ftab, true, true);                        /* :4301 */
     case 4:
@@ -588,9 +606,9 @@ static int hq_phase(hq_ctx* c, int ph)
             hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
                 c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
         return HQ_OK;
-    case 7: return patch ? HQ_OK : hq_xchg_send(c, &c->dn, unew, false, false);     /* :4315 */
+    case 7: return hq_xchg_send(c, &c->dn, unew, false, false);                      /* :4315 */
     case 8:
-        if (!patch) HQ_TRY(hq_xchg_recv(c, &c->dn, unew, false, false));
+        HQ_TRY(hq_xchg_recv(c, &c->dn, unew, false, false));
         if (patch) {
             if (c->overlap) HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));
             int n = c->now, p = c->prev, sp = c->spare;
@@ -623,50 +641,72 @@ static int hq_step(hq_ctx* c)
  */
 static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
 {
-    if (c->an.ctotal == 0 && c->an.stotal == 0) return HQ_OK;
-    std::vector<int32_t> slot((size_t)c->N, -1), cs, ss, oin, ois;
+    if (c->an.ctotal == 0 && c->an.stotal == 0 && c->dn.ctotal == 0 && c->dn.stotal == 0) return HQ_OK;
+    /*
+     * Interface set: every node named in a schedule, plus the anchors of owned hanging nodes that
+     * other ranks share (their force is complete only after the dangling-node contribution
+     * exchange, psolve.c:4298-4299, so the anchors cannot be finished inside the patch kernel).
+     */
+    std::vector<int32_t> slot((size_t)c->N, -1);
+    std::vector<char> nonowned((size_t)c->N, 0), dn_shared((size_t)c->N, 0);
     int32_t nI = 0;
-    auto slots_of = [&](int32_t count, const hq_messenger* list, std::vector<int32_t>& out, bool owned) {
+    auto slot_of = [&](int32_t n) { if (slot[n] < 0) slot[n] = nI++; return slot[n]; };
+    auto translate = [&](int32_t count, const hq_messenger* list, std::vector<int32_t>& out, char* mark) {
         for (int32_t i = 0; i < count; i++)
             for (int32_t k = 0; k < list[i].nodecount; k++) {
-                int32_t n = list[i].mapping[k];
-                if (slot[n] < 0) {
-                    slot[n] = nI++;
-                    if (owned) { oin.push_back(n); ois.push_back(slot[n]); }
-                }
-                out.push_back(slot[n]);
+                out.push_back(slot_of(list[i].mapping[k]));
+                if (mark) mark[list[i].mapping[k]] = 1;
             }
     };
-    slots_of(d->an_sched.s_count, d->an_sched.first_s, ss, true);
-    slots_of(d->an_sched.c_count, d->an_sched.first_c, cs, false);
+    std::vector<int32_t> an_ss, an_cs, dn_ss, dn_cs;
+    translate(d->an_sched.s_count, d->an_sched.first_s, an_ss, nullptr);
+    translate(d->an_sched.c_count, d->an_sched.first_c, an_cs, nonowned.data());
+    translate(d->dn_sched.s_count, d->dn_sched.first_s, dn_ss, dn_shared.data());
+    translate(d->dn_sched.c_count, d->dn_sched.first_c, dn_cs, nonowned.data());
+    std::vector<int32_t> sd;                                /* {src slot, dst slot, deps} */
+    for (int32_t k = 0; k < c->ldnnum; k++) {
+        int32_t dnode = d->dn_ldnid[k];
+        if (!dn_shared[dnode]) continue;
+        int32_t deps = d->dn_ptr[k + 1] - d->dn_ptr[k];
+        for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) {
+            sd.push_back(slot_of(dnode));
+            sd.push_back(slot_of(d->dn_lanid[a]));
+            sd.push_back(deps);
+        }
+    }
+    std::vector<int32_t> oin, ois;
+    for (int32_t n = 0; n < c->N; n++)
+        if (slot[n] >= 0 && !nonowned[n]) { oin.push_back(n); ois.push_back(slot[n]); }
     c->nI = nI;
     c->nOI = (int32_t)oin.size();
+    c->nSD = (int32_t)(sd.size() / 3);
     HQ_TRY(hq_dev_alloc(c, &c->d_iforce, (size_t)nI * 3));
     HQ_HIP(hipMemset(c->d_iforce, 0, sizeof(double) * 3 * (size_t)nI));
-    if (!cs.empty()) {
-        HQ_TRY(hq_dev_alloc(c, &c->an.d_cmap_f, cs.size()));
-        HQ_HIP(hipMemcpy(c->an.d_cmap_f, cs.data(), 4 * cs.size(), hipMemcpyHostToDevice));
-    }
-    if (!ss.empty()) {
-        HQ_TRY(hq_dev_alloc(c, &c->an.d_smap_f, ss.size()));
-        HQ_HIP(hipMemcpy(c->an.d_smap_f, ss.data(), 4 * ss.size(), hipMemcpyHostToDevice));
-    }
+    auto upload = [&](const std::vector<int32_t>& v, int32_t** dst) -> int {
+        if (v.empty()) return HQ_OK;
+        HQ_TRY(hq_dev_alloc(c, dst, v.size()));
+        HQ_HIP(hipMemcpy(*dst, v.data(), 4 * v.size(), hipMemcpyHostToDevice));
+        return HQ_OK;
+    };
+    HQ_TRY(upload(an_cs, &c->an.d_cmap_f));
+    HQ_TRY(upload(an_ss, &c->an.d_smap_f));
+    HQ_TRY(upload(dn_cs, &c->dn.d_cmap_f));
+    HQ_TRY(upload(dn_ss, &c->dn.d_smap_f));
+    HQ_TRY(upload(sd, &c->d_sd_ent));
     if (c->nOI) {
-        /* records of the contribution receive buffer per owned interface node, messenger order */
-        std::vector<int32_t> oi_index((size_t)nI, -1), ptr((size_t)c->nOI + 1, 0), pos(ss.size());
+        /* records of the anchored-node contribution receive buffer per owned interface node,
+         * messenger order */
+        std::vector<int32_t> oi_index((size_t)nI, -1), ptr((size_t)c->nOI + 1, 0), pos(an_ss.size());
         for (int32_t i = 0; i < c->nOI; i++) oi_index[ois[i]] = i;
-        for (size_t r = 0; r < ss.size(); r++) ptr[oi_index[ss[r]] + 1]++;
+        for (size_t r = 0; r < an_ss.size(); r++) ptr[oi_index[an_ss[r]] + 1]++;
         for (int32_t i = 0; i < c->nOI; i++) ptr[i + 1] += ptr[i];
         std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-        for (size_t r = 0; r < ss.size(); r++) pos[fill[oi_index[ss[r]]]++] = (int32_t)r;
-        HQ_TRY(hq_dev_alloc(c, &c->d_oi_node, oin.size()));
-        HQ_TRY(hq_dev_alloc(c, &c->d_oi_slot, ois.size()));
-        HQ_TRY(hq_dev_alloc(c, &c->d_oi_ptr, ptr.size()));
-        HQ_TRY(hq_dev_alloc(c, &c->d_oi_pos, pos.size()));
-        HQ_HIP(hipMemcpy(c->d_oi_node, oin.data(), 4 * oin.size(), hipMemcpyHostToDevice));
-        HQ_HIP(hipMemcpy(c->d_oi_slot, ois.data(), 4 * ois.size(), hipMemcpyHostToDevice));
-        HQ_HIP(hipMemcpy(c->d_oi_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice));
-        HQ_HIP(hipMemcpy(c->d_oi_pos, pos.data(), 4 * pos.size(), hipMemcpyHostToDevice));
+        for (size_t r = 0; r < an_ss.size(); r++) pos[fill[oi_index[an_ss[r]]]++] = (int32_t)r;
+        if (pos.empty()) pos.push_back(0);
+        HQ_TRY(upload(oin, &c->d_oi_node));
+        HQ_TRY(upload(ois, &c->d_oi_slot));
+        HQ_TRY(upload(ptr, &c->d_oi_ptr));
+        HQ_TRY(upload(pos, &c->d_oi_pos));
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
@@ -728,13 +768,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "hipStreamCreate failed%s", ""));
 
-    /* hanging nodes shared between ranks (dn_sched) need the reference's two extra exchanges:
-     * scatter variant only */
-    bool has_dn_sched = d->dn_sched.c_count || d->dn_sched.s_count;
     int variant = d->variant;
-    if (variant == HQ_VARIANT_AUTO) variant = has_dn_sched ? HQ_VARIANT_SCATTER : HQ_VARIANT_PATCH;
-    if (variant == HQ_VARIANT_PATCH && has_dn_sched)
-        return bail(hq_fail(HQ_ERR_ARG, "patch variant does not take hanging nodes shared between ranks%s", ""));
+    if (variant == HQ_VARIANT_AUTO) variant = HQ_VARIANT_PATCH;
     if (c->ldnnum && (!d->dn_ldnid || !d->dn_ptr || !d->dn_lanid))
         return bail(hq_fail(HQ_ERR_ARG, "dangling-node tables missing%s", ""));
     for (int32_t k = 0; k < c->ldnnum; k++) {
@@ -801,8 +836,24 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
     } else {
         int64_t pb = 0;
+        /* hanging nodes the patches may distribute themselves: owned and not shared with any rank
+         * (the shared ones wait for the contribution exchange, hq_setup_interface) */
+        std::vector<char> shared_dn((size_t)c->N, 0);
+        for (int32_t i = 0; i < d->dn_sched.s_count; i++)
+            for (int32_t k = 0; k < d->dn_sched.first_s[i].nodecount; k++) {
+                int32_t n = d->dn_sched.first_s[i].mapping[k];
+                if (n < 0 || n >= c->N) return bail(hq_fail(HQ_ERR_ARG, "messenger node id out of range%s", ""));
+                shared_dn[n] = 1;
+            }
+        std::vector<int32_t> l_id, l_ptr(1, 0), l_anc;
+        for (int32_t k = 0; k < c->ldnnum; k++) {
+            if (shared_dn[d->dn_ldnid[k]]) continue;
+            l_id.push_back(d->dn_ldnid[k]);
+            for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) l_anc.push_back(d->dn_lanid[a]);
+            l_ptr.push_back((int32_t)l_anc.size());
+        }
         hq_dangling dn;
-        dn.n = c->ldnnum; dn.id = d->dn_ldnid; dn.ptr = d->dn_ptr; dn.anchor = d->dn_lanid;
+        dn.n = (int32_t)l_id.size(); dn.id = l_id.data(); dn.ptr = l_ptr.data(); dn.anchor = l_anc.data();
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
                             dn, &pb);
         if (rc != 0)
@@ -810,6 +861,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
                                 hq_patch_error()));
         c->bytes += pb;
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
+        if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
@@ -827,10 +879,12 @@ extern "C" int hq_destroy(hq_ctx* c)
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
-                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos };
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_ent };
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->an.d_cmap_f && c->an.d_cmap_f != c->an.d_cmap) hipFree(c->an.d_cmap_f);
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
+    if (c->dn.d_cmap_f && c->dn.d_cmap_f != c->dn.d_cmap) hipFree(c->dn.d_cmap_f);
+    if (c->dn.d_smap_f && c->dn.d_smap_f != c->dn.d_smap) hipFree(c->dn.d_smap_f);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);

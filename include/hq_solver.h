@@ -41,10 +41,10 @@ typedef enum {
 
 /* Element-kernel variants (hq_desc.variant). */
 enum {
-    HQ_VARIANT_AUTO    = 0,  /* PATCH unless hanging nodes are shared between ranks (dn_sched) */
-    HQ_VARIANT_SCATTER = 1,  /* element kernel + fp64 atomics, node kernel; any mesh           */
-    HQ_VARIANT_PATCH   = 2   /* owner-computes patches, one fused kernel; hanging nodes are    */
-                             /* handled when their anchors are anchored nodes of this rank     */
+    HQ_VARIANT_AUTO    = 0,  /* = PATCH                                                        */
+    HQ_VARIANT_SCATTER = 1,  /* element kernel + fp64 atomics, node kernel                     */
+    HQ_VARIANT_PATCH   = 2   /* owner-computes patches, one fused kernel (+ interface kernels  */
+                             /* on partitions); anchors of hanging nodes must be anchored      */
 };
 
 /*

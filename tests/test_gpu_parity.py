@@ -326,19 +326,24 @@ def test_larger_two_level_meshes_against_oracle(variant, shape):
     s.close()
 
 
-def test_octree_mesh_on_eight_partitions_against_reference():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_octree_mesh_on_eight_partitions_against_reference(variant):
     """The reference's 8-rank run of its two-level mesh: hanging nodes shared between
     ranks (dn_sched), anchors harbored indirectly, the four exchanges of a step and both
     compute_adjust passes -- eight contexts stepped in one process on one GPU against the
-    reference's per-rank checkpoint stripes."""
+    reference's per-rank checkpoint stripes.  Scatter kernels, and the patch kernel with the
+    interface table carrying shared hanging nodes and their anchors."""
     from hercules_amd import capi
     pr = H.c5_np8_problem()
     g, parts = pr["golden"], pr["parts"]
+    mesh = pr["mesh"]
     solvers = []
     for p in parts:
         r = p["rank"]
         s = ha.Solver(p["lnid"], pr["ets"][r], pr["nts"][r], pr["dt"], dangling=p["dangling"],
-                      an_sched=p["an_sched"], dn_sched=p["dn_sched"], rank=r, nranks=8)
+                      an_sched=p["an_sched"], dn_sched=p["dn_sched"], rank=r, nranks=8, variant=variant,
+                      node_xyz=mesh["node_q"][p["nodes"]])
+        assert s.info()["variant"] == variant
         if len(pr["loaded"][r]):
             s.set_source(pr["loaded"][r], pr["forces"][r])
         solvers.append(s)
