@@ -41,12 +41,15 @@ WORKLOADS = {
     "m1": (128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0),
     # two-level octree box (hanging nodes): nx, ny, nz_fine, h_fine, dt, freq  (+ 96 coarse layers)
     "o1": (512, 512, 64, 1000.0 / 512, 9.0e-5, 200.0),
+    # BASELINE config 5 scale: 184M-element two-level octree (134M fine + 50M coarse), 1 GPU
+    "o2": (1024, 1024, 128, 1000.0 / 1024, 4.5e-5, 400.0),
 }
-OCT_COARSE_LAYERS = {"o1": 96}
+OCT_COARSE_LAYERS = {"o1": 96, "o2": 192}
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
-                  "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)"}
+                  "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)",
+                  "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)"}
 
 
 def usable_cores():

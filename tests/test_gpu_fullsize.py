@@ -152,13 +152,15 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-def test_eight_partitions_of_the_8m_box_match_one_partition():
-    """BASELINE config 4 in miniature on one GPU: the 8M box cut 8 ways (octor blocks),
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_eight_partitions_of_the_8m_box_match_one_partition(wl):
+    """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
     single-partition run."""
     from hercules_amd import capi
-    nx, ny, nz, h, dt, freq = 256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0
-    nsteps = 4
+    nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
+                               "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
+    nsteps = 3
     one = host.Box(nx, ny, nz, h, dt, freq)
     u = _field(one, 31337)
     ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
