@@ -31,8 +31,9 @@ def build_solver(force=False):
     srcs.append(os.path.join(ROOT, "include", "hq_solver.h"))
     if force or _newer(SOLVER_LIB, srcs):
         cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-               "-fvisibility=hidden", "-fopenmp", "-Wno-unused-value",
-               "-o", SOLVER_LIB, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+               "-fvisibility=hidden", "-fopenmp", "-Wno-unused-value"] + \
+              os.environ.get("HQ_EXTRA_FLAGS", "").split() + \
+              ["-o", SOLVER_LIB, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
         subprocess.check_call(cmd, cwd=CSRC)
     return SOLVER_LIB
 

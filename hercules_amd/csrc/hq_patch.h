@@ -85,7 +85,8 @@ struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
     std::vector<uint16_t> pidx;      /* [npairs][8] patch-local node ids */
     std::vector<int32_t>  pelem;     /* [npairs] element id (host only)  */
-    std::vector<int32_t>  halo;      /* concatenated halo node ids        */
+    std::vector<int32_t>  halo;      /* halo node ids, patch p's list at p * hstride */
+    int32_t               hstride = 0;
     std::vector<int32_t>  ds_ptr;    /* [P+1] hanging-node distribution entries per patch */
     std::vector<int32_t>  ds_ent;    /* [n][3] = {src local, dst local (owned anchor), deps} */
 };
@@ -103,6 +104,7 @@ struct hq_patch_plan {
     int32_t npatches = 0;
     int64_t npairs = 0;
     int64_t nhalo = 0;
+    int32_t hstride = 0;             /* ints between consecutive patches' halo id lists */
     hq_patch_desc* d_desc = nullptr;
     uint4*   d_pidx = nullptr;
     double*  d_pc1 = nullptr;
@@ -331,8 +333,15 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             continue;
         }
 
-        for (int32_t p = 0; p < P; p++) hoff[p + 1] = hoff[p] + (int64_t)halos[p].size();
-        H->halo.assign((size_t)hoff[P], 0);
+        /* halo id lists at a fixed stride: a workgroup finds its list from its patch number alone
+         * and reads it while its descriptor is still in flight (one memory latency less in the
+         * dependent chain descriptor -> ids -> node data), and can be prefetched by an earlier
+         * workgroup.  Padded so the unconditional first-round id loads stay inside the table. */
+        size_t hs = 32;
+        for (int32_t p = 0; p < P; p++) hs = std::max(hs, (halos[p].size() + 31) / 32 * 32);
+        H->hstride = (int32_t)hs;
+        for (int32_t p = 0; p <= P; p++) hoff[p] = (int64_t)p * (int64_t)hs;
+        H->halo.assign((size_t)hoff[P] + 4 * HQ_PATCH_MAX_THREADS / 3 + 64, 0);
         H->desc.assign((size_t)P, hq_patch_desc());
         H->pidx.assign((size_t)npairs * 8, 0);
 #pragma omp parallel for schedule(dynamic, 64)
@@ -397,6 +406,17 @@ struct hq_pair_data {
     double beta, c1, c2;
 };
 
+#ifdef HQ_PATCH_PROFILING
+/* DIAG == 6: thread 0 of every workgroup stamps the shader clock at the phase boundaries into
+ * g_hq_stamps[patch][8]; hq_patch_report_stamps() prints the mean cycles per phase.  Never in
+ * the shipped build. */
+__device__ unsigned long long* g_hq_stamps = nullptr;
+static void hq_patch_report_stamps(void);
+#define HQ_STAMP(k) do { if (DIAG == 6 && threadIdx.x == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HQ_STAMP(k) do { } while (0)
+#endif
+
 typedef unsigned int hq_u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT, typename T>
@@ -448,7 +468,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
                 const int32_t* __restrict__ if_ptr, const int32_t* __restrict__ if_ent,
                 double* __restrict__ iforce, const int32_t* __restrict__ ds_ptr,
-                const int32_t* __restrict__ ds_ent)
+                const int32_t* __restrict__ ds_ent, int32_t hstride)
 {
     extern __shared__ __align__(16) double s_mem[];
     double* __restrict__ s_u1 = s_mem;
@@ -460,10 +480,17 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (slot >= npatches) return;
     const int p = order ? order[slot] : slot;
-    const hq_patch_desc D = desc[p];
     const int tid = threadIdx.x, T = blockDim.x;
+    HQ_STAMP(0);
+    /* first-round halo ids: their address needs only p, so they travel with the descriptor */
+    const int32_t* __restrict__ hl = halo + (int64_t)p * hstride;
+    int32_t hid[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hid[k] = hq_ld<NT>(&hl[(k * T + tid) / 3]);
+    const hq_patch_desc D = desc[p];
     const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
     for (int i = own3 + tid; i < 3 * D.nacc; i += T) s_f[i] = 0.0;   /* hanging nodes on owned anchors */
+    if (DIAG == 6 && D.nown > 0) HQ_STAMP(1);
 
     hq_pair_data cur;
     if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + tid);
@@ -471,7 +498,6 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     {   /* stage: owned nodes are one contiguous run of doubles, halo nodes a gather */
         const double* g1 = u1g + 3 * (int64_t)D.base;
         const double* g2 = u2g + 3 * (int64_t)D.base;
-        const int32_t* hl = halo + D.halo_off;
         for (int i0 = 0; i0 < own3 || i0 < halo3; i0 += 4 * T) {
             double a1[4], a2[4], b1[4], b2[4];
 #pragma unroll
@@ -481,7 +507,9 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 if (i < own3) { a1[k] = g1[i]; a2[k] = g2[i]; }
                 if (i < halo3) {
                     int h = i / 3, d = i - 3 * h;
-                    int64_t g = 3 * (int64_t)hq_ld<NT>(&hl[h]) + d;
+                    int32_t id = hid[k];
+                    if (i0 > 0) id = hq_ld<NT>(&hl[h]);
+                    int64_t g = 3 * (int64_t)id + d;
                     b1[k] = u1g[g]; b2[k] = u2g[g];
                 }
             }
@@ -493,7 +521,9 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
             }
         }
     }
+    HQ_STAMP(2);
     __syncthreads();
+    HQ_STAMP(3);
 
     /* nodal constants of "my" node for the update below: n_t (psolve.h:210-214), or its
      * 3-double form where no dashpot makes the axes differ */
@@ -546,6 +576,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         }
         cur = nxt;
     }
+    HQ_STAMP(4);
     if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
         for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += T) {
             int ln = src_ent[2 * k], li = src_ent[2 * k + 1];
@@ -561,6 +592,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         }
     }
     __syncthreads();
+    HQ_STAMP(5);
 
     /* solver_compute_displacement, psolve.c:4078-4106: one thread per owned node */
     for (int n = tid; n < (DIAG == 3 ? (tid == 0 ? 1 : 0) : D.nown); n += T) {
@@ -591,6 +623,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
             o[0] = s_f[3 * ln]; o[1] = s_f[3 * ln + 1]; o[2] = s_f[3 * ln + 2];
         }
     }
+    HQ_STAMP(6);
 }
 
 /*
@@ -855,6 +888,9 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 
 static void hq_patch_free(hq_patch_plan* P)
 {
+#ifdef HQ_PATCH_PROFILING
+    if (P->npatches) hq_patch_report_stamps();
+#endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
                      P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent };
     for (void* p : ptrs) if (p) hipFree(p);
@@ -890,6 +926,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
+    P->hstride = H.hstride;
     std::vector<double> v((size_t)P->npairs);
     size_t np = (size_t)P->npairs ? (size_t)P->npairs : 1, nh = H.halo.size() ? H.halo.size() : 1;
 #define HQ_PA(ptr, bytes_)                                                                   \
@@ -996,6 +1033,32 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
     return 0;
 }
 
+#ifdef HQ_PATCH_PROFILING
+static unsigned long long* g_hq_stamp_buf = nullptr;
+static int32_t g_hq_stamp_n = 0;
+static void hq_patch_report_stamps(void)
+{
+    if (!g_hq_stamp_buf) return;
+    std::vector<unsigned long long> h((size_t)g_hq_stamp_n * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), g_hq_stamp_buf, 64 * (size_t)g_hq_stamp_n, hipMemcpyDeviceToHost);
+    const char* name[6] = { "descriptor", "issue+wait staging, LDS write", "barrier 1", "element loop", "src/ds + barrier 2", "update + stores issued" };
+    double sum[6] = { 0, 0, 0, 0, 0, 0 };
+    long cnt = 0;
+    for (int32_t p = 0; p < g_hq_stamp_n; p++) {
+        const unsigned long long* s = &h[8 * (size_t)p];
+        if (!s[6] || !s[0]) continue;
+        for (int k = 0; k < 6; k++) sum[k] += (double)(s[k + 1] - s[k]);
+        cnt++;
+    }
+    fprintf(stderr, "hq patch stamps (mean shader cycles per workgroup over %ld patches, last step):\n", cnt);
+    double tot = 0;
+    for (int k = 0; k < 6; k++) tot += sum[k] / (cnt ? cnt : 1);
+    for (int k = 0; k < 6; k++) fprintf(stderr, "  %-34s %9.0f  (%4.1f %%)\n", name[k], sum[k] / (cnt ? cnt : 1), 100.0 * sum[k] / (cnt ? cnt : 1) / tot);
+    fprintf(stderr, "  %-34s %9.0f\n", "total", tot);
+}
+#endif
+
 /* launch patches order[first .. first+count) (order == identity when there is no interface) */
 static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const double* u1,
                             const double* u2, double* un, const double* nt, const double* F, double dt2,
@@ -1024,11 +1087,24 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (diag == 3) kern = hq_k_patch_step<false, 3>;
     if (diag == 4) kern = hq_k_patch_step<false, 4>;
     if (diag == 5) kern = hq_k_patch_step<false, 5>;
+    if (diag == 6) {
+        kern = hq_k_patch_step<false, 6>;
+        static unsigned long long* d_st = nullptr;
+        static int32_t st_n = 0;
+        if (!d_st) {
+            st_n = P->npatches;
+            hipMalloc((void**)&d_st, 64 * (size_t)st_n);
+            hipMemset(d_st, 0, 64 * (size_t)st_n);
+            hipMemcpyToSymbol(HIP_SYMBOL(g_hq_stamps), &d_st, sizeof d_st);
+            g_hq_stamp_buf = d_st; g_hq_stamp_n = st_n;
+        }
+    }
 #endif
     kern<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
         count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
         P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
-        (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent);
+        (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
+        P->hstride);
 }
 
 #endif /* HQ_PATCH_H */
