@@ -29,7 +29,9 @@
 #include <algorithm>
 #include <array>
 #include <string>
+#include <unordered_map>
 #include <vector>
+#include <cstring>
 
 #include "hq_kernels.h"
 
@@ -78,8 +80,11 @@ struct hq_patch_desc {
     int32_t flags;       /* HQ_PATCH_ISO: every owned node has axis-independent n_t */
     int32_t nacc;        /* local nodes with a force accumulator: owned + the first   */
                          /* (nacc - nown) halo nodes = hanging nodes on owned anchors */
+    int64_t pidx_off;    /* into pidx: this patch's rows, or the identical rows of an  */
+                         /* earlier patch (regular regions repeat one local connectivity) */
 };
 #define HQ_PATCH_ISO 1
+#define HQ_PATCH_UNIFORM 2   /* every element of the patch has the same (c1, c2, beta): read once */
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -87,6 +92,7 @@ struct hq_patch_host {
     std::vector<int32_t>  pelem;     /* [npairs] element id (host only)  */
     std::vector<int32_t>  halo;      /* halo node ids, patch p's list at p * hstride */
     int32_t               hstride = 0;
+    int32_t               ndistinct = 0;   /* distinct local connectivities among the patches */
     std::vector<int32_t>  ds_ptr;    /* [P+1] hanging-node distribution entries per patch */
     std::vector<int32_t>  ds_ent;    /* [n][3] = {src local, dst local (owned anchor), deps} */
 };
@@ -105,6 +111,7 @@ struct hq_patch_plan {
     int64_t npairs = 0;
     int64_t nhalo = 0;
     int32_t hstride = 0;             /* ints between consecutive patches' halo id lists */
+    int32_t ndistinct = 0, nuniform = 0;
     hq_patch_desc* d_desc = nullptr;
     uint4*   d_pidx = nullptr;
     double*  d_pc1 = nullptr;
@@ -122,7 +129,7 @@ struct hq_patch_plan {
     int32_t  nb = 0;
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
     int32_t* d_ds_ent = nullptr;
-    int32_t  max_nown = 0, max_nhalo = 0;
+    int32_t  max_nown = 0, max_nhalo = 0, max_npairs = 0;
     std::vector<int32_t> h_halo;     /* host copies kept only for meshes with hanging nodes */
     std::vector<int64_t> h_halo_off;
     std::vector<int32_t> h_nvirt;
@@ -368,6 +375,35 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
                 for (int c = 0; c < 8; c++) H->pidx[(size_t)q * 8 + c] = (uint16_t)local_of(id[c]);
             }
         }
+        /* regular regions repeat one local connectivity: a patch whose rows equal those of an
+         * earlier patch reads that patch's rows (which then stay in L2) instead of its own */
+        {
+            std::unordered_map<uint64_t, std::vector<int32_t>> seen;
+            int32_t ndistinct = 0;
+            const bool dedup = !getenv("HQ_PATCH_NO_DEDUP");
+            for (int32_t p = 0; p < P; p++) {
+                hq_patch_desc& D = H->desc[p];
+                D.pidx_off = D.pair_off;
+                if (!dedup || D.npairs == 0) continue;
+                const uint16_t* blk = H->pidx.data() + 8 * (size_t)D.pair_off;
+                const size_t nb = 16 * (size_t)D.npairs;
+                uint64_t h = 1469598103934665603ull ^ (uint64_t)D.npairs;
+                const uint64_t* w = reinterpret_cast<const uint64_t*>(blk);
+                for (size_t i = 0; i < nb / 8; i++) { h ^= w[i]; h *= 1099511628211ull; }
+                auto& cand = seen[h];
+                bool found = false;
+                for (int32_t r : cand) {
+                    const hq_patch_desc& R = H->desc[r];
+                    if (R.npairs == D.npairs && !memcmp(H->pidx.data() + 8 * (size_t)R.pair_off, blk, nb)) {
+                        D.pidx_off = R.pair_off;
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found) { cand.push_back(p); ndistinct++; }
+            }
+            H->ndistinct = ndistinct;
+        }
         if (dn.n > 0) {
             /* distribution entries, hanging nodes in table order (the reference's loop order) */
             std::vector<std::vector<int32_t>> ent((size_t)P);
@@ -412,9 +448,12 @@ struct hq_pair_data {
  * the shipped build. */
 __device__ unsigned long long* g_hq_stamps = nullptr;
 static void hq_patch_report_stamps(void);
+static int hq_patch_kernel_choice(void);
 #define HQ_STAMP(k) do { if (DIAG == 6 && threadIdx.x == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HQ_STAMPD(k) do { if (tid0 == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p0 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HQ_STAMP(k) do { } while (0)
+#define HQ_STAMPD(k) do { } while (0)
 #endif
 
 typedef unsigned int hq_u32x4 __attribute__((ext_vector_type(4)));
@@ -426,19 +465,18 @@ __device__ __forceinline__ T hq_ld(const T* p)
     return *p;
 }
 
+/* element row: local node ids at pidx[gi], coefficients at [gc] */
 template <bool NT>
 __device__ __forceinline__ hq_pair_data hq_pair_load(const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                                                      const double* __restrict__ pc2,
-                                                     const double* __restrict__ pbeta, int64_t g)
+                                                     const double* __restrict__ pbeta, int64_t gi, int64_t gc)
 {
     hq_pair_data d;
-    /* streamed once per step: non-temporal, so that the node data the neighbouring
-     * patches re-read keeps its place in the XCD's L2 */
-    hq_u32x4 r = hq_ld<NT>(reinterpret_cast<const hq_u32x4*>(pidx) + g);
+    hq_u32x4 r = hq_ld<NT>(reinterpret_cast<const hq_u32x4*>(pidx) + gi);
     d.raw.x = r.x; d.raw.y = r.y; d.raw.z = r.z; d.raw.w = r.w;
-    d.beta = hq_ld<NT>(&pbeta[g]);
-    d.c1 = hq_ld<NT>(&pc1[g]);
-    d.c2 = hq_ld<NT>(&pc2[g]);
+    d.beta = hq_ld<NT>(&pbeta[gc]);
+    d.c1 = hq_ld<NT>(&pc1[gc]);
+    d.c2 = hq_ld<NT>(&pc2[gc]);
     return d;
 }
 
@@ -493,7 +531,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     if (DIAG == 6 && D.nown > 0) HQ_STAMP(1);
 
     hq_pair_data cur;
-    if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + tid);
+    const int cstep = (D.flags & HQ_PATCH_UNIFORM) ? 0 : 1;     /* uniform patch: every row reads coefficient 0 */
+    if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pidx_off + tid, D.pair_off + cstep * tid);
 
     {   /* stage: owned nodes are one contiguous run of doubles, halo nodes a gather */
         const double* g1 = u1g + 3 * (int64_t)D.base;
@@ -546,7 +585,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 
     for (int q = tid; q < (DIAG == 1 ? 0 : D.npairs); q += T) {
         hq_pair_data nxt;
-        if (q + T < D.npairs) nxt = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pair_off + q + T);
+        if (q + T < D.npairs)
+            nxt = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pidx_off + q + T, D.pair_off + cstep * (q + T));
         const uint4 raw = cur.raw;
         const double beta = cur.beta;
         int l[8];
@@ -626,191 +666,120 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     HQ_STAMP(6);
 }
 
+__device__ __forceinline__ hq_patch_desc hq_patch_desc_or_empty(const hq_patch_desc* __restrict__ desc, int p)
+{
+    hq_patch_desc D = desc[p < 0 ? 0 : p];
+    if (p < 0) { D.nown = 0; D.nhalo = 0; D.npairs = 0; D.nacc = 0; D.flags = 0; }
+    return D;
+}
+
 /*
- * Persistent, software-pipelined form of hq_k_patch_step.  A workgroup walks the patches
- * slot, slot + W, slot + 2W, ... of its XCD's run; while it computes patch j the loads that
- * stage patch j+1 (owned run + halo gather, KO + KH doubles per array per thread) are
- * already in flight into registers, and the halo ids / descriptor of patch j+2 behind them,
- * so the memory system stays busy during the element loop (the non-pipelined kernel moves
- * no bytes while both resident workgroups compute).  T = 256 threads: 2 waves per SIMD,
- * 256 registers per lane to hold the in-flight patch.
- *
- * EXPERIMENT (opt-in, HQ_PATCH_PIPE=1), parity-green but 12 % slower than hq_k_patch_step on
- * the 64M box (3.49 vs 3.11 ms): the in-flight patch costs 256 registers per lane = 8 waves
- * per CU, and at 2 waves per SIMD the element loop loses more than the overlap gains.
- * AHEAD = false (only descriptor + halo ids one patch ahead, 512 threads) spills 79 VGPRs at
- * the 128-register budget and is not instantiated.  Kept as the starting point for a
- * loader-wave design (2 loader + 6 compute waves per 512-thread workgroup).
+ * hq_k_patch_pers: the patch step as ONE persistent 1024-thread workgroup per CU with two LDS
+ * node buffers and a register prefetch one patch deep.  With 1024 threads a patch is one local
+ * node (u1, u2: 12 registers), one element row (10) and one 3-double n_t row (6) per thread, so
+ * the node data of patch k+1 can be requested at the top of iteration k, fly during the element
+ * section of patch k, and be written to the other LDS buffer after it -- the CU's memory pipe is
+ * busy while its VALU/LDS pipes are, which two independent workgroups per CU (hq_k_patch_step)
+ * achieve only by chance.  The element row of patch k+1 is requested after the element section
+ * (its registers are free then) and flies during the update.  Plain loads and __syncthreads
+ * throughout: the compiler's own vmcnt waits are the right ones (issue order = order of use).
  */
-template <int T, int KO, int KH, bool AHEAD, int WPS, int NR>
-__global__ void __launch_bounds__(T, WPS)
-hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
-                const hq_patch_desc* __restrict__ desc,
+#define HQ_PERS_THREADS 1024
+
+__global__ void __launch_bounds__(HQ_PERS_THREADS)
+hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
+                int32_t nfacc, const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
                 const double* __restrict__ u2g, double* __restrict__ ung,
                 const double* __restrict__ nt, const double* __restrict__ nt3,
-                const int32_t* __restrict__ src_ptr,
-                const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
-                const int32_t* __restrict__ if_ptr, const int32_t* __restrict__ if_ent,
-                double* __restrict__ iforce, const int32_t* __restrict__ ds_ptr,
-                const int32_t* __restrict__ ds_ent)
+                const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
+                const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
+                const int32_t* __restrict__ if_ent, double* __restrict__ iforce,
+                const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride)
 {
     extern __shared__ __align__(16) double s_mem[];
-    double* __restrict__ s_u1 = s_mem;
-    double* __restrict__ s_u2 = s_mem + 3 * nlmax;
-    double* __restrict__ s_f = s_mem + 6 * nlmax;
-
-    const int tid = threadIdx.x;
-    const int W = (int)(gridDim.x >> 3);                       /* workgroups per XCD */
-    const int xcd = (int)(blockIdx.x & 7);
-    const int end = min((xcd + 1) * per_xcd, npatches);
+    double* __restrict__ s_f = s_mem + 12 * nlmax;      /* after the two node buffers */
+    const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
+    const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int end = min((xcd + 1) * per_xcd, count);
     int slot = xcd * per_xcd + (int)(blockIdx.x >> 3);
     if (slot >= end) return;
+#define HQ_SLOT_PATCH(s) ((s) < end ? (order ? order[(s)] : (s)) : -1)
+    /* halo id of this thread's local node of patch (P_, DD) (0 where that node is owned or absent) */
+#define HQ_PERS_ID(P_, DD) \
+    ((tid >= (DD).nown && tid < (DD).nown + (DD).nhalo) ? halo[(int64_t)(P_) * hstride + (tid - (DD).nown)] : 0)
 
-    int p = order ? order[slot] : slot;
-    hq_patch_desc D = desc[p];
-    double a1[KO], a2[KO], b1[KH], b2[KH];
-    int hid[KH];
-    hq_pair_data cur;
-
-#define HQ_PIPE_IDS(DD)                                                                   \
-    {                                                                                     \
-        const int32_t* hl_ = halo + (DD).halo_off;                                        \
-        _Pragma("unroll") for (int k = 0; k < KH; k++) {                                  \
-            int i_ = k * T + tid;                                                         \
-            hid[k] = (i_ < 3 * (DD).nhalo) ? hl_[i_ / 3] : 0;                             \
-        }                                                                                 \
+    int p0 = HQ_SLOT_PATCH(slot), p1 = HQ_SLOT_PATCH(slot + W), p2 = HQ_SLOT_PATCH(slot + 2 * W);
+    hq_patch_desc D0 = hq_patch_desc_or_empty(desc, p0);
+    hq_patch_desc D1 = hq_patch_desc_or_empty(desc, p1);
+    hq_patch_desc D2 = hq_patch_desc_or_empty(desc, p2);
+    hq_u32x4 c_raw = { 0, 0, 0, 0 };                    /* element row of the CURRENT patch (pidx; beta, c1, c2) */
+    double c_beta = 0.0, c_c1 = 0.0, c_c2 = 0.0;
+    int32_t idn;                                        /* gather id of the NEXT patch's local node */
+#define HQ_PERS_ROW(DD)                                                                         \
+    {                                                                                           \
+        const int q_ = tid < (DD).npairs ? tid : 0;                                             \
+        const int64_t gc_ = (DD).pair_off + (((DD).flags & HQ_PATCH_UNIFORM) ? 0 : q_);         \
+        c_raw = *(reinterpret_cast<const hq_u32x4*>(pidx) + ((DD).pidx_off + q_));              \
+        c_beta = pbeta[gc_]; c_c1 = pc1[gc_]; c_c2 = pc2[gc_];                                  \
     }
-#define HQ_PIPE_ISSUE(DD)                                                                 \
-    {                                                                                     \
-        const double* g1_ = u1g + 3 * (int64_t)(DD).base;                                 \
-        const double* g2_ = u2g + 3 * (int64_t)(DD).base;                                 \
-        _Pragma("unroll") for (int k = 0; k < KO; k++) {                                  \
-            int i_ = k * T + tid;                                                         \
-            if (i_ < 3 * (DD).nown) { a1[k] = g1_[i_]; a2[k] = g2_[i_]; }                 \
-        }                                                                                 \
-        _Pragma("unroll") for (int k = 0; k < KH; k++) {                                  \
-            int i_ = k * T + tid;                                                         \
-            if (i_ < 3 * (DD).nhalo) {                                                    \
-                int64_t g_ = 3 * (int64_t)hid[k] + (i_ - 3 * (i_ / 3));                   \
-                b1[k] = u1g[g_]; b2[k] = u2g[g_];                                         \
-            }                                                                             \
-        }                                                                                 \
-        if (tid < (DD).npairs) cur = hq_pair_load<false>(pidx, pc1, pc2, pbeta, (DD).pair_off + tid); \
-    }
-
-    HQ_PIPE_IDS(D)
-    if (AHEAD) HQ_PIPE_ISSUE(D)
-    int slot_n = slot + W;
-    bool has_n = slot_n < end;
-    int pn = 0;
-    hq_patch_desc Dn = D;
-    if (has_n) {
-        pn = order ? order[slot_n] : slot_n;
-        Dn = desc[pn];
-        if (AHEAD) HQ_PIPE_IDS(Dn)
-    }
-
-    for (;;) {
-        const int own3 = D.nown * 3, halo3 = D.nhalo * 3;
-        if (!AHEAD) {
-            /* the ids of this patch's halo arrived during the previous patch: one latency
-             * (the data itself) instead of three (descriptor -> ids -> data) */
-            HQ_PIPE_ISSUE(D)
-            if (has_n) HQ_PIPE_IDS(Dn)
-        }
-        /* registers -> LDS */
+    {   /* prologue: patch 0 into buffer 0 */
+        const int tid = tid0;
+        for (int i = tid; i < nfacc; i += T) s_f[i] = 0.0;
+        HQ_PERS_ROW(D0)
+        const int32_t id0 = HQ_PERS_ID(p0, D0);
+        idn = HQ_PERS_ID((p1 < 0 ? 0 : p1), D1);
+        if (tid < D0.nown + D0.nhalo) {
+            const int64_t g = tid < D0.nown ? (int64_t)D0.base + tid : (int64_t)id0;
 #pragma unroll
-        for (int k = 0; k < KO; k++) {
-            int i = k * T + tid;
-            if (i < own3) { s_u1[i] = a1[k]; s_u2[i] = a2[k]; }
+            for (int d = 0; d < 3; d++) {
+                s_mem[3 * tid + d] = u1g[3 * g + d];
+                s_mem[3 * nlmax + 3 * tid + d] = u2g[3 * g + d];
+            }
         }
-#pragma unroll
-        for (int k = 0; k < KH; k++) {
-            int i = k * T + tid;
-            if (i < halo3) { s_u1[own3 + i] = b1[k]; s_u2[own3 + i] = b2[k]; }
-        }
-        for (int i = tid; i < 3 * D.nacc; i += T) s_f[i] = 0.0;
-        hq_pair_data mine = cur;
         __syncthreads();
+    }
 
-        /* vmcnt retires in order: everything THIS patch still needs from memory (pair data of
-         * the later rounds, nodal constants) is requested first, the next patch's staging loads
-         * last, so no wait inside the element loop is ordered behind them */
-        const bool iso = (D.flags & HQ_PATCH_ISO) != 0;
-        hq_pair_data pr[NR - 1];
-#pragma unroll
-        for (int r = 1; r < NR; r++)
-            if (r * T + tid < D.npairs) pr[r - 1] = hq_pair_load<false>(pidx, pc1, pc2, pbeta, D.pair_off + r * T + tid);
-        double np[7];
-        if (tid < D.nown) {
-            if (iso) {
-                const double* q = nt3 + 3 * ((int64_t)D.base + tid);
-                np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
-                np[2] = np[3] = np[1];
-                np[5] = np[6] = np[4];
-            } else {
-                const double* q = nt + 7 * ((int64_t)D.base + tid);
-#pragma unroll
-                for (int k = 0; k < 7; k++) np[k] = q[k];
-            }
-        }
-        int slot_nn = slot_n + W;
-        bool has_nn = has_n && slot_nn < end;
-        int pnn = 0;
-        hq_patch_desc Dnn = Dn;
-        if (AHEAD && has_n) HQ_PIPE_ISSUE(Dn)
-        if (has_nn) {
-            pnn = order ? order[slot_nn] : slot_nn;
-            Dnn = desc[pnn];
-            if (AHEAD) HQ_PIPE_IDS(Dnn)
-        }
+    for (int k = 0;; k++) {
+        /* keep the per-patch address arithmetic inside the iteration: hipcc otherwise hoists
+         * table + f(thread) for every table out of the loop and spills */
+        HQ_STAMPD(0);
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        double* __restrict__ s_u1 = s_mem + (k & 1) * 6 * nlmax;
+        double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
+        double* __restrict__ n_u1 = s_mem + ((k + 1) & 1) * 6 * nlmax;
+        double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
 
+        /* 1. the request that flies during the element section: the node data of patch k+1 */
+        /* (loads are unconditional, from a clamped address where the thread has nothing to load:
+         * straight-line code lets the compiler count vmcnt exactly instead of waiting for all) */
+        double a1[3], a2[3];
+        const bool have_node = tid < D1.nown + D1.nhalo;
+        {
+            const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0);
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int q = r * T + tid;
-            if (r > 0) mine = pr[r - 1];
-            if (q < D.npairs) {
-                const uint4 raw = mine.raw;
-                const double beta = mine.beta;
-                int l[8];
-                l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
-                l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
-                l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
-                l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
-                double X[8], Y[8], Z[8];
-#pragma unroll
-                for (int n = 0; n < 8; n++) {
-                    const double* a = &s_u1[3 * l[n]];
-                    const double* b = &s_u2[3 * l[n]];
-                    double a0 = a[0], a1_ = a[1], a2_ = a[2];
-                    X[n] = a0 + beta * (a0 - b[0]);
-                    Y[n] = a1_ + beta * (a1_ - b[1]);
-                    Z[n] = a2_ + beta * (a2_ - b[2]);
-                }
-                hq_element_force(X, Y, Z, mine.c1, mine.c2);
-#pragma unroll
-                for (int n = 0; n < 8; n++) {
-                    if (l[n] < D.nacc) {
-                        atomicAdd(&s_f[3 * l[n] + 0], X[n]);
-                        atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
-                        atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
-                    }
-                }
-            }
+            for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
         }
-        for (int q = NR * T + tid; q < D.npairs; q += T) {       /* patches with unusually many elements */
-            mine = hq_pair_load<false>(pidx, pc1, pc2, pbeta, D.pair_off + q);
-            const uint4 raw = mine.raw;
-            const double beta = mine.beta;
-            int l[8];
+        const int p3 = HQ_SLOT_PATCH(slot + 3 * W);
+        const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
+
+        HQ_STAMPD(1);
+        /* 2. element section of patch k on the current buffer: one element per thread (the
+         *    planner keeps patches at <= 1024 elements) */
+        const bool has_elem = tid < D0.npairs;
+        int l[8];
+        double X[8], Y[8], Z[8];
+        if (has_elem) {
+            const hq_u32x4 raw = c_raw;
+            const double beta = c_beta;
             l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
             l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
             l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
             l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
-            double X[8], Y[8], Z[8];
+#pragma unroll
             for (int n = 0; n < 8; n++) {
                 const double* a = &s_u1[3 * l[n]];
                 const double* b = &s_u2[3 * l[n]];
@@ -819,68 +788,109 @@ hq_k_patch_pipe(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 Y[n] = a1_ + beta * (a1_ - b[1]);
                 Z[n] = a2_ + beta * (a2_ - b[2]);
             }
-            hq_element_force(X, Y, Z, mine.c1, mine.c2);
+            hq_element_force(X, Y, Z, c_c1, c_c2);
+        }
+        HQ_STAMPD(2);
+        /* 3. the element row is consumed: request what flies during the atomics, the barrier and
+         *    the LDS write below: n_t of this patch's node (3-double form; patches with dashpot
+         *    nodes read the 7-double row at the update), element row of patch k+1, halo id of
+         *    patch k+2 */
+        const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
+        double n3[3];
+        {
+            const double* q = nt3 + 3 * ((int64_t)D0.base + (tid < D0.nown ? tid : 0));
+            n3[0] = q[0]; n3[1] = q[1]; n3[2] = q[2];
+        }
+        HQ_PERS_ROW(D1)
+        int32_t idnn;
+        {
+            const int h = tid - D2.nown;
+            idnn = halo[(int64_t)(p2 < 0 ? 0 : p2) * hstride + ((h >= 0 && h < D2.nhalo) ? h : 0)];
+        }
+        if (has_elem) {
+#pragma unroll
             for (int n = 0; n < 8; n++) {
-                if (l[n] < D.nacc) {
+                if (l[n] < D0.nacc) {
                     atomicAdd(&s_f[3 * l[n] + 0], X[n]);
                     atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
                     atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
                 }
             }
         }
-        if (F) {
-            for (int k = src_ptr[p] + tid; k < src_ptr[p + 1]; k += T) {
-                int ln = src_ent[2 * k], li = src_ent[2 * k + 1];
+
+        if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
+            for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += T) {
+                int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
                 for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * ln + d], F[3 * li + d] * dt2);
             }
         }
-        if (ds_ptr && ds_ptr[p + 1] > ds_ptr[p]) {
+        if (ds_ptr && ds_ptr[p0 + 1] > ds_ptr[p0]) {     /* compute_adjust DISTRIBUTION, psolve.c:5942-5987 */
             __syncthreads();
-            for (int k = ds_ptr[p] + tid; k < ds_ptr[p + 1]; k += T) {
-                const int src = ds_ent[3 * k], dst = ds_ent[3 * k + 1];
-                const double deps = (double)(unsigned)ds_ent[3 * k + 2];
+            for (int i = ds_ptr[p0] + tid; i < ds_ptr[p0 + 1]; i += T) {
+                const int src = ds_ent[3 * i], dst = ds_ent[3 * i + 1];
+                const double deps = (double)(unsigned)ds_ent[3 * i + 2];
                 for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
             }
         }
         __syncthreads();
+        HQ_STAMPD(3);
 
-        for (int n = tid; n < D.nown; n += T) {
-            if (n != tid) {
-                if (iso) {
-                    const double* q = nt3 + 3 * ((int64_t)D.base + n);
-                    np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
-                    np[2] = np[3] = np[1];
-                    np[5] = np[6] = np[4];
-                } else {
-                    const double* q = nt + 7 * ((int64_t)D.base + n);
+        /* 4. patch k+1 into the other buffer (last read an iteration ago) */
+        if (have_node) {
 #pragma unroll
-                    for (int k = 0; k < 7; k++) np[k] = q[k];
-                }
-            }
-            double* out = ung + 3 * ((int64_t)D.base + n);
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
-                out[d] = f / np[0];
-            }
+            for (int d = 0; d < 3; d++) { n_u1[3 * tid + d] = a1[d]; n_u2[3 * tid + d] = a2[d]; }
         }
-        if (if_ptr) {
-            for (int k = if_ptr[p] + tid; k < if_ptr[p + 1]; k += T) {
-                int ln = if_ent[2 * k];
-                double* o = iforce + 3 * (int64_t)if_ent[2 * k + 1];
+        /* the element row and gather id requested above are the youngest loads: the compiler's wait
+         * for them sits here, before the update's stores are in the queue */
+        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idnn));
+        HQ_STAMPD(4);
+        /* 5. interface partial forces (psolve.c:4301), then update + re-zero the accumulators */
+        if (if_ptr && if_ptr[p0 + 1] > if_ptr[p0]) {
+            for (int i = if_ptr[p0] + tid; i < if_ptr[p0 + 1]; i += T) {
+                int ln = if_ent[2 * i];
+                double* o = iforce + 3 * (int64_t)if_ent[2 * i + 1];
                 o[0] = s_f[3 * ln]; o[1] = s_f[3 * ln + 1]; o[2] = s_f[3 * ln + 2];
             }
+            __syncthreads();
         }
-        if (!has_n) break;
-        __syncthreads();                                       /* LDS is reused by the next patch */
-        D = Dn; p = pn;
-        Dn = Dnn; pn = pnn;
-        has_n = has_nn;
-        slot_n = slot_nn;
+        if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
+            const int n = tid;
+            double* out = ung + 3 * ((int64_t)D0.base + n);
+            if (iso) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double f = s_f[3 * n + d] + (n3[1] * s_u1[3 * n + d] - n3[2] * s_u2[3 * n + d]);
+                    s_f[3 * n + d] = 0.0;
+                    out[d] = f / n3[0];
+                }
+            } else {
+                const double* q = nt + 7 * ((int64_t)D0.base + n);
+                double np[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) np[i] = q[i];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
+                    s_f[3 * n + d] = 0.0;
+                    out[d] = f / np[0];
+                }
+            }
+        }
+        for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;
+        HQ_STAMPD(5);
+        __syncthreads();
+        HQ_STAMPD(6);
+        if (p1 < 0) break;
+        slot += W;
+        p0 = p1; p1 = p2; p2 = p3;
+        D0 = D1; D1 = D2; D2 = D3;
+        idn = idnn;
     }
-#undef HQ_PIPE_IDS
-#undef HQ_PIPE_ISSUE
+#undef HQ_SLOT_PATCH
+#undef HQ_PERS_ID
+#undef HQ_PERS_ROW
 }
+
 
 /* ------------------------------------------------------------------------ */
 /* device plan                                                              */
@@ -923,6 +933,23 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         }
         D.flags = iso ? HQ_PATCH_ISO : 0;
     }
+    int32_t nuniform = 0;
+    if (!getenv("HQ_PATCH_NO_UNIFORM")) {
+        for (auto& D : H.desc) {
+            bool uni = D.npairs > 0;
+            const int32_t e0 = D.npairs > 0 ? H.pelem[(size_t)D.pair_off] : 0;
+            for (int64_t q = D.pair_off; q < D.pair_off + D.npairs && uni; q++) {
+                const int32_t e = H.pelem[(size_t)q];
+                uni = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
+            }
+            if (uni) { D.flags |= HQ_PATCH_UNIFORM; nuniform++; }
+        }
+    }
+    P->ndistinct = H.ndistinct;
+    P->nuniform = nuniform;
+    if (getenv("HQ_PATCH_VERBOSE"))
+        fprintf(stderr, "hq patch plan: %zu patches, %d distinct local connectivities, %d with uniform coefficients\n",
+                H.desc.size(), H.ndistinct, nuniform);
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
@@ -963,7 +990,11 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         for (int64_t q = 0; q < P->npairs; q++) v[(size_t)q] = src[k][H.pelem[(size_t)q]];
         hipMemcpy(dst[k], v.data(), 8 * (size_t)P->npairs, hipMemcpyHostToDevice);
     }
-    for (auto& D : H.desc) { P->max_nown = std::max(P->max_nown, D.nown); P->max_nhalo = std::max(P->max_nhalo, D.nhalo); }
+    for (auto& D : H.desc) {
+        P->max_nown = std::max(P->max_nown, D.nown);
+        P->max_nhalo = std::max(P->max_nhalo, D.nhalo);
+        P->max_npairs = std::max(P->max_npairs, D.npairs);
+    }
     P->patch_base.resize(H.desc.size());
     P->patch_nown.resize(H.desc.size());
     for (size_t p = 0; p < H.desc.size(); p++) { P->patch_base[p] = H.desc[p].base; P->patch_nown[p] = H.desc[p].nown; }
@@ -1042,7 +1073,10 @@ static void hq_patch_report_stamps(void)
     std::vector<unsigned long long> h((size_t)g_hq_stamp_n * 8);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), g_hq_stamp_buf, 64 * (size_t)g_hq_stamp_n, hipMemcpyDeviceToHost);
-    const char* name[6] = { "descriptor", "issue+wait staging, LDS write", "barrier 1", "element loop", "src/ds + barrier 2", "update + stores issued" };
+    static const int pipe_ = hq_patch_kernel_choice();
+    const char* name0[6] = { "descriptor", "issue+wait staging, LDS write", "barrier 1", "element loop", "src/ds + barrier 2", "update + stores issued" };
+    const char* name4[6] = { "row wait + node loads issued", "element section", "row/n_t loads, src/ds, barrier", "wait node data, LDS write", "update + stores issued", "barrier" };
+    const char** name = pipe_ == 4 ? name4 : name0;
     double sum[6] = { 0, 0, 0, 0, 0, 0 };
     long cnt = 0;
     for (int32_t p = 0; p < g_hq_stamp_n; p++) {
@@ -1059,6 +1093,22 @@ static void hq_patch_report_stamps(void)
 }
 #endif
 
+/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 0 = hq_k_patch_step always */
+static int hq_patch_kernel_choice(void)
+{
+    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 4;
+    return v;
+}
+
+/* hq_k_patch_pers wants one local node and one element per thread and two node buffers in LDS
+ * (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
+static bool hq_patch_uses_pers(const hq_patch_plan* P)
+{
+    if (hq_patch_kernel_choice() != 4) return false;
+    if (P->cfg.nlmax > HQ_PERS_THREADS || P->max_npairs > HQ_PERS_THREADS) return false;
+    return (12 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double) <= 160 * 1024;
+}
+
 /* launch patches order[first .. first+count) (order == identity when there is no interface) */
 static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const double* u1,
                             const double* u2, double* un, const double* nt, const double* F, double dt2,
@@ -1068,16 +1118,32 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     int per_xcd = (count + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double);
     static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
-    /* persistent pipelined form: needs every patch to fit its per-thread staging registers */
-    static const int pipe = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 0;
-    if (pipe == 1 && 3 * P->max_nown <= 256 * 9 && 3 * P->max_nhalo <= 256 * 6) {
-        int grid = 256 * 2;
-        while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
-        hq_k_patch_pipe<256, 9, 6, true, 2, 3><<<grid, 256, lds, stream>>>(
-            count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
-            P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
-            (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent);
-        return;
+    static const int pipe = hq_patch_kernel_choice();
+#ifdef HQ_PATCH_PROFILING
+    if (getenv("HQ_PATCH_DIAG") && atoi(getenv("HQ_PATCH_DIAG")) == 6) {
+        static unsigned long long* d_st = nullptr;
+        if (!d_st) {
+            hipMalloc((void**)&d_st, 64 * (size_t)P->npatches);
+            hipMemset(d_st, 0, 64 * (size_t)P->npatches);
+            hipMemcpyToSymbol(HIP_SYMBOL(g_hq_stamps), &d_st, sizeof d_st);
+            g_hq_stamp_buf = d_st; g_hq_stamp_n = P->npatches;
+        }
+    }
+#endif
+    /* (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
+    if (hq_patch_uses_pers(P)) {
+        const int32_t nfacc = 3 * (P->cfg.pmax + P->cfg.vmax);
+        size_t lds4 = (12 * (size_t)P->cfg.nlmax + (size_t)nfacc) * sizeof(double);
+        {
+            int grid = 256;
+            while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
+            hq_k_patch_pers<<<grid, HQ_PERS_THREADS, lds4, stream>>>(
+                count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, nfacc, P->d_desc, P->d_pidx,
+                P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
+                (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
+                P->hstride);
+            return;
+        }
     }
     auto kern = nt_hint ? hq_k_patch_step<true, 0> : hq_k_patch_step<false, 0>;
 #ifdef HQ_PATCH_PROFILING   /* ablation builds for profiles/: results are WRONG by construction */
@@ -1087,18 +1153,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (diag == 3) kern = hq_k_patch_step<false, 3>;
     if (diag == 4) kern = hq_k_patch_step<false, 4>;
     if (diag == 5) kern = hq_k_patch_step<false, 5>;
-    if (diag == 6) {
-        kern = hq_k_patch_step<false, 6>;
-        static unsigned long long* d_st = nullptr;
-        static int32_t st_n = 0;
-        if (!d_st) {
-            st_n = P->npatches;
-            hipMalloc((void**)&d_st, 64 * (size_t)st_n);
-            hipMemset(d_st, 0, 64 * (size_t)st_n);
-            hipMemcpyToSymbol(HIP_SYMBOL(g_hq_stamps), &d_st, sizeof d_st);
-            g_hq_stamp_buf = d_st; g_hq_stamp_n = st_n;
-        }
-    }
+    if (diag == 6) kern = hq_k_patch_step<false, 6>;
 #endif
     kern<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
         count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
