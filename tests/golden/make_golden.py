@@ -324,9 +324,8 @@ CASES = {
     "c5_three_level": case_three_level,
     "c5_two_level_np8": lambda: case_octree_np("c5_two_level_np8", "c5_two_level", 8, "0.5", 200,
                                                [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
-    "c5_three_level_np5": lambda: case_octree_np("c5_three_level_np5", "c5_three_level", 5, "0.4", 100,
-                                                 ["layers", 3, 0, 1500, 150, 1800, 2, 2500, 2000, 2300, 4, 6000, 3464, 2700],
-                                                 100, 0.25),
+    # (a 5-rank run of the three-level mesh was tried and is NOT a fixture: on 5 ranks the
+    #  reference's mesher refines that model uniformly, so it pins nothing the others do not)
 }
 
 if __name__ == "__main__":
