@@ -784,9 +784,45 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
         disp = (double*)malloc(sizeof(double) * 3 * (size_t)rp->nstations);
         if (!u || !disp) { free(F); free(u); free(disp); return HQ_ERR_NOMEM; }
     }
+    /* output planes */
+    double *pu = NULL, *pbuf = NULL;
+    FILE** pfp = NULL;
+    int64_t npp = 0;
     int rc = HQ_OK;
+    if (rp->nplanes > 0 && rp->plane_rate > 0 && rp->plane_dir) {
+        for (int32_t i = 0; i < rp->nplanes; i++) npp += rp->plane_npoints[i];
+        pu = (double*)malloc(sizeof(double) * 24 * (size_t)(npp ? npp : 1));
+        pbuf = (double*)calloc((size_t)(npp ? npp : 1) * 3, sizeof(double));
+        pfp = (FILE**)calloc((size_t)rp->nplanes, sizeof(FILE*));
+        if (!pu || !pbuf || !pfp) rc = HQ_ERR_NOMEM;
+        for (int32_t i = 0; i < rp->nplanes && rc == HQ_OK; i++) {
+            char path[1200];
+            snprintf(path, sizeof path, "%s/planedisplacements.%d", rp->plane_dir, i);
+            pfp[i] = fopen(path, step0 > 0 ? "ab" : "wb");     /* a restart continues the file */
+            if (!pfp[i]) rc = HQ_ERR_ARG;
+        }
+    }
     int32_t step = step0, end = step0 + nsteps, win_end = step0;
     while (step < end && rc == HQ_OK) {
+        if (pfp && step % rp->plane_rate == 0) {                 /* solver_output_planes, :4279 */
+            rc = hq_gather(ctx, (int32_t)(npp * 8), rp->plane_ids, pu, NULL);
+            if (rc != HQ_OK) break;
+            int64_t off = 0;
+            for (int32_t i = 0; i < rp->nplanes && rc == HQ_OK; i++) {
+                for (int64_t s = off; s < off + rp->plane_npoints[i]; s++) {
+                    if (rp->plane_mine && !rp->plane_mine[s]) continue;
+                    for (int d = 0; d < 3; d++) {                /* Old_planes_print, io_planes.c:176-200 */
+                        double acc = 0.0;
+                        for (int c = 0; c < 8; c++) acc += rp->plane_phi[8 * s + c] * pu[(8 * s + c) * 3 + d];
+                        pbuf[3 * s + d] = acc;
+                    }
+                }
+                size_t n = 3 * (size_t)rp->plane_npoints[i];
+                if (fwrite(pbuf + 3 * off, sizeof(double), n, pfp[i]) != n) rc = HQ_ERR_ARG;
+                off += rp->plane_npoints[i];
+            }
+            if (rc != HQ_OK) break;
+        }
         if (u && step % rp->station_rate == 0) {                 /* solver_output_stations, :4280 */
             rc = hq_gather(ctx, rp->nstations * 8, rp->station_ids, u, NULL);
             if (rc != HQ_OK) break;
@@ -816,12 +852,69 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
             int32_t ns = (step / rp->station_rate + 1) * rp->station_rate;
             if (ns < next) next = ns;
         }
+        if (pfp) {
+            int32_t ns = (step / rp->plane_rate + 1) * rp->plane_rate;
+            if (ns < next) next = ns;
+        }
         rc = hq_run(ctx, next - step);
         step = next;
     }
     if (rc == HQ_OK) rc = hq_sync(ctx);
-    free(F); free(u); free(disp);
+    if (pfp) for (int32_t i = 0; i < rp->nplanes; i++) if (pfp[i]) fclose(pfp[i]);
+    free(F); free(u); free(disp); free(pu); free(pbuf); free(pfp);
     return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* output planes: geometry                                                  */
+/* ------------------------------------------------------------------------ */
+
+
+/* compute_global_coords (geometrics.c:33-70) with rake = 0, over the grid of
+ * Old_output_planes_construct_strips (io_planes.c:489-520) */
+int hqh_plane_points(const hqh_plane* pl, double* xyz)
+{
+    if (!pl || !xyz || pl->n_strike < 0 || pl->n_dip < 0) return HQ_ERR_ARG;
+    const double d = pl->dip_deg * HQH_PI / 180, l = 0.0 * HQH_PI / 180, p = pl->strike_deg * HQH_PI / 180;
+    for (int32_t i = 0; i < pl->n_strike; i++)
+        for (int32_t j = 0; j < pl->n_dip; j++) {
+            const double x = i * pl->step_strike, y = j * pl->step_dip, z = 0;
+            double* o = xyz + 3 * ((int64_t)i * pl->n_dip + j);
+            o[0] = (cos(p) * cos(l) + sin(p) * cos(d) * sin(l)) * x - (-cos(p) * sin(l) + sin(p) * cos(d) * cos(l)) * y -
+                   (-sin(p) * sin(d)) * z + pl->origin[0];
+            o[1] = (sin(p) * cos(l) - cos(p) * cos(d) * sin(l)) * x - (-sin(p) * sin(l) - cos(p) * cos(d) * cos(l)) * y -
+                   (cos(p) * sin(d)) * z + pl->origin[1];
+            o[2] = -sin(d) * sin(l) * x + sin(d) * cos(l) * y + cos(d) * z + pl->origin[2];
+        }
+    return HQ_OK;
+}
+
+/* compute_domain_coords_linearinterp (geometrics.c:178-244): Newton iteration on the bilinear
+ * map of the four corners; csi follows latitude and scales to len_x, eta longitude / len_y */
+int hqh_domain_coords(double lon, double lat, const double lon_corners[4], const double lat_corners[4],
+                      double len_x, double len_y, double* x, double* y)
+{
+    if (!lon_corners || !lat_corners || !x || !y) return HQ_ERR_ARG;
+    const double X = lat, Y = lon;
+    const double *Xi = lat_corners, *Yi = lon_corners;
+    const double Ax = 4 * X - (Xi[0] + Xi[1] + Xi[2] + Xi[3]), Ay = 4 * Y - (Yi[0] + Yi[1] + Yi[2] + Yi[3]);
+    const double Bx = -Xi[0] + Xi[1] + Xi[2] - Xi[3], By = -Yi[0] + Yi[1] + Yi[2] - Yi[3];
+    const double Cx = -Xi[0] - Xi[1] + Xi[2] + Xi[3], Cy = -Yi[0] - Yi[1] + Yi[2] + Yi[3];
+    const double Dx = Xi[0] - Xi[1] + Xi[2] - Xi[3], Dy = Yi[0] - Yi[1] + Yi[2] - Yi[3];
+    double xn0 = 0, xn1 = 0, res = 1e10;
+    for (int it = 0; res > 1e-6; it++) {
+        if (it > 100) return HQ_ERR_ARG;                     /* corners do not span a quadrilateral */
+        const double m00 = Bx + Dx * xn1, m01 = Cx + Dx * xn0, m10 = By + Dy * xn1, m11 = Cy + Dy * xn0;
+        const double f0 = -Ax + Bx * xn0 + Cx * xn1 + Dx * xn0 * xn1;
+        const double f1 = -Ay + By * xn0 + Cy * xn1 + Dy * xn0 * xn1;
+        const double det = m00 * m11 - m10 * m01;
+        const double d0 = -(f0 * m11 - f1 * m01) / det, d1 = -(f1 * m00 - f0 * m10) / det;
+        res = fabs(f0) + fabs(f1);
+        xn0 += d0; xn1 += d1;
+    }
+    *x = .5 * (xn0 + 1) * len_x;
+    *y = .5 * (xn1 + 1) * len_y;
+    return HQ_OK;
 }
 
 /* ------------------------------------------------------------------------ */

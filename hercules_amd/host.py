@@ -45,7 +45,38 @@ class _RunParams(ctypes.Structure):
                 ("rise_time", ctypes.c_double), ("source_window", ctypes.c_int32),
                 ("nstations", ctypes.c_int32), ("station_ids", ctypes.c_void_p),
                 ("station_phi", ctypes.c_void_p), ("station_rate", ctypes.c_int32),
-                ("station_fn", STATION_FN), ("station_user", ctypes.c_void_p)]
+                ("station_fn", STATION_FN), ("station_user", ctypes.c_void_p),
+                ("nplanes", ctypes.c_int32), ("plane_npoints", ctypes.c_void_p),
+                ("plane_ids", ctypes.c_void_p), ("plane_phi", ctypes.c_void_p),
+                ("plane_mine", ctypes.c_void_p), ("plane_rate", ctypes.c_int32),
+                ("plane_dir", ctypes.c_char_p)]
+
+
+class _Plane(ctypes.Structure):
+    _fields_ = [("origin", ctypes.c_double * 3), ("step_strike", ctypes.c_double), ("n_strike", ctypes.c_int32),
+                ("step_dip", ctypes.c_double), ("n_dip", ctypes.c_int32), ("strike_deg", ctypes.c_double),
+                ("dip_deg", ctypes.c_double)]
+
+
+def plane_points(origin, step_strike, n_strike, step_dip, n_dip, strike_deg, dip_deg):
+    """Grid points of an output plane, [n_strike * n_dip, 3] (hqh_plane_points)."""
+    lib = load_library()
+    pl = _Plane((ctypes.c_double * 3)(*[float(v) for v in origin]), float(step_strike), int(n_strike),
+                float(step_dip), int(n_dip), float(strike_deg), float(dip_deg))
+    out = np.zeros((int(n_strike) * int(n_dip), 3))
+    capi._check(lib.hqh_plane_points(ctypes.byref(pl), out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def domain_coords(lon, lat, lon_corners, lat_corners, len_x, len_y):
+    """(longitude, latitude) -> domain (x, y) through the four surface corners (hqh_domain_coords)."""
+    lib = load_library()
+    lc = (ctypes.c_double * 4)(*[float(v) for v in lon_corners])
+    la = (ctypes.c_double * 4)(*[float(v) for v in lat_corners])
+    x, y = ctypes.c_double(), ctypes.c_double()
+    capi._check(lib.hqh_domain_coords(ctypes.c_double(lon), ctypes.c_double(lat), lc, la, ctypes.c_double(len_x),
+                                      ctypes.c_double(len_y), ctypes.byref(x), ctypes.byref(y)))
+    return x.value, y.value
 
 
 _lib = None
@@ -175,9 +206,24 @@ class Box:
         return ids, phi, mine
 
     def run_params(self, loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
-                   station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None):
+                   station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
+                   planes=None, plane_rate=0, plane_dir=None):
+        """planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
+        every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
         rp = _RunParams()
         keep = []
+        if planes and plane_rate > 0 and plane_dir is not None:
+            npts = np.array([len(p[0]) for p in planes], np.int32)
+            pid = np.ascontiguousarray(np.concatenate([np.asarray(p[0]).reshape(-1, 8) for p in planes]), np.int32)
+            pph = np.ascontiguousarray(np.concatenate([np.asarray(p[1]).reshape(-1, 8) for p in planes]), np.float64)
+            keep += [npts, pid, pph]
+            rp.nplanes, rp.plane_npoints, rp.plane_ids, rp.plane_phi = len(planes), npts.ctypes.data, pid.ctypes.data, pph.ctypes.data
+            if any(len(p) > 2 for p in planes):
+                pm = np.ascontiguousarray(np.concatenate([np.asarray(p[2]) if len(p) > 2 else np.ones(len(p[0]))
+                                                          for p in planes]), np.int32)
+                keep.append(pm)
+                rp.plane_mine = pm.ctypes.data
+            rp.plane_rate, rp.plane_dir = int(plane_rate), os.fsencode(plane_dir)
         if force_file is not None:
             rp.force_file = os.fsencode(force_file)
             l = np.ascontiguousarray(loaded, np.int32)

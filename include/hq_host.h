@@ -111,6 +111,17 @@ typedef struct {
     int32_t        station_rate;     /* output_stations_print_rate; 0 = never      */
     hqh_station_fn station_fn;
     void*          station_user;
+    /* output planes (io_planes.c): every plane_rate steps, 3 doubles per grid point of every
+     * plane appended to <plane_dir>/planedisplacements.<i> (Old_print_plane_displacements,
+     * io_planes.c:252-270).  Points of all planes concatenated; plane_mine (may be NULL) = 0
+     * where the containing element is on another partition: that value is left as last written */
+    int32_t        nplanes;
+    const int32_t* plane_npoints;    /* [nplanes] */
+    const int32_t* plane_ids;        /* [sum npoints][8] */
+    const double*  plane_phi;        /* [sum npoints][8] */
+    const int32_t* plane_mine;       /* [sum npoints] or NULL */
+    int32_t        plane_rate;       /* output_planes_print_rate; 0 = never */
+    const char*    plane_dir;        /* output_planes_directory */
 } hqh_run_params;
 
 /* solver_run: steps [step0, step0 + nsteps) on `ctx`. */
@@ -143,6 +154,28 @@ HQ_API int hqh_checkpoint_write(hq_ctx* ctx, const char* path, int32_t step, int
                                 int32_t nharbored, int32_t nharboredmax);
 HQ_API int hqh_checkpoint_read(hq_ctx* ctx, const char* path, int32_t rank, int32_t nranks,
                                int32_t nharbored, int32_t* step);
+
+/*
+ * Output planes (io_planes.c:280-520).  A plane is a grid of n_strike x n_dip points from an
+ * origin (domain coordinates, metres) along strike and down dip; point index =
+ * iStrike * n_dip + iDownDip.  hqh_plane_points restates compute_global_coords
+ * (geometrics.c:33-70, rake = 0); hqh_domain_coords the (longitude, latitude) -> domain x, y
+ * map through the four surface corners (compute_domain_coords_linearinterp,
+ * geometrics.c:178-244; x follows latitude).  Containing elements and weights of the points:
+ * hqh_stations.
+ */
+typedef struct {
+    double  origin[3];
+    double  step_strike;
+    int32_t n_strike;
+    double  step_dip;
+    int32_t n_dip;
+    double  strike_deg, dip_deg;
+} hqh_plane;
+
+HQ_API int hqh_plane_points(const hqh_plane* pl, double* xyz);
+HQ_API int hqh_domain_coords(double lon, double lat, const double lon_corners[4], const double lat_corners[4],
+                             double len_x, double len_y, double* x, double* y);
 
 /* One station line in the reference's text format (psolve.c:6727-6731). */
 HQ_API int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3]);

@@ -7,6 +7,7 @@ import ctypes
 import os
 import subprocess
 
+import math
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -267,6 +268,59 @@ def station_weights(points_m, h, nx, ny, nz, lnid, elem_ijk):
         ids.append(lnid[e])
         phis.append(phi)
     return np.array(ids, np.int32), np.array(phis)
+
+
+def domain_coords_linearinterp(lon, lat, lon_corners, lat_corners, len_eta, len_csi):
+    """(longitude, latitude) -> domain x, y: Newton iteration on the bilinear map of the four
+    surface corners (compute_domain_coords_linearinterp, geometrics.c:178-244)."""
+    X, Y = lat, lon
+    Xi, Yi = [float(v) for v in lat_corners], [float(v) for v in lon_corners]
+    Ax = 4 * X - (Xi[0] + Xi[1] + Xi[2] + Xi[3]); Ay = 4 * Y - (Yi[0] + Yi[1] + Yi[2] + Yi[3])
+    Bx = -Xi[0] + Xi[1] + Xi[2] - Xi[3];          By = -Yi[0] + Yi[1] + Yi[2] - Yi[3]
+    Cx = -Xi[0] - Xi[1] + Xi[2] + Xi[3];          Cy = -Yi[0] - Yi[1] + Yi[2] + Yi[3]
+    Dx = Xi[0] - Xi[1] + Xi[2] - Xi[3];           Dy = Yi[0] - Yi[1] + Yi[2] - Yi[3]
+    xn = [0.0, 0.0]
+    res = 1e10
+    while res > 1e-6:
+        m00 = Bx + Dx * xn[1]; m01 = Cx + Dx * xn[0]
+        m10 = By + Dy * xn[1]; m11 = Cy + Dy * xn[0]
+        f0 = -Ax + Bx * xn[0] + Cx * xn[1] + Dx * xn[0] * xn[1]
+        f1 = -Ay + By * xn[0] + Cy * xn[1] + Dy * xn[0] * xn[1]
+        det = m00 * m11 - m10 * m01
+        d0 = -(f0 * m11 - f1 * m01) / det
+        d1 = -(f1 * m00 - f0 * m10) / det
+        res = abs(f0) + abs(f1)
+        xn[0] += d0; xn[1] += d1
+    return 0.5 * (xn[0] + 1) * len_csi, 0.5 * (xn[1] + 1) * len_eta
+
+
+def plane_points(origin_xyz, step_strike, n_strike, step_dip, n_dip, strike_deg, dip_deg):
+    """Grid of an output plane in domain coordinates, index = iStrike * n_dip + iDownDip
+    (Old_output_planes_construct_strips io_planes.c:489-520; compute_global_coords with
+    rake = 0, geometrics.c:33-70).  -> [n_strike * n_dip, 3]"""
+    PI = 3.14159265358979323846
+    d, l, p = dip_deg * PI / 180, 0.0 * PI / 180, strike_deg * PI / 180
+    out = np.empty((n_strike * n_dip, 3))
+    for i in range(n_strike):
+        for j in range(n_dip):
+            x, y, z = i * step_strike, j * step_dip, 0.0
+            gx = (math.cos(p) * math.cos(l) + math.sin(p) * math.cos(d) * math.sin(l)) * x \
+                - (-math.cos(p) * math.sin(l) + math.sin(p) * math.cos(d) * math.cos(l)) * y \
+                - (-math.sin(p) * math.sin(d)) * z
+            gy = (math.sin(p) * math.cos(l) - math.cos(p) * math.cos(d) * math.sin(l)) * x \
+                - (-math.sin(p) * math.sin(l) - math.cos(p) * math.cos(d) * math.cos(l)) * y \
+                - (math.cos(p) * math.sin(d)) * z
+            gz = -math.sin(d) * math.sin(l) * x + math.sin(d) * math.cos(l) * y + math.cos(d) * z
+            out[i * n_dip + j] = (gx + origin_xyz[0], gy + origin_xyz[1], gz + origin_xyz[2])
+    return out
+
+
+def plane_displacements(tm1, ids, phi):
+    """Old_planes_print (io_planes.c:151-200): sum over the 8 nodes in lnid order, per component."""
+    out = np.zeros((len(ids), 3))
+    for c in range(8):
+        out += phi[:, c:c + 1] * tm1[ids[:, c]]
+    return out
 
 
 # ---------------------------------------------------------------------------

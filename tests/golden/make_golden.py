@@ -61,7 +61,8 @@ use_infinite_qk = no
 
 
 def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
-                  nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None):
+                  nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None, planes=None,
+                  plane_rate=50):
     """Run the reference in a scratch dir; return (dir, stdout)."""
     run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
     src = os.path.join(REF, "examples", "simple")
@@ -93,6 +94,13 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
         text = setkey(text, "simulation_wave_max_freq_hz", freq)
     if dt is not None:
         text = setkey(text, "simulation_delta_time_sec", dt)
+    if planes:
+        # io_planes.c: "output_planes =" is followed by one line per plane
+        # (lat long depth  dStrike nStrike  dDip nDip  strike dip), read from planes_input_file
+        text = setkey(text, "number_output_planes", len(planes))
+        text = setkey(text, "output_planes_print_rate", plane_rate)
+        open(os.path.join(run, "in", "planes.in"), "w").write(
+            "output_planes =\n" + "\n".join(" ".join(str(v) for v in p) for p in planes) + "\n")
     open(os.path.join(run, "parameters.in"), "w").write(text)
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(MPI, "lib"))
     out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", str(nranks), PSOLVE,
@@ -182,6 +190,25 @@ def case_short(name, **kw):
                         stations=st, dt=1e-3, end_time=1.0, freq=5.0)
     shutil.rmtree(run)
     print(name, "ok", sorted(ck))
+
+
+def case_planes():
+    """Two output planes (io_planes.c), one horizontal at depth, one dipping 60 degrees with a
+    strike of 30; every grid point inside the mesh."""
+    planes = [(300.0, 200.0, 100.0, 50.0, 9, 40.0, 7, 0.0, 0.0),
+              (250.0, 300.0, 20.0, 45.0, 8, 35.0, 6, 30.0, 60.0)]
+    run, out = run_reference("c1_planes", "0.4", 400, planes=planes, plane_rate=50)
+    ids, F = read_forces(run)
+    arrays = {}
+    for i, p in enumerate(planes):
+        raw = np.fromfile(os.path.join(run, "out", "planes", "planedisplacements.%d" % i), "<f8")
+        arrays["plane%d" % i] = raw.reshape(-1, p[4] * p[6], 3)
+    np.savez_compressed(os.path.join(HERE, "c1_planes.npz"), loaded_lnid=ids, forces=F,
+                        plane_specs=np.array(planes), plane_rate=50,
+                        surface_corners_lon_lat=np.array([[0.0, 0.0], [0.0, 1000.0], [1000.0, 1000.0], [1000.0, 0.0]]),
+                        domain_xyz=np.array([1000.0, 1000.0, 500.0]), dt=1e-3, end_time=0.4, freq=5.0, **arrays)
+    shutil.rmtree(run)
+    print("c1_planes ok", {k: v.shape for k, v in arrays.items()})
 
 
 def case_full():
@@ -319,6 +346,7 @@ CASES = {
     "c1_none": lambda: case_short("c1_none", damping="none"),
     "c1_mass": lambda: case_short("c1_mass", damping="mass"),
     "c1_full": case_full,
+    "c1_planes": case_planes,
     "c1_np8": case_np8,
     "c5_two_level": case_two_level,
     "c5_three_level": case_three_level,

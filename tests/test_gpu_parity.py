@@ -359,3 +359,34 @@ def test_octree_mesh_on_eight_partitions_against_reference(variant):
             assert np.abs(tm1 - ref1).max() <= TOL * scale and np.abs(tm2 - ref2).max() <= TOL * scale
     for s in solvers:
         s.close()
+
+
+def test_output_planes_written_by_the_c_solver_run(tmp_path):
+    """hqh_solver_run with two output planes, driven by the reference's own force file: the files
+    equal planedisplacements.<i> as the REAL reference wrote them (tests/golden/c1_planes.npz)."""
+    from hercules_amd import host
+    g = H.load("c1_planes")
+    box = host.Box(H.C1_NX, H.C1_NY, H.C1_NZ, H.C1_H, 1e-3, 5.0)
+    lonc, latc = g["surface_corners_lon_lat"][:, 0], g["surface_corners_lon_lat"][:, 1]
+    planes = []
+    for spec in g["plane_specs"]:
+        lat, lon, depth, ds, ns, dd, nd, strike, dip = spec
+        x, y = host.domain_coords(lon, lat, lonc, latc, g["domain_xyz"][0], g["domain_xyz"][1])
+        pts = host.plane_points((x, y, depth), ds, int(ns), dd, int(nd), strike, dip)
+        ids, phi, mine = box.stations(pts)
+        assert mine.all()
+        planes.append((ids, phi))
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    nsteps = int(round(float(g["end_time"]) / float(g["dt"])))
+    s = box.create_solver()
+    rp = box.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=64, planes=planes,
+                        plane_rate=int(g["plane_rate"]), plane_dir=str(tmp_path))
+    box.solver_run(s, rp, 0, 150)            # in two calls: the second one appends
+    box.solver_run(s, rp, 150, nsteps - 150)
+    s.close()
+    for i, (ids, _) in enumerate(planes):
+        got = np.fromfile(tmp_path / ("planedisplacements.%d" % i), "<f8").reshape(-1, len(ids), 3)
+        ref = g["plane%d" % i]
+        assert got.shape == ref.shape
+        assert H.rel_linf(got, ref) < TOL

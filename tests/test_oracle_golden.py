@@ -249,3 +249,42 @@ def test_octree_mesh_on_eight_ranks_tables_and_fields():
             scale = max(np.abs(ref1).max(), 1.0)
             assert np.abs(tm1s[p["rank"]] - ref2).max() <= 1e-12 * scale
             assert np.abs(tm2s[p["rank"]] - ref1).max() <= 1e-12 * scale
+
+
+def test_output_planes_against_the_reference_files():
+    """planedisplacements.<i> as the REAL reference wrote them (two planes, one dipping 60 degrees
+    at strike 30, every 50 steps): plane geometry (compute_domain_coords_linearinterp,
+    compute_global_coords), containing element + trilinear weights, and the field itself."""
+    g = H.load("c1_planes")
+    p = H.c1_problem()
+    lonc, latc = g["surface_corners_lon_lat"][:, 0], g["surface_corners_lon_lat"][:, 1]
+    planes = []
+    for spec in g["plane_specs"]:
+        lat, lon, depth, ds, ns, dd, nd, strike, dip = spec
+        x, y = ho.domain_coords_linearinterp(lon, lat, lonc, latc, g["domain_xyz"][1], g["domain_xyz"][0])
+        pts = ho.plane_points((x, y, depth), ds, int(ns), dd, int(nd), strike, dip)
+        assert pts.min() >= 0 and (pts <= g["domain_xyz"]).all()
+        planes.append(ho.station_weights(pts, H.C1_H, H.C1_NX, H.C1_NY, H.C1_NZ, p["lnid"], p["elem_ijk"]))
+    x, y = ho.domain_coords_linearinterp(200.0, 300.0, lonc, latc, 1000.0, 1000.0)
+    assert abs(x - 300.0) < 1e-9 and abs(y - 200.0) < 1e-9      # x <- latitude, y <- longitude
+    nsteps = int(round(float(g["end_time"]) / float(g["dt"])))
+    tm1 = np.zeros((p["N"], 3))
+    tm2 = np.zeros((p["N"], 3))
+    cap_ids = np.concatenate([ids.reshape(-1) for ids, _ in planes])
+    cap = ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, 0, nsteps, p["dt"],
+                        damping=p["damping"], loaded_lnid=g["loaded_lnid"], forces=g["forces"],
+                        cap_lnid=cap_ids)
+    rate = int(g["plane_rate"])
+    off = 0
+    for i, (ids, phi) in enumerate(planes):
+        ref = g["plane%d" % i]
+        assert ref.shape[0] == (nsteps + rate - 1) // rate
+        n = ids.size
+        for k in range(ref.shape[0]):
+            u = cap[k * rate, off:off + n].reshape(len(ids), 8, 3)
+            got = np.zeros((len(ids), 3))
+            for c in range(8):
+                got += phi[:, c:c + 1] * u[:, c]
+            assert np.abs(got - ref[k]).max() <= 1e-12 * max(np.abs(ref[k]).max(), 1e-300)
+        off += n
+        assert np.abs(ref[-1]).max() > 1e-3
