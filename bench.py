@@ -139,6 +139,33 @@ def cpu_baseline(seconds_target=12.0):
         return port
 
 
+def seeded_field(node_ijk, nx, ny, nz_fine=None):
+    """Displacements as a function of the global node coordinates (so every copy of a shared node
+    starts equal).  Two-level box (nz_fine given): a fine node of the interface plane z = nz_fine
+    that is no coarse vertex hangs, and starts at the mean of its anchors (its 2 edge or 4 face
+    neighbours, compute_adjust ASSIGNMENT)."""
+    ijk = np.asarray(node_ijk).astype(np.int64)
+
+    def raw(i, j, k):
+        gid = (k * (ny + 1) + j) * (nx + 1) + i
+        out = np.empty((len(gid), 3))
+        for d in range(3):
+            x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
+            out[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+        return out
+    i, j, k = ijk[:, 0], ijk[:, 1], ijk[:, 2]
+    u = raw(i, j, k)
+    if nz_fine is not None:
+        on = k == nz_fine
+        ox, oy = on & (i % 2 == 1), on & (j % 2 == 1)
+        xe, ye, zf = ox & ~oy, oy & ~ox, ox & oy
+        u[xe] = 0.5 * (raw(i[xe] - 1, j[xe], k[xe]) + raw(i[xe] + 1, j[xe], k[xe]))
+        u[ye] = 0.5 * (raw(i[ye], j[ye] - 1, k[ye]) + raw(i[ye], j[ye] + 1, k[ye]))
+        u[zf] = 0.25 * (raw(i[zf] - 1, j[zf] - 1, k[zf]) + raw(i[zf] + 1, j[zf] - 1, k[zf]) +
+                        raw(i[zf] - 1, j[zf] + 1, k[zf]) + raw(i[zf] + 1, j[zf] + 1, k[zf]))
+    return u
+
+
 def inproc_diagnostic(args):
     import hercules_amd as ha
     from hercules_amd import capi, host as hhost
@@ -146,14 +173,19 @@ def inproc_diagnostic(args):
     P = args.inproc_parts
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
     boxes, solvers = [], []
+    octree = args.workload in OCT_COARSE_LAYERS
     for r in range(P):
-        b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P)
-        ijk = b.node_ijk.astype(np.int64)
-        gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
-        u1 = np.empty((len(gid), 3))
-        for d in range(3):
-            x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
-            u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+        if octree:
+            b = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq, rank=r, nranks=P)
+            sch = b.schedules()
+            peers = set(q for kind in sch.values() for lst in kind.values() for q, _ in lst)
+            b.info = {"total_elements": nx * ny * nz + (nx // 2) * (ny // 2) * OCT_COARSE_LAYERS[args.workload],
+                      "shared_nodes": int(sum(len(m) for kind in sch.values() for lst in kind.values() for _, m in lst)),
+                      "nneighbors": len(peers)}
+            u1 = seeded_field(b.node_xyz, nx, ny, nz)
+        else:
+            b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P)
+            u1 = seeded_field(b.node_ijk, nx, ny)
         solvers.append(b.create_solver(variant=variant, tm1=u1, tm2=u1 * (1.0 - 1e-3)))
         boxes.append(b)
     capi.group_link(solvers)
@@ -215,31 +247,20 @@ def main():
     octree = args.workload in OCT_COARSE_LAYERS
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
     if octree:
-        if world != 1:
-            raise SystemExit("the two-level workload is single-partition")
-        box = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq)
-        box.info = {"nharbored": box.N, "total_elements": box.E, "lenum": box.E, "total_nodes": box.N}
+        box = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq, rank=rank, nranks=world)
+        total_e = (nx * ny * nz) + (nx // 2) * (ny // 2) * OCT_COARSE_LAYERS[args.workload]
+        box.info = {"nharbored": box.N, "total_elements": total_e, "lenum": box.E,
+                    "total_nodes": (nx + 1) * (ny + 1) * (nz + 1) + (nx // 2 + 1) * (ny // 2 + 1) * OCT_COARSE_LAYERS[args.workload]}
         box.node_ijk = box.node_xyz
     else:
         box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
     N = box.info["nharbored"]
     # seeded random start: identical on every rank for shared nodes
     # because it is a function of the global node coordinates
-    ijk = box.node_ijk.astype(np.int64)
-    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
-    u1 = np.empty((N, 3))
-    for d in range(3):
-        x = (gid * 3 + d + 12345) * np.int64(2654435761) % np.int64(2 ** 31)
-        u1[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+    u1 = seeded_field(box.node_ijk, nx, ny, nz if octree else None)
     u2 = u1 * (1.0 - 1e-3)
-    if octree:                                   # hanging nodes start at the mean of their anchors
-        ids, ptr, anc = box.dangling
-        for a in (u1, u2):
-            cnt = np.diff(ptr)
-            sums = np.add.reduceat(a[anc], ptr[:-1], axis=0)
-            a[ids] = sums / cnt[:, None]
     solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2)
-    del u1, u2, ijk, gid
+    del u1, u2
     if world > 1:
         idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(idbuf, src=0)

@@ -927,14 +927,151 @@ struct hqh_octbox {
     int32_t ldnnum;
     int32_t *lnid, *node_xyz, *dn_id, *dn_ptr, *dn_anchor;
     double *etable, *ntable;
+    /* partitions only */
+    int32_t *owner, *gid;
+    hq_messenger *mc[2], *ms[2];    /* [0] anchored-node schedule, [1] dangling-node schedule */
+    int32_t nc[2], ns[2];
+    int32_t *cmap[2], *smap[2];
 };
 
 void hqh_octbox_destroy(hqh_octbox* b)
 {
     if (!b) return;
     free(b->lnid); free(b->node_xyz); free(b->dn_id); free(b->dn_ptr); free(b->dn_anchor);
-    free(b->etable); free(b->ntable);
+    free(b->etable); free(b->ntable); free(b->owner); free(b->gid);
+    for (int s = 0; s < 2; s++) { free(b->mc[s]); free(b->ms[s]); free(b->cmap[s]); free(b->smap[s]); }
     free(b);
+}
+
+/* Cut rank `me`'s part out of the whole box in `b` (see hq_host.h); `ek` = the sorted Z-values
+ * of the element corners (element id = position). */
+static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
+{
+    const hqh_octbox_params* p = &b->p;
+    const int32_t nx = p->nx, ny = p->ny, nzf = p->nz_fine, nzt = p->nz_fine + 2 * p->nz_coarse;
+    const int64_t E = b->E, N = b->N;
+    int rc = HQ_ERR_NOMEM;
+    /* leaf of every fine cell / coarse cell -> element id */
+    const int64_t nfc = (int64_t)nx * ny * nzf, ncc = (int64_t)(nx / 2) * (ny / 2) * p->nz_coarse;
+    int32_t* fcell = (int32_t*)malloc(sizeof(int32_t) * (size_t)nfc);
+    int32_t* ccell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncc ? ncc : 1));
+    uint64_t* harb = (uint64_t*)calloc((size_t)N, sizeof(uint64_t));
+    int32_t* gowner = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    int32_t* g2l = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    uint8_t* hang = (uint8_t*)calloc((size_t)N, 1);
+    int32_t *lnid = NULL, *xyz = NULL, *own = NULL, *gid = NULL, *dn_id = NULL, *dn_ptr = NULL, *dn_anchor = NULL;
+    double *et = NULL, *nt = NULL;
+    if (!fcell || !ccell || !harb || !gowner || !g2l || !hang) goto done;
+#define HQH_ERANK(e) ((int)((((int64_t)(e) + 1) * P - 1) / E))     /* octor.c:4939-4944 */
+    for (int64_t e = 0; e < E; e++) {
+        int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+        if (k < nzf) fcell[((int64_t)k * ny + j) * nx + i] = (int32_t)e;
+        else ccell[((int64_t)((k - nzf) / 2) * (ny / 2) + j / 2) * (nx / 2) + i / 2] = (int32_t)e;
+        const uint64_t bit = 1ull << HQH_ERANK(e);
+        for (int c = 0; c < 8; c++) harb[b->lnid[8 * e + c]] |= bit;             /* element vertices */
+    }
+    for (int64_t n = 0; n < N; n++) {                                            /* owners */
+        const int32_t* c = &b->node_xyz[3 * n];
+        int32_t ax = c[0] < nx ? c[0] : nx - 1, ay = c[1] < ny ? c[1] : ny - 1, az = c[2] < nzt ? c[2] : nzt - 1;
+        int32_t e = az < nzf ? fcell[((int64_t)az * ny + ay) * nx + ax]
+                             : ccell[((int64_t)((az - nzf) / 2) * (ny / 2) + ay / 2) * (nx / 2) + ax / 2];
+        gowner[n] = HQH_ERANK(e);
+        harb[n] |= 1ull << gowner[n];
+    }
+    for (int32_t k = 0; k < b->ldnnum; k++) {                                    /* indirect sharing */
+        hang[b->dn_id[k]] = 1;
+        const uint64_t bit = 1ull << gowner[b->dn_id[k]];
+        for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++) harb[b->dn_anchor[a]] |= bit;
+    }
+    {
+        const uint64_t mebit = 1ull << me;
+        int64_t nh = 0;
+        for (int64_t n = 0; n < N; n++) g2l[n] = (harb[n] & mebit) ? (int32_t)nh++ : -1;
+        const int64_t elo = (int64_t)me * E / P, ehi = (int64_t)(me + 1) * E / P, ne = ehi - elo;
+        int32_t ndn = 0, nan = 0;
+        for (int32_t k = 0; k < b->ldnnum; k++)
+            if (gowner[b->dn_id[k]] == me) { ndn++; nan += b->dn_ptr[k + 1] - b->dn_ptr[k]; }
+        lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)(ne ? ne : 1));
+        et = (double*)malloc(sizeof(double) * 4 * (size_t)(ne ? ne : 1));
+        xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(nh ? nh : 1));
+        own = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nh ? nh : 1));
+        gid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nh ? nh : 1));
+        nt = (double*)malloc(sizeof(double) * 7 * (size_t)(nh ? nh : 1));
+        dn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ndn ? ndn : 1));
+        dn_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ndn + 1));
+        dn_anchor = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nan ? nan : 1));
+        if (!lnid || !et || !xyz || !own || !gid || !nt || !dn_id || !dn_ptr || !dn_anchor) goto done;
+        for (int64_t e = elo; e < ehi; e++) {
+            for (int c = 0; c < 8; c++) lnid[8 * (e - elo) + c] = g2l[b->lnid[8 * e + c]];
+            memcpy(et + 4 * (e - elo), b->etable + 4 * e, 4 * sizeof(double));
+        }
+        for (int64_t n = 0; n < N; n++) {
+            const int32_t l = g2l[n];
+            if (l < 0) continue;
+            memcpy(xyz + 3 * (int64_t)l, b->node_xyz + 3 * n, 3 * sizeof(int32_t));
+            memcpy(nt + 7 * (int64_t)l, b->ntable + 7 * n, 7 * sizeof(double));
+            own[l] = gowner[n];
+            gid[l] = (int32_t)n;
+        }
+        {   /* dnodeTable: the hanging nodes this rank owns, in (local = global) node order */
+            int32_t kd = 0, na = 0;
+            dn_ptr[0] = 0;
+            for (int32_t k = 0; k < b->ldnnum; k++) {
+                if (gowner[b->dn_id[k]] != me) continue;
+                dn_id[kd] = g2l[b->dn_id[k]];
+                for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++) dn_anchor[na++] = g2l[b->dn_anchor[a]];
+                dn_ptr[++kd] = na;
+            }
+        }
+        /* schedule_build (psolve.c:4704-4863): a node someone else owns goes on the c-list of its
+         * owner, a node I own on the s-list of every other rank that harbors it; hanging nodes in
+         * dn_sched, the rest in an_sched */
+        for (int s = 0; s < 2; s++) {
+            int64_t ccount[64], scount[64], cfill[64], sfill[64];
+            memset(ccount, 0, sizeof ccount); memset(scount, 0, sizeof scount);
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1) {
+                    int64_t ct = 0, st = 0;
+                    for (int r = 0; r < P; r++) { ct += ccount[r]; st += scount[r]; b->nc[s] += ccount[r] > 0; b->ns[s] += scount[r] > 0; }
+                    b->cmap[s] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ct ? ct : 1));
+                    b->smap[s] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(st ? st : 1));
+                    b->mc[s] = (hq_messenger*)calloc((size_t)(b->nc[s] ? b->nc[s] : 1), sizeof(hq_messenger));
+                    b->ms[s] = (hq_messenger*)calloc((size_t)(b->ns[s] ? b->ns[s] : 1), sizeof(hq_messenger));
+                    if (!b->cmap[s] || !b->smap[s] || !b->mc[s] || !b->ms[s]) goto done;
+                    int64_t co = 0, so = 0;
+                    int ic = 0, is = 0;
+                    for (int r = 0; r < P; r++) {            /* messengers in ascending rank order */
+                        if (ccount[r]) { b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++; }
+                        if (scount[r]) { b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++; }
+                    }
+                }
+                for (int64_t l = 0; l < nh; l++) {
+                    const int64_t g = gid[l];
+                    if ((int)hang[g] != s) continue;
+                    if (own[l] != me) {
+                        if (pass == 0) ccount[own[l]]++; else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
+                        continue;
+                    }
+                    uint64_t m = harb[g] & ~mebit;
+                    for (int r = 0; m; r++, m >>= 1)
+                        if (m & 1) { if (pass == 0) scount[r]++; else b->smap[s][sfill[r]++] = (int32_t)l; }
+                }
+            }
+        }
+        free(b->lnid); free(b->node_xyz); free(b->etable); free(b->ntable);
+        free(b->dn_id); free(b->dn_ptr); free(b->dn_anchor);
+        b->lnid = lnid; b->node_xyz = xyz; b->etable = et; b->ntable = nt;
+        b->dn_id = dn_id; b->dn_ptr = dn_ptr; b->dn_anchor = dn_anchor;
+        b->owner = own; b->gid = gid;
+        lnid = xyz = own = gid = dn_id = dn_ptr = dn_anchor = NULL; et = nt = NULL;
+        b->E = ne; b->N = nh; b->ldnnum = ndn;
+        rc = HQ_OK;
+    }
+#undef HQH_ERANK
+done:
+    free(fcell); free(ccell); free(harb); free(gowner); free(g2l); free(hang);
+    free(lnid); free(xyz); free(own); free(gid); free(dn_id); free(dn_ptr); free(dn_anchor); free(et); free(nt);
+    return rc;
 }
 
 /* Lysmer dashpot of one element corner from the element's six face bits
@@ -969,6 +1106,8 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
         return HQ_ERR_ARG;
     const int32_t nx = p->nx, ny = p->ny, nzf = p->nz_fine, nzt = p->nz_fine + 2 * p->nz_coarse;
     if (nx > 2047 || ny > 2047 || nzt > 2047 || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    const int P = p->nranks > 1 ? p->nranks : 1;
+    if (P > 64 || p->rank < 0 || p->rank >= P) return HQ_ERR_ARG;
     hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
     if (!b) return HQ_ERR_NOMEM;
     b->p = *p;
@@ -1105,7 +1244,7 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
         }
     }
 #undef HQH_LOC
-    free(ek); free(loc);
+    free(loc);
     /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors */
     for (int32_t k = 0; k < b->ldnnum; k++) {
         double part[7];
@@ -1114,6 +1253,11 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
         for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
             for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
     }
+    if (P > 1) {
+        int rc = octbox_cut(b, ek, p->rank, P);
+        if (rc != HQ_OK) { free(ek); hqh_octbox_destroy(b); return rc; }
+    }
+    free(ek);
     *out = b;
     return HQ_OK;
 }
@@ -1126,8 +1270,23 @@ int hqh_octbox_desc(const hqh_octbox* b, hq_desc* d)
     d->lnid = b->lnid; d->node_xyz = b->node_xyz;
     d->dn_ldnid = b->dn_id; d->dn_ptr = b->dn_ptr; d->dn_lanid = b->dn_anchor;
     d->eTable = b->etable; d->nTable = b->ntable;
-    d->deltaT = b->p.deltaT; d->rank = 0; d->nranks = 1;
+    d->an_sched.c_count = b->nc[0]; d->an_sched.first_c = b->mc[0];
+    d->an_sched.s_count = b->ns[0]; d->an_sched.first_s = b->ms[0];
+    d->dn_sched.c_count = b->nc[1]; d->dn_sched.first_c = b->mc[1];
+    d->dn_sched.s_count = b->ns[1]; d->dn_sched.first_s = b->ms[1];
+    d->deltaT = b->p.deltaT;
+    d->rank = b->p.nranks > 1 ? b->p.rank : 0;
+    d->nranks = b->p.nranks > 1 ? b->p.nranks : 1;
     d->variant = HQ_VARIANT_AUTO;
+    return HQ_OK;
+}
+
+/* messenger lists for tests: sched 0 = an, 1 = dn; list 0 = c, 1 = s */
+int hqh_octbox_schedule(const hqh_octbox* b, int32_t sched, int32_t list, int32_t* count, const hq_messenger** first)
+{
+    if (!b || !count || !first || sched < 0 || sched > 1 || list < 0 || list > 1) return HQ_ERR_ARG;
+    *count = list ? b->ns[sched] : b->nc[sched];
+    *first = list ? b->ms[sched] : b->mc[sched];
     return HQ_OK;
 }
 
@@ -1142,6 +1301,8 @@ const void* hqh_octbox_view(const hqh_octbox* b, int32_t which, int64_t* count)
     case 4: *count = b->dn_ptr[b->ldnnum]; return b->dn_anchor;
     case 5: *count = b->E * 4; return b->etable;
     case 6: *count = b->N * 7; return b->ntable;
+    case 7: *count = b->owner ? b->N : 0; return b->owner;
+    case 8: *count = b->gid ? b->N : 0; return b->gid;
     }
     return NULL;
 }

@@ -267,22 +267,24 @@ class _OctParams(ctypes.Structure):
                 ("vp_bot", ctypes.c_float), ("vs_bot", ctypes.c_float), ("rho_bot", ctypes.c_float),
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
 
 
 class OctBox:
-    """Two-level layered box with hanging nodes (hqh_octbox)."""
+    """Two-level layered box with hanging nodes (hqh_octbox), whole or one of nranks partitions."""
 
     def __init__(self, nx, ny, nz_fine, nz_coarse, h, dt, freq, top=(3000.0, 1732.0, 2200.0),
                  bottom=(6000.0, 3464.0, 2700.0), damping="rayleigh", threshold_damping=0.05,
-                 threshold_vpvs=3.0, halfspace=True):
+                 threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1):
         lib = load_library()
         lib.hqh_octbox_view.restype = ctypes.c_void_p
         lib.hqh_octbox_view.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
         lib.hqh_octbox_destroy.restype = None
         lib.hqh_octbox_destroy.argtypes = [ctypes.c_void_p]
         p = _OctParams(nx, ny, nz_fine, nz_coarse, h, top[0], top[1], top[2], bottom[0], bottom[1], bottom[2],
-                       dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace))
+                       dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace),
+                       int(rank), int(nranks))
+        self.rank, self.nranks = int(rank), int(nranks)
         self._h = ctypes.c_void_p()
         rc = lib.hqh_octbox_create(ctypes.byref(p), ctypes.byref(self._h))
         if rc != 0:
@@ -300,11 +302,26 @@ class OctBox:
         self.dangling = (view(2, np.int32, 1), view(3, np.int32, 1), view(4, np.int32, 1))
         self.etable = view(5, np.float64, 4)
         self.ntable = view(6, np.float64, 7)
+        self.owner = view(7, np.int32, 1)
+        self.gid = view(8, np.int32, 1)
         self.E, self.N, self.ldnnum = len(self.lnid), len(self.node_xyz), len(self.dangling[0])
+
+    def schedules(self):
+        """{"an": {"c": [(procid, mapping)], "s": [...]}, "dn": {...}} (copies)."""
+        d = capi._Desc()
+        self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
+        out = {}
+        for name, sch in (("an", d.an_sched), ("dn", d.dn_sched)):
+            out[name] = {}
+            for key, cnt, first in (("c", sch.c_count, sch.first_c), ("s", sch.s_count, sch.first_s)):
+                out[name][key] = [(first[i].procid,
+                                   _view(first[i].mapping, (first[i].nodecount,), np.int32).copy())
+                                  for i in range(cnt)]
+        return out
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self.lnid = self.node_xyz = self.dangling = self.etable = self.ntable = None
+            self.lnid = self.node_xyz = self.dangling = self.etable = self.ntable = self.owner = self.gid = None
             self._lib.hqh_octbox_destroy(self._h)
             self._h = ctypes.c_void_p()
 

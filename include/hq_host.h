@@ -185,9 +185,19 @@ HQ_API int hqh_station_format(char* buf, int32_t cap, double time, const double 
  * layers of elements of edge 2h -- what the reference's Vs rule (quake_util.c:215-225)
  * makes of a soft layer over a stiff half-space; a 2:1 interface whose fine nodes that are
  * not coarse vertices are hanging nodes (octor node_setproperty, octor.c:3280-3860).
- * One partition.  Produces octor's tables: elements in octree pre-order, nodes in Z-order,
+ * Produces octor's tables: elements in octree pre-order, nodes in Z-order,
  * dnodeTable with anchors in octor's list order (octor.c:6493-6612), eTable, and nTable
  * after the hanging-node mass distribution (psolve.c:3498-3507).
+ *
+ * With nranks > 1 the box is cut the way octor_partitiontree / octor_extractmesh leave it on
+ * rank `rank`: a contiguous block of the pre-ordered leaves (octor.c:4939-4944); a node is
+ * owned by the rank whose leaf contains its far-boundary-adjusted point (octor.c:5466-5475);
+ * the rank harbors the vertices of its elements, the nodes it owns (direct sharing,
+ * octor.c:5516-5793) and the anchors of the hanging nodes it owns (indirect sharing,
+ * node_harboranchored octor.c:3916-4042, :5795-6040); dnodeTable lists the hanging nodes it
+ * OWNS; an_sched / dn_sched are schedule_build's (psolve.c:4704-4863), messengers by ascending
+ * rank; nTable carries the summed masses of shared nodes (what solver_init's exchange leaves,
+ * psolve.c:3498-3507).  Every rank builds the whole box first and cuts its part out.
  */
 typedef struct hqh_octbox hqh_octbox;
 
@@ -202,14 +212,20 @@ typedef struct {
     int32_t damping;
     double  threshold_damping, threshold_vpvs;
     int32_t halfspace;
+    int32_t rank, nranks;        /* this partition / number of partitions (0, 0 or 1 = the whole
+                                    box); nranks <= 64 */
 } hqh_octbox_params;
 
 HQ_API int  hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out);
 HQ_API void hqh_octbox_destroy(hqh_octbox* box);
 HQ_API int  hqh_octbox_desc(const hqh_octbox* box, hq_desc* desc);
 /* views: which = 0 lnid [E][8], 1 node_xyz [N][3] (fine-edge units), 2 dn_ldnid, 3 dn_ptr,
- * 4 dn_lanid (int32); 5 eTable [E][4], 6 nTable [N][7] (double).  *count = entries. */
+ * 4 dn_lanid (int32); 5 eTable [E][4], 6 nTable [N][7] (double); 7 owner [N], 8 global node
+ * id [N] (int32; partitions only).  *count = entries. */
 HQ_API const void* hqh_octbox_view(const hqh_octbox* box, int32_t which, int64_t* count);
+/* messenger lists of a partition: sched 0 = an_sched, 1 = dn_sched; list 0 = c-list, 1 = s-list */
+HQ_API int hqh_octbox_schedule(const hqh_octbox* box, int32_t sched, int32_t list, int32_t* count,
+                               const hq_messenger** first);
 
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);

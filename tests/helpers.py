@@ -93,7 +93,7 @@ def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), ha
     etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, dt, freq)
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
-                N=N, E=E, dt=dt, emin=1)
+                N=N, E=E, dt=dt, emin=1, mesh=m)
 
 
 def c5_np8_problem():

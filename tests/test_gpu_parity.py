@@ -390,3 +390,39 @@ def test_output_planes_written_by_the_c_solver_run(tmp_path):
         ref = g["plane%d" % i]
         assert got.shape == ref.shape
         assert H.rel_linf(got, ref) < TOL
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape,nranks", [((16, 8, 6, 3), 5), ((32, 32, 4, 6), 8)])
+def test_partitioned_two_level_box_of_the_c_host(variant, shape, nranks):
+    """The two-level box with hanging nodes cut into octor's partitions by the C host
+    (hqh_octbox_create, nranks > 1), all partitions stepped in one process with the in-process
+    transport (all four exchanges of a step): every harbored copy equals the oracle's run of the
+    whole box."""
+    from hercules_amd import capi, host
+    nx, ny, nzf, nzc = shape
+    nsteps = 20
+    ref = H.two_level_mesh(nx, ny, nzf, nzc)
+    N = ref["N"]
+    rng = np.random.default_rng(7)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    # hanging nodes carry the mean of their anchors (compute_adjust ASSIGNMENT)
+    ho.compute_adjust(u1, 1, ref["dangling"])
+    ho.compute_adjust(u2, 1, ref["dangling"])
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(ref["lnid"], ref["etable"], ref["ntable"], o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
+    boxes = [host.OctBox(nx, ny, nzf, nzc, 31.25, ref["dt"], 5.0, rank=r, nranks=nranks) for r in range(nranks)]
+    assert sum(b.E for b in boxes) == ref["E"]
+    assert sum(int((b.owner == r).sum()) for r, b in enumerate(boxes)) == N
+    solvers = [b.create_solver(variant=variant, tm1=u1[b.gid], tm2=u2[b.gid]) for b in boxes]
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for r, (b, s) in enumerate(zip(boxes, solvers)):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[b.gid]) < TOL, (r, "tm1")
+        assert H.rel_linf(tm2, o1[b.gid]) < TOL, (r, "tm2")
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()

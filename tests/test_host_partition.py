@@ -214,3 +214,37 @@ def test_plane_geometry_of_the_c_host_equals_the_restatement():
     x, y = host.domain_coords(lonq[2], latq[2], lonq, latq, 1000.0, 2000.0)
     xo, yo = ho.domain_coords_linearinterp(lonq[2], latq[2], lonq, latq, 2000.0, 1000.0)
     assert abs(x - xo) < 1e-9 and abs(y - yo) < 1e-9
+
+
+@pytest.mark.parametrize("shape,nranks", [((16, 8, 6, 3), 2), ((16, 8, 6, 3), 5), ((8, 12, 2, 1), 3),
+                                          ((32, 32, 4, 6), 8)])
+def test_two_level_box_partitions_of_the_c_host_are_octors(shape, nranks):
+    """hqh_octbox_create with nranks > 1 against ho.octree_partition -- the restatement of octor's
+    per-rank tables that reproduces the REAL reference's 8-rank run of this very mesh
+    (c5_two_level_np8): harbored node sets, local connectivity, owners, the dnodeTable of owned
+    hanging nodes, and both schedules, all exactly; nTable = the whole box's (summed) rows."""
+    nx, ny, nzf, nzc = shape
+    ref = H.two_level_mesh(nx, ny, nzf, nzc)
+    parts = ho.octree_partition(ref["mesh"], nranks, (nx, ny, nzf + 2 * nzc))
+    whole = host.OctBox(nx, ny, nzf, nzc, 31.25, 1e-3, 5.0)
+    g_nt, g_et = whole.ntable.copy(), whole.etable.copy()
+    whole.close()
+    for r in range(nranks):
+        ob = host.OctBox(nx, ny, nzf, nzc, 31.25, 1e-3, 5.0, rank=r, nranks=nranks)
+        p = parts[r]
+        assert np.array_equal(ob.gid, p["nodes"])
+        assert np.array_equal(ob.lnid, p["lnid"])
+        assert np.array_equal(ob.owner, p["owner"])
+        assert np.array_equal(ob.node_xyz, ref["node_q"][p["nodes"]])
+        for a, b in zip(ob.dangling, p["dangling"]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(ob.etable, g_et[p["elems"]])
+        assert np.array_equal(ob.ntable, g_nt[p["nodes"]])
+        sch = ob.schedules()
+        for kind, key in (("an", "an_sched"), ("dn", "dn_sched")):
+            for lst in ("c", "s"):
+                got, exp = sch[kind][lst], p[key].get(lst, [])
+                assert [q for q, _ in got] == [q for q, _ in exp]
+                for (_, a), (_, b) in zip(got, exp):
+                    assert np.array_equal(a, b)
+        ob.close()
