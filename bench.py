@@ -45,11 +45,28 @@ WORKLOADS = {
     "o2": (1024, 1024, 128, 1000.0 / 1024, 4.5e-5, 400.0),
 }
 OCT_COARSE_LAYERS = {"o1": 96, "o2": 192}
+# layered-basin models meshed by the Vs rule (hqh_layered_column) on several octree levels:
+# name: (nx, ny, finest h [m], dt, freq, points per wavelength, coarsest cell [m], cells in depth,
+#        [(ztop, vp, vs, rho), ...])
+OCT_LAYERED = {
+    # BASELINE config 5: a TeraShake-scale layered basin, 102.4 km x 102.4 km x 80 km, 0.5 Hz:
+    # 100 m elements down to 16 km, then 200 / 400 / 800 m: 189M elements on four octree levels
+    "o3": (1024, 1024, 100.0, 0.02, 0.5, 8, 800.0, 100,
+           [(0.0, 1100.0, 600.0, 2000.0), (16000.0, 2000.0, 1100.0, 2300.0), (28800.0, 3600.0, 2000.0, 2500.0),
+            (54400.0, 6000.0, 3464.0, 2700.0)]),
+    "o3s": (256, 256, 100.0, 0.02, 0.5, 8, 800.0, 25,
+            [(0.0, 1100.0, 600.0, 2000.0), (4000.0, 2000.0, 1100.0, 2300.0), (7200.0, 3600.0, 2000.0, 2500.0),
+             (13600.0, 6000.0, 3464.0, 2700.0)]),
+}
+for _k, _v in OCT_LAYERED.items():
+    WORKLOADS[_k] = (_v[0], _v[1], 0, _v[2], _v[3], _v[4])
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
                   "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)",
-                  "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)"}
+                  "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
+                  "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",
+                  "o3s": "3M-element layered basin on four octree levels (small version of o3)"}
 
 
 def usable_cores():
@@ -139,11 +156,11 @@ def cpu_baseline(seconds_target=12.0):
         return port
 
 
-def seeded_field(node_ijk, nx, ny, nz_fine=None):
+def seeded_field(node_ijk, nx, ny, interfaces=()):
     """Displacements as a function of the global node coordinates (so every copy of a shared node
-    starts equal).  Two-level box (nz_fine given): a fine node of the interface plane z = nz_fine
-    that is no coarse vertex hangs, and starts at the mean of its anchors (its 2 edge or 4 face
-    neighbours, compute_adjust ASSIGNMENT)."""
+    starts equal).  Octree boxes: interfaces = [(z of the plane, finer edge hf), ...] in finest
+    units; a node of such a plane that is not on the coarser grid hangs, and starts at the mean of
+    its anchors (its 2 edge or 4 face neighbours at +-hf, compute_adjust ASSIGNMENT)."""
     ijk = np.asarray(node_ijk).astype(np.int64)
 
     def raw(i, j, k):
@@ -155,15 +172,41 @@ def seeded_field(node_ijk, nx, ny, nz_fine=None):
         return out
     i, j, k = ijk[:, 0], ijk[:, 1], ijk[:, 2]
     u = raw(i, j, k)
-    if nz_fine is not None:
-        on = k == nz_fine
-        ox, oy = on & (i % 2 == 1), on & (j % 2 == 1)
+    for z, hf in interfaces:
+        on = k == z
+        ox, oy = on & (i % (2 * hf) == hf), on & (j % (2 * hf) == hf)
         xe, ye, zf = ox & ~oy, oy & ~ox, ox & oy
-        u[xe] = 0.5 * (raw(i[xe] - 1, j[xe], k[xe]) + raw(i[xe] + 1, j[xe], k[xe]))
-        u[ye] = 0.5 * (raw(i[ye], j[ye] - 1, k[ye]) + raw(i[ye], j[ye] + 1, k[ye]))
-        u[zf] = 0.25 * (raw(i[zf] - 1, j[zf] - 1, k[zf]) + raw(i[zf] + 1, j[zf] - 1, k[zf]) +
-                        raw(i[zf] - 1, j[zf] + 1, k[zf]) + raw(i[zf] + 1, j[zf] + 1, k[zf]))
+        u[xe] = 0.5 * (raw(i[xe] - hf, j[xe], k[xe]) + raw(i[xe] + hf, j[xe], k[xe]))
+        u[ye] = 0.5 * (raw(i[ye], j[ye] - hf, k[ye]) + raw(i[ye], j[ye] + hf, k[ye]))
+        u[zf] = 0.25 * (raw(i[zf] - hf, j[zf] - hf, k[zf]) + raw(i[zf] + hf, j[zf] - hf, k[zf]) +
+                        raw(i[zf] - hf, j[zf] + hf, k[zf]) + raw(i[zf] + hf, j[zf] + hf, k[zf]))
     return u
+
+
+def make_octbox(workload, rank, nranks):
+    """-> (OctBox, total elements, total nodes, interfaces for seeded_field)"""
+    from hercules_amd import host as hhost
+    nx, ny, nz, h, dt, freq = WORKLOADS[workload]
+    if workload in OCT_LAYERED:
+        _, _, _, _, _, ppw, h0, ncoarse, model = OCT_LAYERED[workload]
+        col = hhost.layered_column(model, h0, ncoarse, freq * ppw)
+        hf, levels = hhost.levels_from_column(col)
+        assert hf == h
+        box = hhost.OctBox(nx, ny, 0, 0, h, dt, freq, levels=levels, rank=rank, nranks=nranks)
+    else:
+        nzc = OCT_COARSE_LAYERS[workload]
+        levels = [(nz, None), (nzc, None)]
+        box = hhost.OctBox(nx, ny, nz, nzc, h, dt, freq, rank=rank, nranks=nranks)
+    E = N = z = 0
+    interfaces = []
+    for L, (n, _) in enumerate(levels):
+        E += (nx >> L) * (ny >> L) * n
+        N += ((nx >> L) + 1) * ((ny >> L) + 1) * n
+        if L > 0:
+            interfaces.append((z, 1 << (L - 1)))
+        z += n << L
+    N += (nx + 1) * (ny + 1)
+    return box, E, N, interfaces
 
 
 def inproc_diagnostic(args):
@@ -173,16 +216,16 @@ def inproc_diagnostic(args):
     P = args.inproc_parts
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
     boxes, solvers = [], []
-    octree = args.workload in OCT_COARSE_LAYERS
+    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED
     for r in range(P):
         if octree:
-            b = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq, rank=r, nranks=P)
+            b, total_e, _, interfaces = make_octbox(args.workload, r, P)
             sch = b.schedules()
             peers = set(q for kind in sch.values() for lst in kind.values() for q, _ in lst)
-            b.info = {"total_elements": nx * ny * nz + (nx // 2) * (ny // 2) * OCT_COARSE_LAYERS[args.workload],
+            b.info = {"total_elements": total_e,
                       "shared_nodes": int(sum(len(m) for kind in sch.values() for lst in kind.values() for _, m in lst)),
                       "nneighbors": len(peers)}
-            u1 = seeded_field(b.node_xyz, nx, ny, nz)
+            u1 = seeded_field(b.node_xyz, nx, ny, interfaces)
         else:
             b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P)
             u1 = seeded_field(b.node_ijk, nx, ny)
@@ -244,20 +287,19 @@ def main():
 
     nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
-    octree = args.workload in OCT_COARSE_LAYERS
+    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+    interfaces = ()
     if octree:
-        box = hhost.OctBox(nx, ny, nz, OCT_COARSE_LAYERS[args.workload], h, dt, freq, rank=rank, nranks=world)
-        total_e = (nx * ny * nz) + (nx // 2) * (ny // 2) * OCT_COARSE_LAYERS[args.workload]
-        box.info = {"nharbored": box.N, "total_elements": total_e, "lenum": box.E,
-                    "total_nodes": (nx + 1) * (ny + 1) * (nz + 1) + (nx // 2 + 1) * (ny // 2 + 1) * OCT_COARSE_LAYERS[args.workload]}
+        box, total_e, total_n, interfaces = make_octbox(args.workload, rank, world)
+        box.info = {"nharbored": box.N, "total_elements": total_e, "lenum": box.E, "total_nodes": total_n}
         box.node_ijk = box.node_xyz
     else:
         box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
     N = box.info["nharbored"]
     # seeded random start: identical on every rank for shared nodes
     # because it is a function of the global node coordinates
-    u1 = seeded_field(box.node_ijk, nx, ny, nz if octree else None)
+    u1 = seeded_field(box.node_ijk, nx, ny, interfaces)
     u2 = u1 * (1.0 - 1e-3)
     solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2)
     del u1, u2

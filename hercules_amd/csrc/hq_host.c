@@ -19,6 +19,7 @@
  * parallelises over nodes, and every harbored copy holds the complete sums: no
  * initial mass exchange (psolve.c:3498-3507) is needed.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -921,8 +922,14 @@ int hqh_domain_coords(double lon, double lat, const double lon_corners[4], const
 /* two-level layered box (hanging nodes)                                    */
 /* ------------------------------------------------------------------------ */
 
+#define HQH_MAXLEVELS 8
+
 struct hqh_octbox {
-    hqh_octbox_params p;
+    hqh_octlevels_params p;         /* (the two-level parameters are translated into these) */
+    int32_t layers[HQH_MAXLEVELS];  /* element layers per level */
+    int32_t lay0[HQH_MAXLEVELS + 1];/* index of every level's first element layer; [nlevels] = total */
+    float *vp, *vs, *rho;           /* [total element layers], from the top */
+    int32_t ztop[HQH_MAXLEVELS + 1];/* top plane of every level's slab, finest-edge units; [nlevels] = bottom */
     int64_t E, N;
     int32_t ldnnum;
     int32_t *lnid, *node_xyz, *dn_id, *dn_ptr, *dn_anchor;
@@ -939,45 +946,56 @@ void hqh_octbox_destroy(hqh_octbox* b)
     if (!b) return;
     free(b->lnid); free(b->node_xyz); free(b->dn_id); free(b->dn_ptr); free(b->dn_anchor);
     free(b->etable); free(b->ntable); free(b->owner); free(b->gid);
+    free(b->vp); free(b->vs); free(b->rho);
     for (int s = 0; s < 2; s++) { free(b->mc[s]); free(b->ms[s]); free(b->cmap[s]); free(b->smap[s]); }
     free(b);
+}
+
+/* level of the slab that contains plane z < bottom (finest units) */
+static int octbox_level_at(const hqh_octbox* b, int32_t z)
+{
+    int L = 0;
+    while (L + 1 < b->p.nlevels && z >= b->ztop[L + 1]) L++;
+    return L;
 }
 
 /* Cut rank `me`'s part out of the whole box in `b` (see hq_host.h); `ek` = the sorted Z-values
  * of the element corners (element id = position). */
 static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
 {
-    const hqh_octbox_params* p = &b->p;
-    const int32_t nx = p->nx, ny = p->ny, nzf = p->nz_fine, nzt = p->nz_fine + 2 * p->nz_coarse;
+    const int32_t nx = b->p.nx, ny = b->p.ny, nzt = b->ztop[b->p.nlevels], NL = b->p.nlevels;
     const int64_t E = b->E, N = b->N;
     int rc = HQ_ERR_NOMEM;
-    /* leaf of every fine cell / coarse cell -> element id */
-    const int64_t nfc = (int64_t)nx * ny * nzf, ncc = (int64_t)(nx / 2) * (ny / 2) * p->nz_coarse;
-    int32_t* fcell = (int32_t*)malloc(sizeof(int32_t) * (size_t)nfc);
-    int32_t* ccell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncc ? ncc : 1));
+    /* leaf of every cell of every level's slab -> element id */
+    int32_t* cell[HQH_MAXLEVELS];
+    for (int L = 0; L < HQH_MAXLEVELS; L++) cell[L] = NULL;
     uint64_t* harb = (uint64_t*)calloc((size_t)N, sizeof(uint64_t));
     int32_t* gowner = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
     int32_t* g2l = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
     uint8_t* hang = (uint8_t*)calloc((size_t)N, 1);
     int32_t *lnid = NULL, *xyz = NULL, *own = NULL, *gid = NULL, *dn_id = NULL, *dn_ptr = NULL, *dn_anchor = NULL;
     double *et = NULL, *nt = NULL;
-    if (!fcell || !ccell || !harb || !gowner || !g2l || !hang) goto done;
+    if (!harb || !gowner || !g2l || !hang) goto done;
+    for (int L = 0; L < NL; L++) {
+        int64_t n = (int64_t)(nx >> L) * (ny >> L) * b->layers[L];
+        cell[L] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+        if (!cell[L]) goto done;
+    }
 #define HQH_ERANK(e) ((int)((((int64_t)(e) + 1) * P - 1) / E))     /* octor.c:4939-4944 */
+#define HQH_CELL(L, i, j, k) cell[L][((int64_t)(((k) - b->ztop[L]) >> (L)) * (ny >> (L)) + ((j) >> (L))) * (nx >> (L)) + ((i) >> (L))]
     for (int64_t e = 0; e < E; e++) {
         int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
-        if (k < nzf) fcell[((int64_t)k * ny + j) * nx + i] = (int32_t)e;
-        else ccell[((int64_t)((k - nzf) / 2) * (ny / 2) + j / 2) * (nx / 2) + i / 2] = (int32_t)e;
+        HQH_CELL(octbox_level_at(b, k), i, j, k) = (int32_t)e;
         const uint64_t bit = 1ull << HQH_ERANK(e);
         for (int c = 0; c < 8; c++) harb[b->lnid[8 * e + c]] |= bit;             /* element vertices */
     }
     for (int64_t n = 0; n < N; n++) {                                            /* owners */
         const int32_t* c = &b->node_xyz[3 * n];
         int32_t ax = c[0] < nx ? c[0] : nx - 1, ay = c[1] < ny ? c[1] : ny - 1, az = c[2] < nzt ? c[2] : nzt - 1;
-        int32_t e = az < nzf ? fcell[((int64_t)az * ny + ay) * nx + ax]
-                             : ccell[((int64_t)((az - nzf) / 2) * (ny / 2) + ay / 2) * (nx / 2) + ax / 2];
-        gowner[n] = HQH_ERANK(e);
+        gowner[n] = HQH_ERANK(HQH_CELL(octbox_level_at(b, az), ax, ay, az));
         harb[n] |= 1ull << gowner[n];
     }
+#undef HQH_CELL
     for (int32_t k = 0; k < b->ldnnum; k++) {                                    /* indirect sharing */
         hang[b->dn_id[k]] = 1;
         const uint64_t bit = 1ull << gowner[b->dn_id[k]];
@@ -1069,7 +1087,8 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
     }
 #undef HQH_ERANK
 done:
-    free(fcell); free(ccell); free(harb); free(gowner); free(g2l); free(hang);
+    for (int L = 0; L < HQH_MAXLEVELS; L++) free(cell[L]);
+    free(harb); free(gowner); free(g2l); free(hang);
     free(lnid); free(xyz); free(own); free(gid); free(dn_id); free(dn_ptr); free(dn_anchor); free(et); free(nt);
     return rc;
 }
@@ -1098,24 +1117,45 @@ static int face_dashpot(int face, int corner, int halfspace, float size, float V
     return 1;
 }
 
-int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
+int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
 {
     if (!p || !out) return HQ_ERR_ARG;
     *out = NULL;
-    if (p->nx < 2 || p->ny < 2 || p->nz_fine < 2 || p->nz_coarse < 1 || (p->nx & 1) || (p->ny & 1) || (p->nz_fine & 1))
-        return HQ_ERR_ARG;
-    const int32_t nx = p->nx, ny = p->ny, nzf = p->nz_fine, nzt = p->nz_fine + 2 * p->nz_coarse;
-    if (nx > 2047 || ny > 2047 || nzt > 2047 || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    const int NL = p->nlevels;
+    if (NL < 1 || NL > HQH_MAXLEVELS || !p->layers || !p->vp || !p->vs || !p->rho) return HQ_ERR_ARG;
+    const int32_t nx = p->nx, ny = p->ny;
+    if (nx < 1 || ny < 1 || (nx & ((1 << (NL - 1)) - 1)) || (ny & ((1 << (NL - 1)) - 1))) return HQ_ERR_ARG;
+    if (p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
     const int P = p->nranks > 1 ? p->nranks : 1;
     if (P > 64 || p->rank < 0 || p->rank >= P) return HQ_ERR_ARG;
     hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
     if (!b) return HQ_ERR_NOMEM;
     b->p = *p;
-    int64_t Ef = (int64_t)nx * ny * nzf, Ec = (int64_t)(nx / 2) * (ny / 2) * p->nz_coarse;
-    int64_t E = Ef + Ec;
-    int64_t Nf = (int64_t)(nx + 1) * (ny + 1) * (nzf + 1), Nc = (int64_t)(nx / 2 + 1) * (ny / 2 + 1) * p->nz_coarse;
-    int64_t N = Nf + Nc;
-    if (E > 0x7fffffff / 8 || N > 0x7fffffff / 8) { free(b); return HQ_ERR_ARG; }
+    int64_t E = 0, N = 0;
+    b->ztop[0] = 0; b->lay0[0] = 0;
+    for (int L = 0; L < NL; L++) {
+        b->layers[L] = p->layers[L];
+        /* every slab at least one layer thick and aligned to the next level's cells (an octree) */
+        if (p->layers[L] < 1) { free(b); return HQ_ERR_ARG; }
+        b->lay0[L + 1] = b->lay0[L] + p->layers[L];
+        b->ztop[L + 1] = b->ztop[L] + (p->layers[L] << L);
+        if (L + 1 < NL && (b->ztop[L + 1] & ((2 << L) - 1))) { free(b); return HQ_ERR_ARG; }
+        E += (int64_t)(nx >> L) * (ny >> L) * p->layers[L];
+        /* node planes of the slab except its top one (which belongs to the finer slab above) */
+        N += (int64_t)((nx >> L) + 1) * ((ny >> L) + 1) * p->layers[L];
+    }
+    const int32_t nzt = b->ztop[NL], nlay = b->lay0[NL];
+    N += (int64_t)(nx + 1) * (ny + 1);                           /* the free surface */
+    b->vp = (float*)malloc(sizeof(float) * (size_t)nlay);
+    b->vs = (float*)malloc(sizeof(float) * (size_t)nlay);
+    b->rho = (float*)malloc(sizeof(float) * (size_t)nlay);
+    if (!b->vp || !b->vs || !b->rho) { hqh_octbox_destroy(b); return HQ_ERR_NOMEM; }
+    memcpy(b->vp, p->vp, sizeof(float) * (size_t)nlay);
+    memcpy(b->vs, p->vs, sizeof(float) * (size_t)nlay);
+    memcpy(b->rho, p->rho, sizeof(float) * (size_t)nlay);
+    b->p.layers = b->layers; b->p.vp = b->vp; b->p.vs = b->vs; b->p.rho = b->rho;
+    if (nx > 2047 || ny > 2047 || nzt > 2047) { hqh_octbox_destroy(b); return HQ_ERR_ARG; }
+    if (E > 0x7fffffff / 8 || N > 0x7fffffff / 8) { hqh_octbox_destroy(b); return HQ_ERR_ARG; }
     b->E = E; b->N = N;
     int64_t G = (int64_t)(nx + 1) * (ny + 1) * (nzt + 1);
     uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
@@ -1128,30 +1168,35 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
     if (!ek || !nk || !loc || !b->lnid || !b->node_xyz || !b->etable || !b->ntable) {
         free(ek); free(nk); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM;
     }
-    /* elements: octree pre-order = Z-order of the lower-left corner (fine-edge units) */
+    /* elements: octree pre-order = Z-order of the lower-left corner (finest-edge units) */
     int64_t t = 0;
-    for (int32_t k = 0; k < nzf; k++)
-        for (int32_t j = 0; j < ny; j++)
-            for (int32_t i = 0; i < nx; i++) ek[t++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
-    for (int32_t k = nzf; k < nzt; k += 2)
-        for (int32_t j = 0; j < ny; j += 2)
-            for (int32_t i = 0; i < nx; i += 2) ek[t++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
-    /* nodes: Z-order of the far-boundary-adjusted coordinates (octor.c:6100-6106, 6166) */
+    for (int L = 0; L < NL; L++) {
+        const int32_t s = 1 << L;
+        for (int32_t k = b->ztop[L]; k < b->ztop[L + 1]; k += s)
+            for (int32_t j = 0; j < ny; j += s)
+                for (int32_t i = 0; i < nx; i += s) ek[t++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    }
+    /* nodes: Z-order of the far-boundary-adjusted coordinates (octor.c:6100-6106, 6166); the
+     * plane between two slabs carries the finer slab's grid */
     t = 0;
-    for (int32_t k = 0; k <= nzt; k++) {
-        int step = (k <= nzf) ? 1 : 2;
-        if (k > nzf && ((k - nzf) & 1)) continue;
-        for (int32_t j = 0; j <= ny; j += step)
-            for (int32_t i = 0; i <= nx; i += step) {
-                uint32_t dx = (i == nx) ? (uint32_t)(2 * i - 1) : (uint32_t)(2 * i);
-                uint32_t dy = (j == ny) ? (uint32_t)(2 * j - 1) : (uint32_t)(2 * j);
-                uint32_t dz = (k == nzt) ? (uint32_t)(2 * k - 1) : (uint32_t)(2 * k);
-                nk[t++] = zvalue(dx, dy, dz);
-            }
+    for (int L = 0; L < NL; L++) {
+        const int32_t s = 1 << L;
+        for (int32_t k = b->ztop[L] + (L == 0 ? 0 : s); k <= b->ztop[L + 1]; k += s)
+            for (int32_t j = 0; j <= ny; j += s)
+                for (int32_t i = 0; i <= nx; i += s) {
+                    uint32_t dx = (i == nx) ? (uint32_t)(2 * i - 1) : (uint32_t)(2 * i);
+                    uint32_t dy = (j == ny) ? (uint32_t)(2 * j - 1) : (uint32_t)(2 * j);
+                    uint32_t dz = (k == nzt) ? (uint32_t)(2 * k - 1) : (uint32_t)(2 * k);
+                    nk[t++] = zvalue(dx, dy, dz);
+                }
     }
     if (t != N || radix_sort_u64(ek, E, 36) != 0 || radix_sort_u64(nk, N, 36) != 0) {
         free(ek); free(nk); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM;
     }
+    /* a node of the plane on top of level L's slab (L >= 1) that is not on level L's grid hangs */
+#define HQH_HANGS(c, Lout)                                                                     \
+    (((Lout) = octbox_level_at(b, (c)[2] < nzt ? (c)[2] : nzt - 1)) >= 1 && (c)[2] == b->ztop[(Lout)] && \
+     (((c)[0] & ((1 << (Lout)) - 1)) || ((c)[1] & ((1 << (Lout)) - 1))))
     memset(loc, 0xff, sizeof(int32_t) * (size_t)G);
     int32_t ldn = 0;
     for (int64_t n = 0; n < N; n++) {
@@ -1160,7 +1205,8 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
         for (int q = 0; q < 3; q++) c[q] = (d[q] & 1) ? lim[q] : (int32_t)(d[q] >> 1);
         for (int q = 0; q < 3; q++) b->node_xyz[3 * n + q] = c[q];
         loc[((int64_t)c[2] * (ny + 1) + c[1]) * (nx + 1) + c[0]] = (int32_t)n;
-        if (c[2] == nzf && ((c[0] & 1) || (c[1] & 1))) ldn++;       /* fine node that is no coarse vertex */
+        int Lh;
+        if (HQH_HANGS(c, Lh)) ldn++;
     }
     free(nk);
     b->ldnnum = ldn;
@@ -1175,32 +1221,41 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
         b->dn_ptr[0] = 0;
         for (int64_t n = 0; n < N; n++) {
             const int32_t* c = &b->node_xyz[3 * n];
-            if (c[2] != nzf || !((c[0] & 1) || (c[1] & 1))) continue;
+            int Lh;
+            if (!HQH_HANGS(c, Lh)) continue;
+            const int32_t h = 1 << (Lh - 1), m = (1 << Lh) - 1, z = c[2];    /* finer edge; coarse-grid mask */
             b->dn_id[kdn] = (int32_t)n;
-            if ((c[0] & 1) && (c[1] & 1)) {                      /* ZFACE: (+,+) (-,+) (+,-) (-,-) */
-                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1] + 1, nzf);
-                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1] + 1, nzf);
-                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1] - 1, nzf);
-                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1] - 1, nzf);
-            } else if (c[0] & 1) {                               /* XEDGE: +s then -s */
-                b->dn_anchor[na++] = HQH_LOC(c[0] + 1, c[1], nzf);
-                b->dn_anchor[na++] = HQH_LOC(c[0] - 1, c[1], nzf);
+            if ((c[0] & m) && (c[1] & m)) {                      /* ZFACE: (+,+) (-,+) (+,-) (-,-) */
+                b->dn_anchor[na++] = HQH_LOC(c[0] + h, c[1] + h, z);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - h, c[1] + h, z);
+                b->dn_anchor[na++] = HQH_LOC(c[0] + h, c[1] - h, z);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - h, c[1] - h, z);
+            } else if (c[0] & m) {                               /* XEDGE: +s then -s */
+                b->dn_anchor[na++] = HQH_LOC(c[0] + h, c[1], z);
+                b->dn_anchor[na++] = HQH_LOC(c[0] - h, c[1], z);
             } else {                                             /* YEDGE */
-                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] + 1, nzf);
-                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] - 1, nzf);
+                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] + h, z);
+                b->dn_anchor[na++] = HQH_LOC(c[0], c[1] - h, z);
             }
             b->dn_ptr[++kdn] = na;
         }
     }
-    /* element constants per level (mu_and_lambda + psolve.c:3387-3409, 3436-3437) */
+#undef HQH_HANGS
+    /* element constants per element layer (mu_and_lambda + psolve.c:3387-3409, 3436-3437) */
     double aBase, bBase, dt = p->deltaT, dt2 = dt * dt;
     rayleigh_base(p->freq, p->damping, &aBase, &bBase);
-    double lc[2][4], la[2], lM[2];
-    float lvp[2], lvs[2] = { p->vs_top, p->vs_bot }, lrho[2] = { p->rho_top, p->rho_bot }, lh[2];
-    lvp[0] = p->vp_top; lvp[1] = p->vp_bot;
-    lh[0] = (float)p->h; lh[1] = (float)(2 * p->h);
-    for (int L = 0; L < 2; L++) {
-        float Vp = lvp[L], Vs = lvs[L], rho = lrho[L], h = lh[L];
+    double (*lc)[4] = (double (*)[4])malloc(sizeof(double) * 4 * (size_t)nlay);
+    double* la = (double*)malloc(sizeof(double) * (size_t)nlay);
+    double* lM = (double*)malloc(sizeof(double) * (size_t)nlay);
+    float* lvp = (float*)malloc(sizeof(float) * (size_t)nlay);
+    float* lh = (float*)malloc(sizeof(float) * (size_t)nlay);
+    if (!lc || !la || !lM || !lvp || !lh) {
+        free(lc); free(la); free(lM); free(lvp); free(lh); free(ek); free(loc); hqh_octbox_destroy(b); return HQ_ERR_NOMEM;
+    }
+    for (int L = 0; L < NL; L++)
+    for (int32_t q = b->lay0[L]; q < b->lay0[L + 1]; q++) {
+        float Vp = b->vp[q], Vs = b->vs[q], rho = b->rho[q], h = (float)(p->h * (1 << L));
+        lh[q] = h;
         double mu = rho * Vs * Vs, lambda;
         if (Vp > (Vs * p->threshold_vpvs)) lambda = rho * Vs * Vs * p->threshold_vpvs * p->threshold_vpvs - 2 * mu;
         else lambda = rho * Vp * Vp - 2 * mu;
@@ -1208,30 +1263,33 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
             if (Vs < 500) Vp = 2.45 * Vs; else if (Vs < 1200) Vp = 2 * Vs; else Vp = 1.87 * Vs;
             lambda = rho * Vp * Vp;
         }
-        if (lambda < 0) { free(ek); free(loc); hqh_octbox_destroy(b); return HQ_ERR_ARG; }
-        lvp[L] = Vp;
+        if (lambda < 0) {
+            free(lc); free(la); free(lM); free(lvp); free(lh); free(ek); free(loc); hqh_octbox_destroy(b); return HQ_ERR_ARG;
+        }
+        lvp[q] = Vp;
         double zeta = 10 / Vs;
         if (zeta > p->threshold_damping) zeta = p->threshold_damping;
         double a = zeta * aBase, bb = zeta * bBase;
-        lc[L][0] = dt2 * h * mu / 9; lc[L][1] = dt2 * h * lambda / 9;
-        lc[L][2] = bb * dt * h * mu / 9; lc[L][3] = bb * dt * h * lambda / 9;
-        la[L] = a;
+        lc[q][0] = dt2 * h * mu / 9; lc[q][1] = dt2 * h * lambda / 9;
+        lc[q][2] = bb * dt * h * mu / 9; lc[q][3] = bb * dt * h * lambda / 9;
+        la[q] = a;
         double mass = rho * h * h * h;
-        lM[L] = mass / 8;
+        lM[q] = mass / 8;
     }
     /* connectivity, eTable, nTable (the reference's element loop, psolve.c:3360-3473) */
     for (int64_t e = 0; e < E; e++) {
         int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
-        int L = (k >= nzf) ? 1 : 0, s = L ? 2 : 1;
+        int L = octbox_level_at(b, k), s = 1 << L;
+        const int32_t q = b->lay0[L] + ((k - b->ztop[L]) >> L);  /* element layer */
         int face = (i == 0) | ((j == 0) << 1) | ((k == 0) << 2) | ((i + s == nx) << 3) | ((j + s == ny) << 4) |
                    ((k + s == nzt) << 5);
-        for (int q = 0; q < 4; q++) b->etable[4 * e + q] = lc[L][q];
-        double M = lM[L], a = la[L];
+        for (int c4 = 0; c4 < 4; c4++) b->etable[4 * e + c4] = lc[q][c4];
+        double M = lM[q], a = la[q];
         for (int c = 0; c < 8; c++) {
             int32_t n = HQH_LOC(i + s * (c & 1), j + s * ((c >> 1) & 1), k + s * ((c >> 2) & 1));
             b->lnid[8 * e + c] = n;
             double dash[3];
-            int bnd = face_dashpot(face, c, p->halfspace, lh[L], lvp[L], lvs[L], lrho[L], dash);
+            int bnd = face_dashpot(face, c, p->halfspace, lh[q], lvp[q], b->vs[q], b->rho[q], dash);
             double* np = &b->ntable[7 * (int64_t)n];
             np[0] += M;
             for (int ax = 0; ax < 3; ax++) {
@@ -1243,6 +1301,7 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
             }
         }
     }
+    free(lc); free(la); free(lM); free(lvp); free(lh);
 #undef HQH_LOC
     free(loc);
     /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors */
@@ -1260,6 +1319,102 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
     free(ek);
     *out = b;
     return HQ_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* layered model -> column of octree leaves (Vs rule + 2:1 balance)          */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { double z0, edge; float vp, vs, rho; } hqh_leaf;
+
+/* setrec (psolve.c:1307-1397) for a leaf of a depth-only model */
+static void layered_setrec(const hqh_layered_model* m, double vscut, hqh_leaf* lf)
+{
+    static const double pts[3] = { 0.01, 1, 1.99 };
+    const double half = lf->edge / 2;
+    float bvs = FLT_MAX, bvp = 0, brho = 0;
+    for (int i = 0; i < 3; i++) {
+        const double z = lf->z0 + pts[i] * half;
+        int L = 0;
+        while (L + 1 < m->nlayers && z >= m->ztop[L + 1]) L++;
+        if (m->vs[L] < bvs) { bvs = m->vs[L]; bvp = m->vp[L]; brho = m->rho[L]; }
+        if (m->vs[L] <= vscut) break;
+    }
+    if (bvs <= vscut) {                                   /* adjust Vs and Vp, psolve.c:1389-1394 */
+        const double ratio = bvp / bvs;
+        bvs = (float)vscut;
+        bvp = (float)(vscut * ratio);
+    }
+    lf->vp = bvp; lf->vs = bvs; lf->rho = brho;
+}
+
+int hqh_layered_column(const hqh_layered_model* m, double h0, int32_t ncoarse, double factor, double vscut,
+                       int32_t cap, double* edge, float* vp, float* vs, float* rho, int32_t* nleaves)
+{
+    if (!m || m->nlayers < 1 || !m->ztop || !m->vp || !m->vs || !m->rho || h0 <= 0 || ncoarse < 1 || factor <= 0 ||
+        cap < 1 || !edge || !vp || !vs || !rho || !nleaves)
+        return HQ_ERR_ARG;
+    int32_t n = 0, capw = cap;
+    hqh_leaf* w = (hqh_leaf*)malloc(sizeof(hqh_leaf) * (size_t)capw);
+    if (!w) return HQ_ERR_NOMEM;
+#define HQH_SPLIT(i)                                                                         \
+    do {                                                                                     \
+        if (n + 1 > capw) { free(w); return HQ_ERR_ARG; }                                    \
+        memmove(w + (i) + 1, w + (i), sizeof(hqh_leaf) * (size_t)(n - (i)));                 \
+        n++;                                                                                 \
+        w[(i)].edge /= 2;                                                                    \
+        w[(i) + 1].edge = w[(i)].edge; w[(i) + 1].z0 = w[(i)].z0 + w[(i)].edge;              \
+        layered_setrec(m, vscut, &w[(i)]); layered_setrec(m, vscut, &w[(i) + 1]);            \
+    } while (0)
+    if (ncoarse > capw) { free(w); return HQ_ERR_ARG; }
+    for (int32_t i = 0; i < ncoarse; i++) { w[i].z0 = i * h0; w[i].edge = h0; layered_setrec(m, vscut, &w[i]); }
+    n = ncoarse;
+    /* octor_refinetree: vsrule (quake_util.c:215-225) */
+    for (int32_t i = 0; i < n;) {
+        if (!(w[i].edge <= w[i].vs / factor) && w[i].edge > h0 / 65536) HQH_SPLIT(i);
+        else i++;
+    }
+    /* octor_balancetree: no leaf more than twice its neighbour */
+    for (int again = 1; again;) {
+        again = 0;
+        for (int32_t i = 0; i + 1 < n; i++) {
+            if (w[i].edge > 2 * w[i + 1].edge * (1 + 1e-12)) { HQH_SPLIT(i); again = 1; break; }
+            if (w[i + 1].edge > 2 * w[i].edge * (1 + 1e-12)) { HQH_SPLIT(i + 1); again = 1; break; }
+        }
+    }
+#undef HQH_SPLIT
+    for (int32_t i = 0; i < n; i++) { edge[i] = w[i].edge; vp[i] = w[i].vp; vs[i] = w[i].vs; rho[i] = w[i].rho; }
+    *nleaves = n;
+    free(w);
+    return HQ_OK;
+}
+
+/* the two-level box: nz_fine layers of edge h over nz_coarse layers of edge 2h */
+int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
+{
+    if (!p || !out) return HQ_ERR_ARG;
+    *out = NULL;
+    if (p->nx < 2 || p->ny < 2 || p->nz_fine < 2 || p->nz_coarse < 1 || (p->nx & 1) || (p->ny & 1) || (p->nz_fine & 1))
+        return HQ_ERR_ARG;
+    int32_t layers[2] = { p->nz_fine, p->nz_coarse };
+    const int32_t nlay = p->nz_fine + p->nz_coarse;
+    float* m = (float*)malloc(sizeof(float) * 3 * (size_t)nlay);
+    if (!m) return HQ_ERR_NOMEM;
+    for (int32_t i = 0; i < nlay; i++) {
+        m[i] = i < p->nz_fine ? p->vp_top : p->vp_bot;
+        m[nlay + i] = i < p->nz_fine ? p->vs_top : p->vs_bot;
+        m[2 * nlay + i] = i < p->nz_fine ? p->rho_top : p->rho_bot;
+    }
+    hqh_octlevels_params q;
+    memset(&q, 0, sizeof q);
+    q.nx = p->nx; q.ny = p->ny; q.nlevels = 2; q.layers = layers; q.h = p->h;
+    q.vp = m; q.vs = m + nlay; q.rho = m + 2 * nlay;
+    q.deltaT = p->deltaT; q.freq = p->freq; q.damping = p->damping;
+    q.threshold_damping = p->threshold_damping; q.threshold_vpvs = p->threshold_vpvs; q.halfspace = p->halfspace;
+    q.rank = p->rank; q.nranks = p->nranks;
+    int rc = hqh_octbox_create_levels(&q, out);
+    free(m);
+    return rc;
 }
 
 int hqh_octbox_desc(const hqh_octbox* b, hq_desc* d)

@@ -270,12 +270,64 @@ class _OctParams(ctypes.Structure):
                 ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
 
 
+class _Layered(ctypes.Structure):
+    _fields_ = [("nlayers", ctypes.c_int32), ("ztop", ctypes.c_void_p), ("vp", ctypes.c_void_p),
+                ("vs", ctypes.c_void_p), ("rho", ctypes.c_void_p)]
+
+
+def layered_column(layers, h0, ncoarse, factor, vscut=0.0):
+    """Leaves (edge, vp, vs, rho) from the top of the column the reference's mesher makes of the
+    layered model layers = [(ztop, vp, vs, rho), ...] (hqh_layered_column: Vs rule + 2:1 balance)."""
+    lib = load_library()
+    zt = np.array([l[0] for l in layers], np.float64)
+    m = [np.array([l[1 + c] for l in layers], np.float32) for c in range(3)]
+    mod = _Layered(len(layers), zt.ctypes.data, m[0].ctypes.data, m[1].ctypes.data, m[2].ctypes.data)
+    cap = 4096
+    edge = np.zeros(cap)
+    out = [np.zeros(cap, np.float32) for _ in range(3)]
+    n = ctypes.c_int32()
+    capi._check(lib.hqh_layered_column(ctypes.byref(mod), ctypes.c_double(h0), ctypes.c_int32(ncoarse),
+                                       ctypes.c_double(factor), ctypes.c_double(vscut), ctypes.c_int32(cap),
+                                       edge.ctypes.data_as(ctypes.c_void_p), out[0].ctypes.data_as(ctypes.c_void_p),
+                                       out[1].ctypes.data_as(ctypes.c_void_p), out[2].ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.byref(n)))
+    return [(float(edge[i]), float(out[0][i]), float(out[1][i]), float(out[2][i])) for i in range(n.value)]
+
+
+def levels_from_column(column):
+    """(finest edge, levels for OctBox(levels=...)) from layered_column(); the column must coarsen
+    monotonically with depth."""
+    h = min(c[0] for c in column)
+    levels = []
+    for e, vp, vs, rho in column:
+        L = int(round(np.log2(e / h)))
+        if levels and L < len(levels) - 1:
+            raise ValueError("column refines again with depth")
+        while len(levels) <= L:
+            levels.append([0, []])
+        levels[L][0] += 1
+        levels[L][1].append((vp, vs, rho))
+    return h, [(n, mats) for n, mats in levels]
+
+
+class _OctLevels(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nlevels", ctypes.c_int32),
+                ("layers", ctypes.c_void_p), ("h", ctypes.c_double),
+                ("vp", ctypes.c_void_p), ("vs", ctypes.c_void_p), ("rho", ctypes.c_void_p),
+                ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
+                ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+
+
 class OctBox:
-    """Two-level layered box with hanging nodes (hqh_octbox), whole or one of nranks partitions."""
+    """Layered box on two (or, with `levels`, any number of) octree levels with hanging nodes
+    (hqh_octbox), whole or one of nranks partitions.  levels = [(layers, vp, vs, rho), ...] or
+    [(layers, [(vp, vs, rho) per element layer]), ...] from the top, level L with elements of edge
+    h * 2^L; nz_fine / nz_coarse / top / bottom are ignored then."""
 
     def __init__(self, nx, ny, nz_fine, nz_coarse, h, dt, freq, top=(3000.0, 1732.0, 2200.0),
                  bottom=(6000.0, 3464.0, 2700.0), damping="rayleigh", threshold_damping=0.05,
-                 threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1):
+                 threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1, levels=None):
         lib = load_library()
         lib.hqh_octbox_view.restype = ctypes.c_void_p
         lib.hqh_octbox_view.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
@@ -286,7 +338,20 @@ class OctBox:
                        int(rank), int(nranks))
         self.rank, self.nranks = int(rank), int(nranks)
         self._h = ctypes.c_void_p()
-        rc = lib.hqh_octbox_create(ctypes.byref(p), ctypes.byref(self._h))
+        if levels is not None:
+            lay = np.array([l[0] for l in levels], np.int32)
+            # a level's material: one (vp, vs, rho) for all its element layers, or a list of them
+            per = []
+            for l in levels:
+                per += [tuple(l[1:4])] * int(l[0]) if not isinstance(l[1], (list, tuple)) else list(l[1])
+            assert len(per) == int(lay.sum())
+            mats = [np.array([m[c] for m in per], np.float32) for c in range(3)]
+            q = _OctLevels(nx, ny, len(levels), lay.ctypes.data, h, mats[0].ctypes.data, mats[1].ctypes.data,
+                           mats[2].ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
+                           int(halfspace), int(rank), int(nranks))
+            rc = lib.hqh_octbox_create_levels(ctypes.byref(q), ctypes.byref(self._h))
+        else:
+            rc = lib.hqh_octbox_create(ctypes.byref(p), ctypes.byref(self._h))
         if rc != 0:
             raise capi.HqError("hqh_octbox_create failed: %d" % rc)
         self._lib = lib

@@ -217,6 +217,47 @@ typedef struct {
 } hqh_octbox_params;
 
 HQ_API int  hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out);
+
+/*
+ * The same on any number of octree levels: from the top, layers[L] layers of elements of edge
+ * h * 2^L (L = 0 .. nlevels-1 <= 7), every element layer with its own material -- the mesh the
+ * reference's mesher makes of a layered model whose Vs rule asks for coarser elements with depth
+ * (pinned on its own three-level mesh, tests/golden/c5_three_level).  nx, ny in finest edges,
+ * multiples of 2^(nlevels-1); every slab must end on a plane the next level's cells align to.
+ */
+typedef struct {
+    int32_t        nx, ny;
+    int32_t        nlevels;
+    const int32_t* layers;       /* [nlevels] element layers of edge h * 2^L */
+    double         h;            /* finest edge, metres */
+    const float   *vp, *vs, *rho;/* [sum of layers[]]: one material per element layer, from the top */
+    double         deltaT, freq;
+    int32_t        damping;
+    double         threshold_damping, threshold_vpvs;
+    int32_t        halfspace;
+    int32_t        rank, nranks;
+} hqh_octlevels_params;
+
+HQ_API int  hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out);
+
+/*
+ * The column of leaves the reference's mesher makes of a layered model (material a function of
+ * depth only), from the top: octor_refinetree with toexpand = vsrule (psolve.c:2185-2210,
+ * quake_util.c:215-225: split while edge > Vs / factor, factor = simulation_wave_max_freq_hz x
+ * simulation_node_per_wavelength) on the material setrec gives a leaf (psolve.c:1307-1397: the
+ * minimum-Vs sample of the points at 0.01, 1 and 1.99 half-edges; stop at the first sample with
+ * Vs <= vscut, which is then raised to vscut at the same Vp/Vs), then octor_balancetree (2:1
+ * between neighbours, new leaves re-sampled).  The column starts as `ncoarse` cells of edge h0.
+ * Output: nleaves leaves from the top, edge[] in metres and their materials (capacity `cap`).
+ */
+typedef struct {
+    int32_t       nlayers;
+    const double* ztop;          /* [nlayers] top depth of each layer, metres, [0] = 0 */
+    const float  *vp, *vs, *rho; /* [nlayers] */
+} hqh_layered_model;
+
+HQ_API int hqh_layered_column(const hqh_layered_model* m, double h0, int32_t ncoarse, double factor, double vscut,
+                              int32_t cap, double* edge, float* vp, float* vs, float* rho, int32_t* nleaves);
 HQ_API void hqh_octbox_destroy(hqh_octbox* box);
 HQ_API int  hqh_octbox_desc(const hqh_octbox* box, hq_desc* desc);
 /* views: which = 0 lnid [E][8], 1 node_xyz [N][3] (fine-edge units), 2 dn_ldnid, 3 dn_ptr,

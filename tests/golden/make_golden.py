@@ -286,6 +286,16 @@ def case_three_level():
                  ["layers", 3, 0, 1500, 150, 1800, 2, 2500, 2000, 2300, 4, 6000, 3464, 2700], 100, 0.25)
 
 
+def case_layered():
+    """A layered model that makes the mesher do everything the layered-column helper
+    (hqh_layered_column) restates: Vs rule on the minimum of a leaf's samples (three materials:
+    Vs 200 / 450 / 1200 m/s over 0-62.5 / 62.5-187.5 / 187.5-500 m; f = 0.5 Hz, 8 points per
+    wavelength: edges of 31.25, 62.5 and 250 m), then 2:1 balancing (the 250 m leaves next to
+    62.5 m ones are split), several materials inside one level."""
+    _octree_case("c5_layered", "0.1", 30,
+                 ["layers", 3, 0, 800, 200, 1700, 1, 1500, 450, 2000, 3, 2600, 1200, 2300], 100, 0.5)
+
+
 def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq):
     """The same octree models on `nranks` MPI ranks: per-rank element dumps, force files and
     checkpoint stripes pin octor's multi-rank tables (block partition, ownership by containing
@@ -350,6 +360,7 @@ CASES = {
     "c1_np8": case_np8,
     "c5_two_level": case_two_level,
     "c5_three_level": case_three_level,
+    "c5_layered": case_layered,
     "c5_two_level_np8": lambda: case_octree_np("c5_two_level_np8", "c5_two_level", 8, "0.5", 200,
                                                [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
     # (a 5-rank run of the three-level mesh was tried and is NOT a fixture: on 5 ranks the

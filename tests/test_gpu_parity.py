@@ -279,7 +279,7 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     s.close(); s2.close(); box.close()
 
 
-@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level"])
+@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level", "c5_layered"])
 @pytest.mark.parametrize("variant", VARIANTS + [ha.HQ_VARIANT_AUTO])
 def test_two_level_mesh_with_hanging_nodes_against_reference(variant, mesh):
     """compute_adjust on the reference's own two-level mesh (800 hanging nodes): scatter
@@ -422,6 +422,43 @@ def test_partitioned_two_level_box_of_the_c_host(variant, shape, nranks):
         tm1, tm2 = s.download()
         assert H.rel_linf(tm1, o2[b.gid]) < TOL, (r, "tm1")
         assert H.rel_linf(tm2, o1[b.gid]) < TOL, (r, "tm2")
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()
+
+
+@pytest.mark.parametrize("nranks", [1, 5])
+def test_three_level_box_of_the_c_host(nranks):
+    """The three-level layered box built (and cut into octor's partitions) by the C host,
+    stepped on the GPU, against the oracle on the mesh the REAL reference generated for the same
+    model (tests/golden/c5_three_level)."""
+    from hercules_amd import capi, host
+    real = H.c5_problem("c5_three_level")
+    g = real["golden"]
+    mats = {float(r[0]): (float(r[1]), float(r[0]), float(r[2])) for r in np.unique(g["mat_vs_vp_rho"], axis=0)}
+    levels = [(2,) + mats[150.0], (1,) + mats[2000.0], (1,) + mats[3464.0]]
+    N, nsteps = real["N"], 40
+    rng = np.random.default_rng(11)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    ho.compute_adjust(u1, 1, real["dangling"])
+    ho.compute_adjust(u2, 1, real["dangling"])
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(real["lnid"], real["etable"], real["ntable"], o1, o2, 0, nsteps, real["dt"], dangling=real["dangling"])
+    boxes = [host.OctBox(16, 16, 0, 0, 62.5, real["dt"], float(g["freq"]), levels=levels, rank=r, nranks=nranks)
+             for r in range(nranks)]
+    gids = [b.gid if nranks > 1 else np.arange(N) for b in boxes]
+    solvers = [b.create_solver(tm1=u1[i], tm2=u2[i]) for b, i in zip(boxes, gids)]
+    if nranks > 1:
+        capi.group_link(solvers)
+        capi.group_run(solvers, nsteps)
+    else:
+        solvers[0].run(nsteps)
+    for r, (s, i) in enumerate(zip(solvers, gids)):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[i]) < TOL, (r, "tm1")
+        assert H.rel_linf(tm2, o1[i]) < TOL, (r, "tm2")
     for s in solvers:
         s.close()
     for b in boxes:

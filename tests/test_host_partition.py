@@ -248,3 +248,73 @@ def test_two_level_box_partitions_of_the_c_host_are_octors(shape, nranks):
                 for (_, a), (_, b) in zip(got, exp):
                     assert np.array_equal(a, b)
         ob.close()
+
+
+def test_three_level_box_of_the_c_host_is_the_references_mesh():
+    """hqh_octbox_create_levels on the model of tests/golden/c5_three_level (2 layers of 62.5 m
+    elements, 1 of 125 m, 1 of 250 m; three materials that take every branch of mu_and_lambda):
+    connectivity, node order, hanging-node table incl. anchor order, eTable, nTable -- all equal to
+    the mesh the REAL reference generated; and its partitions to octor's per-rank tables."""
+    real = H.c5_problem("c5_three_level")
+    g = real["golden"]
+    mats = {float(r[0]): (float(r[1]), float(r[0]), float(r[2])) for r in np.unique(g["mat_vs_vp_rho"], axis=0)}
+    levels = [(2,) + mats[150.0], (1,) + mats[2000.0], (1,) + mats[3464.0]]
+    ob = host.OctBox(16, 16, 0, 0, 62.5, 1e-3, float(g["freq"]), levels=levels)
+    assert ob.E == real["E"] == int(g["total_elements"]) and ob.N == real["N"] == int(g["total_nodes"])
+    assert ob.ldnnum == int(g["total_dangling"])
+    assert np.array_equal(ob.lnid, real["lnid"])
+    assert np.array_equal(ob.node_xyz, real["node_q"])
+    for a, b in zip(ob.dangling, real["dangling"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ob.etable, real["etable"])
+    assert np.array_equal(ob.ntable, real["ntable"])
+    g_nt = ob.ntable.copy()
+    ob.close()
+    m = ho.octree_mesh_from_elem_ticks(g["elem_ticks"], H.C1_FAR_TICKS)
+    for nranks in (3, 8):
+        parts = ho.octree_partition(m, nranks, (16, 16, 8))
+        for r in range(nranks):
+            ob = host.OctBox(16, 16, 0, 0, 62.5, 1e-3, float(g["freq"]), levels=levels, rank=r, nranks=nranks)
+            p = parts[r]
+            assert np.array_equal(ob.gid, p["nodes"]) and np.array_equal(ob.lnid, p["lnid"])
+            assert np.array_equal(ob.owner, p["owner"])
+            for a, b in zip(ob.dangling, p["dangling"]):
+                assert np.array_equal(a, b)
+            assert np.array_equal(ob.ntable, g_nt[p["nodes"]])
+            sch = ob.schedules()
+            for kind, key in (("an", "an_sched"), ("dn", "dn_sched")):
+                for lst in ("c", "s"):
+                    got, exp = sch[kind][lst], p[key].get(lst, [])
+                    assert [q for q, _ in got] == [q for q, _ in exp]
+                    for (_, a), (_, b) in zip(got, exp):
+                        assert np.array_equal(a, b)
+            ob.close()
+
+
+def test_layered_model_column_and_mesh_are_the_references():
+    """hqh_layered_column (Vs rule on the minimum-Vs sample + 2:1 balance) and the box built from it
+    against the mesh the REAL reference made of the same layered model (tests/golden/c5_layered:
+    three materials, edges of 31.25 / 62.5 / 125 m after balancing, two materials inside one level)."""
+    g = H.load("c5_layered")
+    model = [(0.0, 800.0, 200.0, 1700.0), (62.5, 1500.0, 450.0, 2000.0), (187.5, 2600.0, 1200.0, 2300.0)]
+    col = host.layered_column(model, 500.0, 1, 8 * float(g["freq"]), vscut=100.0)
+    et = g["elem_ticks"]
+    tick = 1000.0 / 2 ** 30
+    first = (et[:, 0, 0] == 0) & (et[:, 0, 1] == 0)
+    ref = sorted((float(et[e, 0, 2]) * tick, float(et[e, 7, 0] - et[e, 0, 0]) * tick) + tuple(g["mat_vs_vp_rho"][e])
+                 for e in np.nonzero(first)[0])
+    assert len(col) == len(ref)
+    z = 0.0
+    for (edge, vp, vs, rho), (z0, e0, rvs, rvp, rrho) in zip(col, ref):
+        assert (z, edge, vp, vs, rho) == (z0, e0, rvp, rvs, rrho)
+        z += edge
+    h, levels = host.levels_from_column(col)
+    assert h == 31.25 and [n for n, _ in levels] == [2, 3, 2]
+    real = H.c5_problem("c5_layered")
+    ob = host.OctBox(32, 32, 0, 0, h, 1e-3, float(g["freq"]), levels=levels)
+    assert ob.E == int(g["total_elements"]) and ob.N == int(g["total_nodes"]) and ob.ldnnum == int(g["total_dangling"])
+    assert np.array_equal(ob.lnid, real["lnid"]) and np.array_equal(ob.node_xyz, real["node_q"])
+    for a, b in zip(ob.dangling, real["dangling"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ob.etable, real["etable"]) and np.array_equal(ob.ntable, real["ntable"])
+    ob.close()

@@ -217,6 +217,22 @@ def test_three_level_mesh_all_material_branches_bitwise():
     assert np.abs(tm2).max() > 10.0
 
 
+def test_layered_model_mesh_checkpoints_bitwise():
+    """The reference on a three-material layered model whose mesh needs 2:1 balancing (edges of
+    31.25 / 62.5 / 125 m, 1008 hanging nodes, two materials inside one level): bit-identical."""
+    p = H.c5_problem("c5_layered")
+    g = p["golden"]
+    assert p["E"] == int(g["total_elements"]) == 2944 and len(p["dangling"][0]) == int(g["total_dangling"]) == 1008
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"], dangling=p["dangling"])
+        done = int(step)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k]) and np.array_equal(tm2, g["ckpt_tm1"][k])
+    assert np.abs(tm2).max() > 1.0
+
+
 def test_octree_mesh_on_eight_ranks_tables_and_fields():
     """The reference ran its two-level mesh on 8 MPI ranks.  octor's multi-rank tables
     restated from the global view (block partition, ownership by containing leaf, direct +
