@@ -1,3 +1,4 @@
+#define _FILE_OFFSET_BITS 64
 /*
  * hq_host.c -- C host side of the MI355X engine (include/hq_host.h).
  *
@@ -1319,6 +1320,271 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
     free(ek);
     *out = b;
     return HQ_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* mesh.e reader (read-only walk of the reference's etree / B-tree file)     */
+/* ------------------------------------------------------------------------ */
+
+static uint32_t rd_u32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static int64_t rd_i64(const unsigned char* p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return (int64_t)v; }
+
+int hqh_etree_read(const char* path, int64_t* n, int32_t* value_size, uint32_t** ticks, int32_t** level, void** values)
+{
+    if (!path || !n || !value_size || !ticks || !level || !values) return HQ_ERR_ARG;
+    *n = 0; *ticks = NULL; *level = NULL; *values = NULL;
+    FILE* f = fopen(path, "rb");
+    if (!f) return HQ_ERR_ARG;
+    int rc = HQ_ERR_ARG;
+    unsigned char* page = NULL;
+    uint32_t* tk = NULL; int32_t* lv = NULL; unsigned char* val = NULL;
+    /* etree header (etree.c readheader): endian char, version, dimensions, rootlevel,
+     * appmetasize, then leaf / index counts of 32 levels, 4 bytes each: 273 bytes */
+    unsigned char eh[273], bh[33];
+    if (fread(eh, 1, sizeof eh, f) != sizeof eh || eh[0] != 'L' || rd_u32(eh + 1) != 1 || rd_u32(eh + 5) != 3) goto done;
+    /* B-tree meta data (btree.c metahdrsize): endian, pagesize, pagecount, rootpagenum, keysize,
+     * valuesize, asciischemasize; page p lives at p * pagesize (page 0 = these headers) */
+    if (fread(bh, 1, sizeof bh, f) != sizeof bh || bh[0] != 'L') goto done;
+    const uint32_t pagesize = rd_u32(bh + 1), keysize = rd_u32(bh + 21), vsize = rd_u32(bh + 25);
+    const int64_t pagecount = rd_i64(bh + 5), root = rd_i64(bh + 13);
+    if (pagesize < 64 || pagesize > (1u << 24) || keysize != 13 || vsize == 0 || vsize > pagesize || root < 1 || root > pagecount) goto done;
+    int64_t total = 0;
+    for (int L = 0; L < 32; L++) total += rd_u32(eh + 17 + 8 * L);      /* leaf octants per level */
+    page = (unsigned char*)malloc(pagesize);
+    tk = (uint32_t*)malloc(sizeof(uint32_t) * 3 * (size_t)(total ? total : 1));
+    lv = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total ? total : 1));
+    val = (unsigned char*)malloc((size_t)vsize * (size_t)(total ? total : 1));
+    if (!page || !tk || !lv || !val) { rc = HQ_ERR_NOMEM; goto done; }
+    /* page header (btree.c setheader): right sibling i64 @0, (parent address) @8, count i32 @16,
+     * (parent entry) @20, type 'l' / 'i' @24, entries from 25; index entry = key + child page i64 */
+    int64_t pg = root;
+    for (int depth = 0;; depth++) {
+        if (depth > 64 || fseeko(f, (off_t)pg * pagesize, SEEK_SET) != 0 || fread(page, 1, pagesize, f) != pagesize) goto done;
+        if (page[24] == 'l') break;
+        if (page[24] != 'i' || (int32_t)rd_u32(page + 16) < 1) goto done;
+        pg = rd_i64(page + 25 + keysize);                                 /* leftmost child */
+        if (pg < 1 || pg > pagecount) goto done;
+    }
+    int64_t got = 0;
+    for (int64_t guard = 0; pg != -1; guard++) {
+        if (guard > pagecount || pg < 1 || pg > pagecount) goto done;
+        if (fseeko(f, (off_t)pg * pagesize, SEEK_SET) != 0 || fread(page, 1, pagesize, f) != pagesize || page[24] != 'l') goto done;
+        const int32_t cnt = (int32_t)rd_u32(page + 16);
+        if (cnt < 0 || 25 + (int64_t)cnt * (keysize + vsize) > pagesize || got + cnt > total) goto done;
+        for (int32_t e = 0; e < cnt; e++) {
+            const unsigned char* k = page + 25 + (size_t)e * (keysize + vsize);
+            if (!(k[0] & 0x80)) continue;                                 /* interior octant record */
+            /* locational key (code.c): level | 0x80, then the 96-bit little-endian Morton code,
+             * bit 3 i + d = bit i of coordinate d (x, y, z) */
+            uint32_t c[3] = { 0, 0, 0 };
+            for (int bit = 0; bit < 96; bit++)
+                if (k[1 + (bit >> 3)] & (1u << (bit & 7))) c[bit % 3] |= 1u << (bit / 3);
+            tk[3 * got] = c[0]; tk[3 * got + 1] = c[1]; tk[3 * got + 2] = c[2];
+            lv[got] = k[0] & 0x7f;
+            memcpy(val + (size_t)got * vsize, k + keysize, vsize);
+            got++;
+        }
+        pg = rd_i64(page);
+    }
+    *n = got; *value_size = (int32_t)vsize; *ticks = tk; *level = lv; *values = val;
+    tk = NULL; lv = NULL; val = NULL;
+    rc = HQ_OK;
+done:
+    fclose(f);
+    free(page); free(tk); free(lv); free(val);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* octree mesh from its leaves (octor_extractmesh + solver_init, one partition) */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { uint64_t key; int64_t idx; } hqh_keyidx;
+
+static int cmp_keyidx(const void* a, const void* b)
+{
+    const hqh_keyidx* x = (const hqh_keyidx*)a; const hqh_keyidx* y = (const hqh_keyidx*)b;
+    return x->key < y->key ? -1 : (x->key > y->key ? 1 : (x->idx < y->idx ? -1 : (x->idx > y->idx)));
+}
+
+int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, const float* edata,
+                         const uint32_t far_ticks[3], const hqh_init_params* ip, hqh_octbox** out)
+{
+    if (E < 1 || !et || !eedge || !edata || !far_ticks || !ip || !out || ip->deltaT <= 0) return HQ_ERR_ARG;
+    *out = NULL;
+    if (E > 0x7fffffff / 8) return HQ_ERR_ARG;
+    uint32_t emin = eedge[0];
+    for (int64_t e = 1; e < E; e++) if (eedge[e] < emin) emin = eedge[e];
+    if (emin == 0) return HQ_ERR_ARG;
+    uint32_t nq[3];
+    for (int d = 0; d < 3; d++) { if (far_ticks[d] % emin) return HQ_ERR_ARG; nq[d] = far_ticks[d] / emin; if (nq[d] >= (1u << 20)) return HQ_ERR_ARG; }
+    hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
+    hqh_keyidx* ki = (hqh_keyidx*)malloc(sizeof(hqh_keyidx) * 8 * (size_t)E);
+    uint64_t* nkey = NULL;
+    int32_t *touch = NULL, *small = NULL;
+    int rc = HQ_ERR_NOMEM;
+    if (!b || !ki) goto fail;
+    b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.nranks = 1;
+    b->E = E;
+    b->lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)E);
+    b->etable = (double*)malloc(sizeof(double) * 4 * (size_t)E);
+    if (!b->lnid || !b->etable) goto fail;
+    /* every element corner, keyed by the Z-value of its doubled, far-adjusted coordinates */
+    for (int64_t e = 0; e < E; e++) {
+        if (et[3 * e] % emin || et[3 * e + 1] % emin || et[3 * e + 2] % emin || eedge[e] % emin) { rc = HQ_ERR_ARG; goto fail; }
+        const uint32_t s = eedge[e] / emin;
+        for (int c = 0; c < 8; c++) {
+            uint32_t q[3], k2[3];
+            for (int d = 0; d < 3; d++) {
+                q[d] = et[3 * e + d] / emin + (((c >> d) & 1) ? s : 0);
+                if (q[d] > nq[d]) { rc = HQ_ERR_ARG; goto fail; }
+                k2[d] = (q[d] == nq[d]) ? 2 * q[d] - 1 : 2 * q[d];
+            }
+            ki[8 * e + c].key = zvalue(k2[0], k2[1], k2[2]);
+            ki[8 * e + c].idx = 8 * e + c;
+        }
+    }
+    qsort(ki, 8 * (size_t)E, sizeof(hqh_keyidx), cmp_keyidx);
+    int64_t N = 0;
+    for (int64_t i = 0; i < 8 * E; i++) {
+        if (i == 0 || ki[i].key != ki[i - 1].key) N++;
+        b->lnid[ki[i].idx] = (int32_t)(N - 1);
+    }
+    if (N > 0x7fffffff / 8) { rc = HQ_ERR_ARG; goto fail; }
+    b->N = N;
+    nkey = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    b->node_xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)N);
+    b->ntable = (double*)calloc((size_t)N * 7, sizeof(double));
+    touch = (int32_t*)calloc((size_t)N, sizeof(int32_t));
+    small = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    if (!nkey || !b->node_xyz || !b->ntable || !touch || !small) goto fail;
+    {
+        int64_t n = -1;
+        for (int64_t i = 0; i < 8 * E; i++) {
+            if (i == 0 || ki[i].key != ki[i - 1].key) {
+                n++;
+                nkey[n] = ki[i].key;
+                uint32_t d2[3] = { compact3(ki[i].key), compact3(ki[i].key >> 1), compact3(ki[i].key >> 2) };
+                for (int d = 0; d < 3; d++) b->node_xyz[3 * n + d] = (int32_t)((d2[d] & 1) ? nq[d] : (d2[d] >> 1));
+                small[n] = 0x7fffffff;
+            }
+            const int32_t s = (int32_t)(eedge[ki[i].idx / 8] / emin);
+            touch[n]++;
+            if (s < small[n]) small[n] = s;
+        }
+    }
+    free(ki); ki = NULL;
+    /* node_setproperty: anchored unless it misses touches for where it sits; a hanging node sits
+     * on the grid of its smallest toucher but off the next coarser one in 1 (edge) or 2 (face) axes */
+    {
+        int32_t ldn = 0, nanch = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                b->ldnnum = ldn;
+                b->dn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ldn ? ldn : 1));
+                b->dn_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ldn + 1));
+                b->dn_anchor = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nanch ? nanch : 1));
+                if (!b->dn_id || !b->dn_ptr || !b->dn_anchor) goto fail;
+                b->dn_ptr[0] = 0;
+                ldn = 0; nanch = 0;
+            }
+            for (int64_t n = 0; n < N; n++) {
+                const int32_t* c = &b->node_xyz[3 * n];
+                int wh = 0, mods[3], nm = 0;
+                const int tc = touch[n], s = small[n];
+                for (int d = 0; d < 3; d++) wh += (c[d] == 0 || (uint32_t)c[d] == nq[d]);
+                if (tc == 8 || (tc == 4 && wh == 1) || (tc == 2 && wh == 2) || (tc == 1 && wh == 3)) continue;
+                for (int d = 0; d < 3; d++) { mods[d] = (c[d] % (2 * s)) != 0; nm += mods[d]; }
+                if (!((tc == 6 && wh == 0 && nm == 1) || (tc == 4 && wh == 0 && (nm == 1 || nm == 2)) ||
+                      (tc == 2 && (wh == 0 || wh == 1) && nm == 1))) { rc = HQ_ERR_ARG; goto fail; }   /* not a 2:1 octree */
+                int32_t pts[4][3], np = 0;
+                if (nm == 1) {                                    /* edge: -s then +s */
+                    int d = mods[0] ? 0 : (mods[1] ? 1 : 2);
+                    for (int sg = -1; sg <= 1; sg += 2) { memcpy(pts[np], c, sizeof pts[0]); pts[np][d] += sg * s; np++; }
+                } else {                                          /* face: the two in-plane axes, low axis fastest */
+                    int a = mods[0] ? 0 : 1, bb = mods[2] ? 2 : 1;
+                    for (int dep = 0; dep < 4; dep++) {
+                        memcpy(pts[np], c, sizeof pts[0]);
+                        pts[np][a] += (dep & 1) ? s : -s;
+                        pts[np][bb] += (dep & 2) ? s : -s;
+                        np++;
+                    }
+                }
+                if (pass == 1) {
+                    b->dn_id[ldn] = (int32_t)n;
+                    for (int i = np - 1; i >= 0; i--) {           /* the list is built by prepending */
+                        uint32_t k2[3];
+                        for (int d = 0; d < 3; d++) {
+                            if (pts[i][d] < 0 || (uint32_t)pts[i][d] > nq[d]) { rc = HQ_ERR_ARG; goto fail; }
+                            k2[d] = ((uint32_t)pts[i][d] == nq[d]) ? 2 * nq[d] - 1 : 2 * (uint32_t)pts[i][d];
+                        }
+                        const uint64_t key = zvalue(k2[0], k2[1], k2[2]);
+                        int64_t lo = 0, hi = N - 1, hit = -1;
+                        while (lo <= hi) { int64_t m = (lo + hi) / 2; if (nkey[m] < key) lo = m + 1; else if (nkey[m] > key) hi = m - 1; else { hit = m; break; } }
+                        if (hit < 0) { rc = HQ_ERR_ARG; goto fail; }
+                        b->dn_anchor[nanch + (np - 1 - i)] = (int32_t)hit;
+                    }
+                    b->dn_ptr[ldn + 1] = nanch + np;
+                }
+                ldn++; nanch += np;
+            }
+        }
+    }
+    free(nkey); nkey = NULL; free(touch); touch = NULL; free(small); small = NULL;
+    /* solver_init's element loop (psolve.c:3360-3473) */
+    {
+        double aBase, bBase;
+        const double dt = ip->deltaT, dt2 = dt * dt;
+        rayleigh_base(ip->freq, ip->damping, &aBase, &bBase);
+        for (int64_t e = 0; e < E; e++) {
+            float h = edata[4 * e], Vp = edata[4 * e + 1], Vs = edata[4 * e + 2], rho = edata[4 * e + 3];
+            double mu = rho * Vs * Vs, lambda;
+            if (Vp > (Vs * ip->threshold_vpvs)) lambda = rho * Vs * Vs * ip->threshold_vpvs * ip->threshold_vpvs - 2 * mu;
+            else lambda = rho * Vp * Vp - 2 * mu;
+            if (lambda < 0) {
+                if (Vs < 500) Vp = 2.45 * Vs; else if (Vs < 1200) Vp = 2 * Vs; else Vp = 1.87 * Vs;
+                lambda = rho * Vp * Vp;
+            }
+            if (lambda < 0) { rc = HQ_ERR_ARG; goto fail; }
+            double zeta = 10 / Vs;
+            if (zeta > ip->threshold_damping) zeta = ip->threshold_damping;
+            const double a = zeta * aBase, bb = zeta * bBase;
+            b->etable[4 * e] = dt2 * h * mu / 9; b->etable[4 * e + 1] = dt2 * h * lambda / 9;
+            b->etable[4 * e + 2] = bb * dt * h * mu / 9; b->etable[4 * e + 3] = bb * dt * h * lambda / 9;
+            const double mass = rho * h * h * h, M = mass / 8;
+            const uint32_t s = eedge[e] / emin, q[3] = { et[3 * e] / emin, et[3 * e + 1] / emin, et[3 * e + 2] / emin };
+            const int face = (q[0] == 0) | ((q[1] == 0) << 1) | ((q[2] == 0) << 2) | ((q[0] + s == nq[0]) << 3) |
+                             ((q[1] + s == nq[1]) << 4) | ((q[2] + s == nq[2]) << 5);
+            for (int c = 0; c < 8; c++) {
+                double dash[3];
+                int bnd = face_dashpot(face, c, ip->halfspace, h, Vp, Vs, rho, dash);
+                double* np = &b->ntable[7 * (int64_t)b->lnid[8 * e + c]];
+                np[0] += M;
+                for (int ax = 0; ax < 3; ax++) {
+                    np[4 + ax] -= (dt * a * M);
+                    np[1 + ax] -= (dt * a * M);
+                    if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
+                    np[4 + ax] += M;
+                    np[1 + ax] += (M * 2);
+                }
+            }
+        }
+    }
+    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502 */
+    for (int32_t k = 0; k < b->ldnnum; k++) {
+        double part[7];
+        uint32_t deps = (uint32_t)(b->dn_ptr[k + 1] - b->dn_ptr[k]);
+        for (int q = 0; q < 7; q++) part[q] = b->ntable[7 * (int64_t)b->dn_id[k] + q] / deps;
+        for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
+            for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
+    }
+    /* node coordinates in ticks for the patch planner (finest-edge units otherwise) */
+    *out = b;
+    return HQ_OK;
+fail:
+    free(ki); free(nkey); free(touch); free(small);
+    hqh_octbox_destroy(b);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -357,6 +357,11 @@ class OctBox:
         self._lib = lib
         self.dt = dt
 
+        self._load_views()
+
+    def _load_views(self):
+        lib = self._lib
+
         def view(which, dtype, cols):
             n = ctypes.c_int64()
             ptr = lib.hqh_octbox_view(self._h, which, ctypes.byref(n))
@@ -370,6 +375,34 @@ class OctBox:
         self.owner = view(7, np.int32, 1)
         self.gid = view(8, np.int32, 1)
         self.E, self.N, self.ldnnum = len(self.lnid), len(self.node_xyz), len(self.dangling[0])
+
+    @classmethod
+    def from_leaves(cls, elem_ticks, elem_edge, edata, far_ticks, dt, freq, damping="rayleigh",
+                    threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True):
+        """An octree mesh from its leaves in pre-order (hqh_mesh_from_leaves), e.g. those of a
+        mesh.e read with etree_read."""
+        lib = load_library()
+        lib.hqh_octbox_view.restype = ctypes.c_void_p
+        lib.hqh_octbox_view.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
+        lib.hqh_octbox_destroy.restype = None
+        lib.hqh_octbox_destroy.argtypes = [ctypes.c_void_p]
+        et = np.ascontiguousarray(elem_ticks, np.uint32).reshape(-1, 3)
+        ee = np.ascontiguousarray(elem_edge, np.uint32).reshape(-1)
+        ed = np.ascontiguousarray(edata, np.float32).reshape(-1, 4)
+        far = (ctypes.c_uint32 * 3)(*[int(v) for v in far_ticks])
+        ip = _InitParams(dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace))
+        self = cls.__new__(cls)
+        self.rank, self.nranks = 0, 1
+        self._h = ctypes.c_void_p()
+        rc = lib.hqh_mesh_from_leaves(ctypes.c_int64(len(et)), et.ctypes.data_as(ctypes.c_void_p),
+                                      ee.ctypes.data_as(ctypes.c_void_p), ed.ctypes.data_as(ctypes.c_void_p), far,
+                                      ctypes.byref(ip), ctypes.byref(self._h))
+        if rc != 0:
+            raise capi.HqError("hqh_mesh_from_leaves failed: %d" % rc)
+        self._lib = lib
+        self.dt = dt
+        self._load_views()
+        return self
 
     def schedules(self):
         """{"an": {"c": [(procid, mapping)], "s": [...]}, "dn": {...}} (copies)."""
@@ -410,6 +443,38 @@ class OctBox:
         s.N, s.E = d.nharbored, d.lenum
         capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
         return s
+
+
+def etree_read(path):
+    """Leaves of an etree file in key order (hqh_etree_read): ticks [n,3] uint32, level [n],
+    raw payloads [n, value_size] uint8."""
+    lib = load_library()
+    n, vs = ctypes.c_int64(), ctypes.c_int32()
+    pt, pl, pv = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    capi._check(lib.hqh_etree_read(os.fsencode(path), ctypes.byref(n), ctypes.byref(vs), ctypes.byref(pt),
+                                   ctypes.byref(pl), ctypes.byref(pv)))
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    try:
+        ticks = _view(pt.value, (n.value, 3), np.uint32).copy()
+        level = _view(pl.value, (n.value,), np.int32).copy()
+        vals = _view(pv.value, (n.value, vs.value), np.uint8).copy()
+    finally:
+        for p in (pt, pl, pv):
+            libc.free(p)
+    return ticks, level, vals
+
+
+def mesh_payload(values):
+    """mdata_t (psolve.h:84-87) of mesh.e payloads: global node ids [n,8] int64, edata [n,4] float32."""
+    v = np.ascontiguousarray(values)
+    return v[:, :64].copy().view("<i8").reshape(-1, 8), v[:, 64:80].copy().view("<f4").reshape(-1, 4)
+
+
+class _InitParams(ctypes.Structure):
+    _fields_ = [("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
+                ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
+                ("halfspace", ctypes.c_int32)]
 
 
 def forcefile_info(path):

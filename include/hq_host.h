@@ -268,6 +268,40 @@ HQ_API const void* hqh_octbox_view(const hqh_octbox* box, int32_t which, int64_t
 HQ_API int hqh_octbox_schedule(const hqh_octbox* box, int32_t sched, int32_t list, int32_t* count,
                                const hq_messenger** first);
 
+/*
+ * mesh.e: the mesh database the reference's mesher writes (mesh_output, psolve.c:2361-2562) -- an
+ * etree (etree/etree.c, btree.c: 273-byte etree header, B-tree meta data, 4 KiB pages; leaf
+ * entries = 13-byte locational key + payload) keyed by the octant address of every element, payload
+ * mdata_t = { int64 nid[8]; float edgesize, Vp, Vs, rho }.  hqh_etree_read returns the leaves in
+ * key (= octree pre-) order: ticks [n][3] (lower-left corner), level [n], and the raw payloads
+ * [n][*value_size] (malloc'ed, caller frees).  Little-endian files of 3 dimensions only.
+ */
+HQ_API int hqh_etree_read(const char* path, int64_t* n, int32_t* value_size, uint32_t** ticks, int32_t** level,
+                          void** values);
+
+/*
+ * An octree mesh from its leaves, in octor's conventions (octor_extractmesh, octor.c:5268-6650),
+ * one partition: nodes = the distinct element vertices in Z-order of their far-boundary-adjusted
+ * coordinates (octor.c:6100-6106, 6166); hanging nodes by node_setproperty's rules (touch count,
+ * boundary position, alignment to the next coarser grid, octor.c:3280-3860) with anchors in the
+ * order the dnode correlation leaves them (octor.c:6493-6612); eTable / nTable as solver_init
+ * leaves them (psolve.c:3280-3510) incl. the hanging-node mass distribution.  Elements must be in
+ * octree pre-order (as hqh_etree_read returns them).
+ *   elem_ticks [E][3]  lower-left corners, ticks;  elem_edge [E] edge, ticks
+ *   edata      [E][4]  edgesize (m), Vp, Vs, rho   (edata_t, psolve.h:95-97)
+ *   far_ticks  [3]     domain extent (nodes on the far faces are adjusted inwards for ordering)
+ * The result is an hqh_octbox (same accessors: hqh_octbox_desc, hqh_octbox_view, _destroy).
+ */
+typedef struct {
+    double  deltaT, freq;
+    int32_t damping;
+    double  threshold_damping, threshold_vpvs;
+    int32_t halfspace;
+} hqh_init_params;
+
+HQ_API int hqh_mesh_from_leaves(int64_t E, const uint32_t* elem_ticks, const uint32_t* elem_edge, const float* edata,
+                                const uint32_t far_ticks[3], const hqh_init_params* ip, hqh_octbox** out);
+
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);
 

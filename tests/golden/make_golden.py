@@ -293,7 +293,8 @@ def case_layered():
     wavelength: edges of 31.25, 62.5 and 250 m), then 2:1 balancing (the 250 m leaves next to
     62.5 m ones are split), several materials inside one level."""
     _octree_case("c5_layered", "0.1", 30,
-                 ["layers", 3, 0, 800, 200, 1700, 1, 1500, 450, 2000, 3, 2600, 1200, 2300], 100, 0.5)
+                 ["layers", 3, 0, 800, 200, 1700, 1, 1500, 450, 2000, 3, 2600, 1200, 2300], 100, 0.5,
+                 keep_mesh_etree=True)
 
 
 def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq):
@@ -327,8 +328,12 @@ def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, fre
     print(name, "ok", sorted(ckfiles))
 
 
-def _octree_case(name, end_time, ckpt_rate, cvm_args, vscut, freq):
+def _octree_case(name, end_time, ckpt_rate, cvm_args, vscut, freq, keep_mesh_etree=False):
     run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq)
+    extra = {}
+    if keep_mesh_etree:
+        # the mesh database the reference wrote (mesh_output, psolve.c:2361-2562), bz2-compressed
+        extra["mesh_e_bz2"] = np.frombuffer(bz2.compress(open(os.path.join(run, "out", "mesh.e"), "rb").read()), np.uint8)
     ids, F = read_forces(run)
     elem_ticks, mat = read_mesh(run)
     ck = {}
@@ -345,7 +350,7 @@ def _octree_case(name, end_time, ckpt_rate, cvm_args, vscut, freq):
                         ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
                         stations=st, dt=1e-3, end_time=float(end_time), freq=freq,
                         total_elements=counts["Total elements"], total_nodes=counts["Total nodes"],
-                        total_dangling=counts["Total dangling nodes"])
+                        total_dangling=counts["Total dangling nodes"], **extra)
     shutil.rmtree(run)
     print(name, "ok", counts, sorted(ck))
 

@@ -463,3 +463,29 @@ def test_three_level_box_of_the_c_host(nranks):
         s.close()
     for b in boxes:
         b.close()
+
+
+def test_from_the_references_mesh_database_to_its_checkpoints(tmp_path):
+    """End to end on the reference's own files: mesh.e (the mesh database its mesher wrote) read by
+    the C host, tables built from the leaves, its force file streamed by hqh_solver_run -- the
+    field equals the checkpoints the REAL reference wrote for that run (tests/golden/c5_layered:
+    three octree levels after 2:1 balancing, 1008 hanging nodes)."""
+    import bz2
+    from hercules_amd import host
+    g = H.load("c5_layered")
+    path = tmp_path / "mesh.e"
+    path.write_bytes(bz2.decompress(g["mesh_e_bz2"].tobytes()))
+    ticks, level, vals = host.etree_read(str(path))
+    _, edata = host.mesh_payload(vals)
+    edge = np.uint32(1) << (30 - level).astype(np.uint32)
+    ob = host.OctBox.from_leaves(ticks, edge, edata, H.C1_FAR_TICKS, float(g["dt"]), float(g["freq"]))
+    s = ob.create_solver()
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()
+    ob.close()

@@ -318,3 +318,56 @@ def test_layered_model_column_and_mesh_are_the_references():
         assert np.array_equal(a, b)
     assert np.array_equal(ob.etable, real["etable"]) and np.array_equal(ob.ntable, real["ntable"])
     ob.close()
+
+
+def test_mesh_etree_reader_and_mesh_from_leaves(tmp_path):
+    """The mesh.e database the REAL reference wrote for the layered model (tests/golden/c5_layered,
+    mesh_output psolve.c:2361-2562) read by the C host (hqh_etree_read: etree header, B-tree pages,
+    locational keys): every element's corner, level, global node ids and edata; then the mesh tables
+    built from those leaves alone (hqh_mesh_from_leaves) -- connectivity, node order, dnodeTable
+    with anchor order, eTable, nTable -- equal to the restatement pinned on the reference's run."""
+    import bz2
+    g = H.load("c5_layered")
+    real = H.c5_problem("c5_layered")
+    path = tmp_path / "mesh.e"
+    path.write_bytes(bz2.decompress(g["mesh_e_bz2"].tobytes()))
+    ticks, level, vals = host.etree_read(str(path))
+    nid, edata = host.mesh_payload(vals)
+    et = g["elem_ticks"]
+    assert len(ticks) == real["E"] == 2944
+    assert np.array_equal(ticks.astype(np.int64), et[:, 0, :])
+    edge = (et[:, 7, 0] - et[:, 0, 0])
+    assert np.array_equal(np.uint64(1) << (30 - level.astype(np.uint64)), edge.astype(np.uint64))   # octor PIXELLEVEL = 30
+    assert np.array_equal(nid, real["lnid"])                       # global node id = Z-order rank
+    assert np.array_equal(edata[:, 1:], g["mat_vs_vp_rho"][:, [1, 0, 2]])
+    assert np.array_equal(edata[:, 0], (edge * (1000.0 / 2 ** 30)).astype(np.float32))
+    ob = host.OctBox.from_leaves(ticks, edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]))
+    assert ob.E == real["E"] and ob.N == real["N"] and ob.ldnnum == len(real["dangling"][0])
+    assert np.array_equal(ob.lnid, real["lnid"]) and np.array_equal(ob.node_xyz, real["node_q"])
+    for a, b in zip(ob.dangling, real["dangling"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ob.etable, real["etable"]) and np.array_equal(ob.ntable, real["ntable"])
+    ob.close()
+
+
+@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level"])
+def test_mesh_from_leaves_on_the_references_other_meshes(name):
+    """hqh_mesh_from_leaves on the element dumps of the reference's uniform, two-level and
+    three-level meshes."""
+    g = H.load(name)
+    et = g["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = g["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    real = H.c1_problem() if name == "c1_short" else H.c5_problem(name)
+    ob = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]))
+    assert np.array_equal(ob.lnid, real["lnid"])
+    assert np.array_equal(ob.etable, real["etable"]) and np.array_equal(ob.ntable, real["ntable"])
+    if name != "c1_short":
+        for a, b in zip(ob.dangling, real["dangling"]):
+            assert np.array_equal(a, b)
+    else:
+        assert ob.ldnnum == 0
+    ob.close()
