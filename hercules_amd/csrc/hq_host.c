@@ -931,6 +931,7 @@ struct hqh_octbox {
     int32_t lay0[HQH_MAXLEVELS + 1];/* index of every level's first element layer; [nlevels] = total */
     float *vp, *vs, *rho;           /* [total element layers], from the top */
     int32_t ztop[HQH_MAXLEVELS + 1];/* top plane of every level's slab, finest-edge units; [nlevels] = bottom */
+    int32_t far_q[3];               /* domain extent in finest-edge units */
     int64_t E, N;
     int32_t ldnnum;
     int32_t *lnid, *node_xyz, *dn_id, *dn_ptr, *dn_anchor;
@@ -964,10 +965,11 @@ static int octbox_level_at(const hqh_octbox* b, int32_t z)
  * of the element corners (element id = position). */
 static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
 {
-    const int32_t nx = b->p.nx, ny = b->p.ny, nzt = b->ztop[b->p.nlevels], NL = b->p.nlevels;
+    const int32_t nx = b->far_q[0], ny = b->far_q[1], nzt = b->far_q[2], NL = b->p.nlevels;
     const int64_t E = b->E, N = b->N;
     int rc = HQ_ERR_NOMEM;
-    /* leaf of every cell of every level's slab -> element id */
+    /* slab boxes: leaf of every cell of every level's slab -> element id; meshes from leaves
+     * (NL == 0): the leaf containing a point is the last one whose corner precedes it in Z-order */
     int32_t* cell[HQH_MAXLEVELS];
     for (int L = 0; L < HQH_MAXLEVELS; L++) cell[L] = NULL;
     uint64_t* harb = (uint64_t*)calloc((size_t)N, sizeof(uint64_t));
@@ -985,15 +987,25 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
 #define HQH_ERANK(e) ((int)((((int64_t)(e) + 1) * P - 1) / E))     /* octor.c:4939-4944 */
 #define HQH_CELL(L, i, j, k) cell[L][((int64_t)(((k) - b->ztop[L]) >> (L)) * (ny >> (L)) + ((j) >> (L))) * (nx >> (L)) + ((i) >> (L))]
     for (int64_t e = 0; e < E; e++) {
-        int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
-        HQH_CELL(octbox_level_at(b, k), i, j, k) = (int32_t)e;
+        if (NL > 0) {
+            int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+            HQH_CELL(octbox_level_at(b, k), i, j, k) = (int32_t)e;
+        }
         const uint64_t bit = 1ull << HQH_ERANK(e);
         for (int c = 0; c < 8; c++) harb[b->lnid[8 * e + c]] |= bit;             /* element vertices */
     }
     for (int64_t n = 0; n < N; n++) {                                            /* owners */
         const int32_t* c = &b->node_xyz[3 * n];
         int32_t ax = c[0] < nx ? c[0] : nx - 1, ay = c[1] < ny ? c[1] : ny - 1, az = c[2] < nzt ? c[2] : nzt - 1;
-        gowner[n] = HQH_ERANK(HQH_CELL(octbox_level_at(b, az), ax, ay, az));
+        int64_t e;
+        if (NL > 0) e = HQH_CELL(octbox_level_at(b, az), ax, ay, az);
+        else {
+            const uint64_t key = zvalue((uint32_t)ax, (uint32_t)ay, (uint32_t)az);
+            int64_t lo = 0, hi = E - 1;
+            while (lo < hi) { int64_t m = (lo + hi + 1) / 2; if (ek[m] <= key) lo = m; else hi = m - 1; }
+            e = lo;
+        }
+        gowner[n] = HQH_ERANK(e);
         harb[n] |= 1ull << gowner[n];
     }
 #undef HQH_CELL
@@ -1146,6 +1158,7 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
         N += (int64_t)((nx >> L) + 1) * ((ny >> L) + 1) * p->layers[L];
     }
     const int32_t nzt = b->ztop[NL], nlay = b->lay0[NL];
+    b->far_q[0] = nx; b->far_q[1] = ny; b->far_q[2] = nzt;
     N += (int64_t)(nx + 1) * (ny + 1);                           /* the free surface */
     b->vp = (float*)malloc(sizeof(float) * (size_t)nlay);
     b->vs = (float*)malloc(sizeof(float) * (size_t)nlay);
@@ -1424,7 +1437,10 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     int32_t *touch = NULL, *small = NULL;
     int rc = HQ_ERR_NOMEM;
     if (!b || !ki) goto fail;
-    b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.nranks = 1;
+    const int P = ip->nranks > 1 ? ip->nranks : 1;
+    if (P > 64 || ip->rank < 0 || ip->rank >= P) { rc = HQ_ERR_ARG; goto fail; }
+    b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.rank = ip->rank; b->p.nranks = P;
+    for (int d = 0; d < 3; d++) b->far_q[d] = (int32_t)nq[d];
     b->E = E;
     b->lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)E);
     b->etable = (double*)malloc(sizeof(double) * 4 * (size_t)E);
@@ -1578,7 +1594,18 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
         for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
             for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
     }
-    /* node coordinates in ticks for the patch planner (finest-edge units otherwise) */
+    if (P > 1) {
+        /* the leaves' corners in Z-order = octree pre-order (checked), for point location */
+        uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
+        if (!ek) goto fail;
+        for (int64_t e = 0; e < E; e++) {
+            ek[e] = zvalue(et[3 * e] / emin, et[3 * e + 1] / emin, et[3 * e + 2] / emin);
+            if (e && ek[e] <= ek[e - 1]) { free(ek); rc = HQ_ERR_ARG; goto fail; }
+        }
+        rc = octbox_cut(b, ek, ip->rank, P);
+        free(ek);
+        if (rc != HQ_OK) goto fail;
+    }
     *out = b;
     return HQ_OK;
 fail:

@@ -378,7 +378,7 @@ class OctBox:
 
     @classmethod
     def from_leaves(cls, elem_ticks, elem_edge, edata, far_ticks, dt, freq, damping="rayleigh",
-                    threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True):
+                    threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1):
         """An octree mesh from its leaves in pre-order (hqh_mesh_from_leaves), e.g. those of a
         mesh.e read with etree_read."""
         lib = load_library()
@@ -390,9 +390,10 @@ class OctBox:
         ee = np.ascontiguousarray(elem_edge, np.uint32).reshape(-1)
         ed = np.ascontiguousarray(edata, np.float32).reshape(-1, 4)
         far = (ctypes.c_uint32 * 3)(*[int(v) for v in far_ticks])
-        ip = _InitParams(dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace))
+        ip = _InitParams(dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace),
+                         int(rank), int(nranks))
         self = cls.__new__(cls)
-        self.rank, self.nranks = 0, 1
+        self.rank, self.nranks = int(rank), int(nranks)
         self._h = ctypes.c_void_p()
         rc = lib.hqh_mesh_from_leaves(ctypes.c_int64(len(et)), et.ctypes.data_as(ctypes.c_void_p),
                                       ee.ctypes.data_as(ctypes.c_void_p), ed.ctypes.data_as(ctypes.c_void_p), far,
@@ -474,7 +475,7 @@ def mesh_payload(values):
 class _InitParams(ctypes.Structure):
     _fields_ = [("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
 
 
 def forcefile_info(path):

@@ -281,7 +281,7 @@ HQ_API int hqh_etree_read(const char* path, int64_t* n, int32_t* value_size, uin
 
 /*
  * An octree mesh from its leaves, in octor's conventions (octor_extractmesh, octor.c:5268-6650),
- * one partition: nodes = the distinct element vertices in Z-order of their far-boundary-adjusted
+ * whole or one of nranks partitions: nodes = the distinct element vertices in Z-order of their far-boundary-adjusted
  * coordinates (octor.c:6100-6106, 6166); hanging nodes by node_setproperty's rules (touch count,
  * boundary position, alignment to the next coarser grid, octor.c:3280-3860) with anchors in the
  * order the dnode correlation leaves them (octor.c:6493-6612); eTable / nTable as solver_init
@@ -297,6 +297,7 @@ typedef struct {
     int32_t damping;
     double  threshold_damping, threshold_vpvs;
     int32_t halfspace;
+    int32_t rank, nranks;        /* cut into octor's per-rank tables as hqh_octbox_create does (0, 0 or 1: whole mesh) */
 } hqh_init_params;
 
 HQ_API int hqh_mesh_from_leaves(int64_t E, const uint32_t* elem_ticks, const uint32_t* elem_edge, const float* edata,

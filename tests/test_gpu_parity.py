@@ -489,3 +489,38 @@ def test_from_the_references_mesh_database_to_its_checkpoints(tmp_path):
         assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
     s.close()
     ob.close()
+
+
+def test_partitions_cut_from_a_mesh_database(tmp_path):
+    """The reference's layered-model mesh read from its mesh.e, cut into 5 octor partitions by the
+    C host (general octree: Z-order point location), stepped in one process with the in-process
+    transport, against the oracle's run of the whole mesh."""
+    import bz2
+    from hercules_amd import capi, host
+    g = H.load("c5_layered")
+    real = H.c5_problem("c5_layered")
+    path = tmp_path / "mesh.e"
+    path.write_bytes(bz2.decompress(g["mesh_e_bz2"].tobytes()))
+    ticks, level, vals = host.etree_read(str(path))
+    _, edata = host.mesh_payload(vals)
+    edge = np.uint32(1) << (30 - level).astype(np.uint32)
+    N, nsteps, nranks = real["N"], 30, 5
+    rng = np.random.default_rng(5)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    ho.compute_adjust(u1, 1, real["dangling"])
+    ho.compute_adjust(u2, 1, real["dangling"])
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(real["lnid"], real["etable"], real["ntable"], o1, o2, 0, nsteps, real["dt"], dangling=real["dangling"])
+    boxes = [host.OctBox.from_leaves(ticks, edge, edata, H.C1_FAR_TICKS, real["dt"], float(g["freq"]), rank=r,
+                                     nranks=nranks) for r in range(nranks)]
+    solvers = [b.create_solver(tm1=u1[b.gid], tm2=u2[b.gid]) for b in boxes]
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for r, (b, s) in enumerate(zip(boxes, solvers)):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[b.gid]) < TOL and H.rel_linf(tm2, o1[b.gid]) < TOL, r
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()

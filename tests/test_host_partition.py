@@ -371,3 +371,40 @@ def test_mesh_from_leaves_on_the_references_other_meshes(name):
     else:
         assert ob.ldnnum == 0
     ob.close()
+
+
+@pytest.mark.parametrize("name,nranks", [("c5_layered", 8), ("c5_three_level", 5), ("c5_two_level", 8)])
+def test_mesh_from_leaves_partitions_are_octors(name, nranks):
+    """hqh_mesh_from_leaves with nranks > 1 (general octrees: the leaf containing a node is found
+    by Z-order search) against ho.octree_partition, for the reference's own meshes; the two-level
+    one on 8 ranks is the case the REAL reference ran (c5_two_level_np8)."""
+    g = H.load(name)
+    et = g["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = g["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    m = ho.octree_mesh_from_elem_ticks(et, H.C1_FAR_TICKS)
+    far_q = [f // m["emin"] for f in H.C1_FAR_TICKS]
+    parts = ho.octree_partition(m, nranks, far_q)
+    whole = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]))
+    g_nt = whole.ntable.copy()
+    whole.close()
+    for r in range(nranks):
+        ob = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]),
+                                     rank=r, nranks=nranks)
+        p = parts[r]
+        assert np.array_equal(ob.gid, p["nodes"]) and np.array_equal(ob.lnid, p["lnid"])
+        assert np.array_equal(ob.owner, p["owner"])
+        for a, b in zip(ob.dangling, p["dangling"]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(ob.ntable, g_nt[p["nodes"]])
+        sch = ob.schedules()
+        for kind, key in (("an", "an_sched"), ("dn", "dn_sched")):
+            for lst in ("c", "s"):
+                got, exp = sch[kind][lst], p[key].get(lst, [])
+                assert [q for q, _ in got] == [q for q, _ in exp]
+                for (_, a), (_, b) in zip(got, exp):
+                    assert np.array_equal(a, b)
+        ob.close()
