@@ -805,7 +805,17 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
         }
     }
     int32_t step = step0, end = step0 + nsteps, win_end = step0;
+    int ckpt_number = 0;                                         /* CheckpointNumber, io_checkpoint.c:38,126 */
+    const int32_t nharb = b->nharbored;
+    const int do_ckpt = rp->checkpoint_rate > 0 && rp->checkpoint_dir != NULL;
     while (step < end && rc == HQ_OK) {
+        if (do_ckpt && step != step0 && step % rp->checkpoint_rate == 0) {   /* solver_write_checkpoint, :4277 */
+            char path[1200];
+            snprintf(path, sizeof path, "%s/checkpoint.out%d", rp->checkpoint_dir, ckpt_number);
+            rc = hqh_checkpoint_write(ctx, path, step, 0, 1, nharb, nharb);
+            if (rc != HQ_OK) break;
+            ckpt_number = (ckpt_number + 1) % 2;
+        }
         if (pfp && step % rp->plane_rate == 0) {                 /* solver_output_planes, :4279 */
             rc = hq_gather(ctx, (int32_t)(npp * 8), rp->plane_ids, pu, NULL);
             if (rc != HQ_OK) break;
@@ -856,6 +866,10 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
         }
         if (pfp) {
             int32_t ns = (step / rp->plane_rate + 1) * rp->plane_rate;
+            if (ns < next) next = ns;
+        }
+        if (do_ckpt) {
+            int32_t ns = (step / rp->checkpoint_rate + 1) * rp->checkpoint_rate;
             if (ns < next) next = ns;
         }
         rc = hq_run(ctx, next - step);

@@ -49,7 +49,8 @@ class _RunParams(ctypes.Structure):
                 ("nplanes", ctypes.c_int32), ("plane_npoints", ctypes.c_void_p),
                 ("plane_ids", ctypes.c_void_p), ("plane_phi", ctypes.c_void_p),
                 ("plane_mine", ctypes.c_void_p), ("plane_rate", ctypes.c_int32),
-                ("plane_dir", ctypes.c_char_p)]
+                ("plane_dir", ctypes.c_char_p), ("checkpoint_rate", ctypes.c_int32),
+                ("checkpoint_dir", ctypes.c_char_p)]
 
 
 class _Plane(ctypes.Structure):
@@ -207,11 +208,13 @@ class Box:
 
     def run_params(self, loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
                    station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
-                   planes=None, plane_rate=0, plane_dir=None):
+                   planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None):
         """planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
         every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
         rp = _RunParams()
         keep = []
+        if checkpoint_rate > 0 and checkpoint_dir is not None:
+            rp.checkpoint_rate, rp.checkpoint_dir = int(checkpoint_rate), os.fsencode(checkpoint_dir)
         if planes and plane_rate > 0 and plane_dir is not None:
             npts = np.array([len(p[0]) for p in planes], np.int32)
             pid = np.ascontiguousarray(np.concatenate([np.asarray(p[0]).reshape(-1, 8) for p in planes]), np.int32)

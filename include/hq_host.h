@@ -122,6 +122,12 @@ typedef struct {
     const int32_t* plane_mine;       /* [sum npoints] or NULL */
     int32_t        plane_rate;       /* output_planes_print_rate; 0 = never */
     const char*    plane_dir;        /* output_planes_directory */
+    /* checkpoints (solver_write_checkpoint psolve.c:3842-3851, checkpoint_write
+     * io_checkpoint.c:29-127): at every step != step0 that is a multiple of checkpoint_rate the
+     * state goes to <checkpoint_dir>/checkpoint.out0 and .out1 in turn; single partition
+     * (partitions call hqh_checkpoint_write themselves, rank 0 first) */
+    int32_t        checkpoint_rate;  /* checkpointing_rate; 0 = never */
+    const char*    checkpoint_dir;   /* checkpoint_path */
 } hqh_run_params;
 
 /* solver_run: steps [step0, step0 + nsteps) on `ctx`. */

@@ -524,3 +524,26 @@ def test_partitions_cut_from_a_mesh_database(tmp_path):
         s.close()
     for b in boxes:
         b.close()
+
+
+def test_checkpoints_at_the_references_cadence(tmp_path):
+    """hqh_solver_run with checkpointing_rate = 400 on examples/simple: checkpoint.out0 (step 400)
+    and checkpoint.out1 (step 800) as the REAL reference wrote them (tests/golden/c1_short)."""
+    from hercules_amd import host
+    g = H.load("c1_short")
+    N = H.c1_problem()["N"]
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    box = host.Box(H.C1_NX, H.C1_NY, H.C1_NZ, H.C1_H, 1e-3, 5.0)
+    s = box.create_solver()
+    rp = box.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=128, checkpoint_rate=400,
+                        checkpoint_dir=str(tmp_path))
+    box.solver_run(s, rp, 0, 1000)
+    s.close()
+    assert list(g["ckpt_steps"]) == [400, 800]
+    for k, name in enumerate(("checkpoint.out0", "checkpoint.out1")):
+        b = (tmp_path / name).read_bytes()
+        assert list(np.frombuffer(b[:12], "<i4")) == [1, int(g["ckpt_steps"][k]), N] and len(b) == 12 + 2 * N * 24
+        tm2 = np.frombuffer(b[12:12 + N * 24], "<f8").reshape(N, 3)
+        tm1 = np.frombuffer(b[12 + N * 24:], "<f8").reshape(N, 3)
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
