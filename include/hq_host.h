@@ -16,10 +16,14 @@
  *                     double-couple point source
  *   hqh_stations      compute_csi_eta_dzeta (psolve.c:6378-6440)
  *   hqh_solver_run    solver_run (psolve.c:4241-4324): source window, step loop,
- *                     station output cadence, on an hq_ctx
+ *                     station / plane / checkpoint cadence, on an hq_ctx
+ *   hqh_octbox_*      layered boxes on several octree levels with hanging nodes, whole
+ *                     or cut into octor's per-rank tables; hqh_layered_column: the Vs rule
+ *   hqh_etree_read, hqh_mesh_from_leaves   the reference's mesh.e -> octor's mesh tables
+ *   hqh_forcefile_*, hqh_checkpoint_*, hqh_plane_*, hqh_station_format   its file formats
  *
- * The octree mesher, etree/CVM database, slip-function source generator and
- * the I/O planes stay in the reference (out of scope).
+ * The octree mesher itself, the CVM query, the slip-function source generator, the IO-PE
+ * pool and the 4D output stay in the reference (out of scope).
  */
 #ifndef HQ_HOST_H
 #define HQ_HOST_H
