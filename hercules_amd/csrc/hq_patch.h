@@ -761,7 +761,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         {
             const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0);
 #pragma unroll
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 2   /* ablation (results wrong): no node loads */
+            for (int d = 0; d < 3; d++) { a1[d] = 1e-3 * (double)(g & 7); a2[d] = 1e-3; }
+#else
             for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
+#endif
         }
         const int p3 = HQ_SLOT_PATCH(slot + 3 * W);
         const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
@@ -769,7 +773,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         HQ_STAMPD(1);
         /* 2. element section of patch k on the current buffer: one element per thread (the
          *    planner keeps patches at <= 1024 elements) */
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 1   /* ablation (results wrong): no element section */
+        const bool has_elem = tid < 0;
+#else
         const bool has_elem = tid < D0.npairs;
+#endif
         int l[8];
         double X[8], Y[8], Z[8];
         if (has_elem) {
@@ -853,7 +861,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
             __syncthreads();
         }
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 3   /* ablation (results wrong): no update, no stores */
+        if (tid < 0) {
+#else
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
+#endif
             const int n = tid;
             double* out = ung + 3 * ((int64_t)D0.base + n);
             if (iso) {
