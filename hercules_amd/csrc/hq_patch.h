@@ -85,6 +85,8 @@ struct hq_patch_desc {
 };
 #define HQ_PATCH_ISO 1
 #define HQ_PATCH_UNIFORM 2   /* every element of the patch has the same (c1, c2, beta): read once */
+#define HQ_PATCH_WFORM 4     /* uniform, and owned nodes <= nlmax / 2: hq_k_patch_pers keeps w = u1 + beta (u1 - u2) */
+                             /* of all local nodes and u1, u2 of the owned ones in LDS instead of u1, u2 of all */
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -733,10 +735,18 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         idn = HQ_PERS_ID((p1 < 0 ? 0 : p1), D1);
         if (tid < D0.nown + D0.nhalo) {
             const int64_t g = tid < D0.nown ? (int64_t)D0.base + tid : (int64_t)id0;
+            const bool wf = (D0.flags & HQ_PATCH_WFORM) != 0;
+            const double b0 = pbeta[D0.pair_off];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                s_mem[3 * tid + d] = u1g[3 * g + d];
-                s_mem[3 * nlmax + 3 * tid + d] = u2g[3 * g + d];
+                const double x1 = u1g[3 * g + d], x2 = u2g[3 * g + d];
+                if (wf) {
+                    s_mem[3 * tid + d] = x1 + b0 * (x1 - x2);
+                    if (tid < D0.nown) { s_mem[3 * nlmax + 3 * tid + d] = x1; s_mem[3 * nlmax + 3 * (nlmax / 2) + 3 * tid + d] = x2; }
+                } else {
+                    s_mem[3 * tid + d] = x1;
+                    s_mem[3 * nlmax + 3 * tid + d] = x2;
+                }
             }
         }
         __syncthreads();
@@ -752,6 +762,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
         double* __restrict__ n_u1 = s_mem + ((k + 1) & 1) * 6 * nlmax;
         double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
+        /* LDS image of a patch: u1 | u2 of all local nodes; or (HQ_PATCH_WFORM) w of all local nodes |
+         * u1 of the owned | u2 of the owned, which halves the gathers of the element section */
+        const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0, wf1 = (D1.flags & HQ_PATCH_WFORM) != 0;
+        const double beta1 = pbeta[D1.pair_off];         /* the uniform beta of patch k+1 (used if wf1) */
 
         /* 1. the request that flies during the element section: the node data of patch k+1 */
         /* (loads are unconditional, from a clamped address where the thread has nothing to load:
@@ -787,14 +801,22 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
             l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
             l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
+            if (wf0) {
 #pragma unroll
-            for (int n = 0; n < 8; n++) {
-                const double* a = &s_u1[3 * l[n]];
-                const double* b = &s_u2[3 * l[n]];
-                double a0 = a[0], a1_ = a[1], a2_ = a[2];
-                X[n] = a0 + beta * (a0 - b[0]);
-                Y[n] = a1_ + beta * (a1_ - b[1]);
-                Z[n] = a2_ + beta * (a2_ - b[2]);
+                for (int n = 0; n < 8; n++) {
+                    const double* a = &s_u1[3 * l[n]];
+                    X[n] = a[0]; Y[n] = a[1]; Z[n] = a[2];
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const double* a = &s_u1[3 * l[n]];
+                    const double* b = &s_u2[3 * l[n]];
+                    double a0 = a[0], a1_ = a[1], a2_ = a[2];
+                    X[n] = a0 + beta * (a0 - b[0]);
+                    Y[n] = a1_ + beta * (a1_ - b[1]);
+                    Z[n] = a2_ + beta * (a2_ - b[2]);
+                }
             }
             hq_element_force(X, Y, Z, c_c1, c_c2);
         }
@@ -845,8 +867,17 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 
         /* 4. patch k+1 into the other buffer (last read an iteration ago) */
         if (have_node) {
+            if (wf1) {
 #pragma unroll
-            for (int d = 0; d < 3; d++) { n_u1[3 * tid + d] = a1[d]; n_u2[3 * tid + d] = a2[d]; }
+                for (int d = 0; d < 3; d++) n_u1[3 * tid + d] = a1[d] + beta1 * (a1[d] - a2[d]);
+                if (tid < D1.nown) {
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { n_u2[3 * tid + d] = a1[d]; n_u2[3 * (nlmax / 2) + 3 * tid + d] = a2[d]; }
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 3; d++) { n_u1[3 * tid + d] = a1[d]; n_u2[3 * tid + d] = a2[d]; }
+            }
         }
         /* the element row and gather id requested above are the youngest loads: the compiler's wait
          * for them sits here, before the update's stores are in the queue */
@@ -868,10 +899,12 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 #endif
             const int n = tid;
             double* out = ung + 3 * ((int64_t)D0.base + n);
+            const double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;                 /* u1, u2 of the owned nodes */
+            const double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
             if (iso) {
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    double f = s_f[3 * n + d] + (n3[1] * s_u1[3 * n + d] - n3[2] * s_u2[3 * n + d]);
+                    double f = s_f[3 * n + d] + (n3[1] * o_u1[3 * n + d] - n3[2] * o_u2[3 * n + d]);
                     s_f[3 * n + d] = 0.0;
                     out[d] = f / n3[0];
                 }
@@ -882,7 +915,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 for (int i = 0; i < 7; i++) np[i] = q[i];
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
-                    double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
+                    double f = s_f[3 * n + d] + (np[1 + d] * o_u1[3 * n + d] - np[4 + d] * o_u2[3 * n + d]);
                     s_f[3 * n + d] = 0.0;
                     out[d] = f / np[0];
                 }
@@ -946,6 +979,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         D.flags = iso ? HQ_PATCH_ISO : 0;
     }
     int32_t nuniform = 0;
+    const bool wform = !(getenv("HQ_PATCH_WFORM") && atoi(getenv("HQ_PATCH_WFORM")) == 0);
     if (!getenv("HQ_PATCH_NO_UNIFORM")) {
         for (auto& D : H.desc) {
             bool uni = D.npairs > 0;
@@ -954,7 +988,11 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                 const int32_t e = H.pelem[(size_t)q];
                 uni = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
             }
-            if (uni) { D.flags |= HQ_PATCH_UNIFORM; nuniform++; }
+            if (uni) {
+                D.flags |= HQ_PATCH_UNIFORM;
+                nuniform++;
+                if (wform && 2 * D.nown <= P->cfg.nlmax) D.flags |= HQ_PATCH_WFORM;
+            }
         }
     }
     P->ndistinct = H.ndistinct;
