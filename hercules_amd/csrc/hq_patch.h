@@ -767,6 +767,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0, wf1 = (D1.flags & HQ_PATCH_WFORM) != 0;
         const double beta1 = pbeta[D1.pair_off];         /* the uniform beta of patch k+1 (used if wf1) */
 
+        HQ_STAMPD(7);
         /* 1. the request that flies during the element section: the node data of patch k+1 */
         /* (loads are unconditional, from a clamped address where the thread has nothing to load:
          * straight-line code lets the compiler count vmcnt exactly instead of waiting for all) */
@@ -832,6 +833,9 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             n3[0] = q[0]; n3[1] = q[1]; n3[2] = q[2];
         }
         HQ_PERS_ROW(D1)
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4   /* probe: two more (useless, L2-resident) 8-byte loads per thread */
+        double xtra0 = pbeta[D1.pair_off + (tid & 255)], xtra1 = pc1[D1.pair_off + (tid & 255)];
+#endif
         int32_t idnn;
         {
             const int h = tid - D2.nown;
@@ -882,6 +886,9 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* the element row and gather id requested above are the youngest loads: the compiler's wait
          * for them sits here, before the update's stores are in the queue */
         asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idnn));
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4
+        asm volatile("" :: "v"(xtra0), "v"(xtra1));
+#endif
         HQ_STAMPD(4);
         /* 5. interface partial forces (psolve.c:4301), then update + re-zero the accumulators */
         if (if_ptr && if_ptr[p0 + 1] > if_ptr[p0]) {
@@ -1134,6 +1141,15 @@ static void hq_patch_report_stamps(void)
         if (!s[6] || !s[0]) continue;
         for (int k = 0; k < 6; k++) sum[k] += (double)(s[k + 1] - s[k]);
         cnt++;
+    }
+    if (pipe_ == 4) {
+        double pre = 0; long c7 = 0;
+        for (int32_t p = 0; p < g_hq_stamp_n; p++) {
+            const unsigned long long* s = &h[8 * (size_t)p];
+            if (!s[6] || !s[0] || !s[7]) continue;
+            pre += (double)(s[7] - s[0]); c7++;
+        }
+        fprintf(stderr, "  (of the first phase, before the node loads are issued: %.0f)\n", pre / (c7 ? c7 : 1));
     }
     fprintf(stderr, "hq patch stamps (mean shader cycles per workgroup over %ld patches, last step):\n", cnt);
     double tot = 0;

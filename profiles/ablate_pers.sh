@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: ablations of hq_k_patch_pers on the 64M box (ephemeral rebuilds with -DHQ_PERS_DIAG=n;
-# results are WRONG by construction): 1 = no element section, 2 = no node loads, 3 = no update/stores.
-for d in 0 1 2 3; do
+# results are WRONG by construction): 1 = no element section, 2 = no node loads, 3 = no update/stores;
+# 4 = probe (results right): two more 8-byte loads per thread per patch (is the load path the limit?).
+for d in ${DIAGS:-0 1 2 3}; do
   HQ_EXTRA_FLAGS=-DHQ_PERS_DIAG=$d python -c "from hercules_amd import build; build.build_solver(force=True)" > /dev/null
   echo "== HQ_PERS_DIAG=$d"
   python bench.py --workload ${WL:-c3} --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('  ms %.3f  kernel_ms %.3f'%(d['ms_per_step'],d['roofline']['kernel_ms']))"
