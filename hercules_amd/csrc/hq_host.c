@@ -773,7 +773,13 @@ void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_
  */
 int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int32_t step0, int32_t nsteps)
 {
-    if (!ctx || !b || !rp || nsteps < 0) return HQ_ERR_ARG;
+    if (!b) return HQ_ERR_ARG;
+    return hqh_solver_run_on(ctx, b->p.deltaT, b->nharbored, rp, step0, nsteps);
+}
+
+int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_params* rp, int32_t step0, int32_t nsteps)
+{
+    if (!ctx || !rp || nsteps < 0 || deltaT <= 0 || nharb < 0) return HQ_ERR_ARG;
     int32_t win = rp->source_window > 0 ? rp->source_window : 256;
     double* F = NULL;
     double *u = NULL, *disp = NULL;
@@ -806,7 +812,6 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
     }
     int32_t step = step0, end = step0 + nsteps, win_end = step0;
     int ckpt_number = 0;                                         /* CheckpointNumber, io_checkpoint.c:38,126 */
-    const int32_t nharb = b->nharbored;
     const int do_ckpt = rp->checkpoint_rate > 0 && rp->checkpoint_dir != NULL;
     while (step < end && rc == HQ_OK) {
         if (do_ckpt && step != step0 && step % rp->checkpoint_rate == 0) {   /* solver_write_checkpoint, :4277 */
@@ -852,7 +857,7 @@ int hqh_solver_run(hq_ctx* ctx, const hqh_box* b, const hqh_run_params* rp, int3
                 rc = hqh_forcefile_read(rp->force_file, step, n, F);
                 if (rc != HQ_OK) break;
             } else {
-                hqh_source_table(rp, b->p.deltaT, step, n, F);
+                hqh_source_table(rp, deltaT, step, n, F);
             }
             rc = hq_set_source(ctx, rp->nloaded, rp->loaded_lnid, step, n, F);
             if (rc != HQ_OK) break;
@@ -1722,6 +1727,12 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
     int rc = hqh_octbox_create_levels(&q, out);
     free(m);
     return rc;
+}
+
+int hqh_octbox_solver_run(hq_ctx* ctx, const hqh_octbox* b, const hqh_run_params* rp, int32_t step0, int32_t nsteps)
+{
+    if (!b) return HQ_ERR_ARG;
+    return hqh_solver_run_on(ctx, b->p.deltaT, (int32_t)b->N, rp, step0, nsteps);
 }
 
 int hqh_octbox_desc(const hqh_octbox* b, hq_desc* d)

@@ -108,6 +108,54 @@ def _view(ptr, shape, dtype):
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+def run_params(loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
+               station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
+               planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None):
+    """planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
+    every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
+    rp = _RunParams()
+    keep = []
+    if checkpoint_rate > 0 and checkpoint_dir is not None:
+        rp.checkpoint_rate, rp.checkpoint_dir = int(checkpoint_rate), os.fsencode(checkpoint_dir)
+    if planes and plane_rate > 0 and plane_dir is not None:
+        npts = np.array([len(p[0]) for p in planes], np.int32)
+        pid = np.ascontiguousarray(np.concatenate([np.asarray(p[0]).reshape(-1, 8) for p in planes]), np.int32)
+        pph = np.ascontiguousarray(np.concatenate([np.asarray(p[1]).reshape(-1, 8) for p in planes]), np.float64)
+        keep += [npts, pid, pph]
+        rp.nplanes, rp.plane_npoints, rp.plane_ids, rp.plane_phi = len(planes), npts.ctypes.data, pid.ctypes.data, pph.ctypes.data
+        if any(len(p) > 2 for p in planes):
+            pm = np.ascontiguousarray(np.concatenate([np.asarray(p[2]) if len(p) > 2 else np.ones(len(p[0]))
+                                                      for p in planes]), np.int32)
+            keep.append(pm)
+            rp.plane_mine = pm.ctypes.data
+        rp.plane_rate, rp.plane_dir = int(plane_rate), os.fsencode(plane_dir)
+    if force_file is not None:
+        rp.force_file = os.fsencode(force_file)
+        l = np.ascontiguousarray(loaded, np.int32)
+        keep.append(l)
+        rp.nloaded, rp.loaded_lnid = len(l), l.ctypes.data
+    elif loaded is not None and len(loaded):
+        l = np.ascontiguousarray(loaded, np.int32)
+        pt = np.ascontiguousarray(pattern, np.float64)
+        keep += [l, pt]
+        rp.nloaded, rp.loaded_lnid, rp.pattern = len(l), l.ctypes.data, pt.ctypes.data
+    rp.moment, rp.rise_time, rp.source_window = moment, rise_time, source_window
+    if station_ids is not None and len(station_ids) and station_fn is not None:
+        si = np.ascontiguousarray(station_ids, np.int32)
+        sp = np.ascontiguousarray(station_phi, np.float64)
+        n = len(si)
+
+        def _cb(user, step, ns, disp):
+            station_fn(step, np.ctypeslib.as_array(disp, (ns, 3)).copy())
+        cb = STATION_FN(_cb)
+        keep += [si, sp, cb]
+        rp.nstations, rp.station_ids, rp.station_phi = n, si.ctypes.data, sp.ctypes.data
+        rp.station_rate, rp.station_fn = station_rate, cb
+    rp._keep = keep
+    return rp
+
+
+
 class Box:
     """One partition of a uniform layered box (hqh_box)."""
 
@@ -206,51 +254,9 @@ class Box:
             raise capi.HqError("hqh_stations failed: %d" % rc)
         return ids, phi, mine
 
-    def run_params(self, loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
-                   station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
-                   planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None):
-        """planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
-        every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
-        rp = _RunParams()
-        keep = []
-        if checkpoint_rate > 0 and checkpoint_dir is not None:
-            rp.checkpoint_rate, rp.checkpoint_dir = int(checkpoint_rate), os.fsencode(checkpoint_dir)
-        if planes and plane_rate > 0 and plane_dir is not None:
-            npts = np.array([len(p[0]) for p in planes], np.int32)
-            pid = np.ascontiguousarray(np.concatenate([np.asarray(p[0]).reshape(-1, 8) for p in planes]), np.int32)
-            pph = np.ascontiguousarray(np.concatenate([np.asarray(p[1]).reshape(-1, 8) for p in planes]), np.float64)
-            keep += [npts, pid, pph]
-            rp.nplanes, rp.plane_npoints, rp.plane_ids, rp.plane_phi = len(planes), npts.ctypes.data, pid.ctypes.data, pph.ctypes.data
-            if any(len(p) > 2 for p in planes):
-                pm = np.ascontiguousarray(np.concatenate([np.asarray(p[2]) if len(p) > 2 else np.ones(len(p[0]))
-                                                          for p in planes]), np.int32)
-                keep.append(pm)
-                rp.plane_mine = pm.ctypes.data
-            rp.plane_rate, rp.plane_dir = int(plane_rate), os.fsencode(plane_dir)
-        if force_file is not None:
-            rp.force_file = os.fsencode(force_file)
-            l = np.ascontiguousarray(loaded, np.int32)
-            keep.append(l)
-            rp.nloaded, rp.loaded_lnid = len(l), l.ctypes.data
-        elif loaded is not None and len(loaded):
-            l = np.ascontiguousarray(loaded, np.int32)
-            pt = np.ascontiguousarray(pattern, np.float64)
-            keep += [l, pt]
-            rp.nloaded, rp.loaded_lnid, rp.pattern = len(l), l.ctypes.data, pt.ctypes.data
-        rp.moment, rp.rise_time, rp.source_window = moment, rise_time, source_window
-        if station_ids is not None and len(station_ids) and station_fn is not None:
-            si = np.ascontiguousarray(station_ids, np.int32)
-            sp = np.ascontiguousarray(station_phi, np.float64)
-            n = len(si)
-
-            def _cb(user, step, ns, disp):
-                station_fn(step, np.ctypeslib.as_array(disp, (ns, 3)).copy())
-            cb = STATION_FN(_cb)
-            keep += [si, sp, cb]
-            rp.nstations, rp.station_ids, rp.station_phi = n, si.ctypes.data, sp.ctypes.data
-            rp.station_rate, rp.station_fn = station_rate, cb
-        rp._keep = keep
-        return rp
+    def run_params(self, *args, **kw):
+        """See host.run_params."""
+        return run_params(*args, **kw)
 
     def source_table(self, rp, step0, nsteps):
         F = np.zeros((nsteps, rp.nloaded, 3))
@@ -407,6 +413,14 @@ class OctBox:
         self.dt = dt
         self._load_views()
         return self
+
+    def run_params(self, *args, **kw):
+        """See host.run_params."""
+        return run_params(*args, **kw)
+
+    def solver_run(self, solver, rp, step0, nsteps):
+        capi._check(self._lib.hqh_octbox_solver_run(solver._h, self._h, ctypes.byref(rp), ctypes.c_int32(step0),
+                                                    ctypes.c_int32(nsteps)))
 
     def schedules(self):
         """{"an": {"c": [(procid, mapping)], "s": [...]}, "dn": {...}} (copies)."""

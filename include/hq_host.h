@@ -134,9 +134,12 @@ typedef struct {
     const char*    checkpoint_dir;   /* checkpoint_path */
 } hqh_run_params;
 
-/* solver_run: steps [step0, step0 + nsteps) on `ctx`. */
+/* solver_run: steps [step0, step0 + nsteps) on `ctx` (a context made from `box`; or, _on, from
+ * any mesh of `nharbored` nodes and time step deltaT). */
 HQ_API int hqh_solver_run(hq_ctx* ctx, const hqh_box* box, const hqh_run_params* rp,
                           int32_t step0, int32_t nsteps);
+HQ_API int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharbored, const hqh_run_params* rp,
+                             int32_t step0, int32_t nsteps);
 
 /*
  * Files in the reference's formats, so runs can be exchanged with psolve.
@@ -270,6 +273,8 @@ HQ_API int hqh_layered_column(const hqh_layered_model* m, double h0, int32_t nco
                               int32_t cap, double* edge, float* vp, float* vs, float* rho, int32_t* nleaves);
 HQ_API void hqh_octbox_destroy(hqh_octbox* box);
 HQ_API int  hqh_octbox_desc(const hqh_octbox* box, hq_desc* desc);
+HQ_API int  hqh_octbox_solver_run(hq_ctx* ctx, const hqh_octbox* box, const hqh_run_params* rp,
+                                  int32_t step0, int32_t nsteps);
 /* views: which = 0 lnid [E][8], 1 node_xyz [N][3] (fine-edge units), 2 dn_ldnid, 3 dn_ptr,
  * 4 dn_lanid (int32); 5 eTable [E][4], 6 nTable [N][7] (double); 7 owner [N], 8 global node
  * id [N] (int32; partitions only).  *count = entries. */

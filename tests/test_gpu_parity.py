@@ -479,11 +479,13 @@ def test_from_the_references_mesh_database_to_its_checkpoints(tmp_path):
     _, edata = host.mesh_payload(vals)
     edge = np.uint32(1) << (30 - level).astype(np.uint32)
     ob = host.OctBox.from_leaves(ticks, edge, edata, H.C1_FAR_TICKS, float(g["dt"]), float(g["freq"]))
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
     s = ob.create_solver()
-    s.set_source(g["loaded_lnid"], g["forces"])
+    rp = ob.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=32)
     done = 0
     for k, step in enumerate(g["ckpt_steps"]):
-        s.run(int(step) - done)
+        ob.solver_run(s, rp, done, int(step) - done)        # hqh_octbox_solver_run: the force file in windows
         done = int(step)
         tm1, tm2 = s.download()
         assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
