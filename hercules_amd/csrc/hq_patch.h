@@ -749,6 +749,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 }
             }
         }
+        /* nothing loaded here may still be pending when the loop is entered: the compiler merges
+         * this path with the loop's back-edge and would wait vmcnt(0) (i.e. for the previous
+         * patch's stores) at the top of every iteration */
+        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idn));
         __syncthreads();
     }
 
@@ -823,14 +827,22 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         }
         HQ_STAMPD(2);
         /* 3. the element row is consumed: request what flies during the atomics, the barrier and
-         *    the LDS write below: n_t of this patch's node (3-double form; patches with dashpot
-         *    nodes read the 7-double row at the update), element row of patch k+1, halo id of
-         *    patch k+2 */
+         *    the LDS write below: n_t of this patch's node (3-double form, or the 7-double row where
+         *    a dashpot makes the axes differ), element row of patch k+1, halo id of patch k+2 */
         const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
-        double n3[3];
+        double np[7];
         {
-            const double* q = nt3 + 3 * ((int64_t)D0.base + (tid < D0.nown ? tid : 0));
-            n3[0] = q[0]; n3[1] = q[1]; n3[2] = q[2];
+            const int64_t nn = (int64_t)D0.base + (tid < D0.nown ? tid : 0);
+            if (iso) {
+                const double* q = nt3 + 3 * nn;
+                np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
+                np[2] = np[3] = np[1];
+                np[5] = np[6] = np[4];
+            } else {
+                const double* q = nt + 7 * nn;
+#pragma unroll
+                for (int i = 0; i < 7; i++) np[i] = q[i];
+            }
         }
         HQ_PERS_ROW(D1)
 #if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4   /* probe: two more (useless, L2-resident) 8-byte loads per thread */
@@ -908,24 +920,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             double* out = ung + 3 * ((int64_t)D0.base + n);
             const double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;                 /* u1, u2 of the owned nodes */
             const double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
-            if (iso) {
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double f = s_f[3 * n + d] + (n3[1] * o_u1[3 * n + d] - n3[2] * o_u2[3 * n + d]);
-                    s_f[3 * n + d] = 0.0;
-                    out[d] = f / n3[0];
-                }
-            } else {
-                const double* q = nt + 7 * ((int64_t)D0.base + n);
-                double np[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++) np[i] = q[i];
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double f = s_f[3 * n + d] + (np[1 + d] * o_u1[3 * n + d] - np[4 + d] * o_u2[3 * n + d]);
-                    s_f[3 * n + d] = 0.0;
-                    out[d] = f / np[0];
-                }
+            for (int d = 0; d < 3; d++) {
+                double f = s_f[3 * n + d] + (np[1 + d] * o_u1[3 * n + d] - np[4 + d] * o_u2[3 * n + d]);
+                s_f[3 * n + d] = 0.0;
+                out[d] = f / np[0];
             }
         }
         for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;
