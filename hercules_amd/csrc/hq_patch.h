@@ -834,10 +834,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         {
             const int64_t nn = (int64_t)D0.base + (tid < D0.nown ? tid : 0);
             if (iso) {
-                const double* q = nt3 + 3 * nn;
-                np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
-                np[2] = np[3] = np[1];
-                np[5] = np[6] = np[4];
+                const double* q = nt3 + 3 * nn;           /* (no copies of loaded values here: they would */
+                np[0] = q[0]; np[1] = q[1]; np[4] = q[2];  /*  wait for the load; the axes pick at the update) */
             } else {
                 const double* q = nt + 7 * nn;
 #pragma unroll
@@ -922,7 +920,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             const double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                double f = s_f[3 * n + d] + (np[1 + d] * o_u1[3 * n + d] - np[4 + d] * o_u2[3 * n + d]);
+                const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
+                double f = s_f[3 * n + d] + (m2 * o_u1[3 * n + d] - m1 * o_u2[3 * n + d]);
                 s_f[3 * n + d] = 0.0;
                 out[d] = f / np[0];
             }
