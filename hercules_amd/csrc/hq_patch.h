@@ -573,11 +573,9 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     if (tid < D.nown) {
         if (iso) {
             const double* q = nt3 + 3 * ((int64_t)D.base + tid);
-            np[0] = hq_ld<NT>(q);
-            np[1] = hq_ld<NT>(q + 1);
+            np[0] = hq_ld<NT>(q);                /* (no copies of loaded values here: a copy waits */
+            np[1] = hq_ld<NT>(q + 1);            /*  for the load; the axes pick at the update)    */
             np[4] = hq_ld<NT>(q + 2);
-            np[2] = np[3] = np[1];
-            np[5] = np[6] = np[4];
         } else {
             const double* q = nt + 7 * ((int64_t)D.base + tid);
 #pragma unroll
@@ -642,8 +640,6 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
             if (iso) {
                 const double* q = nt3 + 3 * ((int64_t)D.base + n);
                 np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
-                np[2] = np[3] = np[1];
-                np[5] = np[6] = np[4];
             } else {
                 const double* q = nt + 7 * ((int64_t)D.base + n);
 #pragma unroll
@@ -653,7 +649,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         double* out = ung + 3 * ((int64_t)D.base + n);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            double f = s_f[3 * n + d] + (np[1 + d] * s_u1[3 * n + d] - np[4 + d] * s_u2[3 * n + d]);
+            const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
+            double f = s_f[3 * n + d] + (m2 * s_u1[3 * n + d] - m1 * s_u2[3 * n + d]);
             if (NT) __builtin_nontemporal_store(f / np[0], out + d);
             else out[d] = f / np[0];
         }
