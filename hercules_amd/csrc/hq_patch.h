@@ -128,6 +128,7 @@ struct hq_patch_plan {
     int32_t* d_if_ptr = nullptr;     /* [npatches + 1]                    */
     int32_t* d_if_ent = nullptr;     /* [n][2] = {local node, slot}       */
     int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
+    int32_t* d_tickets = nullptr;    /* [16]: per XCD, next slot of hq_k_patch_pers' work queue; workgroups done */
     int32_t  nb = 0;
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
     int32_t* d_ds_ent = nullptr;
@@ -449,13 +450,16 @@ struct hq_pair_data {
  * g_hq_stamps[patch][8]; hq_patch_report_stamps() prints the mean cycles per phase.  Never in
  * the shipped build. */
 __device__ unsigned long long* g_hq_stamps = nullptr;
+__device__ unsigned long long* g_hq_wg = nullptr;      /* [grid][2]: shader clock at workgroup start / exit */
+#define HQ_WG_STAMP(k) do { if (threadIdx.x == 0 && g_hq_wg) g_hq_wg[2 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 static void hq_patch_report_stamps(void);
 static int hq_patch_kernel_choice(void);
 #define HQ_STAMP(k) do { if (DIAG == 6 && threadIdx.x == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define HQ_STAMPD(k) do { if (tid0 == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p0 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HQ_STAMPD(k) do { if (tid0 == 0 && p0 >= 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p0 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HQ_STAMP(k) do { } while (0)
 #define HQ_STAMPD(k) do { } while (0)
+#define HQ_WG_STAMP(k) do { } while (0)
 #endif
 
 typedef unsigned int hq_u32x4 __attribute__((ext_vector_type(4)));
@@ -696,21 +700,44 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
                 const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
                 const int32_t* __restrict__ if_ent, double* __restrict__ iforce,
-                const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride)
+                const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride,
+                int32_t* __restrict__ tickets)
 {
     extern __shared__ __align__(16) double s_mem[];
     double* __restrict__ s_f = s_mem + 12 * nlmax;      /* after the two node buffers */
+    int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_f + nfacc);   /* ring of 4 slots drawn ahead */
     const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
     const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
     const int end = min((xcd + 1) * per_xcd, count);
-    int slot = xcd * per_xcd + (int)(blockIdx.x >> 3);
-    if (slot >= end) return;
+    /* The workgroups of an XCD draw the slots of its run of patches from a counter (tickets[xcd]),
+     * four patches ahead of use (descriptors, gather ids and element rows are requested that far
+     * ahead): patches differ in cost (dashpot faces, far faces, hanging nodes), and with a fixed
+     * slot, slot + W, ... assignment the mean workgroup idled 3 % (64M box) to 9 % (8M box) of the
+     * launch at the end.  The last workgroup out resets the counter for the next launch. */
+    HQ_WG_STAMP(0);
 #define HQ_SLOT_PATCH(s) ((s) < end ? (order ? order[(s)] : (s)) : -1)
+#define HQ_DRAW() (xcd * per_xcd + atomicAdd(&tickets[xcd], 1))
     /* halo id of this thread's local node of patch (P_, DD) (0 where that node is owned or absent) */
 #define HQ_PERS_ID(P_, DD) \
     ((tid >= (DD).nown && tid < (DD).nown + (DD).nhalo) ? halo[(int64_t)(P_) * hstride + (tid - (DD).nown)] : 0)
 
-    int p0 = HQ_SLOT_PATCH(slot), p1 = HQ_SLOT_PATCH(slot + W), p2 = HQ_SLOT_PATCH(slot + 2 * W);
+    if (tid0 == 0) { for (int i = 0; i < 4; i++) s_tick[i] = HQ_DRAW(); }
+    __syncthreads();
+    const int sl0 = __builtin_amdgcn_readfirstlane(s_tick[0]), sl1 = __builtin_amdgcn_readfirstlane(s_tick[1]),
+              sl2 = __builtin_amdgcn_readfirstlane(s_tick[2]);
+    int p0 = HQ_SLOT_PATCH(sl0), p1 = HQ_SLOT_PATCH(sl1), p2 = HQ_SLOT_PATCH(sl2);
+#define HQ_PERS_EXIT()                                                                          \
+    {                                                                                           \
+        if (tid0 == 0 && atomicAdd(&tickets[8 + xcd], 1) == W - 1) {   /* last workgroup of the XCD out */ \
+            tickets[xcd] = 0;                                                                   \
+            tickets[8 + xcd] = 0;                                                               \
+        }                                                                                       \
+        HQ_WG_STAMP(1);                                                                         \
+    }
+    if (p0 < 0) {                                       /* the run was drawn empty before this workgroup got to it */
+        HQ_PERS_EXIT()
+        return;
+    }
     hq_patch_desc D0 = hq_patch_desc_or_empty(desc, p0);
     hq_patch_desc D1 = hq_patch_desc_or_empty(desc, p1);
     hq_patch_desc D2 = hq_patch_desc_or_empty(desc, p2);
@@ -783,8 +810,13 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
 #endif
         }
-        const int p3 = HQ_SLOT_PATCH(slot + 3 * W);
+        const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 3]);   /* drawn an iteration ago */
+        const int p3 = HQ_SLOT_PATCH(slot3);
         const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
+        /* the slot of patch k+4, into the ring before the barrier (drawing it from the last, element-less
+         * wave instead measured 1 % slower) */
+        int32_t drawn = 0;
+        if (tid == 0) drawn = HQ_DRAW();
 
         HQ_STAMPD(1);
         /* 2. element section of patch k on the current buffer: one element per thread (the
@@ -892,7 +924,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         }
         /* the element row and gather id requested above are the youngest loads: the compiler's wait
          * for them sits here, before the update's stores are in the queue */
-        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idnn));
+        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idnn), "+v"(drawn));
+        if (tid == 0) s_tick[k & 3] = drawn;             /* slot (k+4) & 3: its old content was read at iteration k-3 */
 #if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4
         asm volatile("" :: "v"(xtra0), "v"(xtra1));
 #endif
@@ -928,12 +961,14 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         __syncthreads();
         HQ_STAMPD(6);
         if (p1 < 0) break;
-        slot += W;
         p0 = p1; p1 = p2; p2 = p3;
         D0 = D1; D1 = D2; D2 = D3;
         idn = idnn;
     }
+    HQ_PERS_EXIT()
+#undef HQ_PERS_EXIT
 #undef HQ_SLOT_PATCH
+#undef HQ_DRAW
 #undef HQ_PERS_ID
 #undef HQ_PERS_ROW
 }
@@ -949,7 +984,7 @@ static void hq_patch_free(hq_patch_plan* P)
     if (P->npatches) hq_patch_report_stamps();
 #endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
@@ -1018,6 +1053,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     HQ_PA(P->d_pbeta, 8 * np)
     HQ_PA(P->d_halo, 4 * nh)
     HQ_PA(P->d_nt3, 8 * nt3.size())
+    HQ_PA(P->d_tickets, 4 * 16)
+    hipMemset(P->d_tickets, 0, 4 * 16);
     if (dn.n > 0) {
         HQ_PA(P->d_ds_ptr, 4 * H.ds_ptr.size())
         HQ_PA(P->d_ds_ent, 4 * (H.ds_ent.size() ? H.ds_ent.size() : 1))
@@ -1118,6 +1155,7 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
 
 #ifdef HQ_PATCH_PROFILING
 static unsigned long long* g_hq_stamp_buf = nullptr;
+static unsigned long long* g_hq_wg_buf = nullptr;
 static int32_t g_hq_stamp_n = 0;
 static void hq_patch_report_stamps(void)
 {
@@ -1136,6 +1174,17 @@ static void hq_patch_report_stamps(void)
         if (!s[6] || !s[0]) continue;
         for (int k = 0; k < 6; k++) sum[k] += (double)(s[k + 1] - s[k]);
         cnt++;
+    }
+    if (pipe_ == 4 && g_hq_wg_buf) {
+        unsigned long long w[512];
+        hipMemcpy(w, g_hq_wg_buf, sizeof w, hipMemcpyDeviceToHost);
+        /* s_memrealtime: the 100 MHz reference clock, common to the chip */
+        unsigned long long t0 = ~0ull, t1 = 0; double me = 0; int c = 0;
+        for (int i = 0; i < 256; i++) if (w[2 * i] && w[2 * i + 1]) { if (w[2 * i] < t0) t0 = w[2 * i]; if (w[2 * i + 1] > t1) t1 = w[2 * i + 1]; c++; }
+        for (int i = 0; i < 256; i++) if (w[2 * i] && w[2 * i + 1]) me += (double)(w[2 * i + 1] - t0);
+        if (c) fprintf(stderr, "  workgroups of the last launch: %d; first start -> last exit %.1f us, mean exit at %.1f us "
+                       "(the mean workgroup idles %.1f %% at the end)\n", c, (double)(t1 - t0) / 100.0, me / c / 100.0,
+                       100.0 * ((double)(t1 - t0) - me / c) / (double)(t1 - t0));
     }
     if (pipe_ == 4) {
         double pre = 0; long c7 = 0;
@@ -1188,13 +1237,16 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
             hipMemset(d_st, 0, 64 * (size_t)P->npatches);
             hipMemcpyToSymbol(HIP_SYMBOL(g_hq_stamps), &d_st, sizeof d_st);
             g_hq_stamp_buf = d_st; g_hq_stamp_n = P->npatches;
+            hipMalloc((void**)&g_hq_wg_buf, 16 * 256);
+            hipMemset(g_hq_wg_buf, 0, 16 * 256);
+            hipMemcpyToSymbol(HIP_SYMBOL(g_hq_wg), &g_hq_wg_buf, sizeof g_hq_wg_buf);
         }
     }
 #endif
     /* (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
     if (hq_patch_uses_pers(P)) {
         const int32_t nfacc = 3 * (P->cfg.pmax + P->cfg.vmax);
-        size_t lds4 = (12 * (size_t)P->cfg.nlmax + (size_t)nfacc) * sizeof(double);
+        size_t lds4 = (12 * (size_t)P->cfg.nlmax + (size_t)nfacc + 2) * sizeof(double);
         {
             int grid = 256;
             while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
@@ -1202,7 +1254,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
                 count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, nfacc, P->d_desc, P->d_pidx,
                 P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
                 (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
-                P->hstride);
+                P->hstride, P->d_tickets);
             return;
         }
     }

@@ -5,5 +5,5 @@
 HQ_EXTRA_FLAGS=-DHQ_PATCH_PROFILING python -c "from hercules_amd import build; build.build_solver(force=True)"
 for pipe in ${@:-0}; do
   echo "== HQ_PATCH_PIPE=$pipe"
-  HQ_PATCH_PIPE=$pipe HQ_PATCH_DIAG=6 python bench.py --workload ${WL:-c3} --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep -B1 -A10 "hq patch stamps"
+  HQ_PATCH_PIPE=$pipe HQ_PATCH_DIAG=6 python bench.py --workload ${WL:-c3} --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep -B2 -A10 "hq patch stamps"
 done
