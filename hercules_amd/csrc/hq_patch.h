@@ -86,6 +86,7 @@ struct hq_patch_desc {
 #define HQ_PATCH_ISO 1
 #define HQ_PATCH_UNIFORM 2   /* every element of the patch has the same (c1, c2, beta): read once */
 #define HQ_PATCH_WFORM 4     /* uniform, and owned nodes <= nlmax / 2: hq_k_patch_pers keeps w = u1 + beta (u1 - u2) */
+#define HQ_PATCH_NTSAME 8    /* ISO, and every owned node has the same n_t row: all lanes read the first one */
                              /* of all local nodes and u1, u2 of the owned ones in LDS instead of u1, u2 of all */
 
 struct hq_patch_host {
@@ -688,6 +689,17 @@ __device__ __forceinline__ hq_patch_desc hq_patch_desc_or_empty(const hq_patch_d
  * throughout: the compiler's own vmcnt waits are the right ones (issue order = order of use).
  */
 #define HQ_PERS_THREADS 1024
+typedef __attribute__((address_space(3))) double hq_lds_double;
+#define HQ_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+/* &base[3*i] for a row index i < 2^24.  gfx9 has no 32-bit mad, so the compiler takes
+ * v_mad_u64_u32 with a don't-care upper addend register -- and when that register happens to be
+ * the target of a load in flight, the address waits for the load (vmcnt(0) in front of a
+ * ds_add_f64 group).  The 24-bit mad has no such operand. */
+static __device__ __forceinline__ hq_lds_double* hq_lds_row3(hq_lds_double* base, int i) {
+    unsigned b = (unsigned)(__SIZE_TYPE__)base, o;
+    asm("v_mad_u32_u24 %0, %1, 24, %2" : "=v"(o) : "v"(i), "v"(b));
+    return (hq_lds_double*)(__SIZE_TYPE__)o;
+}
 
 __global__ void __launch_bounds__(HQ_PERS_THREADS)
 hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
@@ -704,8 +716,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 int32_t* __restrict__ tickets)
 {
     extern __shared__ __align__(16) double s_mem[];
-    double* __restrict__ s_f = s_mem + 12 * nlmax;      /* after the two node buffers */
-    int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_f + nfacc);   /* ring of 4 slots drawn ahead */
+    double* __restrict__ s_fg = s_mem + 12 * nlmax;     /* after the two node buffers */
+    int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_fg + nfacc);   /* ring of 4 slots drawn ahead */
     const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
     const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
     const int end = min((xcd + 1) * per_xcd, count);
@@ -753,7 +765,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
     }
     {   /* prologue: patch 0 into buffer 0 */
         const int tid = tid0;
-        for (int i = tid; i < nfacc; i += T) s_f[i] = 0.0;
+        for (int i = tid; i < nfacc; i += T) s_fg[i] = 0.0;
         HQ_PERS_ROW(D0)
         const int32_t id0 = HQ_PERS_ID(p0, D0);
         idn = HQ_PERS_ID((p1 < 0 ? 0 : p1), D1);
@@ -786,10 +798,14 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         HQ_STAMPD(0);
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        double* __restrict__ s_u1 = s_mem + (k & 1) * 6 * nlmax;
-        double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
-        double* __restrict__ n_u1 = s_mem + ((k + 1) & 1) * 6 * nlmax;
-        double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
+        /* LDS pointers carry their address space: 32-bit address arithmetic (through generic pointers
+         * hipcc builds LDS addresses with 64-bit multiply-adds whose unused high half can alias a
+         * register with a load pending -- a wait in front of every LDS atomic) */
+        hq_lds_double* __restrict__ s_u1 = (hq_lds_double*)s_mem + (k & 1) * 6 * nlmax;
+        hq_lds_double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
+        hq_lds_double* __restrict__ n_u1 = (hq_lds_double*)s_mem + ((k + 1) & 1) * 6 * nlmax;
+        hq_lds_double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
+        hq_lds_double* __restrict__ s_f = (hq_lds_double*)s_fg;
         /* LDS image of a patch: u1 | u2 of all local nodes; or (HQ_PATCH_WFORM) w of all local nodes |
          * u1 of the owned | u2 of the owned, which halves the gathers of the element section */
         const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0, wf1 = (D1.flags & HQ_PATCH_WFORM) != 0;
@@ -838,14 +854,14 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             if (wf0) {
 #pragma unroll
                 for (int n = 0; n < 8; n++) {
-                    const double* a = &s_u1[3 * l[n]];
+                    const hq_lds_double* a = &s_u1[3 * l[n]];
                     X[n] = a[0]; Y[n] = a[1]; Z[n] = a[2];
                 }
             } else {
 #pragma unroll
                 for (int n = 0; n < 8; n++) {
-                    const double* a = &s_u1[3 * l[n]];
-                    const double* b = &s_u2[3 * l[n]];
+                    const hq_lds_double* a = &s_u1[3 * l[n]];
+                    const hq_lds_double* b = &s_u2[3 * l[n]];
                     double a0 = a[0], a1_ = a[1], a2_ = a[2];
                     X[n] = a0 + beta * (a0 - b[0]);
                     Y[n] = a1_ + beta * (a1_ - b[1]);
@@ -861,7 +877,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
         double np[7];
         {
-            const int64_t nn = (int64_t)D0.base + (tid < D0.nown ? tid : 0);
+            const int64_t nn = (int64_t)D0.base + ((tid < D0.nown && !(D0.flags & HQ_PATCH_NTSAME)) ? tid : 0);
             if (iso) {
                 const double* q = nt3 + 3 * nn;           /* (no copies of loaded values here: they would */
                 np[0] = q[0]; np[1] = q[1]; np[4] = q[2];  /*  wait for the load; the axes pick at the update) */
@@ -884,9 +900,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 #pragma unroll
             for (int n = 0; n < 8; n++) {
                 if (l[n] < D0.nacc) {
-                    atomicAdd(&s_f[3 * l[n] + 0], X[n]);
-                    atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
-                    atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
+                    hq_lds_double* a = hq_lds_row3(s_f, l[n]);
+                    HQ_LDS_ADD(a + 0, X[n]);
+                    HQ_LDS_ADD(a + 1, Y[n]);
+                    HQ_LDS_ADD(a + 2, Z[n]);
                 }
             }
         }
@@ -894,7 +911,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
             for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += T) {
                 int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
-                for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * ln + d], F[3 * li + d] * dt2);
+                for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * ln + d], F[3 * li + d] * dt2);
             }
         }
         if (ds_ptr && ds_ptr[p0 + 1] > ds_ptr[p0]) {     /* compute_adjust DISTRIBUTION, psolve.c:5942-5987 */
@@ -902,7 +919,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             for (int i = ds_ptr[p0] + tid; i < ds_ptr[p0 + 1]; i += T) {
                 const int src = ds_ent[3 * i], dst = ds_ent[3 * i + 1];
                 const double deps = (double)(unsigned)ds_ent[3 * i + 2];
-                for (int d = 0; d < 3; d++) atomicAdd(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
+                for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
             }
         }
         __syncthreads();
@@ -946,8 +963,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 #endif
             const int n = tid;
             double* out = ung + 3 * ((int64_t)D0.base + n);
-            const double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;                 /* u1, u2 of the owned nodes */
-            const double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
+            const hq_lds_double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;          /* u1, u2 of the owned nodes */
+            const hq_lds_double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
@@ -1007,6 +1024,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         nt3[3 * n] = ntab[7 * n]; nt3[3 * n + 1] = ntab[7 * n + 1]; nt3[3 * n + 2] = ntab[7 * n + 4];
     }
     const bool use_iso = !getenv("HQ_PATCH_NO_ISO");
+    int32_t nntsame = 0;
     for (auto& D : H.desc) {
         bool iso = use_iso;
         for (int32_t n = D.base; n < D.base + D.nown && iso; n++) {
@@ -1014,6 +1032,11 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             iso = (q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]);
         }
         D.flags = iso ? HQ_PATCH_ISO : 0;
+        /* interior of a homogeneous region: one n_t row serves the whole patch (bitwise equal rows) */
+        bool same = iso && D.nown > 0 && !getenv("HQ_PATCH_NO_NTSAME");
+        for (int32_t n = D.base + 1; n < D.base + D.nown && same; n++)
+            same = memcmp(&nt3[3 * (size_t)n], &nt3[3 * (size_t)D.base], 24) == 0;
+        if (same) { D.flags |= HQ_PATCH_NTSAME; nntsame++; }
     }
     int32_t nuniform = 0;
     const bool wform = !(getenv("HQ_PATCH_WFORM") && atoi(getenv("HQ_PATCH_WFORM")) == 0);
@@ -1035,8 +1058,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     P->ndistinct = H.ndistinct;
     P->nuniform = nuniform;
     if (getenv("HQ_PATCH_VERBOSE"))
-        fprintf(stderr, "hq patch plan: %zu patches, %d distinct local connectivities, %d with uniform coefficients\n",
-                H.desc.size(), H.ndistinct, nuniform);
+        fprintf(stderr, "hq patch plan: %zu patches, %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
+                H.desc.size(), H.ndistinct, nuniform, nntsame);
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
