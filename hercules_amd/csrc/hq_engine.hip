@@ -1055,7 +1055,8 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
-    return hq_patch_uses_pers(&c->plan) ? "hq_k_patch_pers" : "hq_k_patch_step";
+    if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
+    return (hq_patch_kernel_choice() == 5 && c->plan.cfg.pmax <= HQ_ROLE_ETHREADS) ? "hq_k_patch_roles" : "hq_k_patch_pers";
 }
 
 extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2)

@@ -819,7 +819,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         double a1[3], a2[3];
         const bool have_node = tid < D1.nown + D1.nhalo;
         {
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 7   /* ablation (results wrong): halo rows read as if they followed the owned rows */
+            const int64_t g = ((int64_t)D1.base + tid + (idn & 0)) & 0x3ffffff;
+#else
             const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0);
+#endif
 #pragma unroll
 #if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 2   /* ablation (results wrong): no node loads */
             for (int d = 0; d < 3; d++) { a1[d] = 1e-3 * (double)(g & 7); a2[d] = 1e-3; }
@@ -1512,7 +1516,8 @@ static void hq_patch_report_stamps(void)
 }
 #endif
 
-/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 0 = hq_k_patch_step always */
+/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 5 = hq_k_patch_roles there,
+ * 0 = hq_k_patch_step always */
 static int hq_patch_kernel_choice(void)
 {
     static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 4;
