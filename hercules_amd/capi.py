@@ -14,7 +14,7 @@ _LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
-           "hq_comm_unique_id", "hq_comm_init", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
+           "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel"]
 
@@ -165,6 +165,9 @@ class Solver:
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
         _check(self._lib.hq_comm_init(self._h, buf))
+
+    def comm_selftest(self, count=1024):
+        _check(self._lib.hq_comm_selftest(self._h, ctypes.c_int32(count)))
 
     def run(self, nsteps):
         _check(self._lib.hq_run(self._h, ctypes.c_int32(nsteps)))

@@ -938,6 +938,32 @@ extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
     return HQ_OK;
 }
 
+extern "C" int hq_comm_selftest(hq_ctx* c, int32_t count)
+{
+    if (!c || count < 1) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
+    if (!c->comm) return hq_fail(HQ_ERR_STATE, "hq_comm_selftest needs hq_comm_init%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    hipStream_t xs = c->overlap ? c->cstream : c->stream;
+    std::vector<double> h((size_t)count), back((size_t)count, 0.0);
+    for (int32_t i = 0; i < count; i++) h[i] = 1.0 + 0.5 * i;
+    double *d_out = nullptr, *d_in = nullptr;
+    HQ_HIP(hipMalloc((void**)&d_out, sizeof(double) * count));
+    HQ_HIP(hipMalloc((void**)&d_in, sizeof(double) * count));
+    HQ_HIP(hipMemcpyAsync(d_out, h.data(), sizeof(double) * count, hipMemcpyHostToDevice, xs));
+    HQ_HIP(hipMemsetAsync(d_in, 0, sizeof(double) * count, xs));
+    HQ_NCCL(g_rccl.GroupStart());
+    HQ_NCCL(g_rccl.Recv(d_in, (size_t)count, HQ_NCCL_DOUBLE, c->rank, c->comm, xs));
+    HQ_NCCL(g_rccl.Send(d_out, (size_t)count, HQ_NCCL_DOUBLE, c->rank, c->comm, xs));
+    HQ_NCCL(g_rccl.GroupEnd());
+    HQ_HIP(hipMemcpyAsync(back.data(), d_in, sizeof(double) * count, hipMemcpyDeviceToHost, xs));
+    HQ_HIP(hipStreamSynchronize(xs));
+    hipFree(d_out);
+    hipFree(d_in);
+    for (int32_t i = 0; i < count; i++)
+        if (back[i] != h[i]) return hq_fail(HQ_ERR_COMM, "self send/recv through RCCL returned other data than was sent%s", "");
+    return HQ_OK;
+}
+
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
 {
     if (!ctxs || n < 1) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");

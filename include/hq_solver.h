@@ -138,6 +138,10 @@ HQ_API int hq_get_info(hq_ctx* ctx, hq_info* info);
  */
 HQ_API int hq_comm_unique_id(void* id128);
 HQ_API int hq_comm_init(hq_ctx* ctx, const void* id128);
+/* Diagnostic: one grouped ncclRecv + ncclSend of `count` doubles from this rank to itself, through
+ * the entry points and on the stream the halo exchange uses, checked on the host.  Lets a
+ * single-GPU box exercise the RCCL binding (a communicator of one rank is enough). */
+HQ_API int hq_comm_selftest(hq_ctx* ctx, int32_t count);
 
 /*
  * In-process transport for hosts that drive several partitions from ONE process

@@ -549,3 +549,19 @@ def test_checkpoints_at_the_references_cadence(tmp_path):
         tm2 = np.frombuffer(b[12:12 + N * 24], "<f8").reshape(N, 3)
         tm1 = np.frombuffer(b[12 + N * 24:], "<f8").reshape(N, 3)
         assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+
+
+def test_rccl_binding_on_a_communicator_of_one():
+    """The multi-GPU transport on a one-GPU box: librccl is loaded, a communicator of one rank is
+    created through hq_comm_unique_id / hq_comm_init, and hq_comm_selftest moves doubles from the
+    rank to itself with the grouped ncclRecv/ncclSend the halo exchange issues (same stream, same
+    argument order).  The exchange logic itself is covered by the partitioned-box tests over the
+    in-process transport and by the gloo tests on the host side."""
+    lnid, node_ijk, elem_ijk, et, nt = _box(4, 4, 4)
+    s = ha.Solver(lnid, et, nt, 1e-3, node_xyz=_ticks(node_ijk, 1 << 20))
+    s.comm_init(ha.capi.comm_unique_id())
+    s.comm_selftest(3 * 4096)
+    with pytest.raises(ha.capi.HqError):
+        s.comm_init(ha.capi.comm_unique_id())      # a second communicator is refused
+    s.run(3)                                        # no neighbours: the run is untouched by the communicator
+    s.close()
