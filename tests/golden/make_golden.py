@@ -243,6 +243,44 @@ def case_full():
           np.abs(st[:, :exp.shape[1], 1:] - exp[:, :st.shape[1], 1:]).max())
 
 
+def case_mid():
+    """Mid-size pin: the same material database at f = 40 Hz, dt = 0.5 ms makes
+    the reference's mesher refine examples/simple to 128 x 128 x 64 = 1 048 576 elements /
+    1 081 665 nodes.  One rank, 300 steps, checkpoint at step 200 (52 MB: too big to commit), so
+    the fixture keeps the force file, the field at 4096 seeded-random nodes plus the 256 nodes of
+    largest |u|, each with its tick coordinates (from the reference's own mesh.e, read with the
+    repo's etree reader), and field-wide maxima and sums."""
+    sys.path.insert(0, ROOT)
+    from hercules_amd import host as hhost
+    run, out = run_reference("c2_mid", "0.15", 200, freq=40, dt=0.0005)
+    ids, F = read_forces(run)
+    step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", "checkpoint.out0"))
+    assert step == 200, step
+    tm2, tm1 = blocks[0]
+    ticks, level, vals = hhost.etree_read(os.path.join(run, "out", "mesh.e"))
+    nid, edata = hhost.mesh_payload(vals)
+    E, N = len(nid), len(tm1)
+    edge = 1 << (30 - int(level[0]))                  # octor ticks per element edge (PIXELLEVEL 30, octor.h)
+    assert (level == level[0]).all()
+    node_ticks = np.zeros((N, 3), np.int64)
+    for c in range(8):
+        off = np.array([c & 1, (c >> 1) & 1, (c >> 2) & 1], np.int64) * edge
+        node_ticks[nid[:, c]] = ticks.astype(np.int64) + off
+    rng = np.random.default_rng(12345)
+    amp = np.abs(tm1).max(axis=1)
+    sample = np.unique(np.concatenate([rng.choice(N, 4096, replace=False), np.argsort(amp)[-256:], ids]))
+    np.savez_compressed(os.path.join(HERE, "c2_mid.npz"),
+                        elements=E, nodes=N, edge_ticks=edge, edata=edata[0],
+                        loaded_lnid=ids, loaded_ticks=node_ticks[ids], forces=F[:200],
+                        sample_lnid=sample.astype(np.int32), sample_ticks=node_ticks[sample],
+                        sample_tm1=tm1[sample], sample_tm2=tm2[sample],
+                        max_abs_tm1=np.abs(tm1).max(), max_abs_tm2=np.abs(tm2).max(),
+                        sum_tm1=tm1.sum(axis=0), sum_abs_tm1=np.abs(tm1).sum(axis=0),
+                        ckpt_step=200, dt=0.0005, freq=40.0, end_time=0.15)
+    shutil.rmtree(run)
+    print("c2_mid ok", E, N, "max |tm1|", np.abs(tm1).max())
+
+
 def case_np8():
     run, out = run_reference("c1_np8", "1.0", 400, nranks=8)
     meshes = [read_mesh(run, r) for r in range(8)]
@@ -363,6 +401,7 @@ CASES = {
     "c1_full": case_full,
     "c1_planes": case_planes,
     "c1_np8": case_np8,
+    "c2_mid": case_mid,
     "c5_two_level": case_two_level,
     "c5_three_level": case_three_level,
     "c5_layered": case_layered,

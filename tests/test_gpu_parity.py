@@ -565,3 +565,44 @@ def test_rccl_binding_on_a_communicator_of_one():
         s.comm_init(ha.capi.comm_unique_id())      # a second communicator is refused
     s.run(3)                                        # no neighbours: the run is untouched by the communicator
     s.close()
+
+
+@pytest.mark.parametrize("variant", [ha.HQ_VARIANT_PATCH])
+def test_mid_size_box_against_the_references_checkpoint(variant):
+    """the reference's mesher refines examples/simple to 128 x 128 x 64 =
+    1 048 576 elements at f = 40 Hz, dt = 0.5 ms; tests/golden/c2_mid holds its force file and its
+    step-200 checkpoint at 4 352 nodes (seeded sample + the largest amplitudes), each with the
+    node's tick coordinates from the reference's mesh.e.  The C host side builds the same box
+    (hqh_box_create restates solver_init), nodes are matched BY COORDINATE, and octor's numbering
+    is then asserted to be the one the box has."""
+    from hercules_amd import host as hhost
+    g = H.load("c2_mid")
+    nx, ny, nz = 128, 128, 64
+    box = hhost.Box(nx, ny, nz, 1000.0 / nx, float(g["dt"]), float(g["freq"]))
+    assert box.info["lenum"] == int(g["elements"]) and box.info["nharbored"] == int(g["nodes"])
+    edge = int(g["edge_ticks"])
+
+    def key(ijk):
+        ijk = np.asarray(ijk, np.int64)
+        return ijk[:, 0] + (nx + 1) * (ijk[:, 1] + (ny + 1) * ijk[:, 2])
+
+    lut = np.full((nx + 1) * (ny + 1) * (nz + 1), -1, np.int64)
+    lut[key(box.node_ijk)] = np.arange(len(box.node_ijk))
+    assert (g["sample_ticks"] % edge == 0).all()
+    sample = lut[key(g["sample_ticks"] // edge)]
+    loaded = lut[key(g["loaded_ticks"] // edge)]
+    assert (sample >= 0).all() and (loaded >= 0).all()
+    assert np.array_equal(sample, g["sample_lnid"])           # octor's node order (octor.c:6166) is the box's
+    assert np.array_equal(loaded, g["loaded_lnid"])
+    s = box.create_solver(variant=variant)
+    s.set_source(loaded.astype(np.int32), g["forces"])
+    s.run(int(g["ckpt_step"]))
+    tm1, tm2 = s.gather(sample.astype(np.int32))
+    e1 = np.abs(tm1 - g["sample_tm1"]).max() / float(g["max_abs_tm1"])
+    e2 = np.abs(tm2 - g["sample_tm2"]).max() / float(g["max_abs_tm2"])
+    assert e1 < TOL and e2 < TOL, (e1, e2)
+    f1, f2 = s.download()
+    assert abs(np.abs(f1).max() / float(g["max_abs_tm1"]) - 1.0) < TOL
+    assert np.abs(f1.sum(axis=0) - g["sum_tm1"]).max() <= 1e-9 * np.abs(g["sum_abs_tm1"]).max()
+    s.close()
+    box.close()

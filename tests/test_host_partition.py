@@ -408,3 +408,27 @@ def test_mesh_from_leaves_partitions_are_octors(name, nranks):
                 for (_, a), (_, b) in zip(got, exp):
                     assert np.array_equal(a, b)
         ob.close()
+
+
+def test_million_element_box_has_octors_node_order():
+    """tests/golden/c2_mid: the reference refined examples/simple to 128 x 128 x 64 elements; the
+    fixture's sampled and loaded nodes carry the tick coordinates its mesh.e gives them.  The box
+    the C host side builds numbers those nodes as octor did (octor.c:6166), and the oracle's
+    uniform_mesh agrees."""
+    g = H.load("c2_mid")
+    nx, ny, nz = 128, 128, 64
+    box = host.Box(nx, ny, nz, 1000.0 / nx, float(g["dt"]), float(g["freq"]))
+    assert box.info["lenum"] == int(g["elements"]) and box.info["nharbored"] == int(g["nodes"])
+    edge = int(g["edge_ticks"])
+
+    def key(ijk):
+        ijk = np.asarray(ijk, np.int64)
+        return ijk[:, 0] + (nx + 1) * (ijk[:, 1] + (ny + 1) * ijk[:, 2])
+
+    for node_ijk in (box.node_ijk, ho.uniform_mesh(nx, ny, nz)[2]):
+        lut = np.full((nx + 1) * (ny + 1) * (nz + 1), -1, np.int64)
+        lut[key(node_ijk)] = np.arange(len(node_ijk))
+        assert np.array_equal(lut[key(g["sample_ticks"] // edge)], g["sample_lnid"])
+        assert np.array_equal(lut[key(g["loaded_ticks"] // edge)], g["loaded_lnid"])
+    assert np.allclose(g["edata"], (1000.0 / nx, 6000.0, 3464.0, 2700.0))
+    box.close()
