@@ -14,7 +14,7 @@ _LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
-           "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather",
+           "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel"]
 
@@ -200,6 +200,13 @@ class Solver:
         o2 = np.empty((len(ids), 3))
         _check(self._lib.hq_gather(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o1), _ptr(o2)))
         return o1, o2
+
+    def gather3(self, lnid):
+        """tm1, tm2 and tm3 = u((step - 2) dt) at the given nodes (patch variant)."""
+        ids = np.ascontiguousarray(np.asarray(lnid).reshape(-1), np.int32)
+        o = [np.empty((len(ids), 3)) for _ in range(3)]
+        _check(self._lib.hq_gather3(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o[0]), _ptr(o[1]), _ptr(o[2])))
+        return tuple(o)
 
     def phase_force(self):
         _check(self._lib.hq_phase_force(self._h))

@@ -1085,7 +1085,21 @@ extern "C" const char* hq_dominant_kernel(hq_ctx* c)
     return (hq_patch_kernel_choice() == 5 && c->plan.cfg.pmax <= HQ_ROLE_ETHREADS) ? "hq_k_patch_roles" : "hq_k_patch_pers";
 }
 
+static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3);
+
 extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2)
+{
+    return hq_gather_impl(c, n, lnid, o1, o2, nullptr);
+}
+
+extern "C" int hq_gather3(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3)
+{
+    if (c && o3 && c->variant != HQ_VARIANT_PATCH)
+        return hq_fail(HQ_ERR_STATE, "u(t - 2 dt) is kept by the patch variant only%s", "");
+    return hq_gather_impl(c, n, lnid, o1, o2, o3);
+}
+
+static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3)
 {
     if (!c || n < 0 || (n && !lnid)) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     if (n == 0) return HQ_OK;
@@ -1096,13 +1110,18 @@ extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, 
     int32_t* d_ids = nullptr;
     double* d_o = nullptr;
     HQ_HIP(hipMalloc((void**)&d_ids, sizeof(int32_t) * n));
-    hipError_t e = hipMalloc((void**)&d_o, sizeof(double) * 6 * (size_t)n);
+    hipError_t e = hipMalloc((void**)&d_o, sizeof(double) * 9 * (size_t)n);
     if (e != hipSuccess) { hipFree(d_ids); return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", ""); }
     hipMemcpyAsync(d_ids, lnid, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream);
     hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->now], c->d_u[c->prev],
                                                                          d_o, d_o + 3 * (size_t)n);
     if (o1) hipMemcpyAsync(o1, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
     if (o2) hipMemcpyAsync(o2, d_o + 3 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (o3) {
+        hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->spare], c->d_u[c->spare],
+                                                                             d_o + 6 * (size_t)n, d_o + 6 * (size_t)n);
+        hipMemcpyAsync(o3, d_o + 6 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    }
     e = hq_quiesce(c);
     hipFree(d_ids);
     hipFree(d_o);
@@ -1129,6 +1148,7 @@ extern "C" int hq_upload(hq_ctx* c, const double* tm1, const double* tm2, int32_
     size_t bytes = sizeof(double) * 3 * (size_t)c->N;
     HQ_HIP(hipMemcpy(c->d_u[c->now], tm1, bytes, hipMemcpyHostToDevice));
     HQ_HIP(hipMemcpy(c->d_u[c->prev], tm2, bytes, hipMemcpyHostToDevice));
+    if (c->d_u[2]) HQ_HIP(hipMemset(c->d_u[c->spare], 0, bytes));          /* tm3 after a restart: calloc, psolve.c:3347 */
     c->step = step;
     return HQ_OK;
 }

@@ -755,6 +755,50 @@ int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3]
     return HQ_OK;
 }
 
+int hqh_station_format_derivs(char* buf, int32_t cap, double time, const double* vals, int32_t derivs)
+{
+    if (!buf || cap < 64 + 48 * derivs || !vals || derivs < 0 || derivs > 2) return HQ_ERR_ARG;
+    int n = snprintf(buf, (size_t)cap, "\n%10.6f % 8e % 8e % 8e", time, vals[0], vals[1], vals[2]);
+    for (int k = 1; k <= derivs; k++)
+        n += snprintf(buf + n, (size_t)cap - (size_t)n, " % 8e % 8e % 8e", vals[3 * k], vals[3 * k + 1], vals[3 * k + 2]);
+    return HQ_OK;
+}
+
+int hqh_station_header(char* buf, int32_t cap, int32_t derivs)
+{
+    if (!buf || cap < 160 || derivs < 0 || derivs > 2) return HQ_ERR_ARG;
+    int n = snprintf(buf, (size_t)cap, "#  Time(s)         X|(m)         Y-(m)         Z.(m)");
+    if (derivs >= 1) n += snprintf(buf + n, (size_t)cap - (size_t)n, "       X|(m/s)       Y-(m/s)       Z.(m/s)");
+    if (derivs == 2) n += snprintf(buf + n, (size_t)cap - (size_t)n, "      X|(m/s2)      Y-(m/s2)      Z.(m/s2)");
+    return HQ_OK;
+}
+
+/* interpolate_station_displacements, psolve.c:6705-6787: the displacement sum over the 8 nodes;
+ * for the velocity the same accumulator has phi * tm2 taken off node by node and is divided by dt;
+ * for the acceleration phi * tm2 comes off once more and phi * tm3 is added, over dt^2. */
+int hqh_station_kinematics(const double* phi, const double* tm1, const double* tm2, const double* tm3,
+                           double dt, int32_t derivs, double* vals)
+{
+    if (!phi || !tm1 || !vals || derivs < 0 || derivs > 2 || (derivs >= 1 && !tm2) || (derivs == 2 && !tm3))
+        return HQ_ERR_ARG;
+    double d[3] = { 0.0, 0.0, 0.0 };
+    for (int c = 0; c < 8; c++)
+        for (int a = 0; a < 3; a++) d[a] += phi[c] * tm1[3 * c + a];
+    for (int a = 0; a < 3; a++) vals[a] = d[a];
+    if (derivs >= 1) {
+        for (int c = 0; c < 8; c++)
+            for (int a = 0; a < 3; a++) d[a] -= phi[c] * tm2[3 * c + a];
+        for (int a = 0; a < 3; a++) vals[3 + a] = d[a] / dt;
+    }
+    if (derivs == 2) {
+        const double dt2 = dt * dt;                              /* Param.theDeltaTSquared, psolve.c:998 */
+        for (int c = 0; c < 8; c++)
+            for (int a = 0; a < 3; a++) { d[a] -= phi[c] * tm2[3 * c + a]; d[a] += phi[c] * tm3[3 * c + a]; }
+        for (int a = 0; a < 3; a++) vals[6 + a] = d[a] / dt2;
+    }
+    return HQ_OK;
+}
+
 void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F)
 {
     for (int32_t s = 0; s < nsteps; s++) {
@@ -788,8 +832,9 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
         if (!F) return HQ_ERR_NOMEM;
     }
     if (rp->nstations > 0 && rp->station_rate > 0 && rp->station_fn) {
-        u = (double*)malloc(sizeof(double) * 24 * (size_t)rp->nstations);
-        disp = (double*)malloc(sizeof(double) * 3 * (size_t)rp->nstations);
+        if (rp->station_derivs < 0 || rp->station_derivs > 2) return HQ_ERR_ARG;
+        u = (double*)malloc(sizeof(double) * 24 * 3 * (size_t)rp->nstations);          /* tm1 | tm2 | tm3 rows */
+        disp = (double*)malloc(sizeof(double) * 3 * (size_t)(1 + rp->station_derivs) * (size_t)rp->nstations);
         if (!u || !disp) { free(F); free(u); free(disp); return HQ_ERR_NOMEM; }
     }
     /* output planes */
@@ -841,14 +886,14 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
             if (rc != HQ_OK) break;
         }
         if (u && step % rp->station_rate == 0) {                 /* solver_output_stations, :4280 */
-            rc = hq_gather(ctx, rp->nstations * 8, rp->station_ids, u, NULL);
+            const int dv = rp->station_derivs;
+            const size_t blk = 24 * (size_t)rp->nstations;
+            rc = dv == 2 ? hq_gather3(ctx, rp->nstations * 8, rp->station_ids, u, u + blk, u + 2 * blk)
+                         : hq_gather(ctx, rp->nstations * 8, rp->station_ids, u, dv ? u + blk : NULL);
             if (rc != HQ_OK) break;
             for (int32_t s = 0; s < rp->nstations; s++)
-                for (int d = 0; d < 3; d++) {
-                    double acc = 0.0;
-                    for (int c = 0; c < 8; c++) acc += rp->station_phi[8 * s + c] * u[(8 * s + c) * 3 + d];
-                    disp[3 * s + d] = acc;
-                }
+                hqh_station_kinematics(rp->station_phi + 8 * s, u + 24 * s, u + blk + 24 * s, u + 2 * blk + 24 * s,
+                                       deltaT, dv, disp + 3 * (size_t)(1 + dv) * s);
             rp->station_fn(rp->station_user, step, rp->nstations, disp);
         }
         if (F && step >= win_end) {                              /* solver_read_source_forces, :4282 */

@@ -15,7 +15,8 @@ EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_des
            "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner",
            "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
-           "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format",
+           "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format", "hqh_station_format_derivs",
+           "hqh_station_kinematics", "hqh_station_header",
            "hqh_octbox_create", "hqh_octbox_destroy", "hqh_octbox_desc", "hqh_octbox_view"]
 
 
@@ -50,7 +51,7 @@ class _RunParams(ctypes.Structure):
                 ("plane_ids", ctypes.c_void_p), ("plane_phi", ctypes.c_void_p),
                 ("plane_mine", ctypes.c_void_p), ("plane_rate", ctypes.c_int32),
                 ("plane_dir", ctypes.c_char_p), ("checkpoint_rate", ctypes.c_int32),
-                ("checkpoint_dir", ctypes.c_char_p)]
+                ("checkpoint_dir", ctypes.c_char_p), ("station_derivs", ctypes.c_int32)]
 
 
 class _Plane(ctypes.Structure):
@@ -110,8 +111,11 @@ def _view(ptr, shape, dtype):
 
 def run_params(loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
                station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
-               planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None):
-    """planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
+               planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None,
+               station_derivs=0):
+    """station_derivs: 0 = the station callback gets displacements [n, 3]; 1 = + velocities [n, 6];
+    2 = + accelerations [n, 9] (print_station_velocities / _accelerations).
+    planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
     every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
     rp = _RunParams()
     keep = []
@@ -145,12 +149,15 @@ def run_params(loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_wind
         sp = np.ascontiguousarray(station_phi, np.float64)
         n = len(si)
 
+        ncol = 3 * (1 + int(station_derivs))
+
         def _cb(user, step, ns, disp):
-            station_fn(step, np.ctypeslib.as_array(disp, (ns, 3)).copy())
+            station_fn(step, np.ctypeslib.as_array(disp, (ns, ncol)).copy())
         cb = STATION_FN(_cb)
         keep += [si, sp, cb]
         rp.nstations, rp.station_ids, rp.station_phi = n, si.ctypes.data, sp.ctypes.data
         rp.station_rate, rp.station_fn = station_rate, cb
+        rp.station_derivs = int(station_derivs)
     rp._keep = keep
     return rp
 
@@ -544,8 +551,20 @@ def checkpoint_read(solver, path, rank=0, nranks=1):
     return step.value
 
 
+def station_header(derivs=0):
+    buf = ctypes.create_string_buffer(256)
+    capi._check(load_library().hqh_station_header(buf, 256, ctypes.c_int32(derivs)))
+    return buf.value.decode()
+
+
 def station_format(time, disp):
-    buf = ctypes.create_string_buffer(128)
-    d = np.ascontiguousarray(disp, np.float64)
-    load_library().hqh_station_format(buf, 128, ctypes.c_double(time), d.ctypes.data_as(ctypes.c_void_p))
+    """One station line as the reference prints it; disp of 3, 6 or 9 values (+ velocity, + acceleration)."""
+    buf = ctypes.create_string_buffer(256)
+    d = np.ascontiguousarray(disp, np.float64).reshape(-1)
+    if len(d) == 3:
+        capi._check(load_library().hqh_station_format(buf, 256, ctypes.c_double(time), d.ctypes.data_as(ctypes.c_void_p)))
+    else:
+        capi._check(load_library().hqh_station_format_derivs(buf, 256, ctypes.c_double(time),
+                                                           d.ctypes.data_as(ctypes.c_void_p),
+                                                           ctypes.c_int32(len(d) // 3 - 1)))
     return buf.value.decode()

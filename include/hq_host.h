@@ -95,7 +95,10 @@ HQ_API int hqh_point_source(const hqh_box* box, double x, double y, double z, do
 HQ_API int hqh_stations(const hqh_box* box, int32_t n, const double* xyz, int32_t* ids, double* phi,
                         int32_t* mine);
 
-/* Called at every station print step with interpolated displacements [n][3]. */
+/* Called at every station print step with the interpolated displacements [n][3] -- or, with
+ * station_derivs = 1 | 2, [n][6] | [n][9]: displacement, velocity (u1 - u2) / dt and acceleration
+ * (u1 - 2 u2 + u3) / dt^2 as print_station_velocities / print_station_accelerations add them
+ * (psolve.c:6737-6787). */
 typedef void (*hqh_station_fn)(void* user, int32_t step, int32_t n, const double* disp);
 
 typedef struct {
@@ -132,6 +135,9 @@ typedef struct {
      * (partitions call hqh_checkpoint_write themselves, rank 0 first) */
     int32_t        checkpoint_rate;  /* checkpointing_rate; 0 = never */
     const char*    checkpoint_dir;   /* checkpoint_path */
+    /* 0: stations report displacement; 1: + velocity; 2: + velocity and acceleration (needs the
+     * patch variant: hq_gather3) */
+    int32_t        station_derivs;
 } hqh_run_params;
 
 /* solver_run: steps [step0, step0 + nsteps) on `ctx` (a context made from `box`; or, _on, from
@@ -192,6 +198,15 @@ HQ_API int hqh_domain_coords(double lon, double lat, const double lon_corners[4]
 
 /* One station line in the reference's text format (psolve.c:6727-6731). */
 HQ_API int hqh_station_format(char* buf, int32_t cap, double time, const double disp[3]);
+/* The same with the velocity / acceleration columns (psolve.c:6755-6787): vals = 3 (1 + derivs)
+ * numbers as the station callback gets them. */
+HQ_API int hqh_station_format_derivs(char* buf, int32_t cap, double time, const double* vals, int32_t derivs);
+/* The first line of a station file (psolve.c:6636-6648; no newline: every data line starts with one). */
+HQ_API int hqh_station_header(char* buf, int32_t cap, int32_t derivs);
+/* Displacement, velocity, acceleration of one station from the 8 node rows of tm1, tm2, tm3 (each
+ * [8][3]; tm2 / tm3 may be NULL below derivs 1 / 2), in the reference's order of operations. */
+HQ_API int hqh_station_kinematics(const double* phi, const double* tm1, const double* tm2, const double* tm3,
+                                  double dt, int32_t derivs, double* vals);
 
 /*
  * Two-level layered box: the top nz_fine layers of elements of edge h over nz_coarse

@@ -185,6 +185,14 @@ HQ_API int hq_sync(hq_ctx* ctx);
  * (io_checkpoint.c:98-112) and the 4D output (output.c:1265).
  */
 HQ_API int hq_gather(hq_ctx* ctx, int32_t n, const int32_t* lnid, double* tm1_out, double* tm2_out);
+/*
+ * The same with tm3 = u((step-2)*dt), which the reference keeps when station accelerations are
+ * printed (solver_compute_displacement psolve.c:4093-4101; read at :6762-6778).  The patch variant
+ * has it for free -- it is the buffer the next step overwrites; zero before the second step and
+ * after hq_upload, as the reference's calloc'ed tm3 is.  HQ_ERR_STATE in the scatter variant.
+ */
+HQ_API int hq_gather3(hq_ctx* ctx, int32_t n, const int32_t* lnid, double* tm1_out, double* tm2_out,
+                      double* tm3_out);
 HQ_API int hq_download(hq_ctx* ctx, double* tm1, double* tm2);
 /* checkpoint_read (io_checkpoint.c:134-236): overwrite the fields, set the step. */
 HQ_API int hq_upload(hq_ctx* ctx, const double* tm1, const double* tm2, int32_t step);

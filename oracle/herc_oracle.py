@@ -270,6 +270,42 @@ def station_weights(points_m, h, nx, ny, nz, lnid, elem_ijk):
     return np.array(ids, np.int32), np.array(phis)
 
 
+def station_kinematics(phi, tm1, tm2=None, tm3=None, dt=1.0, derivs=0):
+    """interpolate_station_displacements (psolve.c:6705-6787) for one station: phi [8], tm* [8,3]
+    rows of its element's nodes.  Displacement = sum over the nodes; the velocity takes phi * tm2 off
+    the same accumulator node by node and divides by dt; the acceleration takes phi * tm2 off once
+    more, adds phi * tm3, over dt^2.  -> 3 (1 + derivs) values."""
+    d = [0.0, 0.0, 0.0]
+    for c in range(8):
+        for a in range(3):
+            d[a] += float(phi[c]) * float(tm1[c][a])
+    out = list(d)
+    if derivs >= 1:
+        for c in range(8):
+            for a in range(3):
+                d[a] -= float(phi[c]) * float(tm2[c][a])
+        out += [d[a] / dt for a in range(3)]
+    if derivs == 2:
+        for c in range(8):
+            for a in range(3):
+                d[a] -= float(phi[c]) * float(tm2[c][a])
+                d[a] += float(phi[c]) * float(tm3[c][a])
+        out += [d[a] / (dt * dt) for a in range(3)]
+    return np.array(out)
+
+
+def station_line(time, vals):
+    """A data line of a station file (psolve.c:6727-6787): newline first, "%10.6f", then "% 8e" each."""
+    return "\n%10.6f" % time + "".join(" % 8e" % v for v in vals)
+
+
+def station_header(derivs=0):
+    """psolve.c:6636-6648."""
+    return ("#  Time(s)         X|(m)         Y-(m)         Z.(m)"
+            + ("       X|(m/s)       Y-(m/s)       Z.(m/s)" if derivs >= 1 else "")
+            + ("      X|(m/s2)      Y-(m/s2)      Z.(m/s2)" if derivs == 2 else ""))
+
+
 def domain_coords_linearinterp(lon, lat, lon_corners, lat_corners, len_eta, len_csi):
     """(longitude, latitude) -> domain x, y: Newton iteration on the bilinear map of the four
     surface corners (compute_domain_coords_linearinterp, geometrics.c:178-244)."""

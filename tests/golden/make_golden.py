@@ -62,7 +62,7 @@ use_infinite_qk = no
 
 def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
                   nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None, planes=None,
-                  plane_rate=50):
+                  plane_rate=50, station_derivs=0):
     """Run the reference in a scratch dir; return (dir, stdout)."""
     run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
     src = os.path.join(REF, "examples", "simple")
@@ -88,6 +88,10 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
     text = setkey(text, "simulation_end_time_sec", end_time)
     text = setkey(text, "checkpointing_rate", ckpt_rate)
     text = setkey(text, "type_of_damping", damping)
+    if station_derivs >= 1:
+        text = setkey(text, "print_station_velocities", "yes")
+    if station_derivs >= 2:
+        text = setkey(text, "print_station_accelerations", "yes")
     if vscut is not None:
         text = setkey(text, "simulation_shear_velocity_min", vscut)
     if freq is not None:
@@ -144,13 +148,13 @@ def read_checkpoint(path, harbored=None):
     return step, out
 
 
-def read_station_text(text):
+def read_station_text(text, ncol=4):
     rows = [l.split() for l in text.splitlines() if l.strip() and not l.lstrip().startswith("#")]
-    return np.array([[float(v) for v in r[:4]] for r in rows])
+    return np.array([[float(v) for v in r[:ncol]] for r in rows])
 
 
-def read_stations(run, n=5):
-    return np.stack([read_station_text(open(os.path.join(run, "out", "stations", "station.%d" % i)).read())
+def read_stations(run, n=5, ncol=4):
+    return np.stack([read_station_text(open(os.path.join(run, "out", "stations", "station.%d" % i)).read(), ncol)
                      for i in range(n)])
 
 
@@ -190,6 +194,23 @@ def case_short(name, **kw):
                         stations=st, dt=1e-3, end_time=1.0, freq=5.0)
     shutil.rmtree(run)
     print(name, "ok", sorted(ck))
+
+
+def case_stations_va():
+    """Station files with the velocity and acceleration columns (print_station_velocities /
+    print_station_accelerations = yes, psolve.c:6737-6787; the accelerations make the solver keep
+    tm3, :4093-4101): 600 steps, all five stations, 10 columns; the first lines of station.0 verbatim
+    for the text format."""
+    run, out = run_reference("c1_stations_va", "0.6", 0, station_derivs=2)
+    ids, F = read_forces(run)
+    st = read_stations(run, ncol=10)
+    head = open(os.path.join(run, "out", "stations", "station.0")).read()
+    lines = head.split("\n")
+    np.savez_compressed(os.path.join(HERE, "c1_stations_va.npz"), loaded_lnid=ids, forces=F,
+                        stations=st, station0_text="\n".join(lines[:120]),
+                        station0_lines_300_320="\n".join(lines[-300:-280]), dt=1e-3, end_time=0.6, freq=5.0)
+    shutil.rmtree(run)
+    print("c1_stations_va ok", st.shape, repr(lines[:4]))
 
 
 def case_planes():
@@ -400,6 +421,7 @@ CASES = {
     "c1_mass": lambda: case_short("c1_mass", damping="mass"),
     "c1_full": case_full,
     "c1_planes": case_planes,
+    "c1_stations_va": case_stations_va,
     "c1_np8": case_np8,
     "c2_mid": case_mid,
     "c5_two_level": case_two_level,

@@ -606,3 +606,61 @@ def test_mid_size_box_against_the_references_checkpoint(variant):
     assert np.abs(f1.sum(axis=0) - g["sum_tm1"]).max() <= 1e-9 * np.abs(g["sum_abs_tm1"]).max()
     s.close()
     box.close()
+
+
+def test_station_files_with_velocities_and_accelerations(tmp_path):
+    """hqh_solver_run with station_derivs = 2 on examples/simple, driven by the reference's force
+    file: displacement, velocity and acceleration of the five stations at every step, against the
+    station files the reference wrote with print_station_velocities / _accelerations = yes
+    (tests/golden/c1_stations_va; printed with 7 digits).  The acceleration needs u(t - 2 dt):
+    hq_gather3 reads it from the buffer the next step overwrites."""
+    from hercules_amd import host
+    g = H.load("c1_stations_va")
+    ref = g["stations"]                                  # [5, steps, 10]
+    steps = ref.shape[1]
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    box = host.Box(H.C1_NX, H.C1_NY, H.C1_NZ, H.C1_H, 1e-3, 5.0)
+    ids, phi, mine = box.stations(H.C1_STATIONS)
+    assert mine.all()
+    s = box.create_solver()
+    got = np.zeros((steps, len(ids), 9))
+    text = [host.station_header(2)]
+
+    def on_print(step, vals):
+        got[step] = vals
+        text.append(host.station_format(step * 1e-3, vals[0]))
+
+    rp = box.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=128, station_ids=ids,
+                        station_phi=phi, station_rate=1, station_fn=on_print, station_derivs=2)
+    box.solver_run(s, rp, 0, 250)                       # in two calls, as a restartable driver would
+    box.solver_run(s, rp, 250, steps - 250)
+    for k in range(3):
+        scale = np.abs(ref[:, :, 1 + 3 * k:4 + 3 * k]).max()
+        err = np.abs(got[:, :, 3 * k:3 * k + 3].transpose(1, 0, 2) - ref[:, :, 1 + 3 * k:4 + 3 * k]).max()
+        assert err <= 6e-7 * scale, (k, err, scale)
+    # the text itself: header and the quiet first lines are the reference's bytes
+    ref_lines = str(g["station0_text"]).split("\n")
+    ours = "".join(text).split("\n")
+    assert ours[0] == ref_lines[0]
+    assert ours[1:4] == ref_lines[1:4]
+    # ... and every printed number that is not rounding noise (station 0 sits on the fault plane: its
+    # z components are ~1e-18 of the others) has the reference's digits, up to a rare last-digit flip
+    fields = flips = 0
+    for t in range(1, len(ref_lines) - 1):
+        a, b = ours[t + 1].split(), ref_lines[t + 1].split()
+        assert len(a) == len(b) == 10 and a[0] == b[0]
+        for k in range(1, 10):
+            if abs(float(b[k])) > 1e-6 * np.abs(ref[0, :, 1 + 3 * ((k - 1) // 3):4 + 3 * ((k - 1) // 3)]).max():
+                fields += 1
+                flips += a[k] != b[k]
+    assert fields > 500 and flips <= 3, (fields, flips)
+    # hq_gather3 itself: tm3 of now is tm2 of one step ago
+    a1, a2 = s.gather(ids)
+    s.run(1)
+    b1, b2, b3 = s.gather3(ids)
+    assert np.array_equal(b2, a1) and np.array_equal(b3, a2)
+    sc = box.create_solver(variant=ha.HQ_VARIANT_SCATTER)
+    with pytest.raises(ha.capi.HqError):
+        sc.gather3(ids)
+    s.close(); sc.close(); box.close()

@@ -432,3 +432,27 @@ def test_million_element_box_has_octors_node_order():
         assert np.array_equal(lut[key(g["loaded_ticks"] // edge)], g["loaded_lnid"])
     assert np.allclose(g["edata"], (1000.0 / nx, 6000.0, 3464.0, 2700.0))
     box.close()
+
+
+def test_station_lines_with_velocity_and_acceleration_columns():
+    """hqh_station_header / _format_derivs / _kinematics against the reference's own station file
+    (tests/golden/c1_stations_va) and the oracle's restatement of psolve.c:6705-6787."""
+    g = H.load("c1_stations_va")
+    lines = str(g["station0_text"]).split("\n")
+    assert host.station_header(2) == lines[0] and host.station_header(0) == lines[0][:len(host.station_header(0))]
+    assert ho.station_header(1) == host.station_header(1)
+    for t in (0, 2, 57, 118):
+        assert host.station_format(t * 1e-3, g["stations"][0, t, 1:]) == "\n" + lines[t + 1]
+        assert host.station_format(t * 1e-3, g["stations"][0, t, 1:4]) == ("\n" + lines[t + 1])[:len(ho.station_line(t * 1e-3, g["stations"][0, t, 1:4]))]
+    rng = np.random.default_rng(7)
+    lib = host.load_library()
+    import ctypes
+    for derivs in (0, 1, 2):
+        phi = rng.uniform(0, 0.3, 8)
+        u = rng.normal(size=(3, 8, 3))
+        out = np.zeros(3 * (1 + derivs))
+        rc = lib.hqh_station_kinematics(phi.ctypes.data_as(ctypes.c_void_p), u[0].ctypes.data_as(ctypes.c_void_p),
+                                        u[1].ctypes.data_as(ctypes.c_void_p), u[2].ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_double(1e-3), ctypes.c_int32(derivs), out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        assert np.array_equal(out, ho.station_kinematics(phi, u[0], u[1], u[2], 1e-3, derivs))   # same order of operations

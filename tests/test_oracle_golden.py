@@ -304,3 +304,34 @@ def test_output_planes_against_the_reference_files():
             assert np.abs(got - ref[k]).max() <= 1e-12 * max(np.abs(ref[k]).max(), 1e-300)
         off += n
         assert np.abs(ref[-1]).max() > 1e-3
+
+
+def test_station_velocities_and_accelerations_as_the_reference_prints_them():
+    """tests/golden/c1_stations_va: the reference run with print_station_velocities and
+    print_station_accelerations = yes.  The oracle's loops give the station rows of tm1 at every
+    step; tm2 / tm3 at a print are the rows one / two steps earlier (zero before the start: calloc,
+    psolve.c:3347), and station_kinematics / station_line restate psolve.c:6705-6787.  The text is
+    the reference's, line for line."""
+    g = H.load("c1_stations_va")
+    p = H.c1_problem()
+    steps = g["stations"].shape[1]
+    tm1 = np.zeros((p["N"], 3))
+    tm2 = np.zeros((p["N"], 3))
+    ids, phi = ho.station_weights(H.C1_STATIONS, H.C1_H, H.C1_NX, H.C1_NY, H.C1_NZ, p["lnid"], p["elem_ijk"])
+    cap = ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, 0, steps, p["dt"], loaded_lnid=g["loaded_lnid"],
+                        forces=g["forces"], cap_lnid=ids).reshape(steps, len(ids), 8, 3)
+    zero = np.zeros((8, 3))
+    ref_lines = str(g["station0_text"]).split("\n")
+    assert ref_lines[0] == ho.station_header(2)
+    worst = 0.0
+    # printed with 7 significant digits: compare in units of each quantity's largest value
+    scale = np.repeat([np.abs(g["stations"][:, :, 1 + 3 * k:4 + 3 * k]).max() for k in range(3)], 3)
+    for t in range(steps):
+        for s in range(len(ids)):
+            v = ho.station_kinematics(phi[s], cap[t, s], cap[t - 1, s] if t >= 1 else zero,
+                                      cap[t - 2, s] if t >= 2 else zero, p["dt"], 2)
+            worst = max(worst, float((np.abs(v - g["stations"][s, t, 1:]) / scale).max()))
+            if s == 0 and t + 1 < len(ref_lines):
+                assert ho.station_line(t * p["dt"], v) == "\n" + ref_lines[t + 1]
+    assert worst <= 6e-7                                  # "% 8e": 7 significant digits
+    assert np.abs(g["stations"][:, :, 7:]).max() > 1e3    # accelerations are really there
