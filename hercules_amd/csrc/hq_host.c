@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -764,6 +765,63 @@ int hqh_station_format_derivs(char* buf, int32_t cap, double time, const double*
     return HQ_OK;
 }
 
+/* out_hdr_t as gcc lays it out (psolve.h:120-186): char[29], 3 x int8, ufid[16] at 32, int64 at 48,
+ * 2 x int32 at 56, 4 x int8 at 64, 5 doubles at 72, int64 at 112, 2 x int32 at 120, int64 at 128. */
+#define HQH_OUT_HDR_BYTES 136
+
+int hqh_wavefield_create(const char* path, const hqh_wavefield_info* w, int32_t quantity)
+{
+    if (!path || !w || (quantity != 1 && quantity != 2) || w->output_rate < 1) return HQ_ERR_ARG;
+    unsigned char h[HQH_OUT_HDR_BYTES];
+    memset(h, 0, sizeof h);
+    snprintf((char*)h, 29, "Hercules 4D output v%03u", 0u);      /* HERCULES_4D_FORMAT_VERSION 0, output.c:104 */
+    h[29] = 0;                                                   /* format_version */
+    h[30] = (unsigned char)-1;                                   /* endiannes: never filled in, output.c:536 */
+    h[31] = (unsigned char)-1;                                   /* platform_id */
+    for (int i = 0; i < 4; i++) { int32_t r = (int32_t)random(); memcpy(h + 32 + 4 * i, &r, 4); }   /* generate_fileid */
+    int32_t i32; int64_t i64;
+    i64 = w->total_nodes; memcpy(h + 48, &i64, 8);
+    i32 = (w->total_time_steps - 1) / w->output_rate + 1; memcpy(h + 56, &i32, 4);   /* get_output_time_step_count */
+    i32 = 3; memcpy(h + 60, &i32, 4);
+    h[64] = 8; h[65] = 2; h[66] = 1; h[67] = (unsigned char)quantity;   /* double, FLOAT64, FLOAT_CLASS */
+    const double d[5] = { w->domain_x, w->domain_y, w->domain_z, w->mesh_ticksize, w->delta_t };
+    memcpy(h + 72, d, 40);
+    i64 = w->total_elements; memcpy(h + 112, &i64, 8);
+    i32 = w->output_rate; memcpy(h + 120, &i32, 4);
+    i32 = w->total_time_steps; memcpy(h + 124, &i32, 4);
+    i64 = (int64_t)time(NULL); memcpy(h + 128, &i64, 8);
+    FILE* fp = fopen(path, "w+");
+    if (!fp) return HQ_ERR_ARG;
+    int ok = fwrite(h, sizeof h, 1, fp) == 1;
+    ok = (fclose(fp) == 0) && ok;
+    return ok ? HQ_OK : HQ_ERR_ARG;
+}
+
+int hqh_wavefield_write(const char* path, int64_t total_nodes, int32_t quantity, int32_t out_step, int64_t base_gnid,
+                        int32_t first_owned, int32_t count, const double* tm1, const double* tm2, double dt)
+{
+    if (!path || !tm1 || (quantity == 2 && !tm2) || (quantity != 1 && quantity != 2) || out_step < 0 || count < 0 ||
+        base_gnid < 0 || base_gnid + count > total_nodes)
+        return HQ_ERR_ARG;
+    FILE* fp = fopen(path, "r+");
+    if (!fp) return HQ_ERR_ARG;
+    /* compute_current_offset, output.c:1224-1229: header + stride * step + 24 * first global id */
+    const off_t off = (off_t)HQH_OUT_HDR_BYTES + (off_t)24 * total_nodes * out_step + (off_t)24 * base_gnid;
+    int ok = fseeko(fp, off, SEEK_SET) == 0;
+    if (ok && quantity == 1) {
+        ok = fwrite(tm1 + 3 * (size_t)first_owned, 24, (size_t)count, fp) == (size_t)count;
+    } else if (ok) {
+        for (int32_t i = 0; i < count && ok; i++) {
+            const double* a = tm1 + 3 * (size_t)(first_owned + i);
+            const double* b = tm2 + 3 * (size_t)(first_owned + i);
+            const double v[3] = { (a[0] - b[0]) / dt, (a[1] - b[1]) / dt, (a[2] - b[2]) / dt };
+            ok = fwrite(v, 24, 1, fp) == 1;
+        }
+    }
+    ok = (fclose(fp) == 0) && ok;
+    return ok ? HQ_OK : HQ_ERR_ARG;
+}
+
 int hqh_station_header(char* buf, int32_t cap, int32_t derivs)
 {
     if (!buf || cap < 160 || derivs < 0 || derivs > 2) return HQ_ERR_ARG;
@@ -855,6 +913,14 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
             if (!pfp[i]) rc = HQ_ERR_ARG;
         }
     }
+    /* 4D wavefield files: whole-field download at the (rare) output steps */
+    const int do_wave = rp->wavefield_rate > 0 && (rp->wavefield_disp_file || rp->wavefield_vel_file);
+    double *w1 = NULL, *w2 = NULL;
+    if (do_wave && rc == HQ_OK) {
+        w1 = (double*)malloc(sizeof(double) * 3 * (size_t)(nharb ? nharb : 1));
+        w2 = (double*)malloc(sizeof(double) * 3 * (size_t)(nharb ? nharb : 1));
+        if (!w1 || !w2) rc = HQ_ERR_NOMEM;
+    }
     int32_t step = step0, end = step0 + nsteps, win_end = step0;
     int ckpt_number = 0;                                         /* CheckpointNumber, io_checkpoint.c:38,126 */
     const int do_ckpt = rp->checkpoint_rate > 0 && rp->checkpoint_dir != NULL;
@@ -865,6 +931,20 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
             rc = hqh_checkpoint_write(ctx, path, step, 0, 1, nharb, nharb);
             if (rc != HQ_OK) break;
             ckpt_number = (ckpt_number + 1) % 2;
+        }
+        if (do_wave && step % rp->wavefield_rate == 0) {         /* solver_output_wavefield, :4278 */
+            rc = hq_download(ctx, w1, rp->wavefield_vel_file ? w2 : NULL);
+            const int32_t cnt = rp->wavefield_count > 0 ? rp->wavefield_count : nharb;
+            const int32_t first = rp->wavefield_count > 0 ? rp->wavefield_first_owned : 0;
+            const int64_t gbase = rp->wavefield_count > 0 ? rp->wavefield_base_gnid : 0;
+            const int64_t total = rp->wavefield_total_nodes > 0 ? rp->wavefield_total_nodes : nharb;
+            if (rc == HQ_OK && rp->wavefield_disp_file)
+                rc = hqh_wavefield_write(rp->wavefield_disp_file, total, 1, step / rp->wavefield_rate, gbase, first,
+                                         cnt, w1, NULL, deltaT);
+            if (rc == HQ_OK && rp->wavefield_vel_file)
+                rc = hqh_wavefield_write(rp->wavefield_vel_file, total, 2, step / rp->wavefield_rate, gbase, first,
+                                         cnt, w1, w2, deltaT);
+            if (rc != HQ_OK) break;
         }
         if (pfp && step % rp->plane_rate == 0) {                 /* solver_output_planes, :4279 */
             rc = hq_gather(ctx, (int32_t)(npp * 8), rp->plane_ids, pu, NULL);
@@ -922,12 +1002,16 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
             int32_t ns = (step / rp->checkpoint_rate + 1) * rp->checkpoint_rate;
             if (ns < next) next = ns;
         }
+        if (do_wave) {
+            int32_t ns = (step / rp->wavefield_rate + 1) * rp->wavefield_rate;
+            if (ns < next) next = ns;
+        }
         rc = hq_run(ctx, next - step);
         step = next;
     }
     if (rc == HQ_OK) rc = hq_sync(ctx);
     if (pfp) for (int32_t i = 0; i < rp->nplanes; i++) if (pfp[i]) fclose(pfp[i]);
-    free(F); free(u); free(disp); free(pu); free(pbuf); free(pfp);
+    free(F); free(u); free(disp); free(pu); free(pbuf); free(pfp); free(w1); free(w2);
     return rc;
 }
 

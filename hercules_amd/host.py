@@ -16,7 +16,7 @@ EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_des
            "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
            "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format", "hqh_station_format_derivs",
-           "hqh_station_kinematics", "hqh_station_header",
+           "hqh_station_kinematics", "hqh_station_header", "hqh_wavefield_create", "hqh_wavefield_write",
            "hqh_octbox_create", "hqh_octbox_destroy", "hqh_octbox_desc", "hqh_octbox_view"]
 
 
@@ -51,7 +51,27 @@ class _RunParams(ctypes.Structure):
                 ("plane_ids", ctypes.c_void_p), ("plane_phi", ctypes.c_void_p),
                 ("plane_mine", ctypes.c_void_p), ("plane_rate", ctypes.c_int32),
                 ("plane_dir", ctypes.c_char_p), ("checkpoint_rate", ctypes.c_int32),
-                ("checkpoint_dir", ctypes.c_char_p), ("station_derivs", ctypes.c_int32)]
+                ("checkpoint_dir", ctypes.c_char_p), ("station_derivs", ctypes.c_int32),
+                ("wavefield_rate", ctypes.c_int32), ("wavefield_disp_file", ctypes.c_char_p),
+                ("wavefield_vel_file", ctypes.c_char_p), ("wavefield_total_nodes", ctypes.c_int64),
+                ("wavefield_base_gnid", ctypes.c_int64), ("wavefield_first_owned", ctypes.c_int32),
+                ("wavefield_count", ctypes.c_int32)]
+
+
+class _WavefieldInfo(ctypes.Structure):
+    _fields_ = [("total_nodes", ctypes.c_int64), ("total_elements", ctypes.c_int64),
+                ("domain_x", ctypes.c_double), ("domain_y", ctypes.c_double), ("domain_z", ctypes.c_double),
+                ("mesh_ticksize", ctypes.c_double), ("delta_t", ctypes.c_double),
+                ("output_rate", ctypes.c_int32), ("total_time_steps", ctypes.c_int32)]
+
+
+def wavefield_create(path, quantity, total_nodes, total_elements, domain, ticksize, dt, rate, total_steps):
+    """hqh_wavefield_create: the reference's 4D output file with its 136-byte header; quantity
+    "displacement" or "velocity"."""
+    w = _WavefieldInfo(int(total_nodes), int(total_elements), float(domain[0]), float(domain[1]), float(domain[2]),
+                       float(ticksize), float(dt), int(rate), int(total_steps))
+    capi._check(load_library().hqh_wavefield_create(os.fsencode(path), ctypes.byref(w),
+                                                    ctypes.c_int32({"displacement": 1, "velocity": 2}[quantity])))
 
 
 class _Plane(ctypes.Structure):
@@ -112,8 +132,12 @@ def _view(ptr, shape, dtype):
 def run_params(loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_window=256,
                station_ids=None, station_phi=None, station_rate=0, station_fn=None, force_file=None,
                planes=None, plane_rate=0, plane_dir=None, checkpoint_rate=0, checkpoint_dir=None,
-               station_derivs=0):
-    """station_derivs: 0 = the station callback gets displacements [n, 3]; 1 = + velocities [n, 6];
+               station_derivs=0, wavefield_rate=0, wavefield_disp_file=None, wavefield_vel_file=None,
+               wavefield_total_nodes=0, wavefield_owned=None):
+    """wavefield_*: every wavefield_rate steps the owned nodes' displacement / velocity go to their
+    place in the 4D file(s) made by wavefield_create; wavefield_owned = (base_gnid, first_owned,
+    count) for a partition (None: the whole mesh).
+    station_derivs: 0 = the station callback gets displacements [n, 3]; 1 = + velocities [n, 6];
     2 = + accelerations [n, 9] (print_station_velocities / _accelerations).
     planes: list of (ids [n,8], phi [n,8]) or (ids, phi, mine [n]) per output plane, written
     every plane_rate steps to <plane_dir>/planedisplacements.<i> (the reference's format)."""
@@ -121,6 +145,15 @@ def run_params(loaded=None, pattern=None, moment=1.0, rise_time=0.1, source_wind
     keep = []
     if checkpoint_rate > 0 and checkpoint_dir is not None:
         rp.checkpoint_rate, rp.checkpoint_dir = int(checkpoint_rate), os.fsencode(checkpoint_dir)
+    if wavefield_rate > 0 and (wavefield_disp_file or wavefield_vel_file):
+        rp.wavefield_rate = int(wavefield_rate)
+        if wavefield_disp_file:
+            rp.wavefield_disp_file = os.fsencode(wavefield_disp_file)
+        if wavefield_vel_file:
+            rp.wavefield_vel_file = os.fsencode(wavefield_vel_file)
+        rp.wavefield_total_nodes = int(wavefield_total_nodes)
+        if wavefield_owned is not None:
+            rp.wavefield_base_gnid, rp.wavefield_first_owned, rp.wavefield_count = [int(v) for v in wavefield_owned]
     if planes and plane_rate > 0 and plane_dir is not None:
         npts = np.array([len(p[0]) for p in planes], np.int32)
         pid = np.ascontiguousarray(np.concatenate([np.asarray(p[0]).reshape(-1, 8) for p in planes]), np.int32)

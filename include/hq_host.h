@@ -20,10 +20,10 @@
  *   hqh_octbox_*      layered boxes on several octree levels with hanging nodes, whole
  *                     or cut into octor's per-rank tables; hqh_layered_column: the Vs rule
  *   hqh_etree_read, hqh_mesh_from_leaves   the reference's mesh.e -> octor's mesh tables
- *   hqh_forcefile_*, hqh_checkpoint_*, hqh_plane_*, hqh_station_format   its file formats
+ *   hqh_forcefile_*, hqh_checkpoint_*, hqh_plane_*, hqh_station_*, hqh_wavefield_*   its file formats
  *
- * The octree mesher itself, the CVM query, the slip-function source generator, the IO-PE
- * pool and the 4D output stay in the reference (out of scope).
+ * The octree mesher itself, the CVM query, the slip-function source generator and the IO-PE
+ * pool stay in the reference (out of scope).
  */
 #ifndef HQ_HOST_H
 #define HQ_HOST_H
@@ -138,7 +138,37 @@ typedef struct {
     /* 0: stations report displacement; 1: + velocity; 2: + velocity and acceleration (needs the
      * patch variant: hq_gather3) */
     int32_t        station_derivs;
+    /* 4D wavefield files (solver_output_wavefield psolve.c:3858-3864, po_do_output
+     * output.c:1358-1400): at every step that is a multiple of wavefield_rate the displacement
+     * and / or velocity of the partition's owned nodes goes to its place in the file(s), which
+     * hqh_wavefield_create made.  wavefield_count = 0: the whole mesh is this partition. */
+    int32_t        wavefield_rate;        /* simulation_output_rate; 0 = never */
+    const char*    wavefield_disp_file;   /* output_displacement_file or NULL */
+    const char*    wavefield_vel_file;    /* output_velocity_file or NULL */
+    int64_t        wavefield_total_nodes;
+    int64_t        wavefield_base_gnid;   /* global id of the first owned node */
+    int32_t        wavefield_first_owned; /* its local id */
+    int32_t        wavefield_count;       /* owned nodes (contiguous in local and global order) */
 } hqh_run_params;
+
+/* The reference's 4D output file (out_hdr_t psolve.h:120-186, 136 bytes; then output_steps blocks
+ * of total_nodes x 3 doubles in global node order). */
+typedef struct {
+    int64_t total_nodes, total_elements;
+    double  domain_x, domain_y, domain_z;
+    double  mesh_ticksize;                /* metres per octor tick */
+    double  delta_t;
+    int32_t output_rate;                  /* simulation_output_rate */
+    int32_t total_time_steps;
+} hqh_wavefield_info;
+/* po_init_output_header + po_create_file (output.c:514-598).  quantity: 1 displacement, 2 velocity. */
+HQ_API int hqh_wavefield_create(const char* path, const hqh_wavefield_info* info, int32_t quantity);
+/* write_displacement / write_velocity (output.c:1230-1352) of output step `out_step` (0-based) for
+ * `count` nodes from local id first_owned whose global ids start at base_gnid; tm1, tm2 the
+ * partition's host arrays (tm2 unused for displacement). */
+HQ_API int hqh_wavefield_write(const char* path, int64_t total_nodes, int32_t quantity, int32_t out_step,
+                               int64_t base_gnid, int32_t first_owned, int32_t count, const double* tm1,
+                               const double* tm2, double delta_t);
 
 /* solver_run: steps [step0, step0 + nsteps) on `ctx` (a context made from `box`; or, _on, from
  * any mesh of `nharbored` nodes and time step deltaT). */

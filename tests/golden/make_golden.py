@@ -62,7 +62,7 @@ use_infinite_qk = no
 
 def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
                   nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None, planes=None,
-                  plane_rate=50, station_derivs=0):
+                  plane_rate=50, station_derivs=0, wavefield_rate=0):
     """Run the reference in a scratch dir; return (dir, stdout)."""
     run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
     src = os.path.join(REF, "examples", "simple")
@@ -88,6 +88,14 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
     text = setkey(text, "simulation_end_time_sec", end_time)
     text = setkey(text, "checkpointing_rate", ckpt_rate)
     text = setkey(text, "type_of_damping", damping)
+    if wavefield_rate:
+        # the parallel 4D output (output.c:886-1404): both quantities, every wavefield_rate steps
+        text = setkey(text, "output_parallel", 1)
+        text = setkey(text, "output_displacement", 1)
+        text = setkey(text, "output_velocity", 1)
+        text = setkey(text, "simulation_output_rate", wavefield_rate)
+        text = setkey(text, "output_displacement_file", "out/disp.h4d")
+        text = setkey(text, "output_velocity_file", "out/vel.h4d")
     if station_derivs >= 1:
         text = setkey(text, "print_station_velocities", "yes")
     if station_derivs >= 2:
@@ -211,6 +219,26 @@ def case_stations_va():
                         station0_lines_300_320="\n".join(lines[-300:-280]), dt=1e-3, end_time=0.6, freq=5.0)
     shutil.rmtree(run)
     print("c1_stations_va ok", st.shape, repr(lines[:4]))
+
+
+def case_wavefield():
+    """The 4D output files (output.c:886-1404: out_hdr_t header, then every simulation_output_rate
+    steps all nodes' displacement (disp.h4d) / velocity (tm1 - tm2) / dt (vel.h4d) in global node
+    order): 350 steps, rate 100 -> 4 output steps; one rank and eight ranks (same bytes expected
+    apart from the header's random id and date)."""
+    arrays = {}
+    for nranks in (1, 8):
+        run, out = run_reference("c1_wavefield", "0.35", 0, wavefield_rate=100, nranks=nranks)
+        for q in ("disp", "vel"):
+            arrays["%s_np%d" % (q, nranks)] = np.frombuffer(open(os.path.join(run, "out", q + ".h4d"), "rb").read(), np.uint8)
+        if nranks == 1:
+            ids, F = read_forces(run)
+        shutil.rmtree(run)
+    np.savez_compressed(os.path.join(HERE, "c1_wavefield.npz"), loaded_lnid=ids, forces=F, rate=100,
+                        dt=1e-3, end_time=0.35, freq=5.0, **arrays)
+    print("c1_wavefield ok", {k: v.shape for k, v in arrays.items()},
+          "np1 == np8 past the header:", np.array_equal(arrays["disp_np1"][136:], arrays["disp_np8"][136:]),
+          np.array_equal(arrays["vel_np1"][136:], arrays["vel_np8"][136:]))
 
 
 def case_planes():
@@ -421,6 +449,7 @@ CASES = {
     "c1_mass": lambda: case_short("c1_mass", damping="mass"),
     "c1_full": case_full,
     "c1_planes": case_planes,
+    "c1_wavefield": case_wavefield,
     "c1_stations_va": case_stations_va,
     "c1_np8": case_np8,
     "c2_mid": case_mid,

@@ -664,3 +664,33 @@ def test_station_files_with_velocities_and_accelerations(tmp_path):
     with pytest.raises(ha.capi.HqError):
         sc.gather3(ids)
     s.close(); sc.close(); box.close()
+
+
+def test_4d_wavefield_files_written_by_the_c_solver_run(tmp_path):
+    """hqh_solver_run with the 4D output on (displacement and velocity of every node every 100
+    steps, the reference's out_hdr_t file format), driven by the reference's force file, against
+    disp.h4d / vel.h4d the reference wrote (tests/golden/c1_wavefield)."""
+    from hercules_amd import host
+    g = H.load("c1_wavefield")
+    box = host.Box(H.C1_NX, H.C1_NY, H.C1_NZ, H.C1_H, 1e-3, 5.0)
+    N, E = box.info["nharbored"], box.info["lenum"]
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    paths = {q: str(tmp_path / (q + ".h4d")) for q in ("disp", "vel")}
+    for q, name in (("disp", "displacement"), ("vel", "velocity")):
+        host.wavefield_create(paths[q], name, N, E, (1000.0, 1000.0, 500.0), 1000.0 / 2 ** 30, 1e-3, 100, 349)
+    s = box.create_solver()
+    rp = box.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=64, wavefield_rate=100,
+                        wavefield_disp_file=paths["disp"], wavefield_vel_file=paths["vel"], wavefield_total_nodes=N)
+    box.solver_run(s, rp, 0, 120)
+    box.solver_run(s, rp, 120, 229)                     # 349 steps in all, as the reference ran
+    for q in ("disp", "vel"):
+        ref, ours = g[q + "_np1"].tobytes(), open(paths[q], "rb").read()
+        assert len(ours) == len(ref)
+        assert ours[:32] == ref[:32] and ours[48:128] == ref[48:128]
+        a = np.frombuffer(ours[136:], "<f8").reshape(4, N, 3)
+        b = np.frombuffer(ref[136:], "<f8").reshape(4, N, 3)
+        assert not a[0].any() and not b[0].any()
+        for k in range(1, 4):
+            assert H.rel_linf(a[k], b[k]) < (TOL if q == "disp" else 1e-7)   # velocity: a difference of two fields / dt
+    s.close(); box.close()

@@ -456,3 +456,45 @@ def test_station_lines_with_velocity_and_acceleration_columns():
                                         ctypes.c_double(1e-3), ctypes.c_int32(derivs), out.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
         assert np.array_equal(out, ho.station_kinematics(phi, u[0], u[1], u[2], 1e-3, derivs))   # same order of operations
+
+
+def test_4d_wavefield_files_equal_the_references(tmp_path):
+    """hqh_wavefield_create / _write against disp.h4d and vel.h4d the reference wrote
+    (tests/golden/c1_wavefield: parallel output, rate 100, 349 steps -> 4 output steps): the header
+    byte for byte except the random file id and the date; the data byte for byte, from the oracle's
+    loops (bit-identical to the reference's), written once as a whole and once as two partitions."""
+    import ctypes
+    g = H.load("c1_wavefield")
+    p = H.c1_problem()
+    N, E = p["N"], p["E"]
+    tick = 1000.0 / 2 ** 30
+    lib = host.load_library()
+    fields = []
+    o1, o2 = np.zeros((N, 3)), np.zeros((N, 3))
+    fields.append((o2.copy(), o1.copy()))
+    for k in range(3):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], o1, o2, 100 * k, 100, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"])
+        fields.append((o2.copy(), o1.copy()))           # tm1, tm2 as the print at step 100 (k + 1) sees them
+    for q, name in ((1, "disp"), (2, "vel")):
+        ref = g[name + "_np1"].tobytes()
+        for parts in (1, 2):
+            path = str(tmp_path / ("%s%d.h4d" % (name, parts)))
+            host.wavefield_create(path, {1: "displacement", 2: "velocity"}[q], N, E, (1000.0, 1000.0, 500.0), tick,
+                                  p["dt"], 100, 349)
+            cuts = [0, N] if parts == 1 else [0, 1000, N]
+            for k, (tm1, tm2) in enumerate(fields):
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    # a partition holds its owned nodes somewhere in its local arrays: here at local id 5
+                    l1 = np.vstack([np.full((5, 3), 7.0), tm1[a:b]])
+                    l2 = np.vstack([np.full((5, 3), 9.0), tm2[a:b]])
+                    rc = lib.hqh_wavefield_write(path.encode(), ctypes.c_int64(N), ctypes.c_int32(q), ctypes.c_int32(k),
+                                                 ctypes.c_int64(a), ctypes.c_int32(5), ctypes.c_int32(b - a),
+                                                 l1.ctypes.data_as(ctypes.c_void_p), l2.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.c_double(p["dt"]))
+                    assert rc == 0
+            ours = open(path, "rb").read()
+            assert len(ours) == len(ref) == 136 + 4 * N * 24
+            assert ours[:32] == ref[:32] and ours[48:128] == ref[48:128]     # all but ufid[16] and generation_date
+            assert ours[136:] == ref[136:]
+    assert np.abs(np.frombuffer(ref[136:], "<f8")).max() > 1e3
