@@ -8,7 +8,8 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "csrc", "libhq_host.so")
+# HQ_HOST_LIB: an instrumented build of hq_host.c (tests/sanitize_host.sh), never a fallback
+_LIBPATH = os.environ.get("HQ_HOST_LIB") or os.path.join(_HERE, "csrc", "libhq_host.so")
 
 DAMPING = {"none": 0, "rayleigh": 1, "mass": 2}
 EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_desc", "hqh_box_lnid",
