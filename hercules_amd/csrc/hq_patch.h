@@ -540,6 +540,11 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     for (int i = own3 + tid; i < 3 * D.nacc; i += T) s_f[i] = 0.0;   /* hanging nodes on owned anchors */
     if (DIAG == 6 && D.nown > 0) HQ_STAMP(1);
 
+    /* HQ_PATCH_WFORM (uniform beta, owned <= nlmax / 2): the LDS image is w = u1 + beta (u1 - u2) of
+     * all local nodes | u1 of the owned | u2 of the owned, which halves the gathers of the element loop */
+    const bool wf = (D.flags & HQ_PATCH_WFORM) != 0;
+    const double wbeta = wf ? pbeta[D.pair_off] : 0.0;
+    const int o2off = 3 * (nlmax / 2);
     hq_pair_data cur;
     const int cstep = (D.flags & HQ_PATCH_UNIFORM) ? 0 : 1;     /* uniform patch: every row reads coefficient 0 */
     if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pidx_off + tid, D.pair_off + cstep * tid);
@@ -565,8 +570,13 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int i = i0 + k * T + tid;
-                if (i < own3) { s_u1[i] = a1[k]; s_u2[i] = a2[k]; s_f[i] = 0.0; }
-                if (i < halo3) { s_u1[own3 + i] = b1[k]; s_u2[own3 + i] = b2[k]; }
+                if (wf) {
+                    if (i < own3) { s_u1[i] = a1[k] + wbeta * (a1[k] - a2[k]); s_u2[i] = a1[k]; s_u2[o2off + i] = a2[k]; s_f[i] = 0.0; }
+                    if (i < halo3) s_u1[own3 + i] = b1[k] + wbeta * (b1[k] - b2[k]);
+                } else {
+                    if (i < own3) { s_u1[i] = a1[k]; s_u2[i] = a2[k]; s_f[i] = 0.0; }
+                    if (i < halo3) { s_u1[own3 + i] = b1[k]; s_u2[own3 + i] = b2[k]; }
+                }
             }
         }
     }
@@ -580,7 +590,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     double np[7];
     if (tid < D.nown) {
         if (iso) {
-            const double* q = nt3 + 3 * ((int64_t)D.base + tid);
+            const double* q = nt3 + 3 * ((int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : tid));
             np[0] = hq_ld<NT>(q);                /* (no copies of loaded values here: a copy waits */
             np[1] = hq_ld<NT>(q + 1);            /*  for the load; the axes pick at the update)    */
             np[4] = hq_ld<NT>(q + 2);
@@ -603,14 +613,22 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
         l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
         double X[8], Y[8], Z[8];
+        if (wf) {
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
-            const double* a = &s_u1[3 * (DIAG == 5 ? (tid & 7) : l[n])];
-            const double* b = &s_u2[3 * (DIAG == 5 ? (tid & 7) : l[n])];
-            double a0 = a[0], a1 = a[1], a2 = a[2];
-            X[n] = a0 + beta * (a0 - b[0]);
-            Y[n] = a1 + beta * (a1 - b[1]);
-            Z[n] = a2 + beta * (a2 - b[2]);
+            for (int n = 0; n < 8; n++) {
+                const double* a = &s_u1[3 * (DIAG == 5 ? (tid & 7) : l[n])];
+                X[n] = a[0]; Y[n] = a[1]; Z[n] = a[2];
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const double* a = &s_u1[3 * (DIAG == 5 ? (tid & 7) : l[n])];
+                const double* b = &s_u2[3 * (DIAG == 5 ? (tid & 7) : l[n])];
+                double a0 = a[0], a1 = a[1], a2 = a[2];
+                X[n] = a0 + beta * (a0 - b[0]);
+                Y[n] = a1 + beta * (a1 - b[1]);
+                Z[n] = a2 + beta * (a2 - b[2]);
+            }
         }
         hq_element_force(X, Y, Z, cur.c1, cur.c2);
 #pragma unroll
@@ -646,7 +664,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     for (int n = tid; n < (DIAG == 3 ? (tid == 0 ? 1 : 0) : D.nown); n += T) {
         if (n != tid) {
             if (iso) {
-                const double* q = nt3 + 3 * ((int64_t)D.base + n);
+                const double* q = nt3 + 3 * ((int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : n));
                 np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
             } else {
                 const double* q = nt + 7 * ((int64_t)D.base + n);
@@ -658,7 +676,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
-            double f = s_f[3 * n + d] + (m2 * s_u1[3 * n + d] - m1 * s_u2[3 * n + d]);
+            const double x1 = wf ? s_u2[3 * n + d] : s_u1[3 * n + d], x2 = wf ? s_u2[o2off + 3 * n + d] : s_u2[3 * n + d];
+            double f = s_f[3 * n + d] + (m2 * x1 - m1 * x2);
             if (NT) __builtin_nontemporal_store(f / np[0], out + d);
             else out[d] = f / np[0];
         }
