@@ -243,6 +243,16 @@ def inproc_diagnostic(args):
                       "neighbors": [b.info["nneighbors"] for b in boxes]}))
 
 
+def flush_c_stdio():
+    """fflush(NULL): libraries that printf (RCCL's banner) must not leave text in a C buffer that
+    would reach stdout after this script's one JSON line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +317,7 @@ def main():
         idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(idbuf, src=0)
         solver.comm_init(idbuf[0])
+        flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
     L = nx * h
     total_steps = args.warmup + args.steps
     if not octree:
@@ -382,9 +393,12 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
     solver.close()
     box.close()
+    flush_c_stdio()
+    barrier()                # every rank's library chatter is out before the one JSON line
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
