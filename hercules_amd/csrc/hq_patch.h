@@ -853,7 +853,13 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         HQ_STAMPD(7);
         const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 7]);   /* drawn two iterations ago */
         const int p3 = HQ_SLOT_PATCH(slot3);
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 8   /* ablation (results wrong): no descriptor load in the loop */
+        hq_patch_desc D3 = D2;
+        D3.base = (p3 < 0 ? 0 : p3) * 512; D3.pair_off = (int64_t)(p3 < 0 ? 0 : p3) * 700;
+        if (p3 < 0) { D3.nown = 0; D3.nhalo = 0; D3.npairs = 0; D3.nacc = 0; D3.flags = 0; }
+#else
         const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
+#endif
         /* the slot of patch k+4, into the ring before the barrier (drawing it from the last, element-less
          * wave instead measured 1 % slower) */
         int32_t drawn = 0;
