@@ -844,7 +844,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0);
 #endif
 #pragma unroll
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 2   /* ablation (results wrong): no node loads */
+#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 2 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no node loads */
             for (int d = 0; d < 3; d++) { a1[d] = 1e-3 * (double)(g & 7); a2[d] = 1e-3; }
 #else
             for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
@@ -863,12 +863,16 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* the slot of patch k+4, into the ring before the barrier (drawing it from the last, element-less
          * wave instead measured 1 % slower) */
         int32_t drawn = 0;
+#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 12 || HQ_PERS_DIAG == 14)   /* ablation: skeleton with a fixed slot order instead of the ticket atomic */
+        if (tid == 0) drawn = xcd * per_xcd + (int)(blockIdx.x >> 3) + (k + 5) * W;
+#else
         if (tid == 0) drawn = HQ_DRAW();
+#endif
 
         HQ_STAMPD(1);
         /* 2. element section of patch k on the current buffer: one element per thread (the
          *    planner keeps patches at <= 1024 elements) */
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 1   /* ablation (results wrong): no element section */
+#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 1 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no element section */
         const bool has_elem = tid < 0;
 #else
         const bool has_elem = tid < D0.npairs;
@@ -947,7 +951,11 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
         }
 
+#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 13 || HQ_PERS_DIAG == 14)   /* ablation: skeleton without the source look-up */
+        if (F && tid0 > 4096) {
+#else
         if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
+#endif
             for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += T) {
                 int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
                 for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * ln + d], F[3 * li + d] * dt2);
@@ -961,7 +969,9 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
             }
         }
+#if !(defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 11)   /* ablation 11 (results wrong): nor this one */
         __syncthreads();
+#endif
         HQ_STAMPD(3);
 
         /* 4. patch k+1 into the other buffer (last read an iteration ago) */
@@ -997,7 +1007,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
             __syncthreads();
         }
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 3   /* ablation (results wrong): no update, no stores */
+#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 3 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no update, no stores */
         if (tid < 0) {
 #else
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
@@ -1016,7 +1026,9 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         }
         for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;
         HQ_STAMPD(5);
+#if !(defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 10 || HQ_PERS_DIAG == 11))   /* ablations 10, 11 (results wrong): skeleton without this barrier */
         __syncthreads();
+#endif
         HQ_STAMPD(6);
         if (p1 < 0) break;
         p0 = p1; p1 = p2; p2 = p3;

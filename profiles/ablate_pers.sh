@@ -3,6 +3,8 @@
 # results are WRONG by construction): 1 = no element section, 2 = no node loads, 3 = no update/stores;
 # 7 = halo rows read from behind the owned rows (dense; results wrong): what do the scattered halo lines cost?
 # 8 = no descriptor load in the loop (the next descriptor is made up from the previous one; results wrong)
+# 9 = 1 + 2 + 3 together: the skeleton of an iteration; 10 = 9 without the end-of-iteration barrier; 11 = 9 without both barriers
+# 12 = 9 with a fixed slot order instead of the ticket atomic; 13 = 9 without the source look-up; 14 = both
 # 4 = probe (results right): two more 8-byte loads per thread per patch (is the load path the limit?).
 for d in ${DIAGS:-0 1 2 3}; do
   HQ_EXTRA_FLAGS=-DHQ_PERS_DIAG=$d python -c "from hercules_amd import build; build.build_solver(force=True)" > /dev/null
