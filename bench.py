@@ -256,8 +256,8 @@ def flush_c_stdio():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("HQ_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="auto", choices=["auto", "scatter", "patch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
