@@ -887,6 +887,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
             l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
             l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 15   /* ablation (results wrong): lane-linear local ids -- no LDS bank conflicts in gather and atomics */
+#pragma unroll
+            for (int n = 0; n < 8; n++) l[n] = (tid + 73 * n) & 511;
+#endif
             if (wf0) {
 #pragma unroll
                 for (int n = 0; n < 8; n++) {
@@ -936,6 +940,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             /* the local ids again from the packed row (4 registers across the force arithmetic
              * instead of 8: the kernel sits at the 128-register limit of 16 waves per CU) */
             asm volatile("" : "+v"(rawk));
+#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 15
+            rawk.x = (uint32_t)((tid & 511) | (((tid + 73) & 511) << 16)); rawk.y = (uint32_t)(((tid + 146) & 511) | (((tid + 219) & 511) << 16));
+            rawk.z = (uint32_t)(((tid + 292) & 511) | (((tid + 365) & 511) << 16)); rawk.w = (uint32_t)(((tid + 438) & 511) | (((tid + 511) & 511) << 16));
+#endif
             l[0] = rawk.x & 0xffff; l[1] = rawk.x >> 16;
             l[2] = rawk.y & 0xffff; l[3] = rawk.y >> 16;
             l[4] = rawk.z & 0xffff; l[5] = rawk.z >> 16;

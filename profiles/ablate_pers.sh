@@ -5,6 +5,7 @@
 # 8 = no descriptor load in the loop (the next descriptor is made up from the previous one; results wrong)
 # 9 = 1 + 2 + 3 together: the skeleton of an iteration; 10 = 9 without the end-of-iteration barrier; 11 = 9 without both barriers
 # 12 = 9 with a fixed slot order instead of the ticket atomic; 13 = 9 without the source look-up; 14 = both
+# 15 = lane-linear local ids in gather and atomics (no LDS bank conflicts; results wrong)
 # 4 = probe (results right): two more 8-byte loads per thread per patch (is the load path the limit?).
 for d in ${DIAGS:-0 1 2 3}; do
   HQ_EXTRA_FLAGS=-DHQ_PERS_DIAG=$d python -c "from hercules_amd import build; build.build_solver(force=True)" > /dev/null
