@@ -65,3 +65,48 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+
+def residue_variant():
+    """Can the planner alone do it (owned rows stay in id = Z order, as the kernel's thread <-> node
+    map wants)?  Owned row mod 32 is the interleaved (x mod 4, y mod 4, z mod 2), so any 4 x 4 x 2
+    window of elements reads 32 distinct classes at every corner IF the halo rows follow the same
+    rule: the aligned 8^3 cube of elements in lanes 0..511 becomes conflict-free (128 passes for 128
+    instructions with 1472 row slots, 162 with the 1024 there are).  But the 217 elements of the -1
+    layer lie on three faces, where only 8 of the 32 classes occur: their 56 instructions keep ~210
+    passes, and the total stays where it is.  Hence the lattice form, whose owned rows are not in id
+    order."""
+    n = 24
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(n, n, n)
+    own = np.nonzero(np.all((node_ijk >= 8) & (node_ijk < 16), axis=1))[0]
+    base, nown = int(own.min()), len(own)
+    owned = set(range(base, base + nown))
+    elems = [e for e in range(len(lnid)) if any(int(v) in owned for v in lnid[e])]
+    halo = sorted({int(v) for e in elems for v in lnid[e]} - owned)
+
+    def res(ijk):
+        x, y, z = int(ijk[0]) % 4, int(ijk[1]) % 4, int(ijk[2]) % 2
+        return (x & 1) | ((y & 1) << 1) | ((z & 1) << 2) | ((x >> 1) << 3) | ((y >> 1) << 4)
+
+    inner = [e for e in elems if np.all((elem_ijk[e] >= 8) & (elem_ijk[e] < 16))]
+    outer = [e for e in elems if e not in set(inner)]
+    for nrows in (1024, 1472):
+        row = {g: g - base for g in owned}
+        free = {c: [r for r in range(512, nrows) if r % 32 == c] for c in range(32)}
+        spill = []
+        for g in sorted(halo, key=lambda g: -int((node_ijk[g] >= 16).any())):     # the +8 faces first
+            c = res(node_ijk[g])
+            if free[c]:
+                row[g] = free[c].pop(0)
+            else:
+                spill.append(g)
+        for g, r in zip(spill, sorted(r for c in free for r in free[c])):
+            row[g] = r
+        print("planner only, %4d row slots (%3d halo nodes off their class): aligned cube %d / %d, whole patch %d / %d"
+              % ((nrows, len(spill)) + passes(list(inner), lnid, row) + passes(list(inner) + outer, lnid, row)))
+
+
+if __name__ == "__main__":
+    main()
+    residue_variant()
