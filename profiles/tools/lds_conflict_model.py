@@ -63,9 +63,6 @@ def main():
     print("lattice rows, lanes on the same lattice (900 lanes, 729 elements):         %d / %d" % passes(lanes, lnid, lat))
 
 
-if __name__ == "__main__":
-    main()
-
 
 
 def residue_variant():
