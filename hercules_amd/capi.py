@@ -16,7 +16,7 @@ HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
-           "hq_run_timed", "hq_dominant_kernel"]
+           "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_check_finite"]
 
 
 class HqError(RuntimeError):
@@ -41,7 +41,7 @@ class _Desc(ctypes.Structure):
                 ("tm1", ctypes.c_void_p), ("tm2", ctypes.c_void_p),
                 ("an_sched", _Schedule), ("dn_sched", _Schedule),
                 ("deltaT", ctypes.c_double), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32), ("node_gnid", ctypes.c_void_p)]
 
 
 class _Info(ctypes.Structure):
@@ -175,6 +175,12 @@ class Solver:
     def sync(self):
         _check(self._lib.hq_sync(self._h))
 
+    def check_finite(self):
+        """Count of NaN / infinite values in tm1, tm2 (solver_check_nan, psolve.c:3769-3782)."""
+        n = ctypes.c_int64()
+        _check(self._lib.hq_check_finite(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def run_timed(self, nsteps):
         tot, ker = ctypes.c_double(), ctypes.c_double()
         _check(self._lib.hq_run_timed(self._h, ctypes.c_int32(nsteps), ctypes.byref(tot), ctypes.byref(ker)))
@@ -183,9 +189,10 @@ class Solver:
     def dominant_kernel(self):
         return self._lib.hq_dominant_kernel(self._h).decode()
 
-    def download(self):
+    def download(self, want_tm2=True):
+        """(tm1, tm2) = u(step dt), u((step - 1) dt); tm2 is None with want_tm2=False."""
         tm1 = np.empty((self.N, 3))
-        tm2 = np.empty((self.N, 3))
+        tm2 = np.empty((self.N, 3)) if want_tm2 else None
         _check(self._lib.hq_download(self._h, _ptr(tm1), _ptr(tm2)))
         return tm1, tm2
 
@@ -218,6 +225,17 @@ class Solver:
         f = np.empty((self.N, 3))
         _check(self._lib.hq_download_force(self._h, _ptr(f)))
         return f
+
+
+PLAN_REPORT = ("patches", "lattice_patches", "pairs", "distinct_row_blocks", "gather_passes", "gather_instructions",
+               "lattice_gather_passes", "faults")
+
+
+def plan_check(desc):
+    """hq_plan_check on a filled _Desc: the planner's host-only self-check (no device needed)."""
+    rep = (ctypes.c_int64 * 8)()
+    _check(load_library().hq_plan_check(ctypes.byref(desc), rep))
+    return dict(zip(PLAN_REPORT, [int(v) for v in rep]))
 
 
 def comm_unique_id():

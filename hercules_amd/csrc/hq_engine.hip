@@ -78,7 +78,7 @@ struct hq_rccl {
     const char* (*GetErrorString)(int);
 };
 static hq_rccl g_rccl = {};
-enum { HQ_NCCL_DOUBLE = 8 };   /* ncclFloat64, rccl.h ncclDataType_t */
+enum { HQ_NCCL_INT64 = 4, HQ_NCCL_DOUBLE = 8 };   /* ncclInt64, ncclFloat64: rccl.h ncclDataType_t */
 
 static int hq_rccl_load(void)
 {
@@ -128,6 +128,11 @@ struct hq_dev_schedule {
     double*  d_s_out = nullptr;  /* sharing      send   [stotal][3]                   */
     double*  d_s_in = nullptr;   /* contribution recv   [stotal][3]                   */
     int32_t  ctotal = 0, stotal = 0;
+    /* HQ_DEBUG_HALO: every record travels with the global identity of its node (psolve.c:5002-5007) */
+    int64_t* d_c_out_id = nullptr;
+    int64_t* d_c_in_id = nullptr;
+    int64_t* d_s_out_id = nullptr;
+    int64_t* d_s_in_id = nullptr;
 };
 
 struct hq_ctx {
@@ -181,6 +186,10 @@ struct hq_ctx {
     int32_t* d_sd_ent = nullptr;      /* other ranks share: [nSD][3] {src slot, dst slot, deps} */
     /* patch variant */
     hq_patch_plan plan;
+    /* HQ_DEBUG_HALO (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) */
+    bool debug_halo = false;
+    int64_t* d_gkey = nullptr;        /* [N] global identity of every harbored node          */
+    int32_t* d_halo_err = nullptr;    /* [2] records whose identity did not match; non-finite values seen by hq_check_finite */
     /* timing */
     std::vector<hipEvent_t> ev;     /* per-launch marks */
     hipEvent_t ev_span[2] = { nullptr, nullptr };
@@ -317,6 +326,32 @@ __global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
     *p = add ? (*p + in[t]) : in[t];
 }
 
+/* HQ_DEBUG_HALO: the sender's node identities beside the records, checked on receipt */
+__global__ void hq_k_pack_id(int32_t count, const int32_t* __restrict__ map, const int64_t* __restrict__ gkey,
+                             int64_t* __restrict__ out)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[t] = gkey[map[t]];
+}
+
+__global__ void hq_k_check_id(int32_t count, const int32_t* __restrict__ map, const int64_t* __restrict__ gkey,
+                              const int64_t* __restrict__ in, int32_t* __restrict__ err)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count && in[t] != gkey[map[t]]) atomicAdd(err, 1);
+}
+
+/* solver_check_nan (psolve.c:3769-3782): count the values that are not finite */
+__global__ void hq_k_count_nonfinite(int64_t n, const double* __restrict__ a, int32_t* __restrict__ cnt)
+{
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = a[i];
+        bad += !(fabs(v) <= 1.7976931348623157e308);          /* NaN and +-inf fail the comparison */
+    }
+    if (bad) atomicAdd(cnt, bad);
+}
+
 __global__ void hq_k_gather(int32_t n, const int32_t* __restrict__ ids,
                             const double* __restrict__ a, const double* __restrict__ b,
                             double* __restrict__ oa, double* __restrict__ ob)
@@ -337,7 +372,8 @@ static inline unsigned hq_blocks(int64_t n, int bs) { return (unsigned)((n + bs 
 static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* out)
 {
     auto load = [&](int32_t count, const hq_messenger* list, std::vector<hq_dev_messenger>& v,
-                    int32_t** d_map, double** d_out, double** d_in, int32_t* total) -> int {
+                    int32_t** d_map, double** d_out, double** d_in, int32_t* total, int64_t** d_out_id,
+                    int64_t** d_in_id) -> int {
         std::vector<int32_t> map;
         for (int32_t i = 0; i < count; i++) {
             if (list[i].nodecount < 0 || (list[i].nodecount > 0 && !list[i].mapping))
@@ -358,11 +394,17 @@ static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* 
             HQ_TRY(hq_dev_alloc(c, d_out, map.size() * 3));
             HQ_TRY(hq_dev_alloc(c, d_in, map.size() * 3));
             HQ_HIP(hipMemcpy(*d_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+            if (c->debug_halo) {
+                HQ_TRY(hq_dev_alloc(c, d_out_id, map.size()));
+                HQ_TRY(hq_dev_alloc(c, d_in_id, map.size()));
+            }
         }
         return HQ_OK;
     };
-    HQ_TRY(load(in->c_count, in->first_c, out->c, &out->d_cmap, &out->d_c_out, &out->d_c_in, &out->ctotal));
-    HQ_TRY(load(in->s_count, in->first_s, out->s, &out->d_smap, &out->d_s_out, &out->d_s_in, &out->stotal));
+    HQ_TRY(load(in->c_count, in->first_c, out->c, &out->d_cmap, &out->d_c_out, &out->d_c_in, &out->ctotal,
+                &out->d_c_out_id, &out->d_c_in_id));
+    HQ_TRY(load(in->s_count, in->first_s, out->s, &out->d_smap, &out->d_s_out, &out->d_s_in, &out->stotal,
+                &out->d_s_out_id, &out->d_s_in_id));
     out->d_cmap_f = out->d_cmap;
     out->d_smap_f = out->d_smap;
     return HQ_OK;
@@ -397,6 +439,11 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     if (!c->comm && !c->group) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init or hq_group_link%s", "");
     if (total)
         hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_out);
+    /* HQ_DEBUG_HALO: the global identity of every record's node travels with it (psolve.c:5002-5007) */
+    int64_t* d_out_id = contribution ? s->d_c_out_id : s->d_s_out_id;
+    int64_t* d_in_id = contribution ? s->d_s_in_id : s->d_c_in_id;
+    if (c->debug_halo && total)
+        hq_k_pack_id<<<hq_blocks(total, 256), 256, 0, xs>>>(total, contribution ? s->d_cmap : s->d_smap, c->d_gkey, d_out_id);
     if (c->group) {
         for (auto& m : snd) {
             if (!m.nodecount) continue;
@@ -410,6 +457,12 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
                 return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
             HQ_HIP(hipMemcpyAsync(p_in + 3 * (int64_t)pm->offset, d_out + 3 * (int64_t)m.offset,
                                   sizeof(double) * 3 * (size_t)m.nodecount, hipMemcpyDeviceToDevice, xs));
+            if (c->debug_halo) {
+                if (!peer->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO must be set for every member of a group%s", "");
+                int64_t* p_in_id = contribution ? ps->d_s_in_id : ps->d_c_in_id;
+                HQ_HIP(hipMemcpyAsync(p_in_id + pm->offset, d_out_id + m.offset, sizeof(int64_t) * (size_t)m.nodecount,
+                                      hipMemcpyDeviceToDevice, xs));
+            }
         }
         HQ_HIP(hipEventRecord(c->ev_sent, xs));
     } else {
@@ -422,9 +475,28 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
             if (m.nodecount)
                 HQ_NCCL(g_rccl.Send(d_out + 3 * (int64_t)m.offset, (size_t)m.nodecount * 3, HQ_NCCL_DOUBLE,
                                     m.procid, c->comm, xs));
+        if (c->debug_halo) {
+            for (auto& m : rcv)
+                if (m.nodecount)
+                    HQ_NCCL(g_rccl.Recv(d_in_id + m.offset, (size_t)m.nodecount, HQ_NCCL_INT64, m.procid, c->comm, xs));
+            for (auto& m : snd)
+                if (m.nodecount)
+                    HQ_NCCL(g_rccl.Send(d_out_id + m.offset, (size_t)m.nodecount, HQ_NCCL_INT64, m.procid, c->comm, xs));
+        }
         HQ_NCCL(g_rccl.GroupEnd());
     }
     return HQ_OK;
+}
+
+/* HQ_DEBUG_HALO: every received record must name the node it is unpacked into (psolve.c:5058-5069);
+ * mismatches are counted and reported by hq_sync */
+static void hq_xchg_check(hq_ctx* c, hq_dev_schedule* s, bool contribution, hipStream_t xs)
+{
+    if (!c->debug_halo) return;
+    const int32_t total = contribution ? s->stotal : s->ctotal;
+    if (total)
+        hq_k_check_id<<<hq_blocks(total, 256), 256, 0, xs>>>(total, contribution ? s->d_smap : s->d_cmap, c->d_gkey,
+                                                              contribution ? s->d_s_in_id : s->d_c_in_id, c->d_halo_err);
 }
 
 static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution, bool force_table)
@@ -438,6 +510,7 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     if (c->group)
         for (auto& m : rcv)
             if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+    hq_xchg_check(c, s, contribution, xs);
     if (!contribution) {
         /* sharing: every non-owned node has exactly one owner, one launch covers all records */
         int32_t total = s->ctotal;
@@ -590,6 +663,7 @@ static int hq_phase(hq_ctx* c, int ph)
             if (c->group)
                 for (auto& m : c->an.s)
                     if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+            hq_xchg_check(c, &c->an, true, xs);
             if (c->nOI)
                 hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
                     c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
@@ -674,6 +748,11 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
             sd.push_back(deps);
         }
     }
+    /* a node I own (s-list) cannot also be one I receive from its owner (c-list) */
+    for (int32_t i = 0; i < d->an_sched.s_count; i++)
+        for (int32_t k = 0; k < d->an_sched.first_s[i].nodecount; k++)
+            if (nonowned[d->an_sched.first_s[i].mapping[k]])
+                return hq_fail(HQ_ERR_ARG, "a node is listed both as owned (s-list) and as harbored from another rank (c-list)%s", "");
     std::vector<int32_t> oin, ois;
     for (int32_t n = 0; n < c->N; n++)
         if (slot[n] >= 0 && !nonowned[n]) { oin.push_back(n); ois.push_back(slot[n]); }
@@ -804,22 +883,51 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_dev_alloc(c, &c->d_dn_id, (size_t)c->ldnnum)) != HQ_OK) return bail(rc);
         if ((rc = hq_dev_alloc(c, &c->d_dn_ptr, (size_t)c->ldnnum + 1)) != HQ_OK) return bail(rc);
         if ((rc = hq_dev_alloc(c, &c->d_dn_anchor, (size_t)na)) != HQ_OK) return bail(rc);
-        hipMemcpy(c->d_dn_id, d->dn_ldnid, sizeof(int32_t) * c->ldnnum, hipMemcpyHostToDevice);
-        hipMemcpy(c->d_dn_ptr, d->dn_ptr, sizeof(int32_t) * (c->ldnnum + 1), hipMemcpyHostToDevice);
-        hipMemcpy(c->d_dn_anchor, d->dn_lanid, sizeof(int32_t) * na, hipMemcpyHostToDevice);
+        if (hipMemcpy(c->d_dn_id, d->dn_ldnid, sizeof(int32_t) * c->ldnnum, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_dn_ptr, d->dn_ptr, sizeof(int32_t) * (c->ldnnum + 1), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_dn_anchor, d->dn_lanid, sizeof(int32_t) * na, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(hq_fail(HQ_ERR_DEVICE, "dangling-node table upload failed%s", ""));
     }
 
-    /* element coefficients: (c1, c2, beta = c3/c1) */
+    if ((rc = hq_dev_alloc(c, &c->d_halo_err, 2)) != HQ_OK) return bail(rc);
+    if (hipMemset(c->d_halo_err, 0, 2 * sizeof(int32_t)) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
+    if (getenv("HQ_DEBUG_HALO") && atoi(getenv("HQ_DEBUG_HALO")) != 0 && c->nranks > 1) {
+        /* the reference's -DDEBUG exchange: every halo record carries the global id of its node and the
+         * receiver checks it (psolve.c:5002-5007, 5058-5069).  Identity = node_t.gnid where the caller
+         * passes it, else a 64-bit mix of the node's coordinates (equal on every rank that harbors it). */
+        if (!d->node_gnid && !d->node_xyz)
+            return bail(hq_fail(HQ_ERR_ARG, "HQ_DEBUG_HALO needs hq_desc.node_gnid or node_xyz%s", ""));
+        std::vector<int64_t> key((size_t)c->N);
+        for (int64_t n = 0; n < c->N; n++) {
+            if (d->node_gnid) { key[(size_t)n] = d->node_gnid[n]; continue; }
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+            for (int k = 0; k < 3; k++) {
+                h ^= (uint64_t)(uint32_t)d->node_xyz[3 * n + k];
+                h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29;
+            }
+            key[(size_t)n] = (int64_t)h;
+        }
+        if ((rc = hq_dev_alloc(c, &c->d_gkey, (size_t)c->N)) != HQ_OK) return bail(rc);
+        if (hipMemcpy(c->d_gkey, key.data(), sizeof(int64_t) * (size_t)c->N, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(hq_fail(HQ_ERR_DEVICE, "node identity upload failed%s", ""));
+        c->debug_halo = true;
+    }
+
+    /* element coefficients: (c1, c2, beta = c3/c1).  The fused product needs c3/c1 == c4/c2 (Rayleigh:
+     * both are b/dt, psolve.c:3386-3409); a table that applies different ratios to K1 and K2 is refused */
     std::vector<double> c1(c->E), c2(c->E), beta(c->E);
     for (int64_t e = 0; e < c->E; e++) {
         const double* ep = d->eTable + 4 * e;
         c1[e] = ep[0]; c2[e] = ep[1];
         beta[e] = (ep[0] != 0.0) ? ep[2] / ep[0] : ((ep[1] != 0.0) ? ep[3] / ep[1] : 0.0);
+        const double lhs = ep[2] * ep[1], rhs = ep[3] * ep[0];
+        if (fabs(lhs - rhs) > 1e-12 * std::max(fabs(lhs), fabs(rhs)))
+            return bail(hq_fail(HQ_ERR_ARG, "eTable is not Rayleigh-proportional (c3/c1 != c4/c2): not the table solver_init builds%s", ""));
     }
 
     if (variant == HQ_VARIANT_SCATTER) {
         if ((rc = hq_dev_alloc(c, &c->d_force, n3)) != HQ_OK) return bail(rc);
-        hipMemset(c->d_force, 0, sizeof(double) * n3);
+        if (hipMemset(c->d_force, 0, sizeof(double) * n3) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
         c->Epad = (c->E + 63) & ~63;
         std::vector<int32_t> soa((size_t)8 * c->Epad, 0);
         for (int64_t e = 0; e < c->E; e++)
@@ -828,10 +936,11 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_dev_alloc(c, &c->d_c1, (size_t)c->E)) != HQ_OK) return bail(rc);
         if ((rc = hq_dev_alloc(c, &c->d_c2, (size_t)c->E)) != HQ_OK) return bail(rc);
         if ((rc = hq_dev_alloc(c, &c->d_beta, (size_t)c->E)) != HQ_OK) return bail(rc);
-        hipMemcpy(c->d_lnid, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice);
-        hipMemcpy(c->d_c1, c1.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
-        hipMemcpy(c->d_c2, c2.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
-        hipMemcpy(c->d_beta, beta.data(), sizeof(double) * c->E, hipMemcpyHostToDevice);
+        if (hipMemcpy(c->d_lnid, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_c1, c1.data(), sizeof(double) * c->E, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_c2, c2.data(), sizeof(double) * c->E, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_beta, beta.data(), sizeof(double) * c->E, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(hq_fail(HQ_ERR_DEVICE, "element table upload failed%s", ""));
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
     } else {
@@ -860,12 +969,105 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));
         c->bytes += pb;
+        /* one persistent workgroup per CU, the same number on every XCD (workgroups are dealt to the XCDs round-robin) */
+        c->plan.grid_cus = std::max(8, prop.multiProcessorCount & ~7);
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
     *out = c;
+    return HQ_OK;
+}
+
+/*
+ * Host-only self-check of the patch planner (no device needed; the -m "not gpu" tests call it):
+ * plans the mesh exactly as hq_create does and verifies that every element row names the LDS rows
+ * of its element's eight nodes, that the accumulate flags are exactly the owned nodes and the
+ * hanging nodes on owned anchors, and counts the LDS passes of the gathers under the bank rule of
+ * MI355X_MICROARCH.md (32-lane groups, rows distinct modulo 32).
+ * report: {patches, lattice patches, (patch, element) pairs, distinct element-row blocks,
+ *          gather passes, gather instructions (per 32-lane group), gather passes of the lattice patches
+ *          (= 23 groups x 8 corners each when conflict-free), faults}
+ */
+extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
+{
+    if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid))
+        return hq_fail(HQ_ERR_ARG, "inconsistent mesh description%s", "");
+    const int64_t E = d->lenum, N = d->nharbored;
+    for (int64_t i = 0; i < E * 8; i++)
+        if (d->lnid[i] < 0 || d->lnid[i] >= N) return hq_fail(HQ_ERR_ARG, "lnid out of range%s", "");
+    std::vector<char> shared_dn((size_t)N, 0);
+    for (int32_t i = 0; i < d->dn_sched.s_count; i++)
+        for (int32_t k = 0; k < d->dn_sched.first_s[i].nodecount; k++) shared_dn[d->dn_sched.first_s[i].mapping[k]] = 1;
+    std::vector<int32_t> l_id, l_ptr(1, 0), l_anc;
+    for (int32_t k = 0; k < d->ldnnum; k++) {
+        if (shared_dn[d->dn_ldnid[k]]) continue;
+        l_id.push_back(d->dn_ldnid[k]);
+        for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) l_anc.push_back(d->dn_lanid[a]);
+        l_ptr.push_back((int32_t)l_anc.size());
+    }
+    hq_dangling dn;
+    dn.n = (int32_t)l_id.size(); dn.id = l_id.data(); dn.ptr = l_ptr.data(); dn.anchor = l_anc.data();
+    hq_patch_cfg cfg = hq_patch_cfg_from_env();
+    if (dn.n > 0 && cfg.vmax == 0) cfg.vmax = 384;
+    hq_patch_host H;
+    const bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && d->node_xyz && cfg.pmax >= HQ_LAT_ACC;
+    if (hq_patch_plan_host(cfg, E, N, d->lnid, d->node_xyz, dn, want_lattice, &H) != 0)
+        return hq_fail(HQ_ERR_ARG, "patch plan: %s", hq_patch_error());
+    const hq_lattice_tab& T = hq_lattice();
+    int64_t nlat = 0, passes = 0, lpasses = 0, instr = 0, bad = 0;
+    std::vector<int32_t> covered((size_t)N, 0);
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : nlat, passes, lpasses, instr, bad)
+    for (int64_t p = 0; p < (int64_t)H.desc.size(); p++) {
+        const hq_patch_desc& D = H.desc[(size_t)p];
+        const bool lat = H.lattice[(size_t)p] != 0;
+        nlat += lat;
+        std::vector<int32_t> node_of_row(lat ? HQ_LAT_ROWS : (size_t)(D.nown + D.nhalo), -1);
+        for (int32_t t = 0; t < D.nown + D.nhalo; t++) {
+            const int32_t g = t < D.nown ? D.base + t : H.halo[(size_t)D.halo_off + (t - D.nown)];
+            const int32_t r = lat ? (int32_t)T.row_of_local[t] : t;
+            if (r < 0 || r >= (int32_t)node_of_row.size() || node_of_row[r] >= 0) { bad++; continue; }
+            node_of_row[r] = g;
+        }
+        for (int32_t t = 0; t < D.nown; t++) {
+#pragma omp atomic
+            covered[(size_t)D.base + t]++;
+        }
+        const uint16_t* rows = H.pidx.data() + 8 * (size_t)D.pidx_off;
+        for (int32_t q = 0; q < D.npairs; q++) {
+            const int32_t* id = d->lnid + 8 * (int64_t)H.pelem[(size_t)D.pair_off + q];
+            for (int c = 0; c < 8; c++) {
+                const int32_t r = rows[8 * (size_t)q + c] & HQ_PIDX_ROW;
+                const bool acc = (rows[8 * (size_t)q + c] & HQ_PIDX_ACC) != 0;
+                if (r >= (int32_t)node_of_row.size() || node_of_row[r] != id[c]) { bad++; continue; }
+                const bool owned = id[c] >= D.base && id[c] < D.base + D.nown;
+                /* an accumulator: owned nodes, and (id-ordered patches) the first nacc - nown halo rows */
+                const bool want = owned || (!lat && r < D.nacc);
+                if (acc != want) bad++;
+                if (lat && acc && r >= HQ_LAT_ACC) bad++;
+            }
+        }
+        for (int32_t w = 0; w < D.npairs; w += 32)
+            for (int c = 0; c < 8; c++) {
+                int cls[32] = { 0 }, mx = 0;
+                for (int32_t q = w; q < std::min(w + 32, D.npairs); q++) {
+                    /* identical rows broadcast; distinct rows of one class take a pass each */
+                    const int32_t r = rows[8 * (size_t)q + c] & HQ_PIDX_ROW;
+                    bool dup = false;
+                    for (int32_t q2 = w; q2 < q; q2++) dup |= ((rows[8 * (size_t)q2 + c] & HQ_PIDX_ROW) == r);
+                    if (!dup) mx = std::max(mx, ++cls[r & 31]);
+                }
+                passes += mx;
+                if (lat) lpasses += mx;
+                instr++;
+            }
+    }
+    for (int64_t n = 0; n < N; n++) if (covered[(size_t)n] != 1) bad++;
+    report[0] = (int64_t)H.desc.size(); report[1] = nlat; report[2] = (int64_t)H.pelem.size();
+    report[3] = H.ndistinct; report[4] = passes; report[5] = instr;
+    report[6] = lpasses; report[7] = bad;
+    if (bad) return hq_fail(HQ_ERR_STATE, "patch plan self-check failed%s", "");
     return HQ_OK;
 }
 
@@ -879,7 +1081,9 @@ extern "C" int hq_destroy(hq_ctx* c)
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
-                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_ent };
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_ent,
+                     c->d_gkey, c->d_halo_err, c->an.d_c_out_id, c->an.d_c_in_id, c->an.d_s_out_id, c->an.d_s_in_id,
+                     c->dn.d_c_out_id, c->dn.d_c_in_id, c->dn.d_s_out_id, c->dn.d_s_in_id };
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->an.d_cmap_f && c->an.d_cmap_f != c->an.d_cmap) hipFree(c->an.d_cmap_f);
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
@@ -1035,6 +1239,36 @@ extern "C" int hq_sync(hq_ctx* c)
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
+    if (c->debug_halo) {
+        int32_t bad = 0;
+        HQ_HIP(hipMemcpy(&bad, c->d_halo_err, sizeof bad, hipMemcpyDeviceToHost));
+        if (bad) {
+            char n[32];
+            snprintf(n, sizeof n, "%d", bad);
+            return hq_fail(HQ_ERR_COMM, "HQ_DEBUG_HALO: %s halo records arrived for another node than the schedule names "
+                                        "(global node ids do not match, psolve.c:5058-5069)", n);
+        }
+    }
+    return HQ_OK;
+}
+
+/* solver_check_nan (psolve.c:3769-3782) on the device-resident fields: tm1, tm2 (and the force
+ * accumulator of the scatter variant).  *nonfinite = number of NaN / infinite values; the call
+ * itself fails only on runtime errors (the reference aborts; here the caller decides). */
+extern "C" int hq_check_finite(hq_ctx* c, int64_t* nonfinite)
+{
+    if (!c || !nonfinite) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hq_quiesce(c));
+    HQ_HIP(hipMemsetAsync(c->d_halo_err + 1, 0, sizeof(int32_t), c->stream));
+    const int64_t n3 = 3 * (int64_t)c->N;
+    const double* arr[3] = { c->d_u[c->now], c->d_u[c->prev], c->d_force };
+    for (const double* a : arr)
+        if (a) hq_k_count_nonfinite<<<2048, 256, 0, c->stream>>>(n3, a, c->d_halo_err + 1);
+    int32_t bad = 0;
+    HQ_HIP(hipMemcpyAsync(&bad, c->d_halo_err + 1, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HQ_HIP(hipStreamSynchronize(c->stream));
+    *nonfinite = bad;
     return HQ_OK;
 }
 
@@ -1081,8 +1315,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
-    if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
-    return (hq_patch_kernel_choice() == 5 && c->plan.cfg.pmax <= HQ_ROLE_ETHREADS) ? "hq_k_patch_roles" : "hq_k_patch_pers";
+    return hq_patch_uses_pers(&c->plan) ? "hq_k_patch_pers" : "hq_k_patch_step";
 }
 
 static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3);

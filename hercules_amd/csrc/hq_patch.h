@@ -63,7 +63,7 @@ static hq_patch_cfg hq_patch_cfg_from_env(void)
     if (c.pmerge > c.pmax) c.pmerge = c.pmax;
     if (c.pmerge < 1) c.pmerge = 1;
     if (c.nlmax < c.pmax + 8) c.nlmax = c.pmax + 8;
-    if (c.nlmax > 0xffff) c.nlmax = 0xffff;
+    if (c.nlmax > 0x7fff) c.nlmax = 0x7fff;          /* HQ_PIDX_ROW: 15-bit rows in the element row */
     c.vmax = geti("HQ_PATCH_VMAX", c.vmax);
     /* LDS: (6 nlmax + 3 (pmax + vmax)) doubles must fit 160 KiB */
     while ((6 * (size_t)c.nlmax + 3 * (size_t)(c.pmax + c.vmax)) * 8 > 160 * 1024) c.nlmax -= 8;
@@ -86,8 +86,9 @@ struct hq_patch_desc {
 #define HQ_PATCH_ISO 1
 #define HQ_PATCH_UNIFORM 2   /* every element of the patch has the same (c1, c2, beta): read once */
 #define HQ_PATCH_WFORM 4     /* uniform, and owned nodes <= nlmax / 2: hq_k_patch_pers keeps w = u1 + beta (u1 - u2) */
-#define HQ_PATCH_NTSAME 8    /* ISO, and every owned node has the same n_t row: all lanes read the first one */
                              /* of all local nodes and u1, u2 of the owned ones in LDS instead of u1, u2 of all */
+#define HQ_PATCH_NTSAME 8    /* ISO, and every owned node has the same n_t row: all lanes read the first one */
+#define HQ_PATCH_LATTICE 16  /* rows and lanes of hq_lattice(): thread t's LDS row is lat_row[t] (hq_k_patch_pers only) */
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -96,6 +97,7 @@ struct hq_patch_host {
     std::vector<int32_t>  halo;      /* halo node ids, patch p's list at p * hstride */
     int32_t               hstride = 0;
     int32_t               ndistinct = 0;   /* distinct local connectivities among the patches */
+    std::vector<char>     lattice;   /* [P] 1 = lattice patch: rows and lanes of hq_lattice()      */
     std::vector<int32_t>  ds_ptr;    /* [P+1] hanging-node distribution entries per patch */
     std::vector<int32_t>  ds_ent;    /* [n][3] = {src local, dst local (owned anchor), deps} */
 };
@@ -129,7 +131,12 @@ struct hq_patch_plan {
     int32_t* d_if_ptr = nullptr;     /* [npatches + 1]                    */
     int32_t* d_if_ent = nullptr;     /* [n][2] = {local node, slot}       */
     int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
-    int32_t* d_tickets = nullptr;    /* [16]: per XCD, next slot of hq_k_patch_pers' work queue; workgroups done */
+    int32_t* d_tickets = nullptr;    /* per XCD, HQ_TICKET_STRIDE ints apart: {next slot of hq_k_patch_pers' work queue, workgroups done} */
+    uint16_t* d_lat_row = nullptr;   /* [1024] LDS row of thread t's local node in a lattice patch             */
+    int32_t  nlattice = 0;           /* lattice patches                                                        */
+    int32_t  nrows = 0;              /* rows of hq_k_patch_pers' LDS image                                     */
+    int32_t  grid_cus = 256;         /* persistent workgroups to launch: the device's CU count, a multiple of 8 */
+    std::vector<char> patch_lat;     /* host copy of the lattice flags                                         */
     int32_t  nb = 0;
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
     int32_t* d_ds_ent = nullptr;
@@ -140,6 +147,13 @@ struct hq_patch_plan {
     std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
     std::vector<int32_t> patch_nown;
 };
+
+/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 0 = hq_k_patch_step always */
+static int hq_patch_kernel_choice(void)
+{
+    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 4;
+    return v;
+}
 
 static thread_local std::string g_patch_err;
 static const char* hq_patch_error(void) { return g_patch_err.c_str(); }
@@ -157,6 +171,158 @@ static inline uint64_t hq_spread3(uint64_t v)
     v = (v | (v << 4))  & 0x10c30c30c30c30c3ULL;
     v = (v | (v << 2))  & 0x1249249249249249ULL;
     return v;
+}
+
+/*
+ * LATTICE patches.  In a uniformly refined region a patch is 8x8x8 owned nodes, their one ring
+ * (a 10x10x10 node lattice, (I, J, K) in [0,10)^3 with the owned nodes at 1..8) and 9x9x9 elements.
+ * LDS operations are served in groups of 32 lanes; a b64 access to 24-byte rows is one pass when the
+ * 32 rows are distinct modulo 32 (MI355X_MICROARCH.md, LDS; profiles/micro/lds_ops.hip: 2.3 against
+ * 4.0 cycles per ds_read_b64, 8 against 16 per ds_add_f64 for id-ordered rows).  With
+ *
+ *     element (ei, ej, ek)  ->  lane  ei + 9 ej + 81 ek                 (729 dense lanes, 12 waves)
+ *     node    (I, J, K)     ->  row   = I + 9 J + 81 K  (mod 32)
+ *
+ * corner c = (di, dj, dk) of lane L is the row  L + di + 9 dj + 81 dk  (mod 32): 32 consecutive
+ * lanes hit 32 different classes for every corner, in the gathers and in the atomics alike.  Nodes
+ * with I, J < 9 sit at exactly I + 9 J + 81 K (rows 0..809, so the accumulator of an owned node is its
+ * row, < 729); the 190 nodes of the I = 9 and J = 9 faces take the first free row of their class
+ * behind them (1051 rows in all).  The halo list of such a patch is kept in one canonical order
+ * (neighbour cube by cube, Z-order inside), so thread t's row is the same for every lattice patch and
+ * is read once per launch (lat_row), and all of them share ONE element-row block.
+ */
+#define HQ_LAT_ROWS 1056         /* image rows of a lattice patch (1051, rounded up to a multiple of 32) */
+#define HQ_LAT_ACC  729          /* accumulator rows: owned nodes sit at rows < 729                      */
+#define HQ_LAT_NOWN 512
+#define HQ_LAT_NHALO 488
+#define HQ_LAT_NELEM 729
+#define HQ_PIDX_ACC 0x8000u      /* element-row entry: local row | HQ_PIDX_ACC where the patch accumulates that corner */
+#define HQ_PIDX_ROW 0x7fffu
+
+struct hq_lattice_tab {
+    uint16_t row_of_ijk[1000];   /* I + 10 J + 100 K -> LDS row                               */
+    int16_t  local_of_ijk[1000]; /* I + 10 J + 100 K -> canonical local node (owned: Z-order) */
+    uint16_t row_of_local[1024]; /* canonical local node -> LDS row (pad: own index)          */
+    uint16_t pidx[HQ_LAT_NELEM][8];
+};
+
+static const hq_lattice_tab& hq_lattice(void)
+{
+    static const hq_lattice_tab tab = [] {
+        hq_lattice_tab t;
+        std::vector<char> used(HQ_LAT_ROWS + 64, 0);
+        for (int K = 0; K < 10; K++)
+            for (int J = 0; J < 9; J++)
+                for (int I = 0; I < 9; I++) {
+                    int r = I + 9 * J + 81 * K;
+                    t.row_of_ijk[I + 10 * J + 100 * K] = (uint16_t)r;
+                    used[r] = 1;
+                }
+        for (int K = 0; K < 10; K++)
+            for (int J = 0; J < 10; J++)
+                for (int I = 0; I < 10; I++) {
+                    if (I < 9 && J < 9) continue;
+                    int r = (I + 9 * J + 81 * K) % 32;
+                    while (used[r]) r += 32;
+                    used[r] = 1;
+                    t.row_of_ijk[I + 10 * J + 100 * K] = (uint16_t)r;
+                }
+        /* canonical local numbering: owned nodes in Z-order, then the halo neighbour cube by
+         * neighbour cube (z, y, x of the cube slowest to fastest), Z-order inside each */
+        auto deint = [](int m, int& x, int& y, int& z) {
+            x = y = z = 0;
+            for (int b = 0; b < 3; b++) {
+                x |= ((m >> (3 * b)) & 1) << b; y |= ((m >> (3 * b + 1)) & 1) << b; z |= ((m >> (3 * b + 2)) & 1) << b;
+            }
+        };
+        for (int i = 0; i < 1000; i++) t.local_of_ijk[i] = -1;
+        for (int i = 0; i < 1024; i++) t.row_of_local[i] = (uint16_t)i;
+        int nl = 0;
+        for (int m = 0; m < 512; m++) {
+            int x, y, z;
+            deint(m, x, y, z);
+            t.local_of_ijk[(x + 1) + 10 * (y + 1) + 100 * (z + 1)] = (int16_t)nl++;
+        }
+        for (int bz = -1; bz <= 1; bz++)
+            for (int by = -1; by <= 1; by++)
+                for (int bx = -1; bx <= 1; bx++) {
+                    if (!bx && !by && !bz) continue;
+                    for (int m = 0; m < 512; m++) {
+                        int x, y, z;
+                        deint(m, x, y, z);
+                        /* position of the neighbour cube's node (x, y, z) on this patch's lattice */
+                        const int I = 1 + 8 * bx + x, J = 1 + 8 * by + y, K = 1 + 8 * bz + z;
+                        if (I < 0 || I > 9 || J < 0 || J > 9 || K < 0 || K > 9) continue;
+                        t.local_of_ijk[I + 10 * J + 100 * K] = (int16_t)nl++;
+                    }
+                }
+        for (int i = 0; i < 1000; i++) t.row_of_local[t.local_of_ijk[i]] = t.row_of_ijk[i];
+        for (int ek = 0; ek < 9; ek++)
+            for (int ej = 0; ej < 9; ej++)
+                for (int ei = 0; ei < 9; ei++)
+                    for (int c = 0; c < 8; c++) {
+                        const int I = ei + (c & 1), J = ej + ((c >> 1) & 1), K = ek + ((c >> 2) & 1);
+                        const bool own = I >= 1 && I <= 8 && J >= 1 && J <= 8 && K >= 1 && K <= 8;
+                        t.pidx[ei + 9 * ej + 81 * ek][c] =
+                            (uint16_t)(t.row_of_ijk[I + 10 * J + 100 * K] | (own ? HQ_PIDX_ACC : 0));
+                    }
+        return t;
+    }();
+    return tab;
+}
+
+/*
+ * Is patch [base, base + 512) with elements `el` (729) and halo `h` (488 ids) a full lattice?  If so,
+ * reorder `el` into lane order and `h` into the canonical halo order.  Checked from the node
+ * coordinates alone (node_t.x/y/z): equal edge for all elements, owned nodes in Z-order of the
+ * lattice, every element's corner c at (e + bits of c), every halo node on the shell.
+ */
+static bool hq_lattice_match(int32_t base, const int32_t* lnid, const int32_t* xyz, int32_t* el, std::vector<int32_t>& h)
+{
+    const hq_lattice_tab& T = hq_lattice();
+    const int32_t* e0 = lnid + 8 * (int64_t)el[0];
+    const int64_t s = (int64_t)xyz[3 * (int64_t)e0[1]] - xyz[3 * (int64_t)e0[0]];
+    if (s <= 0) return false;
+    const int64_t O[3] = { xyz[3 * (int64_t)base] - s, xyz[3 * (int64_t)base + 1] - s, xyz[3 * (int64_t)base + 2] - s };
+    auto ijk = [&](int32_t n) -> int {
+        int q[3];
+        for (int d = 0; d < 3; d++) {
+            const int64_t v = (int64_t)xyz[3 * (int64_t)n + d] - O[d];
+            if (v < 0 || v % s || v / s > 9) return -1;
+            q[d] = (int)(v / s);
+        }
+        return q[0] + 10 * q[1] + 100 * q[2];
+    };
+    for (int t = 0; t < HQ_LAT_NOWN; t++) {
+        const int a = ijk(base + t);
+        if (a < 0 || T.local_of_ijk[a] != t) return false;
+    }
+    int32_t canon[HQ_LAT_NHALO];
+    for (int i = 0; i < HQ_LAT_NHALO; i++) canon[i] = -1;
+    for (int32_t g : h) {
+        const int a = ijk(g);
+        if (a < 0) return false;
+        const int l = T.local_of_ijk[a] - HQ_LAT_NOWN;
+        if (l < 0 || canon[l] >= 0) return false;
+        canon[l] = g;
+    }
+    int32_t lane[HQ_LAT_NELEM];
+    for (int i = 0; i < HQ_LAT_NELEM; i++) lane[i] = -1;
+    for (int q = 0; q < HQ_LAT_NELEM; q++) {
+        const int32_t* id = lnid + 8 * (int64_t)el[q];
+        const int a = ijk(id[0]);
+        if (a < 0) return false;
+        const int ei = a % 10, ej = (a / 10) % 10, ek = a / 100;
+        if (ei > 8 || ej > 8 || ek > 8) return false;
+        for (int c = 1; c < 8; c++)
+            if (ijk(id[c]) != (ei + (c & 1)) + 10 * (ej + ((c >> 1) & 1)) + 100 * (ek + ((c >> 2) & 1))) return false;
+        const int L = ei + 9 * ej + 81 * ek;
+        if (lane[L] >= 0) return false;
+        lane[L] = el[q];
+    }
+    for (int i = 0; i < HQ_LAT_NELEM; i++) el[i] = lane[i];
+    for (int i = 0; i < HQ_LAT_NHALO; i++) h[i] = canon[i];
+    return true;
 }
 
 /*
@@ -238,7 +404,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
  * does not fit LDS is halved and the build repeated.
  */
 static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, const int32_t* lnid,
-                              const int32_t* xyz, const hq_dangling& dn, hq_patch_host* H)
+                              const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H)
 {
     std::vector<int32_t> cuts;
     hq_patch_cuts(cfg, N, xyz, cuts);
@@ -355,6 +521,11 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         H->halo.assign((size_t)hoff[P] + 4 * HQ_PATCH_MAX_THREADS / 3 + 64, 0);
         H->desc.assign((size_t)P, hq_patch_desc());
         H->pidx.assign((size_t)npairs * 8, 0);
+        H->lattice.assign((size_t)P, 0);
+        /* a patch with a hanging-node distribution entry keeps the id-ordered rows (its entries name them) */
+        std::vector<char> has_ds((size_t)P, 0);
+        for (int32_t k = 0; k < dn.n; k++)
+            for (int32_t a = dn.ptr[k]; a < dn.ptr[k + 1]; a++) has_ds[patch_of[dn.anchor[a]]] = 1;
 #pragma omp parallel for schedule(dynamic, 64)
         for (int32_t p = 0; p < P; p++) {
             hq_patch_desc& D = H->desc[p];
@@ -365,6 +536,14 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             D.pair_off = off[p];
             D.halo_off = hoff[p];
             D.nacc = D.nown + nvirt[p];
+            if (want_lattice && xyz && D.nown == HQ_LAT_NOWN && D.nhalo == HQ_LAT_NHALO && D.npairs == HQ_LAT_NELEM &&
+                nvirt[p] == 0 && !has_ds[p] &&
+                hq_lattice_match(D.base, lnid, xyz, &H->pelem[(size_t)off[p]], halos[p])) {
+                H->lattice[p] = 1;
+                memcpy(&H->pidx[(size_t)off[p] * 8], hq_lattice().pidx, sizeof(uint16_t) * 8 * HQ_LAT_NELEM);
+                std::copy(halos[p].begin(), halos[p].end(), H->halo.begin() + hoff[p]);
+                continue;
+            }
             std::copy(halos[p].begin(), halos[p].end(), H->halo.begin() + hoff[p]);
             const std::vector<int32_t>& h = halos[p];
             const int32_t nv = nvirt[p];
@@ -376,7 +555,10 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             };
             for (int64_t q = off[p]; q < off[p + 1]; q++) {
                 const int32_t* id = lnid + 8 * (int64_t)H->pelem[(size_t)q];
-                for (int c = 0; c < 8; c++) H->pidx[(size_t)q * 8 + c] = (uint16_t)local_of(id[c]);
+                for (int c = 0; c < 8; c++) {
+                    const int32_t l = local_of(id[c]);
+                    H->pidx[(size_t)q * 8 + c] = (uint16_t)(l | (l < D.nacc ? (int32_t)HQ_PIDX_ACC : 0));
+                }
             }
         }
         /* regular regions repeat one local connectivity: a patch whose rows equal those of an
@@ -441,6 +623,15 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
 /* kernel                                                                   */
 /* ------------------------------------------------------------------------ */
 
+/* element row (4 dwords): eight 16-bit entries, corner n in half (n & 1) of dword n >> 1 */
+#define HQ_PIDX_UNPACK(l, raw)                                                                  \
+    l[0] = (raw).x & HQ_PIDX_ROW; l[1] = ((raw).x >> 16) & HQ_PIDX_ROW;                          \
+    l[2] = (raw).y & HQ_PIDX_ROW; l[3] = ((raw).y >> 16) & HQ_PIDX_ROW;                          \
+    l[4] = (raw).z & HQ_PIDX_ROW; l[5] = ((raw).z >> 16) & HQ_PIDX_ROW;                          \
+    l[6] = (raw).w & HQ_PIDX_ROW; l[7] = ((raw).w >> 16) & HQ_PIDX_ROW;
+#define HQ_PIDX_WORD(raw, n) ((n) < 2 ? (raw).x : (n) < 4 ? (raw).y : (n) < 6 ? (raw).z : (raw).w)
+#define HQ_PIDX_HAS_ACC(raw, n) ((HQ_PIDX_WORD(raw, n) & (((n) & 1) ? (HQ_PIDX_ACC << 16) : HQ_PIDX_ACC)) != 0)
+
 struct hq_pair_data {
     uint4 raw;
     double beta, c1, c2;
@@ -454,7 +645,6 @@ __device__ unsigned long long* g_hq_stamps = nullptr;
 __device__ unsigned long long* g_hq_wg = nullptr;      /* [grid][2]: shader clock at workgroup start / exit */
 #define HQ_WG_STAMP(k) do { if (threadIdx.x == 0 && g_hq_wg) g_hq_wg[2 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 static void hq_patch_report_stamps(void);
-static int hq_patch_kernel_choice(void);
 #define HQ_STAMP(k) do { if (DIAG == 6 && threadIdx.x == 0 && g_hq_stamps) g_hq_stamps[8 * (size_t)p + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #ifndef HQ_STAMP_TID
 #define HQ_STAMP_TID 0     /* the thread whose view of the phases is recorded */
@@ -608,10 +798,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
         const uint4 raw = cur.raw;
         const double beta = cur.beta;
         int l[8];
-        l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
-        l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
-        l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
-        l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
+        HQ_PIDX_UNPACK(l, raw)
         double X[8], Y[8], Z[8];
         if (wf) {
 #pragma unroll
@@ -634,7 +821,7 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
         for (int n = 0; n < 8; n++) {
             if (DIAG == 4) { if (X[n] + Y[n] + Z[n] == 1.2345e-300) s_f[n] = 1.0; continue; }
-            if (l[n] < D.nacc) {
+            if (HQ_PIDX_HAS_ACC(raw, n)) {
                 atomicAdd(&s_f[3 * l[n] + 0], X[n]);
                 atomicAdd(&s_f[3 * l[n] + 1], Y[n]);
                 atomicAdd(&s_f[3 * l[n] + 2], Z[n]);
@@ -709,8 +896,23 @@ __device__ __forceinline__ hq_patch_desc hq_patch_desc_or_empty(const hq_patch_d
  * achieve only by chance.  The element row of patch k+1 is requested after the element section
  * (its registers are free then) and flies during the update.  Plain loads and __syncthreads
  * throughout: the compiler's own vmcnt waits are the right ones (issue order = order of use).
+ *
+ * LDS image of a patch (`nrows` rows of 3 doubles per array): u1 | u2 of all local nodes, or
+ * (HQ_PATCH_WFORM) w = u1 + beta (u1 - u2) of all local nodes | u1 of the owned | u2 of the owned.
+ * Thread t holds local node t; its LDS row is t, or lat_row[t] in a lattice patch (see hq_lattice:
+ * rows and lanes on one lattice, no bank conflicts in gathers and atomics).  The accumulator of a
+ * node is indexed by its row.
  */
 #define HQ_PERS_THREADS 1024
+#ifndef HQ_TICKET_STRIDE
+#define HQ_TICKET_STRIDE 64      /* ints between the XCDs' work-queue counters: a 256-byte line each */
+#endif
+/* ablations exist in -DHQ_PATCH_PROFILING builds only (-DHQ_EXP=n, profiles/ab_flags.sh) */
+#if defined(HQ_EXP)
+#define HQ_EXP_IS(n) (HQ_EXP == (n))
+#else
+#define HQ_EXP_IS(n) 0
+#endif
 typedef __attribute__((address_space(3))) double hq_lds_double;
 #define HQ_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 /* &base[3*i] for a row index i < 2^24.  gfx9 has no 32-bit mad, so the compiler takes
@@ -724,7 +926,7 @@ static __device__ __forceinline__ hq_lds_double* hq_lds_row3(hq_lds_double* base
 }
 
 __global__ void __launch_bounds__(HQ_PERS_THREADS)
-hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
+hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nrows,
                 int32_t nfacc, const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
@@ -735,10 +937,10 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
                 const int32_t* __restrict__ if_ent, double* __restrict__ iforce,
                 const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride,
-                int32_t* __restrict__ tickets)
+                int32_t* __restrict__ tickets, const uint16_t* __restrict__ lat_row)
 {
     extern __shared__ __align__(16) double s_mem[];
-    double* __restrict__ s_fg = s_mem + 12 * nlmax;     /* after the two node buffers */
+    double* __restrict__ s_fg = s_mem + 12 * nrows;     /* after the two node buffers */
     int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_fg + nfacc);   /* ring of 8: slots drawn 5 patches ahead */
     const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
     const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
@@ -750,21 +952,27 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
      * launch at the end.  The last workgroup out resets the counter for the next launch. */
     HQ_WG_STAMP(0);
 #define HQ_SLOT_PATCH(s) ((s) < end ? (order ? order[(s)] : (s)) : -1)
-#define HQ_DRAW() (xcd * per_xcd + atomicAdd(&tickets[xcd], 1))
+#define HQ_DRAW() (xcd * per_xcd + atomicAdd(&tickets[HQ_TICKET_STRIDE * xcd], 1))
     /* halo id of this thread's local node of patch (P_, DD) (0 where that node is owned or absent) */
 #define HQ_PERS_ID(P_, DD) \
     ((tid >= (DD).nown && tid < (DD).nown + (DD).nhalo) ? halo[(int64_t)(P_) * hstride + (tid - (DD).nown)] : 0)
 
+#if HQ_EXP_IS(14) || HQ_EXP_IS(15)   /* ablation: fixed slot order instead of the work queue (15: results right) */
+    if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = xcd * per_xcd + (int)(blockIdx.x >> 3) + i * W; }
+#else
     if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = HQ_DRAW(); }
+#endif
+    /* this thread's row in a lattice patch: the same for every such patch */
+    int lrow0 = lat_row ? (int)lat_row[tid0] : tid0;
     __syncthreads();
     const int sl0 = __builtin_amdgcn_readfirstlane(s_tick[0]), sl1 = __builtin_amdgcn_readfirstlane(s_tick[1]),
               sl2 = __builtin_amdgcn_readfirstlane(s_tick[2]);
     int p0 = HQ_SLOT_PATCH(sl0), p1 = HQ_SLOT_PATCH(sl1), p2 = HQ_SLOT_PATCH(sl2);
 #define HQ_PERS_EXIT()                                                                          \
     {                                                                                           \
-        if (tid0 == 0 && atomicAdd(&tickets[8 + xcd], 1) == W - 1) {   /* last workgroup of the XCD out */ \
-            tickets[xcd] = 0;                                                                   \
-            tickets[8 + xcd] = 0;                                                               \
+        if (tid0 == 0 && atomicAdd(&tickets[HQ_TICKET_STRIDE * xcd + 1], 1) == W - 1) {   /* last workgroup of the XCD out */ \
+            tickets[HQ_TICKET_STRIDE * xcd] = 0;                                                \
+            tickets[HQ_TICKET_STRIDE * xcd + 1] = 0;                                            \
         }                                                                                       \
         HQ_WG_STAMP(1);                                                                         \
     }
@@ -794,23 +1002,24 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         if (tid < D0.nown + D0.nhalo) {
             const int64_t g = tid < D0.nown ? (int64_t)D0.base + tid : (int64_t)id0;
             const bool wf = (D0.flags & HQ_PATCH_WFORM) != 0;
+            const int row = (D0.flags & HQ_PATCH_LATTICE) ? lrow0 : tid;
             const double b0 = pbeta[D0.pair_off];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 const double x1 = u1g[3 * g + d], x2 = u2g[3 * g + d];
                 if (wf) {
-                    s_mem[3 * tid + d] = x1 + b0 * (x1 - x2);
-                    if (tid < D0.nown) { s_mem[3 * nlmax + 3 * tid + d] = x1; s_mem[3 * nlmax + 3 * (nlmax / 2) + 3 * tid + d] = x2; }
+                    s_mem[3 * row + d] = x1 + b0 * (x1 - x2);
+                    if (tid < D0.nown) { s_mem[3 * nrows + 3 * tid + d] = x1; s_mem[3 * nrows + 3 * (nrows / 2) + 3 * tid + d] = x2; }
                 } else {
-                    s_mem[3 * tid + d] = x1;
-                    s_mem[3 * nlmax + 3 * tid + d] = x2;
+                    s_mem[3 * row + d] = x1;
+                    s_mem[3 * nrows + 3 * row + d] = x2;
                 }
             }
         }
         /* nothing loaded here may still be pending when the loop is entered: the compiler merges
          * this path with the loop's back-edge and would wait vmcnt(0) (i.e. for the previous
          * patch's stores) at the top of every iteration */
-        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idn));
+        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idn), "+v"(lrow0));
         __syncthreads();
     }
 
@@ -823,47 +1032,38 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* LDS pointers carry their address space: 32-bit address arithmetic (through generic pointers
          * hipcc builds LDS addresses with 64-bit multiply-adds whose unused high half can alias a
          * register with a load pending -- a wait in front of every LDS atomic) */
-        hq_lds_double* __restrict__ s_u1 = (hq_lds_double*)s_mem + (k & 1) * 6 * nlmax;
-        hq_lds_double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
-        hq_lds_double* __restrict__ n_u1 = (hq_lds_double*)s_mem + ((k + 1) & 1) * 6 * nlmax;
-        hq_lds_double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
+        hq_lds_double* __restrict__ s_u1 = (hq_lds_double*)s_mem + (k & 1) * 6 * nrows;
+        hq_lds_double* __restrict__ s_u2 = s_u1 + 3 * nrows;
+        hq_lds_double* __restrict__ n_u1 = (hq_lds_double*)s_mem + ((k + 1) & 1) * 6 * nrows;
+        hq_lds_double* __restrict__ n_u2 = n_u1 + 3 * nrows;
         hq_lds_double* __restrict__ s_f = (hq_lds_double*)s_fg;
-        /* LDS image of a patch: u1 | u2 of all local nodes; or (HQ_PATCH_WFORM) w of all local nodes |
-         * u1 of the owned | u2 of the owned, which halves the gathers of the element section */
         const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0, wf1 = (D1.flags & HQ_PATCH_WFORM) != 0;
+        /* this thread's LDS row in patch k (accumulator, u1/u2 of its owned node) and in patch k+1 */
+        const int row0 = (D0.flags & HQ_PATCH_LATTICE) ? lrow0 : tid;
+        const int row1 = (D1.flags & HQ_PATCH_LATTICE) ? lrow0 : tid;
 
         /* 1. the request that flies during the element section: the node data of patch k+1 */
         /* (loads are unconditional, from a clamped address where the thread has nothing to load:
          * straight-line code lets the compiler count vmcnt exactly instead of waiting for all) */
         double a1[3], a2[3];
         const bool have_node = tid < D1.nown + D1.nhalo;
-        {
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 7   /* ablation (results wrong): halo rows read as if they followed the owned rows */
-            const int64_t g = ((int64_t)D1.base + tid + (idn & 0)) & 0x3ffffff;
-#else
-            const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0);
-#endif
-#pragma unroll
-#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 2 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no node loads */
-            for (int d = 0; d < 3; d++) { a1[d] = 1e-3 * (double)(g & 7); a2[d] = 1e-3; }
-#else
-            for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
-#endif
+#define HQ_PERS_NODE_LOADS()                                                                    \
+        {                                                                                       \
+            const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0); \
+            _Pragma("unroll")                                                                   \
+            for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }     \
         }
+#if !HQ_EXP_IS(20)
+        HQ_PERS_NODE_LOADS()
+#endif
         HQ_STAMPD(7);
         const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 7]);   /* drawn two iterations ago */
         const int p3 = HQ_SLOT_PATCH(slot3);
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 8   /* ablation (results wrong): no descriptor load in the loop */
-        hq_patch_desc D3 = D2;
-        D3.base = (p3 < 0 ? 0 : p3) * 512; D3.pair_off = (int64_t)(p3 < 0 ? 0 : p3) * 700;
-        if (p3 < 0) { D3.nown = 0; D3.nhalo = 0; D3.npairs = 0; D3.nacc = 0; D3.flags = 0; }
-#else
         const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
-#endif
         /* the slot of patch k+4, into the ring before the barrier (drawing it from the last, element-less
          * wave instead measured 1 % slower) */
         int32_t drawn = 0;
-#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 12 || HQ_PERS_DIAG == 14)   /* ablation: skeleton with a fixed slot order instead of the ticket atomic */
+#if HQ_EXP_IS(14) || HQ_EXP_IS(15)
         if (tid == 0) drawn = xcd * per_xcd + (int)(blockIdx.x >> 3) + (k + 5) * W;
 #else
         if (tid == 0) drawn = HQ_DRAW();
@@ -872,7 +1072,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         HQ_STAMPD(1);
         /* 2. element section of patch k on the current buffer: one element per thread (the
          *    planner keeps patches at <= 1024 elements) */
-#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 1 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no element section */
+#if HQ_EXP_IS(10) || HQ_EXP_IS(13) || HQ_EXP_IS(14)   /* ablation (results wrong): no element section */
         const bool has_elem = tid < 0;
 #else
         const bool has_elem = tid < D0.npairs;
@@ -883,11 +1083,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         if (has_elem) {
             const hq_u32x4 raw = c_raw;
             const double beta = c_beta;
-            l[0] = raw.x & 0xffff; l[1] = raw.x >> 16;
-            l[2] = raw.y & 0xffff; l[3] = raw.y >> 16;
-            l[4] = raw.z & 0xffff; l[5] = raw.z >> 16;
-            l[6] = raw.w & 0xffff; l[7] = raw.w >> 16;
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 15   /* ablation (results wrong): lane-linear local ids -- no LDS bank conflicts in gather and atomics */
+            HQ_PIDX_UNPACK(l, raw)
+#if HQ_EXP_IS(1) || HQ_EXP_IS(3)     /* ablation (results wrong): lane-linear rows in the gathers */
 #pragma unroll
             for (int n = 0; n < 8; n++) l[n] = (tid + 73 * n) & 511;
 #endif
@@ -914,6 +1111,9 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* 3. the element row is consumed: request what flies during the atomics, the barrier and
          *    the LDS write below: n_t of this patch's node (3-double form, or the 7-double row where
          *    a dashpot makes the axes differ), element row of patch k+1, halo id of patch k+2 */
+#if HQ_EXP_IS(20)    /* experiment: the node loads behind the element arithmetic (waves without an element get here at once) */
+        HQ_PERS_NODE_LOADS()
+#endif
         const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
         double np[7];
         {
@@ -928,29 +1128,32 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
         }
         HQ_PERS_ROW(D1)
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4   /* probe: two more (useless, L2-resident) 8-byte loads per thread */
-        double xtra0 = pbeta[D1.pair_off + (tid & 255)], xtra1 = pc1[D1.pair_off + (tid & 255)];
-#endif
         int32_t idnn;
         {
             const int h = tid - D2.nown;
             idnn = halo[(int64_t)(p2 < 0 ? 0 : p2) * hstride + ((h >= 0 && h < D2.nhalo) ? h : 0)];
         }
         if (has_elem) {
-            /* the local ids again from the packed row (4 registers across the force arithmetic
+            /* the local rows again from the packed element row (4 registers across the force arithmetic
              * instead of 8: the kernel sits at the 128-register limit of 16 waves per CU) */
             asm volatile("" : "+v"(rawk));
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 15
-            rawk.x = (uint32_t)((tid & 511) | (((tid + 73) & 511) << 16)); rawk.y = (uint32_t)(((tid + 146) & 511) | (((tid + 219) & 511) << 16));
-            rawk.z = (uint32_t)(((tid + 292) & 511) | (((tid + 365) & 511) << 16)); rawk.w = (uint32_t)(((tid + 438) & 511) | (((tid + 511) & 511) << 16));
+            HQ_PIDX_UNPACK(l, rawk)
+#if HQ_EXP_IS(2) || HQ_EXP_IS(3)     /* ablation (results wrong): lane-linear rows in the atomics, all of them executed */
+#pragma unroll
+            for (int n = 0; n < 8; n++) l[n] = (tid + 73 * n) & 511;
+            rawk.x = rawk.y = rawk.z = rawk.w = 0x80008000u;
 #endif
-            l[0] = rawk.x & 0xffff; l[1] = rawk.x >> 16;
-            l[2] = rawk.y & 0xffff; l[3] = rawk.y >> 16;
-            l[4] = rawk.z & 0xffff; l[5] = rawk.z >> 16;
-            l[6] = rawk.w & 0xffff; l[7] = rawk.w >> 16;
+#if HQ_EXP_IS(4)                     /* ablation (results wrong): every atomic executed, real rows */
+            rawk.x |= 0x80008000u; rawk.y |= 0x80008000u; rawk.z |= 0x80008000u; rawk.w |= 0x80008000u;
+#pragma unroll
+            for (int n = 0; n < 8; n++) l[n] = l[n] < 729 ? l[n] : 0;
+#endif
+#if HQ_EXP_IS(16)                    /* ablation (results wrong): no atomics */
+            if (X[0] + Y[1] + Z[2] + X[3] + Y[4] + Z[5] + X[6] + Y[7] == 1.2345e-300) rawk.x = 0x80008000u; else rawk.x = rawk.y = rawk.z = rawk.w = 0;
+#endif
 #pragma unroll
             for (int n = 0; n < 8; n++) {
-                if (l[n] < D0.nacc) {
+                if (HQ_PIDX_HAS_ACC(rawk, n)) {
                     hq_lds_double* a = hq_lds_row3(s_f, l[n]);
                     HQ_LDS_ADD(a + 0, X[n]);
                     HQ_LDS_ADD(a + 1, Y[n]);
@@ -959,11 +1162,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
         }
 
-#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 13 || HQ_PERS_DIAG == 14)   /* ablation: skeleton without the source look-up */
-        if (F && tid0 > 4096) {
-#else
         if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
-#endif
             for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += T) {
                 int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
                 for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * ln + d], F[3 * li + d] * dt2);
@@ -977,23 +1176,21 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
             }
         }
-#if !(defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 11)   /* ablation 11 (results wrong): nor this one */
         __syncthreads();
-#endif
         HQ_STAMPD(3);
 
         /* 4. patch k+1 into the other buffer (last read an iteration ago) */
         if (have_node) {
             if (wf1) {
 #pragma unroll
-                for (int d = 0; d < 3; d++) n_u1[3 * tid + d] = a1[d] + c_beta * (a1[d] - a2[d]);   /* c_beta: the row of patch k+1 is here, and every row of a uniform patch holds the patch's beta */
+                for (int d = 0; d < 3; d++) n_u1[3 * row1 + d] = a1[d] + c_beta * (a1[d] - a2[d]);   /* c_beta: the row of patch k+1 is here, and every row of a uniform patch holds the patch's beta */
                 if (tid < D1.nown) {
 #pragma unroll
-                    for (int d = 0; d < 3; d++) { n_u2[3 * tid + d] = a1[d]; n_u2[3 * (nlmax / 2) + 3 * tid + d] = a2[d]; }
+                    for (int d = 0; d < 3; d++) { n_u2[3 * tid + d] = a1[d]; n_u2[3 * (nrows / 2) + 3 * tid + d] = a2[d]; }
                 }
             } else {
 #pragma unroll
-                for (int d = 0; d < 3; d++) { n_u1[3 * tid + d] = a1[d]; n_u2[3 * tid + d] = a2[d]; }
+                for (int d = 0; d < 3; d++) { n_u1[3 * row1 + d] = a1[d]; n_u2[3 * row1 + d] = a2[d]; }
             }
         }
         /* the element row and gather id requested above are the youngest loads: the compiler's wait
@@ -1002,9 +1199,6 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         if (tid == 0) {
             s_tick[(k + 5) & 7] = drawn;                 /* its old content was read at iteration k-6 */
         }
-#if defined(HQ_PERS_DIAG) && HQ_PERS_DIAG == 4
-        asm volatile("" :: "v"(xtra0), "v"(xtra1));
-#endif
         HQ_STAMPD(4);
         /* 5. interface partial forces (psolve.c:4301), then update + re-zero the accumulators */
         if (if_ptr && if_ptr[p0 + 1] > if_ptr[p0]) {
@@ -1015,28 +1209,28 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
             __syncthreads();
         }
-#if defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 3 || HQ_PERS_DIAG >= 9)   /* ablation (results wrong): no update, no stores */
+#if HQ_EXP_IS(12) || HQ_EXP_IS(13) || HQ_EXP_IS(14)   /* ablation (results wrong): no update, no stores */
         if (tid < 0) {
 #else
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
 #endif
             const int n = tid;
             double* out = ung + 3 * ((int64_t)D0.base + n);
-            const hq_lds_double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;          /* u1, u2 of the owned nodes */
-            const hq_lds_double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
+            /* u1, u2 of the owned node: compact by owned index behind w (w-form), else its image row */
+            const hq_lds_double* __restrict__ o_u1 = wf0 ? s_u2 + 3 * n : s_u1 + 3 * row0;
+            const hq_lds_double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nrows / 2) + 3 * n : s_u2 + 3 * row0;
+            hq_lds_double* __restrict__ acc = s_f + 3 * row0;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
-                double f = s_f[3 * n + d] + (m2 * o_u1[3 * n + d] - m1 * o_u2[3 * n + d]);
-                s_f[3 * n + d] = 0.0;
+                double f = acc[d] + (m2 * o_u1[d] - m1 * o_u2[d]);
+                acc[d] = 0.0;
                 out[d] = f / np[0];
             }
         }
-        for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;
+        for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;   /* hanging nodes' accumulators (id-ordered patches) */
         HQ_STAMPD(5);
-#if !(defined(HQ_PERS_DIAG) && (HQ_PERS_DIAG == 10 || HQ_PERS_DIAG == 11))   /* ablations 10, 11 (results wrong): skeleton without this barrier */
         __syncthreads();
-#endif
         HQ_STAMPD(6);
         if (p1 < 0) break;
         p0 = p1; p1 = p2; p2 = p3;
@@ -1051,280 +1245,6 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 #undef HQ_PERS_ROW
 }
 
-/*
- * hq_k_patch_roles (HQ_PATCH_PIPE=5): hq_k_patch_pers with two wave roles.  In the one-role
- * kernel every wave requests its node of patch k+1 at the top of iteration k, and the stamps
- * (profiles/r01/stamps_c3_patch_v9.txt) show all 16 waves held ~4k cycles in that burst -- the
- * CU's vector-memory queue takes the requests at the rate the memory system serves them -- with
- * the element section (2.6k) only starting behind it.  Here
- *   waves 0-11  (one element per thread) run the element section of patch k, request the n_t row of
- *               their node and the element row of patch k+1, and later do the nodal update;
- *   waves 12-15 (four local nodes per thread) request the node data of patch k+1 and write its
- *               LDS image into the other buffer -- they are the ones that sit in the queue;
- * both meet at the barrier the one-role kernel has after its atomics.  Same tables, same LDS
- * layout, same work queue.
- */
-#define HQ_ROLE_ETHREADS 768
-#define HQ_ROLE_LTHREADS 256
-#define HQ_ROLE_NR 4             /* local nodes per loader thread: nlmax <= 1024 */
-
-__global__ void __launch_bounds__(HQ_PERS_THREADS)
-hq_k_patch_roles(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nlmax,
-                 int32_t nfacc, const hq_patch_desc* __restrict__ desc,
-                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
-                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
-                 const int32_t* __restrict__ halo, const double* __restrict__ u1g,
-                 const double* __restrict__ u2g, double* __restrict__ ung,
-                 const double* __restrict__ nt, const double* __restrict__ nt3,
-                 const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
-                 const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
-                 const int32_t* __restrict__ if_ent, double* __restrict__ iforce,
-                 const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride,
-                 int32_t* __restrict__ tickets)
-{
-    extern __shared__ __align__(16) double s_mem[];
-    double* __restrict__ s_fg = s_mem + 12 * nlmax;
-    int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_fg + nfacc);   /* ring of 8: slots drawn 5 patches ahead */
-    const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
-    const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
-    const int end = min((xcd + 1) * per_xcd, count);
-#define HQ_SLOT_PATCH(s) ((s) < end ? (order ? order[(s)] : (s)) : -1)
-#define HQ_DRAW() (xcd * per_xcd + atomicAdd(&tickets[xcd], 1))
-    /* halo id of loader thread st's r-th local node of patch (P_, DD): clamped, unconditional */
-#define HQ_ROLE_ID1(R_, P_, DD)                                                                 \
-    halo[(int64_t)((P_) < 0 ? 0 : (P_)) * hstride +                                             \
-         ((st + (R_) * HQ_ROLE_LTHREADS >= (DD).nown && st + (R_) * HQ_ROLE_LTHREADS < (DD).nown + (DD).nhalo) \
-              ? st + (R_) * HQ_ROLE_LTHREADS - (DD).nown : 0)]
-#define HQ_ROLE_IDS(P_, DD)                                                                     \
-    {                                                                                           \
-        c_raw.x = (uint32_t)HQ_ROLE_ID1(0, P_, DD); c_raw.y = (uint32_t)HQ_ROLE_ID1(1, P_, DD); \
-        c_raw.z = (uint32_t)HQ_ROLE_ID1(2, P_, DD); c_raw.w = (uint32_t)HQ_ROLE_ID1(3, P_, DD); \
-    }
-#define HQ_ROLE_ROW(DD, Q_)                                                                     \
-    {                                                                                           \
-        const int q_ = (Q_) < (DD).npairs ? (Q_) : 0;                                           \
-        const int64_t gc_ = (DD).pair_off + (((DD).flags & HQ_PATCH_UNIFORM) ? 0 : q_);         \
-        c_raw = *(reinterpret_cast<const hq_u32x4*>(pidx) + ((DD).pidx_off + q_));              \
-        c_beta = pbeta[gc_]; c_c1 = pc1[gc_]; c_c2 = pc2[gc_];                                  \
-    }
-#define HQ_ROLE_EXIT()                                                                          \
-    {                                                                                           \
-        if (tid0 == 0 && atomicAdd(&tickets[8 + xcd], 1) == W - 1) {                            \
-            tickets[xcd] = 0;                                                                   \
-            tickets[8 + xcd] = 0;                                                               \
-        }                                                                                       \
-    }
-    if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = HQ_DRAW(); }
-    __syncthreads();
-    const int sl0 = __builtin_amdgcn_readfirstlane(s_tick[0]), sl1 = __builtin_amdgcn_readfirstlane(s_tick[1]),
-              sl2 = __builtin_amdgcn_readfirstlane(s_tick[2]);
-    int p0 = HQ_SLOT_PATCH(sl0), p1 = HQ_SLOT_PATCH(sl1), p2 = HQ_SLOT_PATCH(sl2);
-    if (p0 < 0) {
-        HQ_ROLE_EXIT()
-        return;
-    }
-    hq_patch_desc D0 = hq_patch_desc_or_empty(desc, p0);
-    hq_patch_desc D1 = hq_patch_desc_or_empty(desc, p1);
-    hq_patch_desc D2 = hq_patch_desc_or_empty(desc, p2);
-    /* carried across iterations, 4 dwords both roles share: element threads the packed local node
-     * ids of their element of the CURRENT patch (+ beta, c1, c2); loader threads the gather ids of
-     * their four local nodes of the NEXT patch */
-    hq_u32x4 c_raw = { 0, 0, 0, 0 };
-    double c_beta = 0.0, c_c1 = 0.0, c_c2 = 0.0;
-    {   /* prologue: patch 0 into buffer 0 (one node per thread), first rows / ids */
-        const int tid = tid0, st = tid0 - HQ_ROLE_ETHREADS;
-        for (int i = tid; i < nfacc; i += T) s_fg[i] = 0.0;
-        const int32_t id0 = (tid >= D0.nown && tid < D0.nown + D0.nhalo) ? halo[(int64_t)p0 * hstride + (tid - D0.nown)] : 0;
-        if (tid < HQ_ROLE_ETHREADS) {
-            HQ_ROLE_ROW(D0, tid)
-        } else {
-            HQ_ROLE_IDS(p1, D1)
-        }
-        if (tid < D0.nown + D0.nhalo) {
-            const int64_t g = tid < D0.nown ? (int64_t)D0.base + tid : (int64_t)id0;
-            const bool wf = (D0.flags & HQ_PATCH_WFORM) != 0;
-            const double b0 = pbeta[D0.pair_off];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const double x1 = u1g[3 * g + d], x2 = u2g[3 * g + d];
-                if (wf) {
-                    s_mem[3 * tid + d] = x1 + b0 * (x1 - x2);
-                    if (tid < D0.nown) { s_mem[3 * nlmax + 3 * tid + d] = x1; s_mem[3 * nlmax + 3 * (nlmax / 2) + 3 * tid + d] = x2; }
-                } else {
-                    s_mem[3 * tid + d] = x1;
-                    s_mem[3 * nlmax + 3 * tid + d] = x2;
-                }
-            }
-        }
-        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2));
-        __syncthreads();
-    }
-
-    for (int k = 0;; k++) {
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));                    /* (address arithmetic stays inside the iteration) */
-        const int st = tid - HQ_ROLE_ETHREADS;
-        hq_lds_double* __restrict__ s_u1 = (hq_lds_double*)s_mem + (k & 1) * 6 * nlmax;
-        hq_lds_double* __restrict__ s_u2 = s_u1 + 3 * nlmax;
-        hq_lds_double* __restrict__ n_u1 = (hq_lds_double*)s_mem + ((k + 1) & 1) * 6 * nlmax;
-        hq_lds_double* __restrict__ n_u2 = n_u1 + 3 * nlmax;
-        hq_lds_double* __restrict__ s_f = (hq_lds_double*)s_fg;
-        const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0, wf1 = (D1.flags & HQ_PATCH_WFORM) != 0;
-        const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
-        const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 7]);
-        const int p3 = HQ_SLOT_PATCH(slot3);
-        const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
-        int32_t drawn = 0;
-        if (tid == 0) drawn = HQ_DRAW();
-        double np[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) np[i] = 0.0;
-
-        if (tid < HQ_ROLE_ETHREADS) {
-            /* ---- element waves: patch k on the current buffer ---- */
-            asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2));   /* the row requested last iteration */
-            for (int q = tid; q < D0.npairs; q += HQ_ROLE_ETHREADS) {
-                if (q != tid) HQ_ROLE_ROW(D0, q)          /* patches with more than 768 elements: late row */
-                hq_u32x4 rawk = c_raw;
-                const double beta = c_beta;
-                int l[8];
-                double X[8], Y[8], Z[8];
-                l[0] = rawk.x & 0xffff; l[1] = rawk.x >> 16;
-                l[2] = rawk.y & 0xffff; l[3] = rawk.y >> 16;
-                l[4] = rawk.z & 0xffff; l[5] = rawk.z >> 16;
-                l[6] = rawk.w & 0xffff; l[7] = rawk.w >> 16;
-                if (wf0) {
-#pragma unroll
-                    for (int n = 0; n < 8; n++) {
-                        const hq_lds_double* a = &s_u1[3 * l[n]];
-                        X[n] = a[0]; Y[n] = a[1]; Z[n] = a[2];
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 8; n++) {
-                        const hq_lds_double* a = &s_u1[3 * l[n]];
-                        const hq_lds_double* b = &s_u2[3 * l[n]];
-                        double a0 = a[0], a1_ = a[1], a2_ = a[2];
-                        X[n] = a0 + beta * (a0 - b[0]);
-                        Y[n] = a1_ + beta * (a1_ - b[1]);
-                        Z[n] = a2_ + beta * (a2_ - b[2]);
-                    }
-                }
-                hq_element_force(X, Y, Z, c_c1, c_c2);
-                asm volatile("" : "+v"(rawk));            /* ids again from the packed row: 4 registers across the arithmetic */
-                l[0] = rawk.x & 0xffff; l[1] = rawk.x >> 16;
-                l[2] = rawk.y & 0xffff; l[3] = rawk.y >> 16;
-                l[4] = rawk.z & 0xffff; l[5] = rawk.z >> 16;
-                l[6] = rawk.w & 0xffff; l[7] = rawk.w >> 16;
-#pragma unroll
-                for (int n = 0; n < 8; n++) {
-                    if (l[n] < D0.nacc) {
-                        hq_lds_double* a = hq_lds_row3(s_f, l[n]);
-                        HQ_LDS_ADD(a + 0, X[n]);
-                        HQ_LDS_ADD(a + 1, Y[n]);
-                        HQ_LDS_ADD(a + 2, Z[n]);
-                    }
-                }
-            }
-            /* n_t of this thread's node (psolve.h:210-214; 3-double form where no dashpot acts),
-             * then the element row of patch k+1: both fly over the barrier */
-            {
-                const int64_t nn = (int64_t)D0.base + ((tid < D0.nown && !(D0.flags & HQ_PATCH_NTSAME)) ? tid : 0);
-                if (iso) {
-                    const double* q = nt3 + 3 * nn;
-                    np[0] = q[0]; np[1] = q[1]; np[4] = q[2];
-                } else {
-                    const double* q = nt + 7 * nn;
-#pragma unroll
-                    for (int i = 0; i < 7; i++) np[i] = q[i];
-                }
-            }
-            HQ_ROLE_ROW(D1, tid)
-            if (F) {                                     /* compute_addforce_s, psolve.c:5917-5927 */
-                for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += HQ_ROLE_ETHREADS) {
-                    int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
-                    for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * ln + d], F[3 * li + d] * dt2);
-                }
-            }
-        } else {
-            /* ---- loader waves: patch k+1 into the other buffer ---- */
-            asm volatile("" : "+v"(c_raw));              /* the gather ids requested last iteration */
-            const int32_t idn[HQ_ROLE_NR] = { (int32_t)c_raw.x, (int32_t)c_raw.y, (int32_t)c_raw.z, (int32_t)c_raw.w };
-            const int nl1 = D1.nown + D1.nhalo;
-            const double beta1 = pbeta[D1.pair_off];     /* the uniform beta of patch k+1 (used if wf1) */
-            double a1[HQ_ROLE_NR][3], a2[HQ_ROLE_NR][3];
-#pragma unroll
-            for (int r = 0; r < HQ_ROLE_NR; r++) {
-                const int j = st + r * HQ_ROLE_LTHREADS;
-                const int64_t g = j < D1.nown ? (int64_t)D1.base + j : (j < nl1 ? (int64_t)idn[r] : 0);
-#pragma unroll
-                for (int d = 0; d < 3; d++) { a1[r][d] = u1g[3 * g + d]; a2[r][d] = u2g[3 * g + d]; }
-            }
-            HQ_ROLE_IDS(p2, D2)                          /* gather ids of patch k+2: used next iteration */
-#pragma unroll
-            for (int r = 0; r < HQ_ROLE_NR; r++) {
-                const int j = st + r * HQ_ROLE_LTHREADS;
-                if (j < nl1) {
-                    if (wf1) {
-#pragma unroll
-                        for (int d = 0; d < 3; d++) n_u1[3 * j + d] = a1[r][d] + beta1 * (a1[r][d] - a2[r][d]);
-                        if (j < D1.nown) {
-#pragma unroll
-                            for (int d = 0; d < 3; d++) { n_u2[3 * j + d] = a1[r][d]; n_u2[3 * (nlmax / 2) + 3 * j + d] = a2[r][d]; }
-                        }
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < 3; d++) { n_u1[3 * j + d] = a1[r][d]; n_u2[3 * j + d] = a2[r][d]; }
-                    }
-                }
-            }
-        }
-        if (ds_ptr && ds_ptr[p0 + 1] > ds_ptr[p0]) {     /* compute_adjust DISTRIBUTION, psolve.c:5942-5987 */
-            __syncthreads();
-            for (int i = ds_ptr[p0] + tid; i < ds_ptr[p0 + 1]; i += T) {
-                const int src = ds_ent[3 * i], dst = ds_ent[3 * i + 1];
-                const double deps = (double)(unsigned)ds_ent[3 * i + 2];
-                for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_tick[(k + 5) & 7] = drawn;       /* its old content was read at iteration k-6 */
-        if (if_ptr && if_ptr[p0 + 1] > if_ptr[p0]) {     /* partial forces to the exchange, psolve.c:4301 */
-            for (int i = if_ptr[p0] + tid; i < if_ptr[p0 + 1]; i += T) {
-                int ln = if_ent[2 * i];
-                double* o = iforce + 3 * (int64_t)if_ent[2 * i + 1];
-                o[0] = s_f[3 * ln]; o[1] = s_f[3 * ln + 1]; o[2] = s_f[3 * ln + 2];
-            }
-            __syncthreads();
-        }
-        if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
-            const int n = tid;                           /* (owned nodes <= 768: element threads) */
-            double* out = ung + 3 * ((int64_t)D0.base + n);
-            const hq_lds_double* __restrict__ o_u1 = wf0 ? s_u2 : s_u1;
-            const hq_lds_double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nlmax / 2) : s_u2;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
-                double f = s_f[3 * n + d] + (m2 * o_u1[3 * n + d] - m1 * o_u2[3 * n + d]);
-                s_f[3 * n + d] = 0.0;
-                out[d] = f / np[0];
-            }
-        }
-        for (int i = 3 * D0.nown + tid; i < 3 * D0.nacc; i += T) s_f[i] = 0.0;
-        __syncthreads();
-        if (p1 < 0) break;
-        p0 = p1; p1 = p2; p2 = p3;
-        D0 = D1; D1 = D2; D2 = D3;
-    }
-    HQ_ROLE_EXIT()
-#undef HQ_ROLE_EXIT
-#undef HQ_SLOT_PATCH
-#undef HQ_DRAW
-#undef HQ_ROLE_ID1
-#undef HQ_ROLE_IDS
-#undef HQ_ROLE_ROW
-}
-
 
 /* ------------------------------------------------------------------------ */
 /* device plan                                                              */
@@ -1336,7 +1256,7 @@ static void hq_patch_free(hq_patch_plan* P)
     if (P->npatches) hq_patch_report_stamps();
 #endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
@@ -1351,7 +1271,26 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         P->cfg.vmax = 384;
         while ((6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * 8 > 160 * 1024) P->cfg.nlmax -= 8;
     }
-    if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, &H) != 0) return -1 /* HQ_ERR_ARG */;
+    /* lattice patches exist for hq_k_patch_pers only: plan with them when the configuration can run it,
+     * and again without if this mesh's patches then turn out not to fit it (> 1024 elements in one) */
+    auto pers_fits = [&](int32_t nrows, int32_t max_npairs) {
+        return hq_patch_kernel_choice() == 4 && P->cfg.nlmax <= HQ_PERS_THREADS && max_npairs <= HQ_PERS_THREADS &&
+               (12 * (size_t)nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
+    };
+    bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
+                        pers_fits(std::max(P->cfg.nlmax, HQ_LAT_ROWS), 0);
+    for (;;) {
+        if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H) != 0) return -1 /* HQ_ERR_ARG */;
+        int32_t mp = 0, nl = 0;
+        for (size_t p = 0; p < H.desc.size(); p++) { mp = std::max(mp, H.desc[p].npairs); nl += H.lattice[p]; }
+        P->nlattice = nl;
+        P->nrows = std::max(P->cfg.nlmax, nl ? HQ_LAT_ROWS : 0);
+        if (nl == 0 || pers_fits(P->nrows, mp)) break;
+        want_lattice = false;
+        H = hq_patch_host();
+    }
+    for (size_t p = 0; p < H.desc.size(); p++) H.desc[p].flags = H.lattice[p] ? HQ_PATCH_LATTICE : 0;
+    P->patch_lat = H.lattice;
     /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
      * for every owned node, i.e. no dashpot touches the patch */
     std::vector<double> nt3((size_t)N * 3);
@@ -1366,7 +1305,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             const double* q = ntab + 7 * (int64_t)n;
             iso = (q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]);
         }
-        D.flags = iso ? HQ_PATCH_ISO : 0;
+        D.flags = (D.flags & HQ_PATCH_LATTICE) | (iso ? HQ_PATCH_ISO : 0);
         /* interior of a homogeneous region: one n_t row serves the whole patch (bitwise equal rows) */
         bool same = iso && D.nown > 0 && !getenv("HQ_PATCH_NO_NTSAME");
         for (int32_t n = D.base + 1; n < D.base + D.nown && same; n++)
@@ -1393,8 +1332,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     P->ndistinct = H.ndistinct;
     P->nuniform = nuniform;
     if (getenv("HQ_PATCH_VERBOSE"))
-        fprintf(stderr, "hq patch plan: %zu patches, %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
-                H.desc.size(), H.ndistinct, nuniform, nntsame);
+        fprintf(stderr, "hq patch plan: %zu patches (%d lattice), %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
+                H.desc.size(), P->nlattice, H.ndistinct, nuniform, nntsame);
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
@@ -1411,8 +1350,12 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     HQ_PA(P->d_pbeta, 8 * np)
     HQ_PA(P->d_halo, 4 * nh)
     HQ_PA(P->d_nt3, 8 * nt3.size())
-    HQ_PA(P->d_tickets, 4 * 16)
-    hipMemset(P->d_tickets, 0, 4 * 16);
+    HQ_PA(P->d_tickets, 4 * 8 * HQ_TICKET_STRIDE)
+    hipMemset(P->d_tickets, 0, 4 * 8 * HQ_TICKET_STRIDE);
+    if (P->nlattice) {
+        HQ_PA(P->d_lat_row, sizeof(uint16_t) * 1024)
+        hipMemcpy(P->d_lat_row, hq_lattice().row_of_local, sizeof(uint16_t) * 1024, hipMemcpyHostToDevice);
+    }
     if (dn.n > 0) {
         HQ_PA(P->d_ds_ptr, 4 * H.ds_ptr.size())
         HQ_PA(P->d_ds_ent, 4 * (H.ds_ent.size() ? H.ds_ent.size() : 1))
@@ -1460,7 +1403,8 @@ static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t*
     for (int32_t i = 0; i < nloaded; i++) {
         int32_t p = (int32_t)(std::upper_bound(P->patch_base.begin(), P->patch_base.end(), loaded[i]) -
                               P->patch_base.begin()) - 1;
-        rec.push_back({ p, loaded[i] - P->patch_base[p], i });
+        const int32_t lo = loaded[i] - P->patch_base[p];          /* accumulators are indexed by LDS row */
+        rec.push_back({ p, P->patch_lat[p] ? (int32_t)hq_lattice().row_of_local[lo] : lo, i });
         for (size_t q = 0; q < P->h_nvirt.size(); q++) {
             const int32_t* v = P->h_halo.data() + P->h_halo_off[q];
             const int32_t* hit = std::lower_bound(v, v + P->h_nvirt[q], loaded[i]);
@@ -1488,7 +1432,7 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
     for (int32_t p = 0; p < P->npatches; p++) {
         for (int32_t n = 0; n < P->patch_nown[p]; n++) {
             int32_t sl = slot[P->patch_base[p] + n];
-            if (sl >= 0) { ent.push_back(n); ent.push_back(sl); }
+            if (sl >= 0) { ent.push_back(P->patch_lat[p] ? (int32_t)hq_lattice().row_of_local[n] : n); ent.push_back(sl); }
         }
         ptr[p + 1] = (int32_t)(ent.size() / 2);
     }
@@ -1561,21 +1505,14 @@ static void hq_patch_report_stamps(void)
 }
 #endif
 
-/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 5 = hq_k_patch_roles there,
- * 0 = hq_k_patch_step always */
-static int hq_patch_kernel_choice(void)
-{
-    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 4;
-    return v;
-}
 
 /* hq_k_patch_pers wants one local node and one element per thread and two node buffers in LDS
  * (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
 static bool hq_patch_uses_pers(const hq_patch_plan* P)
 {
-    if (hq_patch_kernel_choice() != 4 && hq_patch_kernel_choice() != 5) return false;
+    if (hq_patch_kernel_choice() != 4) return false;
     if (P->cfg.nlmax > HQ_PERS_THREADS || P->max_npairs > HQ_PERS_THREADS) return false;
-    return (12 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double) <= 160 * 1024;
+    return (12 * (size_t)P->nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
 }
 
 /* launch patches order[first .. first+count) (order == identity when there is no interface) */
@@ -1605,16 +1542,15 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     /* (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
     if (hq_patch_uses_pers(P)) {
         const int32_t nfacc = 3 * (P->cfg.pmax + P->cfg.vmax);
-        size_t lds4 = (12 * (size_t)P->cfg.nlmax + (size_t)nfacc + 4 + 32) * sizeof(double);   /* + ticket ring + prefetch sink */
+        size_t lds4 = (12 * (size_t)P->nrows + (size_t)nfacc + 4) * sizeof(double);   /* + ticket ring */
         {
-            int grid = 256;
+            int grid = P->grid_cus;
             while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
-            auto pk = (hq_patch_kernel_choice() == 5 && P->cfg.pmax <= HQ_ROLE_ETHREADS) ? hq_k_patch_roles : hq_k_patch_pers;
-            pk<<<grid, HQ_PERS_THREADS, lds4, stream>>>(
-                count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, nfacc, P->d_desc, P->d_pidx,
+            hq_k_patch_pers<<<grid, HQ_PERS_THREADS, lds4, stream>>>(
+                count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->nrows, nfacc, P->d_desc, P->d_pidx,
                 P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
                 (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
-                P->hstride, P->d_tickets);
+                P->hstride, P->d_tickets, P->d_lat_row);
             return;
         }
     }

@@ -250,6 +250,14 @@ class Box:
                          _view(first[i].mapping, (first[i].nodecount,), np.int32).copy()) for i in range(cnt)]
         return out
 
+    def plan_check(self):
+        """The patch planner's host-only self-check on this box (capi.plan_check)."""
+        d = capi._Desc()
+        rc = self._lib.hqh_box_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_box_desc failed: %d" % rc)
+        return capi.plan_check(d)
+
     def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
         """hq_create on the arrays the C host side built (no copies through Python)."""
         d = capi._Desc()
@@ -483,6 +491,14 @@ class OctBox:
             self._h = ctypes.c_void_p()
 
     __del__ = close
+
+    def plan_check(self):
+        """The patch planner's host-only self-check on this box (capi.plan_check)."""
+        d = capi._Desc()
+        rc = self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
+        return capi.plan_check(d)
 
     def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
         d = capi._Desc()

@@ -99,6 +99,8 @@ typedef struct {
     int32_t        rank, nranks; /* Global.myID, Global.theGroupSize          */
     int32_t        variant;      /* HQ_VARIANT_*                              */
     int32_t        reserved;
+    const int64_t* node_gnid;    /* [nharbored] node_t.gnid (octor.h:133-147); optional (NULL): only used by
+                                    HQ_DEBUG_HALO, which falls back to a mix of node_xyz */
 } hq_desc;
 
 typedef struct {
@@ -173,8 +175,19 @@ HQ_API int hq_set_source(hq_ctx* ctx, int32_t nloaded, const int32_t* loaded_lni
  */
 HQ_API int hq_run(hq_ctx* ctx, int32_t nsteps);
 
-/* Wait for all enqueued work. */
+/*
+ * Wait for all enqueued work.  With HQ_DEBUG_HALO=1 in the environment at hq_create (the reference's
+ * -DDEBUG build, psolve.c:5002-5007, 5058-5069) every halo record travels with the global identity of
+ * its node and the receiver checks it: hq_sync then returns HQ_ERR_COMM if any record arrived for
+ * another node than the schedule names.
+ */
 HQ_API int hq_sync(hq_ctx* ctx);
+
+/*
+ * solver_check_nan (psolve.c:3769-3782) on the device-resident tm1, tm2 (and force in the scatter
+ * variant): *nonfinite = count of NaN / infinite values.  The reference aborts; here the caller decides.
+ */
+HQ_API int hq_check_finite(hq_ctx* ctx, int64_t* nonfinite);
 
 /*
  * State as the NEXT loop iteration sees it after its swap -- what stations,
@@ -216,6 +229,15 @@ HQ_API int hq_download_force(hq_ctx* ctx, double* force);
  * the average ms per launch of the dominant kernel.
  */
 HQ_API int hq_run_timed(hq_ctx* ctx, int32_t nsteps, double* total_ms, double* kernel_ms_avg);
+
+/*
+ * Host-only self-check of the patch planner (needs no device): plans `desc` as hq_create would and
+ * verifies the element rows, accumulate flags and node coverage of every patch.
+ * report = {patches, lattice patches, (patch, element) pairs, distinct element-row blocks,
+ *           LDS passes of the gathers, gather instructions (per 32-lane group), gather passes of the
+ *           lattice patches (23 groups x 8 corners each when free of bank conflicts), faults}.
+ */
+HQ_API int hq_plan_check(const hq_desc* desc, int64_t report[8]);
 
 /* Name of the dominant kernel as it appears in rocprofv3 kernel traces. */
 HQ_API const char* hq_dominant_kernel(hq_ctx* ctx);

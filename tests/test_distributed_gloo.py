@@ -60,3 +60,32 @@ def test_partitioned_step_over_gloo(tmp_path, world):
         assert np.abs(z["tm1"] - ref1[z["gid"]]).max() <= 1e-12 * scale
         assert np.abs(z["tm2"] - ref2[z["gid"]]).max() <= 1e-12 * scale
     b.close()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two fresh rank processes
+    (it never re-execs and makes no GPU call), they rendezvous on 127.0.0.1 and rank 0's one JSON
+    line says how many ranks it saw.  --dry-launch stops after the rendezvous (no GPU here)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], cwd=ROOT,
+                         env=dict(os.environ, OMP_NUM_THREADS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"dry_launch": True, "n_gpus": 2, "ranks_seen": 2, "ok": True, "launched_by": "bench.py"}
+
+
+def test_bench_under_an_external_launcher_uses_its_world_size():
+    """The driver's form: torch.distributed.run starts the ranks; bench.py takes RANK / WORLD_SIZE
+    from the environment and does not spawn anything itself."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launched_by"] == "external launcher"

@@ -211,3 +211,126 @@ def test_large_two_level_box_variants_agree():
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-11 * scale
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-11 * scale
     ob.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: the layered basin on four octree levels (bench.py workloads o3s / o3)
+# ---------------------------------------------------------------------------------------------
+
+def _basin(workload, rank=0, nranks=1):
+    """(OctBox, total elements, start field of its harbored nodes) of bench.py's layered-basin workloads."""
+    import bench
+    box, total_e, total_n, interfaces = bench.make_octbox(workload, rank, nranks)
+    nx, ny = bench.WORKLOADS[workload][:2]
+    return box, total_e, total_n, bench.seeded_field(box.node_xyz, nx, ny, interfaces)
+
+
+def _run_oct(box, variant, u1, u2, nsteps):
+    s = box.create_solver(variant=variant, tm1=u1, tm2=u2)
+    assert s.info()["variant"] == variant
+    s.run(nsteps)
+    out = s.download()
+    s.close()
+    return out
+
+
+def test_small_basin_variants_agree_and_step_is_linear():
+    """o3s (3.3M elements on four octree levels, hanging nodes on three interfaces): fused patch
+    kernel vs scatter + compute_adjust kernels, linearity of the step, quiescence."""
+    box, E, N, u = _basin("o3s")
+    assert box.E == E and box.N == N and box.ldnnum > 0
+    nsteps = 4
+    v = np.roll(u, 1, axis=1) * 2.0                  # hanging rows stay means of their anchors (linear)
+    a, b = 0.75, -1.5
+    pu = _run_oct(box, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    su = _run_oct(box, ha.HQ_VARIANT_SCATTER, u, 0.999 * u, nsteps)
+    scale = np.abs(pu[0]).max()
+    assert np.isfinite(pu[0]).all() and scale > 0
+    assert np.abs(pu[0] - su[0]).max() <= 1e-11 * scale
+    assert np.abs(pu[1] - su[1]).max() <= 1e-11 * scale
+    pv = _run_oct(box, ha.HQ_VARIANT_PATCH, v, 1.001 * v, nsteps)
+    pw = _run_oct(box, ha.HQ_VARIANT_PATCH, a * u + b * v, a * 0.999 * u + b * 1.001 * v, nsteps)
+    lin = a * pu[0] + b * pv[0]
+    assert np.abs(pw[0] - lin).max() <= 1e-11 * np.abs(lin).max()
+    z = _run_oct(box, ha.HQ_VARIANT_PATCH, np.zeros_like(u), np.zeros_like(u), nsteps)
+    assert not z[0].any() and not z[1].any()
+    # hanging nodes carry the mean of their anchors after every step (compute_adjust ASSIGNMENT, psolve.c:5992-6035)
+    chk = pu[0].copy()
+    ho.compute_adjust(chk, 1, box.dangling)
+    assert np.abs(chk - pu[0]).max() <= 1e-13 * scale
+    box.close()
+
+
+@pytest.mark.parametrize("variant", [ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER])
+def test_small_basin_on_eight_partitions_matches_one_partition(variant):
+    """o3s cut into octor's 8 partitions by the C host (hanging nodes and their anchors on partition
+    interfaces: all four exchanges of a step, psolve.c:4298-4315), in-process transport, against the
+    whole basin on one partition."""
+    from hercules_amd import capi
+    nsteps = 5
+    one, E, N, u = _basin("o3s")
+    ref1, ref2 = _run_oct(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    key = lambda xyz: (xyz[:, 2].astype(np.int64) << 42) | (xyz[:, 1].astype(np.int64) << 21) | xyz[:, 0].astype(np.int64)
+    k1 = key(one.node_xyz)
+    order = np.argsort(k1)
+    one.close()
+    boxes, solvers, maps = [], [], []
+    for r in range(8):
+        b, _, _, ur = _basin("o3s", r, 8)
+        m = order[np.searchsorted(k1[order], key(b.node_xyz))]        # harbored node -> node of the whole basin
+        assert np.array_equal(k1[m], key(b.node_xyz))
+        assert np.array_equal(ur, u[m])                                 # the start field is a function of position
+        boxes.append(b)
+        maps.append(m)
+        solvers.append(b.create_solver(variant=variant, tm1=ur, tm2=0.999 * ur))
+    assert sum(b.E for b in boxes) == E
+    assert sum(b.ldnnum for b in boxes) > 0
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    scale = np.abs(ref1).max()
+    for s, m in zip(solvers, maps):
+        tm1, tm2 = s.download()
+        assert np.abs(tm1 - ref1[m]).max() <= 1e-11 * scale
+        assert np.abs(tm2 - ref2[m]).max() <= 1e-11 * scale
+        s.close()
+    for b in boxes:
+        b.close()
+
+
+def test_full_basin_variants_agree():
+    """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging
+    nodes.  The fused patch kernel against the scatter + compute_adjust kernels (two independent
+    implementations), finiteness, hanging nodes = mean of their anchors, quiescence.  Host memory is
+    kept lean: one field at a time, newest displacement only."""
+    import gc
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 90 * 2 ** 30:
+        pytest.skip("needs ~80 GiB of host memory for the 189M-element mesh tables")
+    box, E, N, u = _basin("o3")
+    assert E > 180e6 and box.ldnnum > 1e6
+    nsteps = 3
+    res = []
+    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
+        s = box.create_solver(variant=variant, tm1=u, tm2=0.999 * u)
+        assert s.info()["variant"] == variant
+        s.run(nsteps)
+        tm1, _ = s.download(want_tm2=False)
+        s.close()
+        res.append(tm1)
+        gc.collect()
+    del u
+    scale = np.abs(res[0]).max()
+    assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
+    assert np.abs(res[0] - res[1]).max() <= 1e-11 * scale
+    del res[1]
+    chk = res[0].copy()
+    ho.compute_adjust(chk, 1, box.dangling)
+    assert np.abs(chk - res[0]).max() <= 1e-13 * scale
+    del chk, res
+    gc.collect()
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH)
+    s.run(nsteps)
+    tm1, _ = s.gather(np.arange(0, N, 4099, dtype=np.int32))
+    assert not tm1.any()
+    s.close()
+    box.close()

@@ -29,10 +29,13 @@ def _box(nx, ny, nz, h=62.5, dt=1e-3, freq=5.0, damping=ho.DAMP_RAYLEIGH, vp=600
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("case,damping", [("c1_short", "rayleigh"), ("c1_none", "none"), ("c1_mass", "mass")])
+@pytest.mark.parametrize("case,damping", [("c1_short", "rayleigh"), ("c1_none", "none"), ("c1_mass", "mass"),
+                                          ("c1_conv", "rayleigh")])
 def test_c1_against_reference_checkpoints(variant, case, damping):
     """examples/simple driven by the reference's own force file; compared with the
-    checkpoints the REAL reference wrote at steps 400 and 800."""
+    checkpoints the REAL reference wrote at steps 400 and 800.  c1_conv: the reference run with
+    stiffness_calculation_method = conventional (compute_addforce_conventional, stiffness.c:121-174):
+    the same operator K u summed in another order, so the one fused HIP formulation must match it too."""
     g = H.load(case)
     p = H.c1_problem(damping)
     s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], node_xyz=_ticks(p["node_ijk"]), variant=variant)
@@ -694,3 +697,58 @@ def test_4d_wavefield_files_written_by_the_c_solver_run(tmp_path):
         for k in range(1, 4):
             assert H.rel_linf(a[k], b[k]) < (TOL if q == "disp" else 1e-7)   # velocity: a difference of two fields / dt
     s.close(); box.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_halo_debug_mode_and_nan_probe(variant, monkeypatch):
+    """HQ_DEBUG_HALO=1 is the reference's -DDEBUG exchange (psolve.c:5002-5007, 5058-5069): every halo
+    record carries the global identity of its node and the receiver checks it.  A correct schedule
+    passes (two-level octree box on 5 partitions: all four exchanges of a step); a schedule with two
+    entries of one side swapped is caught at hq_sync.  hq_check_finite is solver_check_nan
+    (psolve.c:3769-3782)."""
+    from hercules_amd import capi, host
+    monkeypatch.setenv("HQ_DEBUG_HALO", "1")
+    nranks = 5
+    boxes = [host.OctBox(16, 8, 6, 3, 31.25, 1e-3, 5.0, rank=r, nranks=nranks) for r in range(nranks)]
+    ref = H.two_level_mesh(16, 8, 6, 3)
+    rng = np.random.default_rng(7)
+    u1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
+    ho.compute_adjust(u1, 1, ref["dangling"])
+    solvers = [b.create_solver(variant=variant, tm1=u1[b.gid], tm2=u1[b.gid]) for b in boxes]
+    capi.group_link(solvers)
+    capi.group_run(solvers, 6)                       # raises on any identity mismatch
+    assert all(s.check_finite() == 0 for s in solvers)
+    bad = u1[boxes[0].gid].copy()
+    bad[3, 1] = np.nan
+    bad[5, 0] = np.inf
+    solvers[0].upload(bad, bad, 0)
+    assert solvers[0].check_finite() == 4            # two values, in tm1 and in tm2
+    for s in solvers:
+        s.close()
+    # the same partitions with one rank's c-list records in another order than its owner's s-list
+    sch = [b.schedules() for b in boxes]
+    victim = next(r for r in range(nranks) if any(len(m) > 1 for _, m in sch[r]["an"]["c"]))
+    lst = sch[victim]["an"]["c"]
+    k = next(i for i, (_, m) in enumerate(lst) if len(m) > 1)
+    lst[k][1][[0, 1]] = lst[k][1][[1, 0]]
+    solvers = []
+    for r, b in enumerate(boxes):
+        solvers.append(ha.Solver(b.lnid, b.etable, b.ntable, b.dt, tm1=u1[b.gid], tm2=u1[b.gid], node_xyz=b.node_xyz,
+                                 dangling=b.dangling, an_sched=sch[r]["an"], dn_sched=sch[r]["dn"], rank=r,
+                                 nranks=nranks, variant=variant))
+    capi.group_link(solvers)
+    with pytest.raises(capi.HqError, match="HQ_DEBUG_HALO"):
+        capi.group_run(solvers, 2)
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()
+
+
+def test_create_refuses_a_table_that_is_not_rayleigh_proportional():
+    """The fused element product needs c3/c1 == c4/c2 (both are b/dt in solver_init, psolve.c:3386-3409)."""
+    lnid, node_ijk, elem_ijk, et, nt = _box(4, 4, 2)
+    et = et.copy()
+    et[3, 3] *= 1.5
+    with pytest.raises(ha.HqError, match="Rayleigh"):
+        ha.Solver(lnid, et, nt, 1e-3)
