@@ -383,7 +383,7 @@ def measure_traffic(args, keep_dir=None):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
-    out_root = keep_dir or tempfile.mkdtemp(prefix="hq_pmc_", dir="/tmp")
+    out_root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="hq_pmc_", dir="/tmp")
     os.makedirs(out_root, exist_ok=True)
     res = {}
     try:

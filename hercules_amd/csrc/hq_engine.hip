@@ -173,8 +173,9 @@ struct hq_ctx {
     /* patch variant with an interface: the exchange chain runs on its own stream
      * beside the interior patches */
     hipStream_t cstream = nullptr;
-    hipEvent_t ev_bnd = nullptr, ev_shared = nullptr;
+    hipEvent_t ev_bnd = nullptr, ev_shared = nullptr, ev_an_shared = nullptr, ev_assigned = nullptr;
     bool overlap = false;
+    int reserve_cus = 8;              /* CUs the interior launch leaves to the exchange chain (HQ_RESERVE_CUS) */
     /* patch variant: nodes on the partition interface */
     int32_t nI = 0, nOI = 0;
     double* d_iforce = nullptr;       /* [nI][3] partial / summed force of interface nodes */
@@ -636,7 +637,7 @@ static int hq_phase(hq_ctx* c, int ph)
                 HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
             }
             hq_patch_launch(&c->plan, nb, np - nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
-                            c->dt2, c->d_iforce, c->stream);
+                            c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -676,9 +677,20 @@ static int hq_phase(hq_ctx* c, int ph)
     case 5: return hq_xchg_send(c, &c->an, unew, false, false);                      /* :4312 */
     case 6:
         HQ_TRY(hq_xchg_recv(c, &c->an, unew, false, false));
-        if (c->ldnnum)                                                     /* :4313 */
+        if (c->ldnnum) {                                                   /* :4313 */
+            /* the assignment reads anchors that the interior patches (compute stream) and the sharing
+             * exchange (exchange stream) wrote, and the dangling-node sharing below packs what it writes */
+            if (c->overlap) {
+                HQ_HIP(hipEventRecord(c->ev_an_shared, c->cstream));
+                HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_an_shared, 0));
+            }
             hq_k_adjust_assign<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
                 c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, unew);
+            if (c->overlap) {
+                HQ_HIP(hipEventRecord(c->ev_assigned, c->stream));
+                HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_assigned, 0));
+            }
+        }
         return HQ_OK;
     case 7: return hq_xchg_send(c, &c->dn, unew, false, false);                      /* :4315 */
     case 8:
@@ -789,7 +801,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
-    if (!getenv("HQ_NO_OVERLAP") && c->ldnnum == 0) {
+    if (!getenv("HQ_NO_OVERLAP")) {
         /* the exchange chain is short and latency-bound: let its kernels (and RCCL's) get CUs ahead
          * of the thousands of interior patch workgroups queued on the compute stream */
         int prio_lo = 0, prio_hi = 0;
@@ -797,8 +809,11 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         HQ_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio_hi));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_shared, hipEventDisableTiming));
+        HQ_HIP(hipEventCreateWithFlags(&c->ev_an_shared, hipEventDisableTiming));
+        HQ_HIP(hipEventCreateWithFlags(&c->ev_assigned, hipEventDisableTiming));
         HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));
         c->overlap = true;
+        if (getenv("HQ_RESERVE_CUS")) c->reserve_cus = std::max(0, atoi(getenv("HQ_RESERVE_CUS")));
     }
     return HQ_OK;
 }
@@ -963,8 +978,27 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         }
         hq_dangling dn;
         dn.n = (int32_t)l_id.size(); dn.id = l_id.data(); dn.ptr = l_ptr.data(); dn.anchor = l_anc.data();
+        /* nodes whose update is finished elsewhere: hanging nodes (compute_adjust) and the partition interface
+         * (every node a schedule names, and the anchors of owned hanging nodes that other ranks share) */
+        std::vector<char> seed0((size_t)c->N, 0);
+        for (int32_t k = 0; k < c->ldnnum; k++) {
+            seed0[d->dn_ldnid[k]] = 1;
+            if (shared_dn[d->dn_ldnid[k]])
+                for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) seed0[d->dn_lanid[a]] = 1;
+        }
+        for (const hq_schedule* sc : { &d->an_sched, &d->dn_sched })
+            for (int side = 0; side < 2; side++) {
+                const int32_t cnt = side ? sc->s_count : sc->c_count;
+                const hq_messenger* list = side ? sc->first_s : sc->first_c;
+                for (int32_t i = 0; i < cnt; i++)
+                    for (int32_t k = 0; k < list[i].nodecount; k++) {
+                        const int32_t n = list[i].mapping ? list[i].mapping[k] : -1;
+                        if (n < 0 || n >= c->N) return bail(hq_fail(HQ_ERR_ARG, "messenger node id out of range%s", ""));
+                        seed0[n] = 1;
+                    }
+            }
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
-                            dn, &pb);
+                            dn, seed0.data(), &pb);
         if (rc != 0)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));
@@ -1064,6 +1098,15 @@ extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
             }
     }
     for (int64_t n = 0; n < N; n++) if (covered[(size_t)n] != 1) bad++;
+    if (getenv("HQ_PATCH_VERBOSE")) {                      /* owned-node histogram of the patches */
+        int64_t hist[8] = { 0 }, hp[8] = { 0 };
+        for (auto& D : H.desc) {
+            int b = D.nown <= 8 ? 0 : D.nown <= 64 ? 1 : D.nown <= 128 ? 2 : D.nown <= 256 ? 3 : D.nown < 512 ? 4 : D.nown == 512 ? 5 : D.nown <= 640 ? 6 : 7;
+            hist[b]++; hp[b] += D.npairs;
+        }
+        const char* nm[8] = { "<=8", "<=64", "<=128", "<=256", "<512", "=512", "<=640", ">640" };
+        for (int b = 0; b < 8; b++) fprintf(stderr, "hq plan: %8lld patches with %6s owned nodes, %10lld pairs\n", (long long)hist[b], nm[b], (long long)hp[b]);
+    }
     report[0] = (int64_t)H.desc.size(); report[1] = nlat; report[2] = (int64_t)H.pelem.size();
     report[3] = H.ndistinct; report[4] = passes; report[5] = instr;
     report[6] = lpasses; report[7] = bad;
@@ -1093,6 +1136,8 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
     if (c->ev_shared) hipEventDestroy(c->ev_shared);
+    if (c->ev_an_shared) hipEventDestroy(c->ev_an_shared);
+    if (c->ev_assigned) hipEventDestroy(c->ev_assigned);
     if (c->group) {
         /* unlink: the last member to go frees the table */
         std::vector<hq_ctx*>* g = c->group;
@@ -1315,7 +1360,8 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
-    return hq_patch_uses_pers(&c->plan) ? "hq_k_patch_pers" : "hq_k_patch_step";
+    if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
+    return c->plan.seeded ? "hq_k_patch_seed" : "hq_k_patch_pers";
 }
 
 static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3);

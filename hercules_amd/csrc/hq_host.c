@@ -889,8 +889,16 @@ int hqh_solver_run_on(hq_ctx* ctx, double deltaT, int32_t nharb, const hqh_run_p
         F = (double*)malloc(sizeof(double) * 3 * (size_t)rp->nloaded * (size_t)win);
         if (!F) return HQ_ERR_NOMEM;
     }
+    if (rp->checkpoint_rate > 0 && rp->checkpoint_dir != NULL) {
+        /* checkpoint.out<N> holds one stripe per rank behind a common header (io_checkpoint.c:29-127): a
+         * partition cannot write it alone with a groupsize-1 header.  Partitioned callers call
+         * hqh_checkpoint_write themselves (rank, nranks, nharboredmax, a barrier after rank 0 created the file). */
+        hq_info inf;
+        if (hq_get_info(ctx, &inf) != HQ_OK) { free(F); return HQ_ERR_ARG; }
+        if (inf.nranks > 1) { free(F); return HQ_ERR_STATE; }
+    }
     if (rp->nstations > 0 && rp->station_rate > 0 && rp->station_fn) {
-        if (rp->station_derivs < 0 || rp->station_derivs > 2) return HQ_ERR_ARG;
+        if (rp->station_derivs < 0 || rp->station_derivs > 2) { free(F); return HQ_ERR_ARG; }
         u = (double*)malloc(sizeof(double) * 24 * 3 * (size_t)rp->nstations);          /* tm1 | tm2 | tm3 rows */
         disp = (double*)malloc(sizeof(double) * 3 * (size_t)(1 + rp->station_derivs) * (size_t)rp->nstations);
         if (!u || !disp) { free(F); free(u); free(disp); return HQ_ERR_NOMEM; }

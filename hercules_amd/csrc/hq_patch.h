@@ -136,6 +136,8 @@ struct hq_patch_plan {
     int32_t  nlattice = 0;           /* lattice patches                                                        */
     int32_t  nrows = 0;              /* rows of hq_k_patch_pers' LDS image                                     */
     int32_t  grid_cus = 256;         /* persistent workgroups to launch: the device's CU count, a multiple of 8 */
+    int32_t  max_nacc = 0;           /* accumulator rows the patches need (owned + hanging nodes on owned anchors; 729 for lattices) */
+    bool     seeded = false;         /* hq_k_patch_seed: nt3 carries negative mass_simple for nodes whose seed is 0 */
     std::vector<char> patch_lat;     /* host copy of the lattice flags                                         */
     int32_t  nb = 0;
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
@@ -148,10 +150,11 @@ struct hq_patch_plan {
     std::vector<int32_t> patch_nown;
 };
 
-/* HQ_PATCH_PIPE: 4 (default) = hq_k_patch_pers where the plan fits it, 0 = hq_k_patch_step always */
+/* HQ_PATCH_PIPE: 6 (default) = hq_k_patch_seed where the plan fits it (else hq_k_patch_pers, else hq_k_patch_step),
+ * 4 = hq_k_patch_pers where it fits, 0 = hq_k_patch_step always */
 static int hq_patch_kernel_choice(void)
 {
-    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 4;
+    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 6;
     return v;
 }
 
@@ -351,18 +354,27 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
         }
     int m = orall ? __builtin_ctz(orall) : 0;          /* common edge granularity 2^m ticks */
     std::vector<uint64_t> key((size_t)N);
-    for (int64_t n = 0; n < N; n++) {
-        uint64_t q[3];
-        for (int d = 0; d < 3; d++) {
-            /* far-boundary nodes sort one tick inwards (octor.c:6100-6106) */
-            int32_t v = xyz[3 * n + d];
-            if (v == maxc[d] && v > 0) v -= 1;
-            q[d] = (uint64_t)(v >> m);
-            if (q[d] >> 21) { fixed(); return; }
+    /* Nodes on the far boundary of the DOMAIN sort one tick inwards (octor.c:6100-6106).  On a partition
+     * the largest coordinate of an axis is the domain's far face only for the partitions that touch it
+     * (elsewhere those nodes belong to the next partition's cells and sort there), so: the set of axes
+     * whose maximum is treated as far boundary is the first -- all three first -- under which the ids are
+     * in Z-order. */
+    bool sorted = false;
+    for (int mask = 7; mask >= 0 && !sorted; mask--) {
+        sorted = true;
+        for (int64_t n = 0; n < N && sorted; n++) {
+            uint64_t q[3];
+            for (int d = 0; d < 3; d++) {
+                int32_t v = xyz[3 * n + d];
+                if (((mask >> d) & 1) && v == maxc[d] && v > 0) v -= 1;
+                q[d] = (uint64_t)(v >> m);
+                if (q[d] >> 21) { fixed(); return; }
+            }
+            key[n] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
+            if (n && key[n] < key[n - 1]) sorted = false;
         }
-        key[n] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
-        if (n && key[n] < key[n - 1]) { fixed(); return; }     /* not Z-ordered */
     }
+    if (!sorted) { fixed(); return; }                  /* not Z-ordered */
 
     /* k-d style descent over the bits of the Z-value (z, y, x of the coarsest level first):
      * a run of nodes sharing a key prefix is an axis-aligned box; split it at the next bit
@@ -907,12 +919,6 @@ __device__ __forceinline__ hq_patch_desc hq_patch_desc_or_empty(const hq_patch_d
 #ifndef HQ_TICKET_STRIDE
 #define HQ_TICKET_STRIDE 64      /* ints between the XCDs' work-queue counters: a 256-byte line each */
 #endif
-/* ablations exist in -DHQ_PATCH_PROFILING builds only (-DHQ_EXP=n, profiles/ab_flags.sh) */
-#if defined(HQ_EXP)
-#define HQ_EXP_IS(n) (HQ_EXP == (n))
-#else
-#define HQ_EXP_IS(n) 0
-#endif
 typedef __attribute__((address_space(3))) double hq_lds_double;
 #define HQ_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 /* &base[3*i] for a row index i < 2^24.  gfx9 has no 32-bit mad, so the compiler takes
@@ -957,11 +963,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 #define HQ_PERS_ID(P_, DD) \
     ((tid >= (DD).nown && tid < (DD).nown + (DD).nhalo) ? halo[(int64_t)(P_) * hstride + (tid - (DD).nown)] : 0)
 
-#if HQ_EXP_IS(14) || HQ_EXP_IS(15)   /* ablation: fixed slot order instead of the work queue (15: results right) */
-    if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = xcd * per_xcd + (int)(blockIdx.x >> 3) + i * W; }
-#else
     if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = HQ_DRAW(); }
-#endif
     /* this thread's row in a lattice patch: the same for every such patch */
     int lrow0 = lat_row ? (int)lat_row[tid0] : tid0;
     __syncthreads();
@@ -1047,15 +1049,28 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
          * straight-line code lets the compiler count vmcnt exactly instead of waiting for all) */
         double a1[3], a2[3];
         const bool have_node = tid < D1.nown + D1.nhalo;
+#define HQ_PERS_IMAGE_WRITE()                                                                   \
+        if (have_node) {                                                                        \
+            if (wf1) {                                                                          \
+                /* c_beta: the row of patch k+1 is here, and every row of a uniform patch holds the patch's beta */ \
+                _Pragma("unroll")                                                               \
+                for (int d = 0; d < 3; d++) n_u1[3 * row1 + d] = a1[d] + c_beta * (a1[d] - a2[d]); \
+                if (tid < D1.nown) {                                                            \
+                    _Pragma("unroll")                                                           \
+                    for (int d = 0; d < 3; d++) { n_u2[3 * tid + d] = a1[d]; n_u2[3 * (nrows / 2) + 3 * tid + d] = a2[d]; } \
+                }                                                                               \
+            } else {                                                                            \
+                _Pragma("unroll")                                                               \
+                for (int d = 0; d < 3; d++) { n_u1[3 * row1 + d] = a1[d]; n_u2[3 * row1 + d] = a2[d]; } \
+            }                                                                                   \
+        }
 #define HQ_PERS_NODE_LOADS()                                                                    \
         {                                                                                       \
             const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (have_node ? (int64_t)idn : 0); \
             _Pragma("unroll")                                                                   \
             for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }     \
         }
-#if !HQ_EXP_IS(20)
         HQ_PERS_NODE_LOADS()
-#endif
         HQ_STAMPD(7);
         const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 7]);   /* drawn two iterations ago */
         const int p3 = HQ_SLOT_PATCH(slot3);
@@ -1063,20 +1078,12 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* the slot of patch k+4, into the ring before the barrier (drawing it from the last, element-less
          * wave instead measured 1 % slower) */
         int32_t drawn = 0;
-#if HQ_EXP_IS(14) || HQ_EXP_IS(15)
-        if (tid == 0) drawn = xcd * per_xcd + (int)(blockIdx.x >> 3) + (k + 5) * W;
-#else
         if (tid == 0) drawn = HQ_DRAW();
-#endif
 
         HQ_STAMPD(1);
         /* 2. element section of patch k on the current buffer: one element per thread (the
          *    planner keeps patches at <= 1024 elements) */
-#if HQ_EXP_IS(10) || HQ_EXP_IS(13) || HQ_EXP_IS(14)   /* ablation (results wrong): no element section */
-        const bool has_elem = tid < 0;
-#else
         const bool has_elem = tid < D0.npairs;
-#endif
         int l[8];
         double X[8], Y[8], Z[8];
         hq_u32x4 rawk = c_raw;
@@ -1084,10 +1091,6 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             const hq_u32x4 raw = c_raw;
             const double beta = c_beta;
             HQ_PIDX_UNPACK(l, raw)
-#if HQ_EXP_IS(1) || HQ_EXP_IS(3)     /* ablation (results wrong): lane-linear rows in the gathers */
-#pragma unroll
-            for (int n = 0; n < 8; n++) l[n] = (tid + 73 * n) & 511;
-#endif
             if (wf0) {
 #pragma unroll
                 for (int n = 0; n < 8; n++) {
@@ -1111,9 +1114,6 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         /* 3. the element row is consumed: request what flies during the atomics, the barrier and
          *    the LDS write below: n_t of this patch's node (3-double form, or the 7-double row where
          *    a dashpot makes the axes differ), element row of patch k+1, halo id of patch k+2 */
-#if HQ_EXP_IS(20)    /* experiment: the node loads behind the element arithmetic (waves without an element get here at once) */
-        HQ_PERS_NODE_LOADS()
-#endif
         const bool iso = (D0.flags & HQ_PATCH_ISO) != 0;
         double np[7];
         {
@@ -1138,19 +1138,6 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
              * instead of 8: the kernel sits at the 128-register limit of 16 waves per CU) */
             asm volatile("" : "+v"(rawk));
             HQ_PIDX_UNPACK(l, rawk)
-#if HQ_EXP_IS(2) || HQ_EXP_IS(3)     /* ablation (results wrong): lane-linear rows in the atomics, all of them executed */
-#pragma unroll
-            for (int n = 0; n < 8; n++) l[n] = (tid + 73 * n) & 511;
-            rawk.x = rawk.y = rawk.z = rawk.w = 0x80008000u;
-#endif
-#if HQ_EXP_IS(4)                     /* ablation (results wrong): every atomic executed, real rows */
-            rawk.x |= 0x80008000u; rawk.y |= 0x80008000u; rawk.z |= 0x80008000u; rawk.w |= 0x80008000u;
-#pragma unroll
-            for (int n = 0; n < 8; n++) l[n] = l[n] < 729 ? l[n] : 0;
-#endif
-#if HQ_EXP_IS(16)                    /* ablation (results wrong): no atomics */
-            if (X[0] + Y[1] + Z[2] + X[3] + Y[4] + Z[5] + X[6] + Y[7] == 1.2345e-300) rawk.x = 0x80008000u; else rawk.x = rawk.y = rawk.z = rawk.w = 0;
-#endif
 #pragma unroll
             for (int n = 0; n < 8; n++) {
                 if (HQ_PIDX_HAS_ACC(rawk, n)) {
@@ -1180,19 +1167,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         HQ_STAMPD(3);
 
         /* 4. patch k+1 into the other buffer (last read an iteration ago) */
-        if (have_node) {
-            if (wf1) {
-#pragma unroll
-                for (int d = 0; d < 3; d++) n_u1[3 * row1 + d] = a1[d] + c_beta * (a1[d] - a2[d]);   /* c_beta: the row of patch k+1 is here, and every row of a uniform patch holds the patch's beta */
-                if (tid < D1.nown) {
-#pragma unroll
-                    for (int d = 0; d < 3; d++) { n_u2[3 * tid + d] = a1[d]; n_u2[3 * (nrows / 2) + 3 * tid + d] = a2[d]; }
-                }
-            } else {
-#pragma unroll
-                for (int d = 0; d < 3; d++) { n_u1[3 * row1 + d] = a1[d]; n_u2[3 * row1 + d] = a2[d]; }
-            }
-        }
+        HQ_PERS_IMAGE_WRITE()
         /* the element row and gather id requested above are the youngest loads: the compiler's wait
          * for them sits here, before the update's stores are in the queue */
         asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idnn), "+v"(drawn));
@@ -1209,11 +1184,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
             __syncthreads();
         }
-#if HQ_EXP_IS(12) || HQ_EXP_IS(13) || HQ_EXP_IS(14)   /* ablation (results wrong): no update, no stores */
-        if (tid < 0) {
-#else
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
-#endif
             const int n = tid;
             double* out = ung + 3 * ((int64_t)D0.base + n);
             /* u1, u2 of the owned node: compact by owned index behind w (w-form), else its image row */
@@ -1246,6 +1217,298 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 }
 
 
+/*
+ * hq_k_patch_seed: hq_k_patch_pers with ONE barrier per patch.
+ *
+ *   un = (f + m2 u1 - m1 u2) / m0      (solver_compute_displacement, psolve.c:4078-4106)
+ *
+ * The thread that loads node t of patch k+1 (u1, u2 in registers) also has the node's n_t row, so it
+ * SEEDS the node's force accumulator with m2 u1 - m1 u2 when it writes the LDS image; after the
+ * element forces are added (atomics) the accumulator holds the whole numerator and the update is one
+ * LDS read and a division.  u1, u2 of the owned nodes are never stored in LDS, the accumulators are
+ * never re-zeroed, and with three accumulator arrays and two images nothing written in iteration k is
+ * read before the barrier of iteration k, nothing read after it is overwritten before the barrier of
+ * iteration k+1:
+ *
+ *   iteration k:  node loads k+1 | gather, arithmetic, atomics of patch k  (image[k&1], acc[k%3])
+ *                 | image[(k+1)&1], seed acc[(k+1)%3] | BARRIER | update of patch k from acc[k%3]
+ *
+ * so waves drift apart by up to an iteration: one wave's update and node requests run beside another
+ * wave's element arithmetic.  LDS image: w = u1 + beta (u1 - u2) (uniform patches) or u1 | u2, `nrows`
+ * rows per array.  Nodes whose update belongs to someone else -- partition-interface nodes
+ * (hq_k_interface_update finishes them from the pure partial force) and hanging nodes (compute_adjust
+ * overwrites them, and their pure force is what is distributed) -- carry a NEGATIVE mass_simple in the
+ * kernel's private n_t table (nt3): seed 0, divide by |m0|.
+ */
+__global__ void __launch_bounds__(HQ_PERS_THREADS)
+hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order, int32_t nrows,
+                int32_t nfacc, const hq_patch_desc* __restrict__ desc,
+                const uint4* __restrict__ pidx, const double* __restrict__ pc1,
+                const double* __restrict__ pc2, const double* __restrict__ pbeta,
+                const int32_t* __restrict__ halo, const double* __restrict__ u1g,
+                const double* __restrict__ u2g, double* __restrict__ ung,
+                const double* __restrict__ nt, const double* __restrict__ nt3,
+                const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
+                const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
+                const int32_t* __restrict__ if_ent, double* __restrict__ iforce,
+                const int32_t* __restrict__ ds_ptr, const int32_t* __restrict__ ds_ent, int32_t hstride,
+                int32_t* __restrict__ tickets, const uint16_t* __restrict__ lat_row)
+{
+    extern __shared__ __align__(16) double s_mem[];
+    /* LDS: image[2][2][3 nrows] | acc[3][nfacc] | ticket ring */
+    double* __restrict__ s_fg = s_mem + 12 * nrows;
+    int32_t* __restrict__ s_tick = reinterpret_cast<int32_t*>(s_fg + 3 * nfacc);   /* ring of 8: slots drawn 5 patches ahead */
+    const int tid0 = threadIdx.x, T = HQ_PERS_THREADS;
+    const int W = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int end = min((xcd + 1) * per_xcd, count);
+    HQ_WG_STAMP(0);
+#define HQ_SLOT_PATCH(s) ((s) < end ? (order ? order[(s)] : (s)) : -1)
+#define HQ_DRAW() (xcd * per_xcd + atomicAdd(&tickets[HQ_TICKET_STRIDE * xcd], 1))
+#define HQ_PERS_ID(P_, DD) \
+    ((tid >= (DD).nown && tid < (DD).nown + (DD).nhalo) ? halo[(int64_t)(P_) * hstride + (tid - (DD).nown)] : 0)
+    if (tid0 == 0) { for (int i = 0; i < 5; i++) s_tick[i] = HQ_DRAW(); }
+    int lrow0 = lat_row ? (int)lat_row[tid0] : tid0;   /* this thread's row in a lattice patch: the same for every such patch */
+    __syncthreads();
+    const int sl0 = __builtin_amdgcn_readfirstlane(s_tick[0]), sl1 = __builtin_amdgcn_readfirstlane(s_tick[1]),
+              sl2 = __builtin_amdgcn_readfirstlane(s_tick[2]);
+    int p0 = HQ_SLOT_PATCH(sl0), p1 = HQ_SLOT_PATCH(sl1), p2 = HQ_SLOT_PATCH(sl2);
+#define HQ_PERS_EXIT()                                                                          \
+    {                                                                                           \
+        if (tid0 == 0 && atomicAdd(&tickets[HQ_TICKET_STRIDE * xcd + 1], 1) == W - 1) {   /* last workgroup of the XCD out */ \
+            tickets[HQ_TICKET_STRIDE * xcd] = 0;                                                \
+            tickets[HQ_TICKET_STRIDE * xcd + 1] = 0;                                            \
+        }                                                                                       \
+        HQ_WG_STAMP(1);                                                                         \
+    }
+    if (p0 < 0) {                                       /* the run was drawn empty before this workgroup got to it */
+        HQ_PERS_EXIT()
+        return;
+    }
+    hq_patch_desc D0 = hq_patch_desc_or_empty(desc, p0);
+    hq_patch_desc D1 = hq_patch_desc_or_empty(desc, p1);
+    hq_patch_desc D2 = hq_patch_desc_or_empty(desc, p2);
+    hq_u32x4 c_raw = { 0, 0, 0, 0 };                    /* element row of the CURRENT patch (pidx; beta, c1, c2) */
+    double c_beta = 0.0, c_c1 = 0.0, c_c2 = 0.0;
+    double m0 = 1.0;                                    /* |mass_simple| of this thread's owned node of the CURRENT patch */
+    int32_t idn;                                        /* gather id of the NEXT patch's local node */
+#define HQ_PERS_ROW(DD)                                                                         \
+    {                                                                                           \
+        const int q_ = tid < (DD).npairs ? tid : 0;                                             \
+        const int64_t gc_ = (DD).pair_off + (((DD).flags & HQ_PATCH_UNIFORM) ? 0 : q_);         \
+        c_raw = *(reinterpret_cast<const hq_u32x4*>(pidx) + ((DD).pidx_off + q_));              \
+        c_beta = pbeta[gc_]; c_c1 = pc1[gc_]; c_c2 = pc2[gc_];                                  \
+    }
+    /* n_t of this thread's node of patch DD into np[0..6]: mass_simple (negative: seed 0) from the private
+     * 3-double table, the axis terms from it (no dashpot on the patch) or from the 7-double rows */
+#define HQ_SEED_NT(DD)                                                                          \
+    {                                                                                           \
+        const int64_t nn_ = (int64_t)(DD).base + ((tid < (DD).nown && !((DD).flags & HQ_PATCH_NTSAME)) ? tid : 0); \
+        const double* q3_ = nt3 + 3 * nn_;                                                      \
+        np[0] = q3_[0];                                                                         \
+        if ((DD).flags & HQ_PATCH_ISO) { np[1] = q3_[1]; np[4] = q3_[2]; }                      \
+        else {                                                                                  \
+            const double* q7_ = nt + 7 * nn_;                                                   \
+            _Pragma("unroll")                                                                   \
+            for (int i_ = 1; i_ < 7; i_++) np[i_] = q7_[i_];                                    \
+        }                                                                                       \
+    }
+    /* image rows of patch DD from (x1, x2) and the seed of its accumulator: buffers ib_ (image), ab_ (accumulators) */
+#define HQ_SEED_WRITE(DD, x1, x2, beta_, ib_, ab_)                                              \
+    {                                                                                           \
+        const int row_ = ((DD).flags & HQ_PATCH_LATTICE) ? lrow0 : tid;                         \
+        hq_lds_double* iu1_ = (hq_lds_double*)s_mem + (ib_) * 6 * nrows;                        \
+        hq_lds_double* iu2_ = iu1_ + 3 * nrows;                                                 \
+        hq_lds_double* ac_ = (hq_lds_double*)s_fg + (ab_) * nfacc;                              \
+        if (tid < (DD).nown + (DD).nhalo) {                                                     \
+            if ((DD).flags & HQ_PATCH_WFORM) {                                                  \
+                _Pragma("unroll")                                                               \
+                for (int d = 0; d < 3; d++) iu1_[3 * row_ + d] = x1[d] + (beta_) * (x1[d] - x2[d]); \
+            } else {                                                                            \
+                _Pragma("unroll")                                                               \
+                for (int d = 0; d < 3; d++) { iu1_[3 * row_ + d] = x1[d]; iu2_[3 * row_ + d] = x2[d]; } \
+            }                                                                                   \
+        }                                                                                       \
+        if (tid < (DD).nown) {                                                                  \
+            const bool iso_ = ((DD).flags & HQ_PATCH_ISO) != 0;                                 \
+            _Pragma("unroll")                                                                   \
+            for (int d = 0; d < 3; d++) {                                                       \
+                const double m2_ = iso_ ? np[1] : np[1 + d], m1_ = iso_ ? np[4] : np[4 + d];    \
+                ac_[3 * row_ + d] = np[0] < 0.0 ? 0.0 : (m2_ * x1[d] - m1_ * x2[d]);            \
+            }                                                                                   \
+        } else if (tid < (DD).nacc) {               /* hanging nodes on owned anchors (id-ordered patches) */ \
+            _Pragma("unroll")                                                                   \
+            for (int d = 0; d < 3; d++) ac_[3 * tid + d] = 0.0;                                 \
+        }                                                                                       \
+    }
+    {   /* prologue: patch 0 into image 0, its seeds into accumulator array 0 */
+        const int tid = tid0;
+        for (int i = tid; i < 3 * nfacc; i += T) s_fg[i] = 0.0;
+        __syncthreads();
+        HQ_PERS_ROW(D0)
+        const int32_t id0 = HQ_PERS_ID(p0, D0);
+        idn = HQ_PERS_ID((p1 < 0 ? 0 : p1), D1);
+        double np[7] = { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+        HQ_SEED_NT(D0)
+        const int64_t g = tid < D0.nown ? (int64_t)D0.base + tid : (tid < D0.nown + D0.nhalo ? (int64_t)id0 : 0);
+        double x1[3], x2[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * g + d]; x2[d] = u2g[3 * g + d]; }
+        const double b0 = pbeta[D0.pair_off];
+        HQ_SEED_WRITE(D0, x1, x2, b0, 0, 0)
+        m0 = fabs(np[0]);
+        /* nothing loaded here may still be pending when the loop is entered (see hq_k_patch_pers) */
+        asm volatile("" : "+v"(c_raw), "+v"(c_beta), "+v"(c_c1), "+v"(c_c2), "+v"(idn), "+v"(lrow0), "+v"(m0));
+        __syncthreads();
+    }
+
+    int ab = 0;                                         /* accumulator array of the current patch: k % 3 */
+    for (int k = 0;; k++) {
+        HQ_STAMPD(0);
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                    /* (the per-patch address arithmetic stays inside the iteration) */
+        hq_lds_double* __restrict__ s_u1 = (hq_lds_double*)s_mem + (k & 1) * 6 * nrows;
+        hq_lds_double* __restrict__ s_u2 = s_u1 + 3 * nrows;
+        hq_lds_double* __restrict__ s_f = (hq_lds_double*)s_fg + ab * nfacc;
+        const int abn = ab == 2 ? 0 : ab + 1;
+        const bool wf0 = (D0.flags & HQ_PATCH_WFORM) != 0;
+        const int row0 = (D0.flags & HQ_PATCH_LATTICE) ? lrow0 : tid;
+
+        /* 1. the request that flies during the element section: the node data of patch k+1
+         * (unconditional, from a clamped address: straight-line code keeps the compiler's vmcnt exact) */
+        double a1[3], a2[3];
+        {
+            const int64_t g = tid < D1.nown ? (int64_t)D1.base + tid : (tid < D1.nown + D1.nhalo ? (int64_t)idn : 0);
+#pragma unroll
+            for (int d = 0; d < 3; d++) { a1[d] = u1g[3 * g + d]; a2[d] = u2g[3 * g + d]; }
+        }
+        HQ_STAMPD(7);
+        const int slot3 = __builtin_amdgcn_readfirstlane(s_tick[(k + 3) & 7]);   /* drawn two iterations ago */
+        const int p3 = HQ_SLOT_PATCH(slot3);
+        const hq_patch_desc D3 = hq_patch_desc_or_empty(desc, p3);
+        int32_t drawn = 0;
+        if (tid == 0) drawn = HQ_DRAW();
+
+        HQ_STAMPD(1);
+        /* 2. element section of patch k: one element per thread */
+        const bool has_elem = tid < D0.npairs;
+        int l[8];
+        double X[8], Y[8], Z[8];
+        hq_u32x4 rawk = c_raw;
+        if (has_elem) {
+            const hq_u32x4 raw = c_raw;
+            const double beta = c_beta;
+            HQ_PIDX_UNPACK(l, raw)
+            if (wf0) {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const hq_lds_double* a = &s_u1[3 * l[n]];
+                    X[n] = a[0]; Y[n] = a[1]; Z[n] = a[2];
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 8; n++) {
+                    const hq_lds_double* a = &s_u1[3 * l[n]];
+                    const hq_lds_double* b = &s_u2[3 * l[n]];
+                    double a0 = a[0], a1_ = a[1], a2_ = a[2];
+                    X[n] = a0 + beta * (a0 - b[0]);
+                    Y[n] = a1_ + beta * (a1_ - b[1]);
+                    Z[n] = a2_ + beta * (a2_ - b[2]);
+                }
+            }
+            hq_element_force(X, Y, Z, c_c1, c_c2);
+        }
+        HQ_STAMPD(2);
+        /* 3. the element row is consumed: request n_t of this thread's node of patch k+1, the element row of
+         *    patch k+1 and the gather id of patch k+2; they fly during the atomics.  (Requested at the top of
+         *    the iteration instead -- 16 more registers -- the kernel is 12 % SLOWER: every vector-memory
+         *    instruction in the burst at the top delays the element section behind it.) */
+        double np[7];
+        HQ_SEED_NT(D1)
+        hq_u32x4 n_raw;
+        double n_beta, n_c1, n_c2;
+        {
+            const int q_ = tid < D1.npairs ? tid : 0;
+            const int64_t gc_ = D1.pair_off + ((D1.flags & HQ_PATCH_UNIFORM) ? 0 : q_);
+            n_beta = pbeta[gc_];
+            n_raw = *(reinterpret_cast<const hq_u32x4*>(pidx) + (D1.pidx_off + q_));
+            n_c1 = pc1[gc_]; n_c2 = pc2[gc_];
+        }
+        int32_t idnn;
+        {
+            const int h = tid - D2.nown;
+            idnn = halo[(int64_t)(p2 < 0 ? 0 : p2) * hstride + ((h >= 0 && h < D2.nhalo) ? h : 0)];
+        }
+        if (has_elem) {
+            asm volatile("" : "+v"(rawk));               /* the rows again from the packed element row (4 registers across the arithmetic) */
+            HQ_PIDX_UNPACK(l, rawk)
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                if (HQ_PIDX_HAS_ACC(rawk, n)) {
+                    hq_lds_double* a = hq_lds_row3(s_f, l[n]);
+                    HQ_LDS_ADD(a + 0, X[n]);
+                    HQ_LDS_ADD(a + 1, Y[n]);
+                    HQ_LDS_ADD(a + 2, Z[n]);
+                }
+            }
+        }
+        if (F) {                                         /* compute_addforce_s, psolve.c:5917-5927 */
+            for (int i = src_ptr[p0] + tid; i < src_ptr[p0 + 1]; i += T) {
+                int ln = src_ent[2 * i], li = src_ent[2 * i + 1];
+                for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * ln + d], F[3 * li + d] * dt2);
+            }
+        }
+        /* 4. patch k+1: image into the other buffer (last read before the previous barrier), seeds into the next
+         *    accumulator array (last read after the barrier before the previous one) */
+        HQ_SEED_WRITE(D1, a1, a2, n_beta, (k + 1) & 1, abn)    /* n_beta: a uniform patch's rows all hold its beta */
+        const double m0n = fabs(np[0]);
+        asm volatile("" : "+v"(n_raw), "+v"(n_c1), "+v"(n_c2), "+v"(idnn), "+v"(drawn));
+        HQ_STAMPD(3);
+        __syncthreads();
+        HQ_STAMPD(4);
+        if (tid == 0) s_tick[(k + 5) & 7] = drawn;       /* its old content was read at iteration k-6 */
+        if (ds_ptr && ds_ptr[p0 + 1] > ds_ptr[p0]) {     /* compute_adjust DISTRIBUTION, psolve.c:5942-5987 */
+            for (int i = ds_ptr[p0] + tid; i < ds_ptr[p0 + 1]; i += T) {
+                const int src = ds_ent[3 * i], dst = ds_ent[3 * i + 1];
+                const double deps = (double)(unsigned)ds_ent[3 * i + 2];
+                for (int d = 0; d < 3; d++) HQ_LDS_ADD(&s_f[3 * dst + d], s_f[3 * src + d] / deps);
+            }
+            __syncthreads();
+        }
+        /* 5. interface partial forces (psolve.c:4301: pure element force, their seed is 0), then the update */
+        if (if_ptr && if_ptr[p0 + 1] > if_ptr[p0]) {
+            for (int i = if_ptr[p0] + tid; i < if_ptr[p0 + 1]; i += T) {
+                int ln = if_ent[2 * i];
+                double* o = iforce + 3 * (int64_t)if_ent[2 * i + 1];
+                o[0] = s_f[3 * ln]; o[1] = s_f[3 * ln + 1]; o[2] = s_f[3 * ln + 2];
+            }
+        }
+        if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
+            double* out = ung + 3 * ((int64_t)D0.base + tid);
+            const hq_lds_double* __restrict__ acc = s_f + 3 * row0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) out[d] = acc[d] / m0;
+        }
+        HQ_STAMPD(5);
+        HQ_STAMPD(6);
+        if (p1 < 0) break;
+        p0 = p1; p1 = p2; p2 = p3;
+        D0 = D1; D1 = D2; D2 = D3;
+        idn = idnn;
+        m0 = m0n;
+        ab = abn;
+        c_raw = n_raw; c_beta = n_beta; c_c1 = n_c1; c_c2 = n_c2;
+    }
+    HQ_PERS_EXIT()
+#undef HQ_PERS_EXIT
+#undef HQ_SLOT_PATCH
+#undef HQ_DRAW
+#undef HQ_PERS_ID
+#undef HQ_PERS_ROW
+#undef HQ_SEED_NT
+#undef HQ_SEED_WRITE
+}
+
+
 /* ------------------------------------------------------------------------ */
 /* device plan                                                              */
 /* ------------------------------------------------------------------------ */
@@ -1263,7 +1526,7 @@ static void hq_patch_free(hq_patch_plan* P)
 
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
                           const double* c1, const double* c2, const double* beta, const double* ntab,
-                          const hq_dangling& dn, int64_t* bytes)
+                          const hq_dangling& dn, const char* seed0, int64_t* bytes)
 {
     hq_patch_host H;
     P->cfg = hq_patch_cfg_from_env();
@@ -1274,7 +1537,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     /* lattice patches exist for hq_k_patch_pers only: plan with them when the configuration can run it,
      * and again without if this mesh's patches then turn out not to fit it (> 1024 elements in one) */
     auto pers_fits = [&](int32_t nrows, int32_t max_npairs) {
-        return hq_patch_kernel_choice() == 4 && P->cfg.nlmax <= HQ_PERS_THREADS && max_npairs <= HQ_PERS_THREADS &&
+        return (hq_patch_kernel_choice() == 4 || hq_patch_kernel_choice() == 6) && P->cfg.nlmax <= HQ_PERS_THREADS &&
+               max_npairs <= HQ_PERS_THREADS &&
                (12 * (size_t)nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
     };
     bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
@@ -1291,11 +1555,23 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     }
     for (size_t p = 0; p < H.desc.size(); p++) H.desc[p].flags = H.lattice[p] ? HQ_PATCH_LATTICE : 0;
     P->patch_lat = H.lattice;
+    {
+        int32_t mp = 0;
+        P->max_nacc = P->nlattice ? HQ_LAT_ACC : 0;
+        for (auto& D : H.desc) { P->max_nacc = std::max(P->max_nacc, D.nacc); mp = std::max(mp, D.npairs); }
+        /* hq_k_patch_seed: two images and THREE accumulator arrays must fit the 160 KiB of LDS */
+        P->seeded = hq_patch_kernel_choice() == 6 && seed0 &&
+                    P->cfg.nlmax <= HQ_PERS_THREADS && mp <= HQ_PERS_THREADS &&
+                    (12 * (size_t)P->nrows + 9 * (size_t)P->max_nacc + 16) * sizeof(double) <= 160 * 1024;
+    }
     /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
      * for every owned node, i.e. no dashpot touches the patch */
     std::vector<double> nt3((size_t)N * 3);
     for (int64_t n = 0; n < N; n++) {
-        nt3[3 * n] = ntab[7 * n]; nt3[3 * n + 1] = ntab[7 * n + 1]; nt3[3 * n + 2] = ntab[7 * n + 4];
+        /* hq_k_patch_seed: a negative mass_simple marks a node whose accumulator is seeded with 0 (its update belongs
+         * to the interface kernel or to compute_adjust, and its pure force is handed on) */
+        nt3[3 * n] = (P->seeded && seed0[n]) ? -ntab[7 * n] : ntab[7 * n];
+        nt3[3 * n + 1] = ntab[7 * n + 1]; nt3[3 * n + 2] = ntab[7 * n + 4];
     }
     const bool use_iso = !getenv("HQ_PATCH_NO_ISO");
     int32_t nntsame = 0;
@@ -1468,7 +1744,8 @@ static void hq_patch_report_stamps(void)
     static const int pipe_ = hq_patch_kernel_choice();
     const char* name0[6] = { "descriptor", "issue+wait staging, LDS write", "barrier 1", "element loop", "src/ds + barrier 2", "update + stores issued" };
     const char* name4[6] = { "row wait + node loads issued", "element section", "row/n_t loads, src/ds, barrier", "wait node data, LDS write", "update + stores issued", "barrier" };
-    const char** name = pipe_ == 4 ? name4 : name0;
+    const char* name6[6] = { "node requests issued, descriptor", "gather + arithmetic", "row/n_t requests, atomics, image + seeds", "barrier", "update + stores issued", "-" };
+    const char** name = pipe_ == 4 ? name4 : (pipe_ == 6 ? name6 : name0);
     double sum[6] = { 0, 0, 0, 0, 0, 0 };
     long cnt = 0;
     for (int32_t p = 0; p < g_hq_stamp_n; p++) {
@@ -1477,7 +1754,7 @@ static void hq_patch_report_stamps(void)
         for (int k = 0; k < 6; k++) sum[k] += (double)(s[k + 1] - s[k]);
         cnt++;
     }
-    if (pipe_ == 4 && g_hq_wg_buf) {
+    if ((pipe_ == 4 || pipe_ == 6) && g_hq_wg_buf) {
         unsigned long long w[512];
         hipMemcpy(w, g_hq_wg_buf, sizeof w, hipMemcpyDeviceToHost);
         /* s_memrealtime: the 100 MHz reference clock, common to the chip */
@@ -1488,7 +1765,7 @@ static void hq_patch_report_stamps(void)
                        "(the mean workgroup idles %.1f %% at the end)\n", c, (double)(t1 - t0) / 100.0, me / c / 100.0,
                        100.0 * ((double)(t1 - t0) - me / c) / (double)(t1 - t0));
     }
-    if (pipe_ == 4) {
+    if (pipe_ == 4 || pipe_ == 6) {
         double pre = 0; long c7 = 0;
         for (int32_t p = 0; p < g_hq_stamp_n; p++) {
             const unsigned long long* s = &h[8 * (size_t)p];
@@ -1510,7 +1787,7 @@ static void hq_patch_report_stamps(void)
  * (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
 static bool hq_patch_uses_pers(const hq_patch_plan* P)
 {
-    if (hq_patch_kernel_choice() != 4) return false;
+    if (hq_patch_kernel_choice() != 4 && hq_patch_kernel_choice() != 6) return false;
     if (P->cfg.nlmax > HQ_PERS_THREADS || P->max_npairs > HQ_PERS_THREADS) return false;
     return (12 * (size_t)P->nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
 }
@@ -1518,7 +1795,7 @@ static bool hq_patch_uses_pers(const hq_patch_plan* P)
 /* launch patches order[first .. first+count) (order == identity when there is no interface) */
 static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const double* u1,
                             const double* u2, double* un, const double* nt, const double* F, double dt2,
-                            double* iforce, hipStream_t stream)
+                            double* iforce, hipStream_t stream, int reserve_cus = 0)
 {
     if (count <= 0) return;
     int per_xcd = (count + 7) / 8;
@@ -1544,8 +1821,21 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
         const int32_t nfacc = 3 * (P->cfg.pmax + P->cfg.vmax);
         size_t lds4 = (12 * (size_t)P->nrows + (size_t)nfacc + 4) * sizeof(double);   /* + ticket ring */
         {
-            int grid = P->grid_cus;
+            /* a persistent workgroup holds its CU until the queue is empty and stream priorities do not
+             * preempt resident waves: on a partition the interior launch leaves `reserve_cus` CUs (a multiple
+             * of 8, one or more per XCD) to the exchange chain's kernels (pack, RCCL, interface update) */
+            int grid = std::max(8, P->grid_cus - (reserve_cus & ~7));
             while (grid > 8 && (grid >> 3) > per_xcd) grid -= 8;
+            if (P->seeded) {
+                const int32_t nfa = 3 * P->max_nacc;
+                const size_t ldss = (12 * (size_t)P->nrows + 3 * (size_t)nfa + 4) * sizeof(double);
+                hq_k_patch_seed<<<grid, HQ_PERS_THREADS, ldss, stream>>>(
+                    count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->nrows, nfa, P->d_desc, P->d_pidx,
+                    P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
+                    (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
+                    P->hstride, P->d_tickets, P->d_lat_row);
+                return;
+            }
             hq_k_patch_pers<<<grid, HQ_PERS_THREADS, lds4, stream>>>(
                 count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->nrows, nfacc, P->d_desc, P->d_pidx,
                 P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,

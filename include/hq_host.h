@@ -131,8 +131,9 @@ typedef struct {
     const char*    plane_dir;        /* output_planes_directory */
     /* checkpoints (solver_write_checkpoint psolve.c:3842-3851, checkpoint_write
      * io_checkpoint.c:29-127): at every step != step0 that is a multiple of checkpoint_rate the
-     * state goes to <checkpoint_dir>/checkpoint.out0 and .out1 in turn; single partition
-     * (partitions call hqh_checkpoint_write themselves, rank 0 first) */
+     * state goes to <checkpoint_dir>/checkpoint.out0 and .out1 in turn; single partition only:
+     * on a context of nranks > 1 hqh_solver_run returns HQ_ERR_STATE when checkpoint_rate > 0
+     * (partitions call hqh_checkpoint_write themselves with their rank, rank 0 first) */
     int32_t        checkpoint_rate;  /* checkpointing_rate; 0 = never */
     const char*    checkpoint_dir;   /* checkpoint_path */
     /* 0: stations report displacement; 1: + velocity; 2: + velocity and acceleration (needs the
