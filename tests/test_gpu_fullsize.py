@@ -152,12 +152,13 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl", ["c2", "c3"])
-def test_eight_partitions_of_the_8m_box_match_one_partition(wl):
+@pytest.mark.parametrize("wl,overlap", [("c2", 0), ("c2", 1), ("c3", 1)])
+def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
     single-partition run."""
     from hercules_amd import capi
+    monkeypatch.setenv("HQ_OVERLAP", str(overlap))
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3
@@ -261,12 +262,13 @@ def test_small_basin_variants_agree_and_step_is_linear():
     box.close()
 
 
-@pytest.mark.parametrize("variant", [ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER])
-def test_small_basin_on_eight_partitions_matches_one_partition(variant):
+@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 0), (ha.HQ_VARIANT_PATCH, 1), (ha.HQ_VARIANT_SCATTER, 0)])
+def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap, monkeypatch):
     """o3s cut into octor's 8 partitions by the C host (hanging nodes and their anchors on partition
     interfaces: all four exchanges of a step, psolve.c:4298-4315), in-process transport, against the
     whole basin on one partition."""
     from hercules_amd import capi
+    monkeypatch.setenv("HQ_OVERLAP", str(overlap))      # 1: the exchange chain beside the interior patches, as between GPUs
     nsteps = 5
     one, E, N, u = _basin("o3s")
     ref1, ref2 = _run_oct(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)

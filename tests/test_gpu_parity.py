@@ -194,13 +194,17 @@ def test_hanging_node_adjust_and_roundtrip():
     s.close()
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("nranks", [2, 8])
-def test_partitioned_box_matches_single_partition(variant, nranks):
+def test_partitioned_box_matches_single_partition(variant, nranks, overlap, monkeypatch):
     """The same box cut into octor-style block partitions (C host side), all
     partitions stepped in one process on one GPU with the in-process halo
-    transport: every harbored copy must agree with the oracle's single-rank run."""
+    transport: every harbored copy must agree with the oracle's single-rank run.
+    overlap = 1 (HQ_OVERLAP=1): the exchange chain on its own stream beside the interior patches,
+    as between GPUs (the in-process default keeps one stream per partition)."""
     from hercules_amd import capi, host
+    monkeypatch.setenv("HQ_OVERLAP", str(overlap))
     nx, ny, nz, h, dt, freq = 32, 16, 16, 20.0, 4e-4, 20.0
     nsteps = 25
     boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=nranks) for r in range(nranks)]
@@ -395,14 +399,16 @@ def test_output_planes_written_by_the_c_solver_run(tmp_path):
         assert H.rel_linf(got, ref) < TOL
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("shape,nranks", [((16, 8, 6, 3), 5), ((32, 32, 4, 6), 8)])
-def test_partitioned_two_level_box_of_the_c_host(variant, shape, nranks):
+def test_partitioned_two_level_box_of_the_c_host(variant, shape, nranks, overlap, monkeypatch):
     """The two-level box with hanging nodes cut into octor's partitions by the C host
     (hqh_octbox_create, nranks > 1), all partitions stepped in one process with the in-process
     transport (all four exchanges of a step): every harbored copy equals the oracle's run of the
     whole box."""
     from hercules_amd import capi, host
+    monkeypatch.setenv("HQ_OVERLAP", str(overlap))      # 1: exchange chain on its own stream (hanging nodes included)
     nx, ny, nzf, nzc = shape
     nsteps = 20
     ref = H.two_level_mesh(nx, ny, nzf, nzc)
