@@ -138,6 +138,7 @@ struct hq_patch_plan {
     int32_t  grid_cus = 256;         /* persistent workgroups to launch: the device's CU count, a multiple of 8 */
     int32_t  max_nacc = 0;           /* accumulator rows the patches need (owned + hanging nodes on owned anchors; 729 for lattices) */
     bool     seeded = false;         /* hq_k_patch_seed: nt3 carries negative mass_simple for nodes whose seed is 0 */
+    int32_t  pipe = 6;               /* HQ_PATCH_PIPE at plan time                                              */
     std::vector<char> patch_lat;     /* host copy of the lattice flags                                         */
     int32_t  nb = 0;
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
@@ -152,10 +153,9 @@ struct hq_patch_plan {
 
 /* HQ_PATCH_PIPE: 6 (default) = hq_k_patch_seed where the plan fits it (else hq_k_patch_pers, else hq_k_patch_step),
  * 4 = hq_k_patch_pers where it fits, 0 = hq_k_patch_step always */
-static int hq_patch_kernel_choice(void)
+static int hq_patch_kernel_choice(void)              /* read when a plan is built and kept in it (hq_patch_plan.pipe) */
 {
-    static const int v = getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 6;
-    return v;
+    return getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 6;
 }
 
 static thread_local std::string g_patch_err;
@@ -1530,6 +1530,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
 {
     hq_patch_host H;
     P->cfg = hq_patch_cfg_from_env();
+    P->pipe = hq_patch_kernel_choice();
     if (dn.n > 0 && P->cfg.vmax == 0) {
         P->cfg.vmax = 384;
         while ((6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * 8 > 160 * 1024) P->cfg.nlmax -= 8;
@@ -1537,7 +1538,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     /* lattice patches exist for hq_k_patch_pers only: plan with them when the configuration can run it,
      * and again without if this mesh's patches then turn out not to fit it (> 1024 elements in one) */
     auto pers_fits = [&](int32_t nrows, int32_t max_npairs) {
-        return (hq_patch_kernel_choice() == 4 || hq_patch_kernel_choice() == 6) && P->cfg.nlmax <= HQ_PERS_THREADS &&
+        return (P->pipe == 4 || P->pipe == 6) && P->cfg.nlmax <= HQ_PERS_THREADS &&
                max_npairs <= HQ_PERS_THREADS &&
                (12 * (size_t)nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
     };
@@ -1560,7 +1561,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         P->max_nacc = P->nlattice ? HQ_LAT_ACC : 0;
         for (auto& D : H.desc) { P->max_nacc = std::max(P->max_nacc, D.nacc); mp = std::max(mp, D.npairs); }
         /* hq_k_patch_seed: two images and THREE accumulator arrays must fit the 160 KiB of LDS */
-        P->seeded = hq_patch_kernel_choice() == 6 && seed0 &&
+        P->seeded = P->pipe == 6 && seed0 &&
                     P->cfg.nlmax <= HQ_PERS_THREADS && mp <= HQ_PERS_THREADS &&
                     (12 * (size_t)P->nrows + 9 * (size_t)P->max_nacc + 16) * sizeof(double) <= 160 * 1024;
     }
@@ -1741,7 +1742,7 @@ static void hq_patch_report_stamps(void)
     std::vector<unsigned long long> h((size_t)g_hq_stamp_n * 8);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), g_hq_stamp_buf, 64 * (size_t)g_hq_stamp_n, hipMemcpyDeviceToHost);
-    static const int pipe_ = hq_patch_kernel_choice();
+    static const int pipe_ = hq_patch_kernel_choice() == 0 ? 0 : (hq_patch_kernel_choice() == 6 ? 6 : 4);
     const char* name0[6] = { "descriptor", "issue+wait staging, LDS write", "barrier 1", "element loop", "src/ds + barrier 2", "update + stores issued" };
     const char* name4[6] = { "row wait + node loads issued", "element section", "row/n_t loads, src/ds, barrier", "wait node data, LDS write", "update + stores issued", "barrier" };
     const char* name6[6] = { "node requests issued, descriptor", "gather + arithmetic", "row/n_t requests, atomics, image + seeds", "barrier", "update + stores issued", "-" };
@@ -1787,7 +1788,7 @@ static void hq_patch_report_stamps(void)
  * (the planner keeps owned + halo nodes of every patch <= cfg.nlmax) */
 static bool hq_patch_uses_pers(const hq_patch_plan* P)
 {
-    if (hq_patch_kernel_choice() != 4 && hq_patch_kernel_choice() != 6) return false;
+    if (P->pipe != 4 && P->pipe != 6) return false;
     if (P->cfg.nlmax > HQ_PERS_THREADS || P->max_npairs > HQ_PERS_THREADS) return false;
     return (12 * (size_t)P->nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
 }
@@ -1801,7 +1802,6 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     int per_xcd = (count + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double);
     static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
-    static const int pipe = hq_patch_kernel_choice();
 #ifdef HQ_PATCH_PROFILING
     if (getenv("HQ_PATCH_DIAG") && atoi(getenv("HQ_PATCH_DIAG")) == 6) {
         static unsigned long long* d_st = nullptr;

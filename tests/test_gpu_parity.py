@@ -758,3 +758,53 @@ def test_create_refuses_a_table_that_is_not_rayleigh_proportional():
     et[3, 3] *= 1.5
     with pytest.raises(ha.HqError, match="Rayleigh"):
         ha.Solver(lnid, et, nt, 1e-3)
+
+
+@pytest.mark.parametrize("pipe", ["0", "4", "6"])
+def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
+    """The three patch kernels -- hq_k_patch_seed (default, HQ_PATCH_PIPE=6), hq_k_patch_pers (4: the form a
+    mesh falls back to when three accumulator arrays do not fit LDS) and hq_k_patch_step (0: the form for
+    patches of more than 1024 elements) -- on the same problem: the two-level octree box with hanging nodes
+    on 5 partitions (all four exchanges of a step, interface seeds, hanging-node seeds) against the oracle's
+    single-rank run, and a uniform box with lattice patches, dashpot faces and a point source."""
+    from hercules_amd import capi, host
+    monkeypatch.setenv("HQ_PATCH_PIPE", pipe)
+    nranks, nsteps = 5, 12
+    ref = H.two_level_mesh(16, 8, 6, 3)
+    rng = np.random.default_rng(3)
+    u1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (ref["N"], 3)) * 1e-6
+    ho.compute_adjust(u1, 1, ref["dangling"])
+    ho.compute_adjust(u2, 1, ref["dangling"])
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(ref["lnid"], ref["etable"], ref["ntable"], o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
+    boxes = [host.OctBox(16, 8, 6, 3, 31.25, ref["dt"], 5.0, rank=r, nranks=nranks) for r in range(nranks)]
+    solvers = [b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u1[b.gid], tm2=u2[b.gid]) for b in boxes]
+    want = {"0": "hq_k_patch_step", "4": "hq_k_patch_pers", "6": "hq_k_patch_seed"}[pipe]
+    assert solvers[0].dominant_kernel() == want
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for r, (b, s) in enumerate(zip(boxes, solvers)):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[b.gid]) < TOL, (r, "tm1")
+        assert H.rel_linf(tm2, o1[b.gid]) < TOL, (r, "tm2")
+        s.close()
+    for b in boxes:
+        b.close()
+    # uniform box large enough for lattice patches (32 x 32 x 32: 8 interior patches of 64)
+    nx = ny = nz = 32
+    lnid, node_ijk, elem_ijk, et, nt = _box(nx, ny, nz, h=10.0, dt=2e-4)
+    N = len(node_ijk)
+    v1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    v2 = v1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    loaded = np.array([5, 4000, 20000], np.int32)
+    F = rng.uniform(-1, 1, (6, 3, 3)) * 1e6
+    p1, p2 = v2.copy(), v1.copy()
+    ho.solver_run(lnid, et, nt, p1, p2, 0, 6, 2e-4, loaded_lnid=loaded, forces=F)
+    s = ha.Solver(lnid, et, nt, 2e-4, tm1=v1, tm2=v2, node_xyz=_ticks(node_ijk, 1 << 20), variant=ha.HQ_VARIANT_PATCH)
+    assert s.dominant_kernel() == want
+    s.set_source(loaded, F)
+    s.run(6)
+    tm1, tm2 = s.download()
+    assert H.rel_linf(tm1, p2) < TOL and H.rel_linf(tm2, p1) < TOL
+    s.close()
