@@ -628,7 +628,7 @@ static int hq_phase(hq_ctx* c, int ph)
             int32_t k = c->step - c->src_step0;
             const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
                                   ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
-            int32_t nb = c->plan.nb, np = c->plan.npatches;
+            const int32_t nb = c->plan.nb, ne = c->plan.ne;
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             hq_mark(c);
             hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
@@ -637,7 +637,9 @@ static int hq_phase(hq_ctx* c, int ph)
                 HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                 HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
             }
-            hq_patch_launch(&c->plan, nb, np - nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
+            /* interior: the stencil patches (many small workgroups), then the other element-form patches */
+            hq_patch_launch_stencil(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], F, c->dt2, c->stream);
+            hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
                             c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             hq_mark(c);
         } else {
@@ -1370,6 +1372,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
+    if (2 * c->plan.ns > c->plan.npatches) return "hq_k_patch_stencil";
     if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
     return c->plan.seeded ? "hq_k_patch_seed" : "hq_k_patch_pers";
 }

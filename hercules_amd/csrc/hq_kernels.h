@@ -21,6 +21,7 @@
 
 #ifdef HQ_KERNEL_MATH_HOST_CHECK   /* tests/test_kernel_math_cpu.py: g++ compiles the arithmetic alone */
 #define __device__
+#define __host__
 #define __forceinline__ inline
 #else
 #include <hip/hip_runtime.h>
@@ -28,7 +29,7 @@
 
 /* forward butterfly: v[n] (n = node, bit d set = far side of axis d) ->
  * v[m] = sum_n prod_{d in m} sgn_d(n) v[n],  sgn = +1 on the far side. */
-__device__ __forceinline__ void hq_wht_fwd(double v[8])
+__host__ __device__ __forceinline__ void hq_wht_fwd(double v[8])
 {
 #pragma unroll
     for (int s = 1; s < 8; s <<= 1) {
@@ -44,7 +45,7 @@ __device__ __forceinline__ void hq_wht_fwd(double v[8])
 }
 
 /* transposed butterfly: f[n] = sum_m prod_{d in m} sgn_d(n) g[m] */
-__device__ __forceinline__ void hq_wht_inv(double v[8])
+__host__ __device__ __forceinline__ void hq_wht_inv(double v[8])
 {
 #pragma unroll
     for (int s = 1; s < 8; s <<= 1) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void hq_wht_inv(double v[8])
  * In: X,Y,Z = w[n][0..2] per node.  Out: X,Y,Z = f_e[n][0..2].
  * c1, c2 as in e_t (psolve.h:196-198).
  */
-__device__ __forceinline__ void hq_element_force(double X[8], double Y[8], double Z[8],
+__host__ __device__ __forceinline__ void hq_element_force(double X[8], double Y[8], double Z[8],
                                                  double c1, double c2)
 {
     /* stiffness.c:216-218 */

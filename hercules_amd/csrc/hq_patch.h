@@ -88,7 +88,9 @@ struct hq_patch_desc {
 #define HQ_PATCH_WFORM 4     /* uniform, and owned nodes <= nlmax / 2: hq_k_patch_pers keeps w = u1 + beta (u1 - u2) */
                              /* of all local nodes and u1, u2 of the owned ones in LDS instead of u1, u2 of all */
 #define HQ_PATCH_NTSAME 8    /* ISO, and every owned node has the same n_t row: all lanes read the first one */
-#define HQ_PATCH_LATTICE 16  /* rows and lanes of hq_lattice(): thread t's LDS row is lat_row[t] (hq_k_patch_pers only) */
+#define HQ_PATCH_LATTICE 16  /* rows and lanes of hq_lattice(): thread t's LDS row is lat_row[t] (hq_k_patch_pers / _seed only) */
+#define HQ_PATCH_STENCIL 32  /* lattice patch with uniform coefficients, no dashpot, no interface node, no loaded hanging node:
+                              * stepped by hq_k_patch_stencil (the assembled 27-point stencil per owned node) */
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -133,6 +135,9 @@ struct hq_patch_plan {
     int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
     int32_t* d_tickets = nullptr;    /* per XCD, HQ_TICKET_STRIDE ints apart: {next slot of hq_k_patch_pers' work queue, workgroups done} */
     uint16_t* d_lat_row = nullptr;   /* [1024] LDS row of thread t's local node in a lattice patch             */
+    uint16_t* d_lat_row2 = nullptr;  /* [1024] ... in the image of a stencil patch                              */
+    int32_t  ne = 0, ns = 0;         /* d_order = nb interface patches | ne other element-form patches | ns stencil patches */
+    std::vector<int32_t> h_flags;    /* host copy of the patches' flags (hq_patch_set_interface edits them)     */
     int32_t  nlattice = 0;           /* lattice patches                                                        */
     int32_t  nrows = 0;              /* rows of hq_k_patch_pers' LDS image                                     */
     int32_t  grid_cus = 256;         /* persistent workgroups to launch: the device's CU count, a multiple of 8 */
@@ -326,6 +331,95 @@ static bool hq_lattice_match(int32_t base, const int32_t* lnid, const int32_t* x
     for (int i = 0; i < HQ_LAT_NELEM; i++) el[i] = lane[i];
     for (int i = 0; i < HQ_LAT_NHALO; i++) h[i] = canon[i];
     return true;
+}
+
+/*
+ * STENCIL patches.  In a lattice patch whose 729 elements share (c1, c2, beta) the force on an owned node is
+ * a 27-point stencil with 3x3 blocks, S = c1 S1 + c2 S2, assembled from the element matrix: the SAME
+ * operator -(c1 K1 + c2 K2) w that compute_addforce_effective + damping_addforce apply element by element
+ * (stiffness.c:180-237, damping.c:29-103), summed per node instead of per element.  For the trilinear
+ * hexahedron on a uniform lattice the blocks have the symmetry of the cube:
+ *     S[d][a][a] depends only on (|d_a|; the two other |d|): 6 classes p[0..5] =
+ *         (0;0,0) (1;0,0) (0;one 1) (1;one 1) (0;1,1) (1;1,1)
+ *     S[d][a][b] = q[|d_c|] sgn(d_a) sgn(d_b)   (c the third axis; zero unless d_a and d_b are both != 0)
+ * so a node costs 81 LDS reads and 153 fp64 FMAs instead of the 1.42 x (24 reads + 17 atomics, 230 fp64
+ * instructions) of the element form, with no atomics and no accumulator.  The sixteen numbers are not typed
+ * in: hq_stencil() assembles S from the kernels' own element arithmetic (hq_element_force run on the host on
+ * unit vectors) and checks the symmetry; if the check failed no patch would be marked.
+ * LDS rows of a stencil patch: node (I, J, K) of the 10x10x10 lattice at 10 I + 104 J + K (1036 rows): the
+ * 32 consecutive owned nodes of a lane group are a 4x4x2 block of the Z-order, whose rows are then distinct
+ * modulo 32 for every one of the 27 neighbour offsets (the smallest such pitches, found by search).
+ */
+#define HQ_ST_PX 10
+#define HQ_ST_PY 104
+#define HQ_ST_PZ 1
+#define HQ_ST_ROWS 1040
+struct hq_stencil_coef {
+    double p1[6], p2[6];         /* diagonal-block classes of S1, S2 */
+    double q1[2], q2[2];         /* off-diagonal magnitudes of S1, S2 for |d_c| = 0, 1 */
+};
+struct hq_stencil_tab {
+    bool ok;
+    hq_stencil_coef c;
+    uint16_t row2_of_local[1024];    /* canonical local node of a lattice patch -> stencil-image row */
+};
+
+static const hq_stencil_tab& hq_stencil(void)
+{
+    static const hq_stencil_tab tab = [] {
+        hq_stencil_tab t;
+        t.ok = true;
+        const hq_lattice_tab& L = hq_lattice();
+        for (int i = 0; i < 1024; i++) t.row2_of_local[i] = 0;
+        for (int K = 0; K < 10; K++)
+            for (int J = 0; J < 10; J++)
+                for (int I = 0; I < 10; I++)
+                    t.row2_of_local[L.local_of_ijk[I + 10 * J + 100 * K]] = (uint16_t)(HQ_ST_PX * I + HQ_ST_PY * J + HQ_ST_PZ * K);
+        for (int which = 0; which < 2; which++) {
+            /* element matrix E[(n,a)][(m,b)] for (c1, c2) = (1, 0) / (0, 1): columns = forces of unit displacements */
+            double E[24][24];
+            for (int m = 0; m < 8; m++)
+                for (int b = 0; b < 3; b++) {
+                    double X[8] = { 0 }, Y[8] = { 0 }, Z[8] = { 0 };
+                    (b == 0 ? X : b == 1 ? Y : Z)[m] = 1.0;
+                    hq_element_force(X, Y, Z, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
+                    for (int n = 0; n < 8; n++) { E[3 * n][3 * m + b] = X[n]; E[3 * n + 1][3 * m + b] = Y[n]; E[3 * n + 2][3 * m + b] = Z[n]; }
+                }
+            /* the node is corner o of the element whose low corner sits at offset -o (bit k of o set: offset -1 along k);
+             * the neighbour at offset d is corner m of that element with m_k = d_k + o_k */
+            double S[3][3][3][3][3] = {};
+            for (int o = 0; o < 8; o++)
+                for (int m = 0; m < 8; m++) {
+                    int d[3];
+                    for (int k = 0; k < 3; k++) d[k] = -((o >> k) & 1) + ((m >> k) & 1);
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) S[d[0] + 1][d[1] + 1][d[2] + 1][a][b] += E[3 * o + a][3 * m + b];
+                }
+            double* p = which == 0 ? t.c.p1 : t.c.p2;
+            double* q = which == 0 ? t.c.q1 : t.c.q2;
+            p[0] = S[1][1][1][0][0]; p[1] = S[2][1][1][0][0]; p[2] = S[1][2][1][0][0];
+            p[3] = S[2][2][1][0][0]; p[4] = S[1][2][2][0][0]; p[5] = S[2][2][2][0][0];
+            q[0] = S[2][2][1][0][1]; q[1] = S[2][2][2][0][1];
+            double scale = 0;
+            for (int i = 0; i < 6; i++) scale = std::max(scale, fabs(p[i]));
+            auto cls = [](int a, int b, int c) { return (a ? 1 : 0) + 2 * ((b != 0) + (c != 0)); };
+            for (int dx = -1; dx <= 1; dx++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dz = -1; dz <= 1; dz++) {
+                        const int d[3] = { dx, dy, dz };
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) {
+                                const double v = S[dx + 1][dy + 1][dz + 1][a][b];
+                                double want;
+                                if (a == b) want = p[cls(d[a], d[(a + 1) % 3], d[(a + 2) % 3])];
+                                else { const int c = 3 - a - b; want = (d[a] && d[b]) ? q[d[c] ? 1 : 0] * d[a] * d[b] : 0.0; }
+                                if (fabs(v - want) > 1e-13 * scale) t.ok = false;
+                            }
+                    }
+        }
+        return t;
+    }();
+    return tab;
 }
 
 /*
@@ -1509,6 +1603,98 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 }
 
 
+/*
+ * hq_k_patch_stencil: one step of a STENCIL patch (see hq_stencil): one 512-thread workgroup per patch, not
+ * persistent -- the kernel needs 25 KB of LDS and few registers, so several workgroups share a CU and the
+ * hardware overlaps one patch's loads with another's arithmetic.  Thread t loads owned node t (u1, u2, kept
+ * in registers for its own update) and halo node t, writes w = u1 + beta (u1 - u2) of both to the LDS image,
+ * and after ONE barrier evaluates the assembled 27-point stencil for its owned node:
+ *     f = S w,   u(t+dt) = (f + m2 u1 - m1 u2) / m0          (solver_compute_displacement, psolve.c:4078-4106)
+ * No atomics, no accumulators.  Same operator as the element kernels, other summation order.
+ */
+#define HQ_ST_THREADS 512
+#ifdef HQ_ST_WAVES
+#define HQ_ST_ATTR __attribute__((amdgpu_waves_per_eu(HQ_ST_WAVES, HQ_ST_WAVES)))
+#else
+#define HQ_ST_ATTR
+#endif
+__global__ void __launch_bounds__(HQ_ST_THREADS) HQ_ST_ATTR
+hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order,
+                   const hq_patch_desc* __restrict__ desc, const double* __restrict__ pc1,
+                   const double* __restrict__ pc2, const double* __restrict__ pbeta,
+                   const int32_t* __restrict__ halo, int32_t hstride, const double* __restrict__ u1g,
+                   const double* __restrict__ u2g, double* __restrict__ ung, const double* __restrict__ nt3,
+                   const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
+                   const double* __restrict__ F, double dt2, const uint16_t* __restrict__ lat_row,
+                   const uint16_t* __restrict__ lat_row2, hq_stencil_coef sc)
+{
+    __shared__ __align__(16) double s_w[3 * HQ_ST_ROWS];
+    /* workgroups b and b + 8 share an XCD: each XCD walks a contiguous run of Z-ordered patches */
+    const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (slot >= count) return;
+    const int p = order[slot];
+    const int t = threadIdx.x;
+    const hq_patch_desc D = desc[p];
+    const int th = t < HQ_LAT_NHALO ? t : HQ_LAT_NHALO - 1;
+    const int32_t hid = halo[(int64_t)p * hstride + th];
+    const int rowA = lat_row2[t], rowB = lat_row2[HQ_LAT_NOWN + th];
+    const double beta = pbeta[D.pair_off], c1 = pc1[D.pair_off], c2 = pc2[D.pair_off];
+    const int64_t gA = (int64_t)D.base + t, gB = hid;
+    double x1[3], x2[3], y1[3], y2[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * gA + d]; x2[d] = u2g[3 * gA + d]; }
+#pragma unroll
+    for (int d = 0; d < 3; d++) { y1[d] = u1g[3 * gB + d]; y2[d] = u2g[3 * gB + d]; }
+    const double* q3 = nt3 + 3 * ((int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : t));
+    const double m0 = q3[0], m2 = q3[1], m1 = q3[2];
+    hq_lds_double* __restrict__ img = (hq_lds_double*)s_w;
+#pragma unroll
+    for (int d = 0; d < 3; d++) img[3 * rowA + d] = x1[d] + beta * (x1[d] - x2[d]);
+    if (t < HQ_LAT_NHALO) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) img[3 * rowB + d] = y1[d] + beta * (y1[d] - y2[d]);
+    }
+    /* S = c1 S1 + c2 S2: eight wave-uniform numbers */
+    double P[6], Q[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) P[i] = c1 * sc.p1[i] + c2 * sc.p2[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) Q[i] = c1 * sc.q1[i] + c2 * sc.q2[i];
+    __syncthreads();
+    const hq_lds_double* __restrict__ ctr = img + 3 * rowA;
+    double f[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const hq_lds_double* q = ctr + 3 * (HQ_ST_PX * dx + HQ_ST_PY * dy + HQ_ST_PZ * dz);
+                const double ux = q[0], uy = q[1], uz = q[2];
+                const int ax = dx != 0, ay = dy != 0, az = dz != 0;
+                /* diagonal blocks: class = (own axis off the node?) + 2 x (how many of the other two) */
+                f[0] = fma(P[ax + 2 * (ay + az)], ux, f[0]);
+                f[1] = fma(P[ay + 2 * (ax + az)], uy, f[1]);
+                f[2] = fma(P[az + 2 * (ax + ay)], uz, f[2]);
+                /* off-diagonal blocks: q[|third axis|] sgn sgn */
+                if (dx && dy) { const double c = dx * dy > 0 ? Q[az] : -Q[az]; f[0] = fma(c, uy, f[0]); f[1] = fma(c, ux, f[1]); }
+                if (dx && dz) { const double c = dx * dz > 0 ? Q[ay] : -Q[ay]; f[0] = fma(c, uz, f[0]); f[2] = fma(c, ux, f[2]); }
+                if (dy && dz) { const double c = dy * dz > 0 ? Q[ax] : -Q[ax]; f[1] = fma(c, uz, f[1]); f[2] = fma(c, uy, f[2]); }
+            }
+    if (F && src_ptr[p + 1] > src_ptr[p]) {          /* compute_addforce_s, psolve.c:5917-5927 (entries name lattice rows) */
+        const int myrow = lat_row[t];
+        for (int i = src_ptr[p]; i < src_ptr[p + 1]; i++)
+            if (src_ent[2 * i] == myrow) {
+                const int li = src_ent[2 * i + 1];
+                for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
+            }
+    }
+    double* out = ung + 3 * gA;
+#pragma unroll
+    for (int d = 0; d < 3; d++) out[d] = (f[d] + (m2 * x1[d] - m1 * x2[d])) / m0;
+}
+
+
 /* ------------------------------------------------------------------------ */
 /* device plan                                                              */
 /* ------------------------------------------------------------------------ */
@@ -1519,9 +1705,34 @@ static void hq_patch_free(hq_patch_plan* P)
     if (P->npatches) hq_patch_report_stamps();
 #endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row, P->d_lat_row2 };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
+}
+
+/*
+ * Launch order of the patches: [nb patches that own interface nodes | ne other element-form patches | ns stencil
+ * patches], each part in Z-order.  if_ptr (or null): CSR of the interface entries per patch.
+ */
+static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t* bytes)
+{
+    const int32_t np = P->npatches;
+    std::vector<int32_t> order;
+    order.reserve((size_t)np);
+    auto is_if = [&](int32_t p) { return if_ptr && if_ptr[p + 1] > if_ptr[p]; };
+    for (int32_t p = 0; p < np; p++) if (is_if(p)) order.push_back(p);
+    P->nb = (int32_t)order.size();
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && !(P->h_flags[p] & HQ_PATCH_STENCIL)) order.push_back(p);
+    P->ne = (int32_t)order.size() - P->nb;
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && (P->h_flags[p] & HQ_PATCH_STENCIL)) order.push_back(p);
+    P->ns = np - P->nb - P->ne;
+    if (P->nb == 0 && P->ns == 0) return 0;          /* identity order: no table */
+    if (!P->d_order) {
+        if (hipMalloc((void**)&P->d_order, 4 * (size_t)(np ? np : 1)) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+        *bytes += (int64_t)(4 * (size_t)np);
+    }
+    hipMemcpy(P->d_order, order.data(), 4 * order.size(), hipMemcpyHostToDevice);
+    return 0;
 }
 
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
@@ -1606,11 +1817,21 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             }
         }
     }
+    /* stencil patches: lattice, one (c1, c2, beta) for all 729 elements, no dashpot on the patch */
+    if (hq_stencil().ok && !getenv("HQ_PATCH_NO_STENCIL"))
+        for (auto& D : H.desc)
+            if ((D.flags & HQ_PATCH_LATTICE) && (D.flags & HQ_PATCH_UNIFORM) && (D.flags & HQ_PATCH_ISO)) D.flags |= HQ_PATCH_STENCIL;
+    P->h_flags.resize(H.desc.size());
+    for (size_t p = 0; p < H.desc.size(); p++) P->h_flags[p] = H.desc[p].flags;
     P->ndistinct = H.ndistinct;
     P->nuniform = nuniform;
-    if (getenv("HQ_PATCH_VERBOSE"))
-        fprintf(stderr, "hq patch plan: %zu patches (%d lattice), %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
-                H.desc.size(), P->nlattice, H.ndistinct, nuniform, nntsame);
+    {
+        int nst = 0;
+        for (auto& D : H.desc) nst += (D.flags & HQ_PATCH_STENCIL) != 0;
+        if (getenv("HQ_PATCH_VERBOSE"))
+        fprintf(stderr, "hq patch plan: %zu patches (%d lattice, %d stencil), %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
+                H.desc.size(), P->nlattice, nst, H.ndistinct, nuniform, nntsame);
+    }
     P->npatches = (int32_t)H.desc.size();
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
@@ -1632,6 +1853,8 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     if (P->nlattice) {
         HQ_PA(P->d_lat_row, sizeof(uint16_t) * 1024)
         hipMemcpy(P->d_lat_row, hq_lattice().row_of_local, sizeof(uint16_t) * 1024, hipMemcpyHostToDevice);
+        HQ_PA(P->d_lat_row2, sizeof(uint16_t) * 1024)
+        hipMemcpy(P->d_lat_row2, hq_stencil().row2_of_local, sizeof(uint16_t) * 1024, hipMemcpyHostToDevice);
     }
     if (dn.n > 0) {
         HQ_PA(P->d_ds_ptr, 4 * H.ds_ptr.size())
@@ -1665,6 +1888,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     P->patch_base.resize(H.desc.size());
     P->patch_nown.resize(H.desc.size());
     for (size_t p = 0; p < H.desc.size(); p++) { P->patch_base[p] = H.desc[p].base; P->patch_nown[p] = H.desc[p].nown; }
+    if (hq_patch_build_order(P, nullptr, bytes) != 0) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -1714,16 +1938,11 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
         ptr[p + 1] = (int32_t)(ent.size() / 2);
     }
     if (ent.empty()) return 0;
-    {   /* launch order: patches owning interface nodes first, so their partial forces can
-         * travel while the rest of the partition is still being computed */
-        std::vector<int32_t> order;
-        for (int32_t p = 0; p < P->npatches; p++) if (ptr[p + 1] > ptr[p]) order.push_back(p);
-        P->nb = (int32_t)order.size();
-        for (int32_t p = 0; p < P->npatches; p++) if (ptr[p + 1] == ptr[p]) order.push_back(p);
-        if (hipMalloc((void**)&P->d_order, 4 * order.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
-        *bytes += (int64_t)(4 * order.size());
-        hipMemcpy(P->d_order, order.data(), 4 * order.size(), hipMemcpyHostToDevice);
-    }
+    /* launch order: patches owning interface nodes first, so their partial forces can travel while the rest of
+     * the partition is still being computed; they hand partial forces on, so they take the element form */
+    for (int32_t p = 0; p < P->npatches; p++)
+        if (ptr[p + 1] > ptr[p]) P->h_flags[p] &= ~HQ_PATCH_STENCIL;
+    if (hq_patch_build_order(P, ptr.data(), bytes) != 0) return -2;
     if (hipMalloc((void**)&P->d_if_ptr, 4 * ptr.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     if (hipMalloc((void**)&P->d_if_ent, 4 * ent.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
@@ -1859,6 +2078,18 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
         P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
         (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
         P->hstride);
+}
+
+/* the stencil patches: d_order[nb + ne .. nb + ne + ns) */
+static void hq_patch_launch_stencil(const hq_patch_plan* P, const double* u1, const double* u2, double* un,
+                                    const double* F, double dt2, hipStream_t stream)
+{
+    if (P->ns <= 0) return;
+    const int per_xcd = (P->ns + 7) / 8;
+    hq_k_patch_stencil<<<per_xcd * 8, HQ_ST_THREADS, 0, stream>>>(
+        P->ns, per_xcd, P->d_order + P->nb + P->ne, P->d_desc, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->hstride,
+        u1, u2, un, P->d_nt3, P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_lat_row, P->d_lat_row2,
+        hq_stencil().c);
 }
 
 #endif /* HQ_PATCH_H */
