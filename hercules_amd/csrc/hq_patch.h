@@ -1613,12 +1613,7 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
  * No atomics, no accumulators.  Same operator as the element kernels, other summation order.
  */
 #define HQ_ST_THREADS 512
-#ifdef HQ_ST_WAVES
-#define HQ_ST_ATTR __attribute__((amdgpu_waves_per_eu(HQ_ST_WAVES, HQ_ST_WAVES)))
-#else
-#define HQ_ST_ATTR
-#endif
-__global__ void __launch_bounds__(HQ_ST_THREADS) HQ_ST_ATTR
+__global__ void __launch_bounds__(HQ_ST_THREADS)
 hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order,
                    const hq_patch_desc* __restrict__ desc, const double* __restrict__ pc1,
                    const double* __restrict__ pc2, const double* __restrict__ pbeta,
