@@ -631,16 +631,29 @@ static int hq_phase(hq_ctx* c, int ph)
             const int32_t nb = c->plan.nb, ne = c->plan.ne;
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             hq_mark(c);
-            hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
-                            c->d_iforce, c->stream);
-            if (c->overlap) {
-                HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
-                HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+            if (c->plan.ns > 0) {
+                /* ONE persistent launch for all element-form patches, the interface patches at the head of its
+                 * queue; the exchange chain starts behind it and runs beside the stencil kernel -- the bulk of the
+                 * partition, in small workgroups that leave CUs to the chain's kernels as they retire */
+                hq_patch_launch(&c->plan, 0, nb + ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                c->d_iforce, c->stream);
+                if (c->overlap) {
+                    HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
+                    HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                }
+                hq_patch_launch_stencil(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], F, c->dt2, c->stream);
+            } else {
+                /* no stencil patches (octree regions, layered material): interface patches first, then the interior
+                 * launch, which leaves `reserve_cus` CUs to the chain */
+                hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                c->d_iforce, c->stream);
+                if (c->overlap) {
+                    HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
+                    HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                }
+                hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
+                                c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             }
-            /* interior: the stencil patches (many small workgroups), then the other element-form patches */
-            hq_patch_launch_stencil(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], F, c->dt2, c->stream);
-            hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
-                            c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
