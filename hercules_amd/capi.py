@@ -16,7 +16,8 @@ HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
-           "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_check_finite"]
+           "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_check_finite",
+           "hq_stencil_coefficients"]
 
 
 class HqError(RuntimeError):

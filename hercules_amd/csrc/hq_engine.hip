@@ -1132,6 +1132,20 @@ extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
     return HQ_OK;
 }
 
+/*
+ * The sixteen numbers of the assembled 27-point stencil (hq_stencil in hq_patch.h), as hq_k_patch_stencil
+ * uses them: out = {p1[6], p2[6], q1[2], q2[2]} for S = c1 S1 + c2 S2.  Host only; HQ_ERR_STATE if the
+ * cube symmetry the kernel relies on does not hold for the element arithmetic (then no patch is marked).
+ */
+extern "C" int hq_stencil_coefficients(double out[16])
+{
+    if (!out) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    const hq_stencil_tab& t = hq_stencil();
+    for (int i = 0; i < 6; i++) { out[i] = t.c.p1[i]; out[6 + i] = t.c.p2[i]; }
+    for (int i = 0; i < 2; i++) { out[12 + i] = t.c.q1[i]; out[14 + i] = t.c.q2[i]; }
+    return t.ok ? HQ_OK : hq_fail(HQ_ERR_STATE, "the assembled stencil lacks the cube symmetry%s", "");
+}
+
 extern "C" int hq_destroy(hq_ctx* c)
 {
     if (!c) return HQ_OK;

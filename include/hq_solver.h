@@ -239,6 +239,16 @@ HQ_API int hq_run_timed(hq_ctx* ctx, int32_t nsteps, double* total_ms, double* k
  */
 HQ_API int hq_plan_check(const hq_desc* desc, int64_t report[8]);
 
+/*
+ * Host-only: the sixteen coefficients {p1[6], p2[6], q1[2], q2[2]} of the assembled 27-point stencil
+ * S = c1 S1 + c2 S2 that hq_k_patch_stencil applies on uniform lattice patches -- the same operator
+ * -(c1 K1 + c2 K2) that compute_addforce_effective + damping_addforce apply element by element
+ * (stiffness.c:180-237, damping.c:29-103), assembled per node.  Diagonal blocks S[d][a][a]: class
+ * (d_a != 0) + 2 x (number of the other two offsets that are non-zero); off-diagonal S[d][a][b] =
+ * q[d_c != 0] sgn(d_a) sgn(d_b).  HQ_ERR_STATE if the symmetry check of the tables failed.
+ */
+HQ_API int hq_stencil_coefficients(double out[16]);
+
 /* Name of the dominant kernel as it appears in rocprofv3 kernel traces. */
 HQ_API const char* hq_dominant_kernel(hq_ctx* ctx);
 

@@ -55,3 +55,38 @@ def test_butterfly_product_equals_the_element_matrices(lib):
         X, Y, Z = [np.ascontiguousarray(w[:, k]) for k in range(3)]
         lib.element_force(X.ctypes.data_as(dp), Y.ctypes.data_as(dp), Z.ctypes.data_as(dp), 2.0, 3.0)
         assert max(np.abs(X).max(), np.abs(Y).max(), np.abs(Z).max()) <= 1e-14
+
+
+def test_assembled_stencil_coefficients_equal_the_assembled_element_matrices():
+    """hq_k_patch_stencil steps uniform lattice patches with the 27-point stencil S = c1 S1 + c2 S2 assembled
+    from the element matrix.  Its sixteen coefficients (libhq_solver.so builds them on the host from the
+    kernels' own element arithmetic) against the SAME assembly of the reference's K1, K2 (compute_K), and the
+    cube symmetry the kernel relies on checked entry by entry: f(node) = -sum_d (c1 S1 + c2 S2)[d] w(node + d)."""
+    from hercules_amd import build as hbuild
+    import hercules_amd as ha
+    hbuild.build()
+    lib = ha.load_library()
+    out = (ctypes.c_double * 16)()
+    assert lib.hq_stencil_coefficients(out) == 0
+    got = np.array(out[:])
+    K = [np.asarray(k).reshape(8, 8, 3, 3) for k in ho.compute_K()]
+    for which in range(2):
+        S = np.zeros((3, 3, 3, 3, 3))
+        for o in range(8):                      # the node is corner o of the element at offset -o
+            for m in range(8):
+                d = [-((o >> k) & 1) + ((m >> k) & 1) for k in range(3)]
+                S[d[0] + 1, d[1] + 1, d[2] + 1] -= K[which][o, m]      # force = -K w
+        p = got[6 * which:6 * which + 6]
+        q = got[12 + 2 * which:14 + 2 * which]
+        scale = np.abs(S).max()
+        for d in np.ndindex(3, 3, 3):
+            dd = [v - 1 for v in d]
+            for a in range(3):
+                for b in range(3):
+                    if a == b:
+                        others = [dd[k] for k in range(3) if k != a]
+                        want = p[(dd[a] != 0) + 2 * sum(v != 0 for v in others)]
+                    else:
+                        c = 3 - a - b
+                        want = q[int(dd[c] != 0)] * np.sign(dd[a]) * np.sign(dd[b])
+                    assert abs(S[d][a, b] - want) <= 1e-13 * scale, (which, dd, a, b)
