@@ -760,15 +760,20 @@ def test_create_refuses_a_table_that_is_not_rayleigh_proportional():
         ha.Solver(lnid, et, nt, 1e-3)
 
 
-@pytest.mark.parametrize("pipe", ["0", "4", "6"])
+@pytest.mark.parametrize("pipe", ["0", "4", "6", "4-nostencil", "6-nostencil"])
 def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
-    """The three patch kernels -- hq_k_patch_seed (default, HQ_PATCH_PIPE=6), hq_k_patch_pers (4: the form a
+    """The element-form patch kernels -- hq_k_patch_seed (default, HQ_PATCH_PIPE=6), hq_k_patch_pers (4: the form a
     mesh falls back to when three accumulator arrays do not fit LDS) and hq_k_patch_step (0: the form for
-    patches of more than 1024 elements) -- on the same problem: the two-level octree box with hanging nodes
+    patches of more than 1024 elements) -- with and without hq_k_patch_stencil taking the uniform lattice patches
+    (HQ_PATCH_NO_STENCIL=1: the lattice patches go through the element kernels' lattice rows), on the same problem: the two-level octree box with hanging nodes
     on 5 partitions (all four exchanges of a step, interface seeds, hanging-node seeds) against the oracle's
     single-rank run, and a uniform box with lattice patches, dashpot faces and a point source."""
     from hercules_amd import capi, host
+    nostencil = pipe.endswith("-nostencil")      # lattice patches through the element kernels instead of hq_k_patch_stencil
+    pipe = pipe.split("-")[0]
     monkeypatch.setenv("HQ_PATCH_PIPE", pipe)
+    if nostencil:
+        monkeypatch.setenv("HQ_PATCH_NO_STENCIL", "1")
     nranks, nsteps = 5, 12
     ref = H.two_level_mesh(16, 8, 6, 3)
     rng = np.random.default_rng(3)
@@ -802,7 +807,7 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     p1, p2 = v2.copy(), v1.copy()
     ho.solver_run(lnid, et, nt, p1, p2, 0, 6, 2e-4, loaded_lnid=loaded, forces=F)
     s = ha.Solver(lnid, et, nt, 2e-4, tm1=v1, tm2=v2, node_xyz=_ticks(node_ijk, 1 << 20), variant=ha.HQ_VARIANT_PATCH)
-    assert s.dominant_kernel() == want
+    assert s.dominant_kernel() == want              # 8 stencil patches of 64: the element kernel is still the dominant one
     s.set_source(loaded, F)
     s.run(6)
     tm1, tm2 = s.download()
