@@ -336,3 +336,28 @@ def test_full_basin_variants_agree():
     assert not tm1.any()
     s.close()
     box.close()
+
+
+def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels():
+    """1 M-element box, point source, 1500 steps: hq_k_patch_stencil (+ the element kernel at the faces) against
+    the scatter variant -- two formulations of the same operator (assembled 27-point stencil vs element by
+    element with atomics) -- stay together to rounding over a long run; both stay finite."""
+    nx, ny, nz, h, dt, freq = 128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+    nsteps = 1500
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt, source_window=nsteps)
+    F = box.source_table(rp, 0, nsteps)
+    res = []
+    for variant, kernel in ((ha.HQ_VARIANT_PATCH, "hq_k_patch_stencil"), (ha.HQ_VARIANT_SCATTER, "hq_k_element_scatter")):
+        s = box.create_solver(variant=variant)
+        assert s.dominant_kernel() == kernel
+        s.set_source(loaded, F)
+        s.run(nsteps)
+        res.append(s.download()[0])
+        assert s.check_finite() == 0
+        s.close()
+    scale = np.abs(res[1]).max()
+    assert scale > 0 and np.abs(res[0] - res[1]).max() <= 1e-11 * scale
+    box.close()
