@@ -48,7 +48,8 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("npatches", ctypes.c_int32),
                 ("patch_pairs", ctypes.c_int64), ("device_bytes", ctypes.c_int64),
-                ("step", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+                ("step", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32)]
 
 
 _lib = None

@@ -1194,6 +1194,8 @@ extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
     info->device_bytes = c->bytes;
     info->step = c->step;
     info->nranks = c->nranks;
+    info->lattice_patches = c->plan.nlattice;
+    info->stencil_patches = c->plan.ns;
     return HQ_OK;
 }
 

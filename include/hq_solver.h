@@ -110,6 +110,8 @@ typedef struct {
     int64_t device_bytes;        /* device memory owned by the context        */
     int32_t step;                /* next step to be executed                  */
     int32_t nranks;
+    int32_t lattice_patches;     /* patch variant: patches with rows and lanes on one lattice (conflict-free LDS) */
+    int32_t stencil_patches;     /* patch variant: patches stepped by hq_k_patch_stencil                          */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
