@@ -1,4 +1,7 @@
 #!/bin/bash
+# ROUND-1 RECORD: the -DHQ_PERS_DIAG=n ablation bodies this script builds were taken out of the shipping
+# translation unit in round 2 (their results are in DESIGN.md s7 and profiles/r01/ablate_pers_v5.txt); the script is kept
+# as the record of how those numbers were taken and no longer builds anything different from the shipped kernel.
 # GPU box: ablations of hq_k_patch_pers on the 64M box (ephemeral rebuilds with -DHQ_PERS_DIAG=n;
 # results are WRONG by construction): 1 = no element section, 2 = no node loads, 3 = no update/stores;
 # 7 = halo rows read from behind the owned rows (dense; results wrong): what do the scattered halo lines cost?
