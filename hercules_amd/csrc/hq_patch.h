@@ -1643,6 +1643,11 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     const double* q3 = nt3 + 3 * ((int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : t));
     const double m0 = q3[0], m2 = q3[1], m1 = q3[2];
     hq_lds_double* __restrict__ img = (hq_lds_double*)s_w;
+    /* the node's own contribution to its update, m2 u1 - m1 u2, now: u1, u2 and two of the three masses need not
+     * live through the stencil */
+    double rs[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) rs[d] = m2 * x1[d] - m1 * x2[d];
 #pragma unroll
     for (int d = 0; d < 3; d++) img[3 * rowA + d] = x1[d] + beta * (x1[d] - x2[d]);
     if (t < HQ_LAT_NHALO) {
@@ -1686,7 +1691,7 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     }
     double* out = ung + 3 * gA;
 #pragma unroll
-    for (int d = 0; d < 3; d++) out[d] = (f[d] + (m2 * x1[d] - m1 * x2[d])) / m0;
+    for (int d = 0; d < 3; d++) out[d] = (f[d] + rs[d]) / m0;
 }
 
 
