@@ -578,6 +578,7 @@ def main():
                        "nodes": int(box.info["total_nodes"]), "partition": "octor block x%d" % world,
                        "kernel_variant": "patch" if is_patch else "scatter",
                        "patches": int(info["npatches"]), "stencil_patches": int(info["stencil_patches"]),
+                       "ragged_patches": int(info["ragged_patches"]),
                        "patch_elements": int(info["patch_pairs"]),
                        "setup_s": round(setup_s, 1), "finite": nonfinite == 0, "rccl_ranks": rccl_ranks},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch

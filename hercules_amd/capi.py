@@ -49,7 +49,8 @@ class _Info(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("npatches", ctypes.c_int32),
                 ("patch_pairs", ctypes.c_int64), ("device_bytes", ctypes.c_int64),
                 ("step", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32)]
+                ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32),
+                ("ragged_patches", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lib = None

@@ -631,17 +631,20 @@ static int hq_phase(hq_ctx* c, int ph)
             const int32_t nb = c->plan.nb, ne = c->plan.ne;
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             hq_mark(c);
-            if (c->plan.ns > 0) {
+            if (c->plan.ns > 0 || c->plan.nr > 0) {
                 /* ONE persistent launch for all element-form patches, the interface patches at the head of its
                  * queue; the exchange chain starts behind it and runs beside the stencil kernel -- the bulk of the
                  * partition, in small workgroups that leave CUs to the chain's kernels as they retire */
                 hq_patch_launch(&c->plan, 0, nb + ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                                 c->d_iforce, c->stream);
+                hq_patch_launch_stencil(&c->plan, 0, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                        c->d_iforce, c->stream);      /* the stencil patches on the partition interface */
                 if (c->overlap) {
                     HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                     HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
                 }
-                hq_patch_launch_stencil(&c->plan, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], F, c->dt2, c->stream);
+                hq_patch_launch_stencil(&c->plan, 1, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                        c->d_iforce, c->stream);
             } else {
                 /* no stencil patches (octree regions, layered material): interface patches first, then the interior
                  * launch, which leaves `reserve_cus` CUs to the chain */
@@ -815,7 +818,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         HQ_TRY(upload(ptr, &c->d_oi_ptr));
         HQ_TRY(upload(pos, &c->d_oi_pos));
     }
-    if (hq_patch_set_interface(&c->plan, slot.data(), &c->bytes) != 0)
+    if (hq_patch_set_interface(&c->plan, slot.data(), (int64_t)c->N, &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
     if (!getenv("HQ_NO_OVERLAP")) {
         /* the exchange chain is short and latency-bound: let its kernels (and RCCL's) get CUs ahead
@@ -1195,7 +1198,9 @@ extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
     info->step = c->step;
     info->nranks = c->nranks;
     info->lattice_patches = c->plan.nlattice;
-    info->stencil_patches = c->plan.ns;
+    info->stencil_patches = c->plan.nstencil;
+    info->ragged_patches = c->plan.nragged;
+    info->reserved = 0;
     return HQ_OK;
 }
 
@@ -1401,7 +1406,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
-    if (2 * c->plan.ns > c->plan.npatches) return "hq_k_patch_stencil";
+    if (2 * c->plan.nstencil > c->plan.npatches) return "hq_k_patch_stencil";
     if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
     return c->plan.seeded ? "hq_k_patch_seed" : "hq_k_patch_pers";
 }

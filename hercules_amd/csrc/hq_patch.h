@@ -39,10 +39,21 @@
 
 /* Tuning knobs (environment overrides HQ_PATCH_THREADS / _PMAX / _PMERGE / _NLMAX are
  * read once per plan; defaults from the sweeps in profiles/). */
+/* HQ_PATCH_RAGGED=1: lattice-SUBSET patches (domain faces, partition interfaces, far-face cubes) go through
+ * hq_k_patch_stencil too, not only the full lattices.  Measured equal or slower than the element form:
+ * off by default. */
+static inline bool hq_patch_want_ragged(void)
+{
+    const char* e = getenv("HQ_PATCH_RAGGED");
+    return e && atoi(e) != 0;
+}
+
 struct hq_patch_cfg {
     int threads = 512;    /* workgroup size                                          */
     int pmax    = 768;    /* owned nodes per patch (9*9*9 = 729 fits)                */
     int pmerge  = 512;    /* small neighbouring cubes are merged up to this          */
+    int psplit  = 0;      /* a cube with more owned nodes is halved; 0 = pmax, or 512 with HQ_PATCH_RAGGED=1 (the 9-wide
+                           * cubes on the far faces hold 576..729 nodes; hq_k_patch_stencil gives a thread one node)  */
     int nlmax   = 1024;   /* owned + halo nodes staged in LDS (10*10*10 fits)        */
     int vmax    = 0;      /* extra force accumulators for hanging nodes whose anchors */
                           /* the patch owns (set by the planner when the mesh has any) */
@@ -55,12 +66,14 @@ static hq_patch_cfg hq_patch_cfg_from_env(void)
     c.threads = geti("HQ_PATCH_THREADS", c.threads);
     c.pmax = geti("HQ_PATCH_PMAX", c.pmax);
     c.pmerge = geti("HQ_PATCH_PMERGE", c.pmerge);
+    c.psplit = geti("HQ_PATCH_PSPLIT", hq_patch_want_ragged() ? 512 : 0);
     c.nlmax = geti("HQ_PATCH_NLMAX", c.nlmax);
     if (c.threads < 64) c.threads = 64;
     if (c.threads > HQ_PATCH_MAX_THREADS) c.threads = HQ_PATCH_MAX_THREADS;
     c.threads &= ~63;
     if (c.pmax < 8) c.pmax = 8;
     if (c.pmerge > c.pmax) c.pmerge = c.pmax;
+    if (c.psplit > c.pmax || c.psplit < 8) c.psplit = c.pmax;
     if (c.pmerge < 1) c.pmerge = 1;
     if (c.nlmax < c.pmax + 8) c.nlmax = c.pmax + 8;
     if (c.nlmax > 0x7fff) c.nlmax = 0x7fff;          /* HQ_PIDX_ROW: 15-bit rows in the element row */
@@ -89,8 +102,10 @@ struct hq_patch_desc {
                              /* of all local nodes and u1, u2 of the owned ones in LDS instead of u1, u2 of all */
 #define HQ_PATCH_NTSAME 8    /* ISO, and every owned node has the same n_t row: all lanes read the first one */
 #define HQ_PATCH_LATTICE 16  /* rows and lanes of hq_lattice(): thread t's LDS row is lat_row[t] (hq_k_patch_pers / _seed only) */
-#define HQ_PATCH_STENCIL 32  /* lattice patch with uniform coefficients, no dashpot, no interface node, no loaded hanging node:
-                              * stepped by hq_k_patch_stencil (the assembled 27-point stencil per owned node) */
+#define HQ_PATCH_STENCIL 32  /* nodes and elements on the 10x10x10 lattice (all of it or a subset), uniform coefficients, no hanging
+                              * node involved: stepped by hq_k_patch_stencil (the assembled 27-point stencil per owned node) */
+#define HQ_PATCH_RAGGED 64   /* a STENCIL patch that is not the full lattice without dashpot: a domain face, a partition interface,
+                              * a far-face patch of 9 layers (statistics only: the kernel reads the patch shape's table) */
 
 struct hq_patch_host {
     std::vector<hq_patch_desc> desc;
@@ -135,8 +150,18 @@ struct hq_patch_plan {
     int32_t* d_order = nullptr;      /* patch ids: the nb interface patches first, then the rest */
     int32_t* d_tickets = nullptr;    /* per XCD, HQ_TICKET_STRIDE ints apart: {next slot of hq_k_patch_pers' work queue, workgroups done} */
     uint16_t* d_lat_row = nullptr;   /* [1024] LDS row of thread t's local node in a lattice patch             */
-    uint16_t* d_lat_row2 = nullptr;  /* [1024] ... in the image of a stencil patch                              */
-    int32_t  ne = 0, ns = 0;         /* d_order = nb interface patches | ne other element-form patches | ns stencil patches */
+    int32_t  ne = 0, ns = 0, nr = 0; /* d_order = nb interface patches | ne other element-form patches | nr stencil patches with
+                                      * interface nodes | ns other stencil patches */
+    int32_t  nragged = 0, nstencil = 0;  /* STENCIL patches (nr + ns entries: two for a patch of more than 512 nodes), RAGGED ones among them */
+    uint32_t* d_rg_tab = nullptr;    /* tables of the stencil patches (hq_ragged_match), one per patch shape      */
+#ifdef HQ_ST_TIMING
+    bool timing_armed = false; unsigned long long* d_timing = nullptr;
+#endif
+    double*  d_pcoef = nullptr;      /* [P][4] c1, c2, beta of a stencil patch (beside the descriptor: no second hop)  */
+    int64_t* d_rg_off = nullptr;     /* [P] offset of a patch's table in d_rg_tab                                  */
+    double*  d_E1 = nullptr;         /* [576] element matrix blocks for (c1, c2) = (1, 0) ...                      */
+    double*  d_E2 = nullptr;         /* ... and (0, 1)                                                              */
+    int32_t* d_if_slot = nullptr;    /* [N] interface slot of a node or -1 (ragged patches on a partition)          */
     std::vector<int32_t> h_flags;    /* host copy of the patches' flags (hq_patch_set_interface edits them)     */
     int32_t  nlattice = 0;           /* lattice patches                                                        */
     int32_t  nrows = 0;              /* rows of hq_k_patch_pers' LDS image                                     */
@@ -362,6 +387,8 @@ struct hq_stencil_tab {
     bool ok;
     hq_stencil_coef c;
     uint16_t row2_of_local[1024];    /* canonical local node of a lattice patch -> stencil-image row */
+    double E1[576], E2[576];         /* element matrix for (c1, c2) = (1, 0) / (0, 1): E[((o * 8 + m) * 3 + a) * 3 + b] = force on
+                                      * corner o, component a, per unit displacement of corner m, component b */
 };
 
 static const hq_stencil_tab& hq_stencil(void)
@@ -385,6 +412,13 @@ static const hq_stencil_tab& hq_stencil(void)
                     hq_element_force(X, Y, Z, which == 0 ? 1.0 : 0.0, which == 0 ? 0.0 : 1.0);
                     for (int n = 0; n < 8; n++) { E[3 * n][3 * m + b] = X[n]; E[3 * n + 1][3 * m + b] = Y[n]; E[3 * n + 2][3 * m + b] = Z[n]; }
                 }
+            {
+                double* Et = which == 0 ? t.E1 : t.E2;
+                for (int o = 0; o < 8; o++)
+                    for (int m = 0; m < 8; m++)
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) Et[((o * 8 + m) * 3 + a) * 3 + b] = E[3 * o + a][3 * m + b];
+            }
             /* the node is corner o of the element whose low corner sits at offset -o (bit k of o set: offset -1 along k);
              * the neighbour at offset d is corner m of that element with m_k = d_k + o_k */
             double S[3][3][3][3][3] = {};
@@ -420,6 +454,86 @@ static const hq_stencil_tab& hq_stencil(void)
         return t;
     }();
     return tab;
+}
+
+/*
+ * STENCIL patches: the owned nodes (<= 729) and the ring (<= 512) of a patch lie on the 10x10x10 lattice of hq_stencil
+ * -- all of it, or (RAGGED) not: the domain ends at a face, the partition ends, or the far-boundary layer makes the
+ * patch 9 nodes wide.  Table of such a patch (uint32, shared between patches of one shape):
+ *     nloc x: per local node (owned in id order, then the halo list) its lattice row 10 I + 104 J + K, for an owned
+ *             node + 2^11 x the mask of its present elements (bit o: the element whose corner o the node is) + 2^19 x
+ *             its index in the boundary list;
+ *     nbnd x: the owned nodes with an incomplete mask (<= 256), the same word.
+ * -> false if the patch is not a lattice subset (then it stays in the element form).
+ */
+#define HQ_RG_ROW(w) ((int)((w) & 0x7ffu))
+#define HQ_RG_MASK(w) (((w) >> 11) & 0xffu)
+#define HQ_RG_BIDX(w) ((int)(((w) >> 19) & 0xffu))
+static bool hq_ragged_match(int32_t base, int32_t nown, const int32_t* lnid, const int32_t* xyz, const int32_t* el,
+                            int32_t npairs, const std::vector<int32_t>& h, std::vector<uint32_t>& tab, int32_t* nbnd)
+{
+    if (nown < 1 || nown > 512 || npairs < 1 || npairs > 729 || h.empty() || h.size() > 512 || nown + (int32_t)h.size() > 1000) return false;
+    const int32_t* e0 = lnid + 8 * (int64_t)el[0];
+    const int64_t s = (int64_t)xyz[3 * (int64_t)e0[1]] - xyz[3 * (int64_t)e0[0]];
+    if (s <= 0) return false;
+    int64_t O[3];
+    for (int d = 0; d < 3; d++) {
+        int64_t mn = xyz[3 * (int64_t)base + d];
+        for (int32_t t = 1; t < nown; t++) mn = std::min<int64_t>(mn, xyz[3 * ((int64_t)base + t) + d]);
+        O[d] = mn - s;                                  /* the owned nodes start at lattice coordinate 1 */
+    }
+    auto ijk = [&](int32_t n, int q[3]) -> bool {
+        for (int d = 0; d < 3; d++) {
+            const int64_t v = (int64_t)xyz[3 * (int64_t)n + d] - O[d];
+            if (v < 0 || v % s || v / s > 9) return false;
+            q[d] = (int)(v / s);
+        }
+        return true;
+    };
+    const int32_t nloc = nown + (int32_t)h.size();
+    std::vector<uint16_t> row((size_t)nloc);
+    std::vector<int> own_ijk((size_t)nown);
+    for (int32_t t = 0; t < nloc; t++) {
+        int q[3];
+        if (!ijk(t < nown ? base + t : h[(size_t)(t - nown)], q)) return false;
+        if (t < nown) {
+            if (q[0] < 1 || q[1] < 1 || q[2] < 1) return false;
+            own_ijk[(size_t)t] = q[0] + 10 * q[1] + 100 * q[2];
+        }
+        row[(size_t)t] = (uint16_t)(HQ_ST_PX * q[0] + HQ_ST_PY * q[1] + HQ_ST_PZ * q[2]);
+    }
+    bool present[729] = { false };
+    for (int32_t q = 0; q < npairs; q++) {
+        const int32_t* id = lnid + 8 * (int64_t)el[q];
+        int e[3];
+        if (!ijk(id[0], e) || e[0] > 8 || e[1] > 8 || e[2] > 8) return false;
+        for (int c = 1; c < 8; c++) {
+            int v[3];
+            if (!ijk(id[c], v) || v[0] != e[0] + (c & 1) || v[1] != e[1] + ((c >> 1) & 1) || v[2] != e[2] + ((c >> 2) & 1)) return false;
+        }
+        present[e[0] + 9 * e[1] + 81 * e[2]] = true;
+    }
+    std::vector<uint8_t> mask((size_t)nown);
+    std::vector<uint16_t> bidx((size_t)nown, 0xffff), blist;
+    for (int32_t t = 0; t < nown; t++) {
+        const int I = own_ijk[(size_t)t] % 10, J = (own_ijk[(size_t)t] / 10) % 10, K = own_ijk[(size_t)t] / 100;
+        uint8_t m = 0;
+        for (int o = 0; o < 8; o++) {
+            const int ei = I - (o & 1), ej = J - ((o >> 1) & 1), ek = K - ((o >> 2) & 1);
+            if (ei >= 0 && ei < 9 && ej >= 0 && ej < 9 && ek >= 0 && ek < 9 && present[ei + 9 * ej + 81 * ek]) m |= (uint8_t)(1 << o);
+        }
+        if (m == 0) return false;                       /* a node no element touches */
+        mask[(size_t)t] = m;
+        if (m != 0xff) { bidx[(size_t)t] = (uint16_t)blist.size(); blist.push_back((uint16_t)t); }
+    }
+    if (blist.size() > 256) return false;               /* the boundary list is worked off by four waves at most */
+    tab.clear();
+    for (int32_t t = 0; t < nloc; t++)
+        tab.push_back((uint32_t)row[(size_t)t] | (t < nown ? ((uint32_t)mask[(size_t)t] << 11) | ((uint32_t)(bidx[(size_t)t] & 0xff) << 19) : 0u));
+    for (uint16_t t : blist) tab.push_back((uint32_t)row[t] | ((uint32_t)mask[t] << 11));
+    while (tab.size() & 3) tab.push_back(0);             /* 16-byte granules */
+    *nbnd = (int32_t)blist.size();
+    return true;
 }
 
 /*
@@ -480,7 +594,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
     while (!stack.empty()) {
         item it = stack.back();
         stack.pop_back();
-        if (it.hi - it.lo <= cfg.pmax) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
+        if (it.hi - it.lo <= cfg.psplit) { runs.push_back({ (int32_t)it.lo, (int32_t)it.hi }); continue; }
         if (it.bit <= 0) {
             for (int64_t i = it.lo; i < it.hi; i += cfg.pmerge)
                 runs.push_back({ (int32_t)i, (int32_t)std::min<int64_t>(i + cfg.pmerge, it.hi) });
@@ -1604,55 +1718,123 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 
 
 /*
- * hq_k_patch_stencil: one step of a STENCIL patch (see hq_stencil): one 512-thread workgroup per patch, not
- * persistent -- the kernel needs 25 KB of LDS and few registers, so several workgroups share a CU and the
- * hardware overlaps one patch's loads with another's arithmetic.  Thread t loads owned node t (u1, u2, kept
- * in registers for its own update) and halo node t, writes w = u1 + beta (u1 - u2) of both to the LDS image,
- * and after ONE barrier evaluates the assembled 27-point stencil for its owned node:
- *     f = S w,   u(t+dt) = (f + m2 u1 - m1 u2) / m0          (solver_compute_displacement, psolve.c:4078-4106)
+ * hq_k_patch_stencil: one step of a STENCIL patch (see hq_stencil and hq_ragged_match): the patch's nodes and elements
+ * lie on the 10x10x10 lattice -- all of it (the interior of a uniform region) or a subset (a domain face, a partition
+ * interface, the halves of a 9-wide far-face cube: RAGGED).  One 512-thread workgroup per patch, not persistent: few
+ * registers and 25 KB of LDS (42 KB where the launch has ragged patches), so three workgroups share a CU and the
+ * hardware overlaps one patch's loads with another's arithmetic; the patches of a launch are in Z-order, so
+ * neighbours' rings meet in the XCD's L2.  (A persistent, software-pipelined form -- next patch's rows requested
+ * before this patch's stencil, two images -- was measured and is slower: DESIGN.md s7.)
+ * Thread t owns owned node t and loads it and halo node t.  Everything a thread needs is requested up front in the
+ * order of the dependency chain (descriptor, table offset and coefficients ride on the patch number alone; the owned
+ * rows need the descriptor; the halo rows the halo list); w = u1 + beta (u1 - u2) of both nodes goes to the LDS image,
+ * and after ONE barrier
+ *   B: (ragged patches) the owned nodes with an incomplete element mask, <= 256, compacted list of the table: the sum
+ *      over their PRESENT elements' blocks, f = sum_o sum_m E[o][m] w(m), E = c1 E1 + c2 E2 built per patch in LDS,
+ *      the octants dealt to the waves (partial sums in LDS, added in octant order: no atomics, one summation order),
+ *      and a second barrier;
+ *   A: every owned node with all eight elements around it: the assembled 27-point stencil  f = S w;
+ *   then the owner's update  u(t+dt) = (f + m2 u1 - m1 u2) / m0  (solver_compute_displacement, psolve.c:4078-4106)
+ *   with the node's own n_t row (7 doubles where a dashpot acts); in the launch over the interface patches a node on
+ *   the partition interface hands its pure force to the exchange (psolve.c:4301) -- its seed is 0 (negative m0), the
+ *   interface kernel finishes it.
  * No atomics, no accumulators.  Same operator as the element kernels, other summation order.
  */
 #define HQ_ST_THREADS 512
+#define HQ_RG_MAXB 256
+#define HQ_ST_LDS_RAGGED (8 * (576 + 3 * 2 * HQ_RG_MAXB))
+#ifdef HQ_ST_TIMING      /* experiment builds only: per-patch clock stamps of hq_k_patch_stencil */
+__device__ unsigned long long* g_hq_st_time = nullptr;
+#define HQ_ST_STAMP(k) do { if (threadIdx.x == 0 && g_hq_st_time) g_hq_st_time[4 * (size_t)slot + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HQ_ST_STAMP(k) do { } while (0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HQ_SCHED_FENCE() do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(HQ_ST_THREADS)
 hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order,
-                   const hq_patch_desc* __restrict__ desc, const double* __restrict__ pc1,
-                   const double* __restrict__ pc2, const double* __restrict__ pbeta,
+                   const hq_patch_desc* __restrict__ desc, const double* __restrict__ pcoef,
                    const int32_t* __restrict__ halo, int32_t hstride, const double* __restrict__ u1g,
-                   const double* __restrict__ u2g, double* __restrict__ ung, const double* __restrict__ nt3,
-                   const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
-                   const double* __restrict__ F, double dt2, const uint16_t* __restrict__ lat_row,
-                   const uint16_t* __restrict__ lat_row2, hq_stencil_coef sc)
+                   const double* __restrict__ u2g, double* __restrict__ ung, const double* __restrict__ nt,
+                   const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
+                   const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
+                   const uint32_t* __restrict__ rg_tab, const int64_t* __restrict__ rg_off,
+                   const double* __restrict__ E1, const double* __restrict__ E2,
+                   const int32_t* __restrict__ if_slot, double* __restrict__ iforce,
+                   const uint16_t* __restrict__ lat_row, hq_stencil_coef sc)
 {
     __shared__ __align__(16) double s_w[3 * HQ_ST_ROWS];
+    extern __shared__ __align__(16) double s_dyn[];      /* HQ_ST_LDS_RAGGED bytes where the launch has ragged patches */
+    double* s_E = s_dyn;
+    double* s_fb = s_dyn + 576;
     /* workgroups b and b + 8 share an XCD: each XCD walks a contiguous run of Z-ordered patches */
     const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (slot >= count) return;
+    HQ_ST_STAMP(0);
     const int p = order[slot];
     const int t = threadIdx.x;
     const hq_patch_desc D = desc[p];
-    const int th = t < HQ_LAT_NHALO ? t : HQ_LAT_NHALO - 1;
-    const int32_t hid = halo[(int64_t)p * hstride + th];
-    const int rowA = lat_row2[t], rowB = lat_row2[HQ_LAT_NOWN + th];
-    const double beta = pbeta[D.pair_off], c1 = pc1[D.pair_off], c2 = pc2[D.pair_off];
-    const int64_t gA = (int64_t)D.base + t, gB = hid;
+    const int64_t rgo = rg_off[p];
+    const int nown = D.nown, nhalo = D.nhalo;
+    const uint32_t* __restrict__ loc = rg_tab + (rgo & 0xffffffffffll);   /* row, mask, boundary index of the local nodes */
+    const int nbnd = (int)(rgo >> 40);
+    const uint32_t* __restrict__ blist = loc + (nown + nhalo);            /* the boundary nodes' words */
+    const double c1 = pcoef[4 * (int64_t)p], c2 = pcoef[4 * (int64_t)p + 1], beta = pcoef[4 * (int64_t)p + 2];
+    hq_lds_double* __restrict__ img = (hq_lds_double*)s_w;
+    /* lanes past a list read its last entry again (same row, same value) */
+    const bool owner = t < nown;
+    const int lA = owner ? t : nown - 1;
+    const int64_t gA = (int64_t)D.base + lA;
     double x1[3], x2[3], y1[3], y2[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * gA + d]; x2[d] = u2g[3 * gA + d]; }
+    const int hB = t < nhalo ? t : nhalo - 1;                             /* a stencil patch has a halo */
+    const int64_t gB = (int64_t)halo[(int64_t)p * hstride + hB];
+    const uint32_t wA = loc[lA], wB = loc[nown + hB];
+    /* B's lane (j, group): boundary node j, the group's octants; groups = 512 / (boundary nodes rounded up to 64, 128
+     * or 256) = 8, 4 or 2 of 1, 2 or 4 octants: a wave works on ONE octant at a time (uniform E) */
+    const int sh = nbnd <= 64 ? 6 : (nbnd <= 128 ? 7 : 8);
+    const int j = t & ((1 << sh) - 1), grp = t >> sh;
+    const uint32_t wJ = blist[j < nbnd ? j : 0];
+    /* the element matrix blocks of B (L2-resident, the same for every patch): requested with the first loads */
+    double e1a = 0.0, e2a = 0.0, e1b = 0.0, e2b = 0.0;
+    if (nbnd > 0) { e1a = E1[t]; e2a = E2[t]; e1b = E1[512 + (t & 63)]; e2b = E2[512 + (t & 63)]; }
+    HQ_SCHED_FENCE();
 #pragma unroll
     for (int d = 0; d < 3; d++) { y1[d] = u1g[3 * gB + d]; y2[d] = u2g[3 * gB + d]; }
-    const double* q3 = nt3 + 3 * ((int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : t));
-    const double m0 = q3[0], m2 = q3[1], m1 = q3[2];
-    hq_lds_double* __restrict__ img = (hq_lds_double*)s_w;
-    /* the node's own contribution to its update, m2 u1 - m1 u2, now: u1, u2 and two of the three masses need not
-     * live through the stencil */
-    double rs[3];
+    /* the owned node's n_t: mass_simple (negative: the node's seed is 0, its update belongs to the interface kernel or
+     * to compute_adjust) from the private 3-double table; the axis terms from it or, where a dashpot acts on the patch,
+     * from the 7-double rows (then NTSAME is not set) */
+    const int64_t nn = (int64_t)D.base + ((D.flags & HQ_PATCH_NTSAME) ? 0 : lA);
+    const double* q3 = nt3 + 3 * nn;
+    double m0 = q3[0], rs[3];
+    const double m2s = q3[1], m1s = q3[2];
+    HQ_SCHED_FENCE();
+    /* the node's own contribution to its update, m2 u1 - m1 u2, now: u1, u2 and two of the three masses need not live
+     * through the stencil */
 #pragma unroll
-    for (int d = 0; d < 3; d++) rs[d] = m2 * x1[d] - m1 * x2[d];
+    for (int d = 0; d < 3; d++) rs[d] = m2s * x1[d] - m1s * x2[d];
+    if (!(D.flags & HQ_PATCH_ISO)) {
+        const double* q7 = nt + 7 * nn;
 #pragma unroll
-    for (int d = 0; d < 3; d++) img[3 * rowA + d] = x1[d] + beta * (x1[d] - x2[d]);
-    if (t < HQ_LAT_NHALO) {
+        for (int d = 0; d < 3; d++) rs[d] = q7[1 + d] * x1[d] - q7[4 + d] * x2[d];
+    }
+    if (m0 < 0.0) { rs[0] = rs[1] = rs[2] = 0.0; m0 = -m0; }
+    const int myrow = HQ_RG_ROW(wA), rowB = HQ_RG_ROW(wB);
+    const unsigned mymask = HQ_RG_MASK(wA);
+    const unsigned bm = j < nbnd ? HQ_RG_MASK(wJ) : 0u;
+    const int brow = HQ_RG_ROW(wJ);
 #pragma unroll
-        for (int d = 0; d < 3; d++) img[3 * rowB + d] = y1[d] + beta * (y1[d] - y2[d]);
+    for (int d = 0; d < 3; d++) img[3 * myrow + d] = x1[d] + beta * (x1[d] - x2[d]);
+#pragma unroll
+    for (int d = 0; d < 3; d++) img[3 * rowB + d] = y1[d] + beta * (y1[d] - y2[d]);
+    if (nbnd > 0) {
+        s_E[t] = c1 * e1a + c2 * e2a;
+        if (t < 64) s_E[512 + t] = c1 * e1b + c2 * e2b;
     }
     /* S = c1 S1 + c2 S2: eight wave-uniform numbers */
     double P[6], Q[2];
@@ -1661,37 +1843,82 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
 #pragma unroll
     for (int i = 0; i < 2; i++) Q[i] = c1 * sc.q1[i] + c2 * sc.q2[i];
     __syncthreads();
-    const hq_lds_double* __restrict__ ctr = img + 3 * rowA;
-    double f[3] = { 0.0, 0.0, 0.0 };
+    HQ_ST_STAMP(1);
+
+    if (nbnd > 0) {                                      /* B */
+        const int per = 1 << (sh - 6);
+        double g[3] = { 0.0, 0.0, 0.0 };
+        const hq_lds_double* __restrict__ Es = (const hq_lds_double*)s_E;
+#pragma unroll 1
+        for (int k = 0; k < per; k++) {
+            const int o = grp * per + k;
+            if (__builtin_amdgcn_ballot_w64((bm >> o) & 1) == 0) continue;     /* no lane has this element */
+            if ((bm >> o) & 1) {
+                /* the node is corner o of the element: its corner mm sits at offset (mm - o) per axis */
+                const hq_lds_double* c0 = img + 3 * (brow - (HQ_ST_PX * (o & 1) + HQ_ST_PY * ((o >> 1) & 1) + HQ_ST_PZ * ((o >> 2) & 1)));
+                const hq_lds_double* e = Es + o * 72;
+#pragma unroll 2
+                for (int mm = 0; mm < 8; mm++) {
+                    const hq_lds_double* q = c0 + 3 * (HQ_ST_PX * (mm & 1) + HQ_ST_PY * ((mm >> 1) & 1) + HQ_ST_PZ * ((mm >> 2) & 1));
+                    const double ux = q[0], uy = q[1], uz = q[2];
 #pragma unroll
-    for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-                const hq_lds_double* q = ctr + 3 * (HQ_ST_PX * dx + HQ_ST_PY * dy + HQ_ST_PZ * dz);
-                const double ux = q[0], uy = q[1], uz = q[2];
-                const int ax = dx != 0, ay = dy != 0, az = dz != 0;
-                /* diagonal blocks: class = (own axis off the node?) + 2 x (how many of the other two) */
-                f[0] = fma(P[ax + 2 * (ay + az)], ux, f[0]);
-                f[1] = fma(P[ay + 2 * (ax + az)], uy, f[1]);
-                f[2] = fma(P[az + 2 * (ax + ay)], uz, f[2]);
-                /* off-diagonal blocks: q[|third axis|] sgn sgn */
-                if (dx && dy) { const double c = dx * dy > 0 ? Q[az] : -Q[az]; f[0] = fma(c, uy, f[0]); f[1] = fma(c, ux, f[1]); }
-                if (dx && dz) { const double c = dx * dz > 0 ? Q[ay] : -Q[ay]; f[0] = fma(c, uz, f[0]); f[2] = fma(c, ux, f[2]); }
-                if (dy && dz) { const double c = dy * dz > 0 ? Q[ax] : -Q[ax]; f[1] = fma(c, uz, f[1]); f[2] = fma(c, uy, f[2]); }
+                    for (int a = 0; a < 3; a++) g[a] = fma(e[9 * mm + 3 * a], ux, fma(e[9 * mm + 3 * a + 1], uy, fma(e[9 * mm + 3 * a + 2], uz, g[a])));
+                }
             }
-    if (F && src_ptr[p + 1] > src_ptr[p]) {          /* compute_addforce_s, psolve.c:5917-5927 (entries name lattice rows) */
-        const int myrow = lat_row[t];
+        }
+        /* partial sums [group][j]; 2 * 256 slots hold 8 x 64, 4 x 128 or 2 x 256 */
+        hq_lds_double* fb = (hq_lds_double*)s_fb + 3 * ((grp << sh) + j);
+        fb[0] = g[0]; fb[1] = g[1]; fb[2] = g[2];
+        __syncthreads();
+    }
+    HQ_ST_STAMP(2);
+    if (!owner) return;
+
+    double f[3] = { 0.0, 0.0, 0.0 };
+    if (mymask == 0xffu) {                               /* A: all eight elements around the node */
+        const hq_lds_double* __restrict__ ctr = img + 3 * myrow;
+#pragma unroll
+        for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    const hq_lds_double* q = ctr + 3 * (HQ_ST_PX * dx + HQ_ST_PY * dy + HQ_ST_PZ * dz);
+                    const double ux = q[0], uy = q[1], uz = q[2];
+                    const int ax = dx != 0, ay = dy != 0, az = dz != 0;
+                    /* diagonal blocks: class = (own axis off the node?) + 2 x (how many of the other two) */
+                    f[0] = fma(P[ax + 2 * (ay + az)], ux, f[0]);
+                    f[1] = fma(P[ay + 2 * (ax + az)], uy, f[1]);
+                    f[2] = fma(P[az + 2 * (ax + ay)], uz, f[2]);
+                    /* off-diagonal blocks: q[|third axis|] sgn sgn */
+                    if (dx && dy) { const double c = dx * dy > 0 ? Q[az] : -Q[az]; f[0] = fma(c, uy, f[0]); f[1] = fma(c, ux, f[1]); }
+                    if (dx && dz) { const double c = dx * dz > 0 ? Q[ay] : -Q[ay]; f[0] = fma(c, uz, f[0]); f[2] = fma(c, ux, f[2]); }
+                    if (dy && dz) { const double c = dy * dz > 0 ? Q[ax] : -Q[ax]; f[1] = fma(c, uz, f[1]); f[2] = fma(c, uy, f[2]); }
+                }
+    } else {                                             /* B's partial sums, in octant order */
+        const hq_lds_double* fb = (const hq_lds_double*)s_fb + 3 * HQ_RG_BIDX(wA);
+        for (int gq = 0; gq < (HQ_ST_THREADS >> sh); gq++) {
+            f[0] += fb[0]; f[1] += fb[1]; f[2] += fb[2];
+            fb += 3 << sh;
+        }
+    }
+    if (F && src_ptr[p + 1] > src_ptr[p]) {              /* compute_addforce_s, psolve.c:5917-5927 (entries name the local node,
+                                                          * on a lattice patch its row in the element-form image) */
+        const int key = (D.flags & HQ_PATCH_LATTICE) ? (int)lat_row[t] : t;
         for (int i = src_ptr[p]; i < src_ptr[p + 1]; i++)
-            if (src_ent[2 * i] == myrow) {
+            if (src_ent[2 * i] == key) {
                 const int li = src_ent[2 * i + 1];
                 for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
             }
     }
-    double* out = ung + 3 * gA;
+    if (if_slot) {                                       /* partition interface: the pure force goes to the exchange */
+        const int32_t sl = if_slot[(int64_t)D.base + t];
+        if (sl >= 0) { double* o = iforce + 3 * (int64_t)sl; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; }
+    }
+    double* out = ung + 3 * ((int64_t)D.base + t);
 #pragma unroll
     for (int d = 0; d < 3; d++) out[d] = (f[d] + rs[d]) / m0;
+    HQ_ST_STAMP(3);
 }
 
 
@@ -1699,20 +1926,70 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
 /* device plan                                                              */
 /* ------------------------------------------------------------------------ */
 
+#ifdef HQ_ST_TIMING
+static void hq_st_timing_report(hq_patch_plan* P)
+{
+    const int32_t n = P->ns;
+    if (n <= 0 || !P->d_order) return;
+    unsigned long long* d = nullptr;
+    hipMalloc((void**)&d, 32 * (size_t)n);
+    hipMemset(d, 0, 32 * (size_t)n);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_hq_st_time), &d, sizeof d);
+    hipDeviceSynchronize();
+    P->timing_armed = true;
+    P->d_timing = d;
+}
+static void hq_st_timing_print(hq_patch_plan* P)
+{
+    if (!P->d_timing) return;
+    const int32_t n = P->ns;
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(4 * (size_t)n);
+    std::vector<int32_t> ord((size_t)n);
+    hipMemcpy(h.data(), P->d_timing, 32 * (size_t)n, hipMemcpyDeviceToHost);
+    hipMemcpy(ord.data(), P->d_order + P->nb + P->ne + P->nr, 4 * (size_t)n, hipMemcpyDeviceToHost);
+    double sum[4][4] = {}; long cnt[4] = {};
+    unsigned long long t0 = ~0ull, t1 = 0, xend[8] = {};
+    const int per_xcd = (n + 7) / 8;
+    for (int32_t i = 0; i < n; i++) {
+        const unsigned long long* q = &h[4 * (size_t)i];
+        if (!q[0]) continue;
+        const int32_t p = ord[(size_t)i];
+        const bool sec = false;
+        const int cls = !(P->h_flags[p] & HQ_PATCH_RAGGED) ? 0 : (P->patch_nown[p] <= HQ_ST_THREADS ? 1 : (sec ? 3 : 2));
+        cnt[cls]++;
+        for (int k = 1; k < 4; k++) sum[cls][k] += (double)(q[k] - q[0]);
+        t0 = std::min(t0, q[0]); t1 = std::max(t1, q[3]);
+        xend[i / per_xcd] = std::max(xend[i / per_xcd], q[3]);
+    }
+    const char* nm[4] = { "full", "ragged<=512", "far first", "far second" };
+    fprintf(stderr, "[hq_st_timing] last launch: %.1f us (100 MHz clock)\n", (double)(t1 - t0) / 100.0);
+    for (int c = 0; c < 4; c++)
+        if (cnt[c]) fprintf(stderr, "[hq_st_timing] %-12s n=%6ld  barrier %.2f us  afterB %.2f us  end %.2f us\n", nm[c], cnt[c],
+                            sum[c][1] / cnt[c] / 100.0, sum[c][2] / cnt[c] / 100.0, sum[c][3] / cnt[c] / 100.0);
+    for (int x = 0; x < 8; x++) fprintf(stderr, "[hq_st_timing] xcd %d ends at %.1f us\n", x, (double)(xend[x] - t0) / 100.0);
+}
+#endif
+
 static void hq_patch_free(hq_patch_plan* P)
 {
+#ifdef HQ_ST_TIMING
+    hq_st_timing_print(P);
+#endif
 #ifdef HQ_PATCH_PROFILING
     if (P->npatches) hq_patch_report_stamps();
 #endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
-                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row, P->d_lat_row2 };
+                     P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row,
+                     P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2, P->d_if_slot, P->d_pcoef };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
 
 /*
- * Launch order of the patches: [nb patches that own interface nodes | ne other element-form patches | ns stencil
- * patches], each part in Z-order.  if_ptr (or null): CSR of the interface entries per patch.
+ * Launch order of the patches: [nb element-form patches that own interface nodes | ne other element-form patches |
+ * nr stencil patches that own interface nodes | ns other stencil patches], each part in Z-order.
+ * if_ptr (or null): CSR of the interface entries.
  */
 static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t* bytes)
 {
@@ -1720,18 +1997,29 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
     std::vector<int32_t> order;
     order.reserve((size_t)np);
     auto is_if = [&](int32_t p) { return if_ptr && if_ptr[p + 1] > if_ptr[p]; };
-    for (int32_t p = 0; p < np; p++) if (is_if(p)) order.push_back(p);
+    auto st = [&](int32_t p) { return (P->h_flags[p] & HQ_PATCH_STENCIL) != 0; };
+    for (int32_t p = 0; p < np; p++) if (is_if(p) && !st(p)) order.push_back(p);
     P->nb = (int32_t)order.size();
-    for (int32_t p = 0; p < np; p++) if (!is_if(p) && !(P->h_flags[p] & HQ_PATCH_STENCIL)) order.push_back(p);
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && !st(p)) order.push_back(p);
     P->ne = (int32_t)order.size() - P->nb;
-    for (int32_t p = 0; p < np; p++) if (!is_if(p) && (P->h_flags[p] & HQ_PATCH_STENCIL)) order.push_back(p);
-    P->ns = np - P->nb - P->ne;
-    if (P->nb == 0 && P->ns == 0) return 0;          /* identity order: no table */
+    for (int32_t p = 0; p < np; p++) if (is_if(p) && st(p)) order.push_back(p);
+    P->nr = (int32_t)order.size() - P->nb - P->ne;
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p)) order.push_back(p);
+    P->ns = (int32_t)order.size() - P->nb - P->ne - P->nr;
+    P->nragged = P->nstencil = 0;
+    for (int32_t p = 0; p < np; p++) {
+        P->nragged += (P->h_flags[p] & HQ_PATCH_RAGGED) != 0;
+        P->nstencil += (P->h_flags[p] & HQ_PATCH_STENCIL) != 0;
+    }
+    if (P->nb == 0 && P->ns == 0 && P->nr == 0) return 0;          /* identity order: no table */
     if (!P->d_order) {
         if (hipMalloc((void**)&P->d_order, 4 * (size_t)(np ? np : 1)) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
         *bytes += (int64_t)(4 * (size_t)np);
     }
     hipMemcpy(P->d_order, order.data(), 4 * order.size(), hipMemcpyHostToDevice);
+#ifdef HQ_ST_TIMING
+    if (!P->timing_armed) hq_st_timing_report(P);
+#endif
     return 0;
 }
 
@@ -1817,10 +2105,41 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             }
         }
     }
-    /* stencil patches: lattice, one (c1, c2, beta) for all 729 elements, no dashpot on the patch */
-    if (hq_stencil().ok && !getenv("HQ_PATCH_NO_STENCIL"))
-        for (auto& D : H.desc)
-            if ((D.flags & HQ_PATCH_LATTICE) && (D.flags & HQ_PATCH_UNIFORM) && (D.flags & HQ_PATCH_ISO)) D.flags |= HQ_PATCH_STENCIL;
+    /* stencil patches: uniform coefficients, nodes and elements a subset of the lattice, no hanging node's force to
+     * distribute (without HQ_PATCH_RAGGED=1: only the full lattice without dashpot) */
+    std::vector<uint32_t> rg_tab;
+    std::vector<int64_t> rg_off(H.desc.size(), 0);       /* table offset + 2^40 x boundary nodes */
+    if (hq_stencil().ok && xyz && !getenv("HQ_PATCH_NO_STENCIL")) {
+        const bool full_only = !hq_patch_want_ragged();
+        std::vector<std::vector<uint32_t>> tabs(H.desc.size());
+        std::vector<int32_t> nbnds(H.desc.size(), 0);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t p = 0; p < (int64_t)H.desc.size(); p++) {
+            const hq_patch_desc& D = H.desc[(size_t)p];
+            if (!(D.flags & HQ_PATCH_UNIFORM) || D.nacc != D.nown) continue;
+            if (full_only && !((D.flags & HQ_PATCH_LATTICE) && (D.flags & HQ_PATCH_ISO))) continue;
+            if (!H.ds_ptr.empty() && H.ds_ptr[(size_t)p + 1] > H.ds_ptr[(size_t)p]) continue;
+            std::vector<int32_t> h(H.halo.begin() + D.halo_off, H.halo.begin() + D.halo_off + D.nhalo);
+            if (!hq_ragged_match(D.base, D.nown, lnid, xyz, &H.pelem[(size_t)D.pair_off], D.npairs, h, tabs[(size_t)p], &nbnds[(size_t)p]))
+                tabs[(size_t)p].clear();
+        }
+        std::unordered_map<uint64_t, std::vector<int64_t>> seen;        /* one table per patch shape */
+        for (size_t p = 0; p < H.desc.size(); p++) {
+            const std::vector<uint32_t>& tb = tabs[p];
+            if (tb.empty()) continue;
+            uint64_t hsh = 1469598103934665603ull ^ tb.size();
+            for (uint32_t v : tb) { hsh ^= v; hsh *= 1099511628211ull; }
+            int64_t off = -1;
+            for (int64_t c : seen[hsh])
+                if (c + (int64_t)tb.size() <= (int64_t)rg_tab.size() && !memcmp(&rg_tab[(size_t)c], tb.data(), 4 * tb.size())) { off = c; break; }
+            if (off < 0) { off = (int64_t)rg_tab.size(); rg_tab.insert(rg_tab.end(), tb.begin(), tb.end()); seen[hsh].push_back(off); }
+            rg_off[p] = off | ((int64_t)nbnds[p] << 40);
+            H.desc[p].flags |= HQ_PATCH_STENCIL;
+            if (nbnds[p] != 0 || !(H.desc[p].flags & HQ_PATCH_ISO) || H.desc[p].nown != HQ_LAT_NOWN || H.desc[p].nhalo != HQ_LAT_NHALO)
+                H.desc[p].flags |= HQ_PATCH_RAGGED;
+        }
+        for (int i = 0; i < 4; i++) rg_tab.push_back(0); /* a lane past the boundary list reads its first entry's place */
+    }
     P->h_flags.resize(H.desc.size());
     for (size_t p = 0; p < H.desc.size(); p++) P->h_flags[p] = H.desc[p].flags;
     P->ndistinct = H.ndistinct;
@@ -1853,8 +2172,26 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     if (P->nlattice) {
         HQ_PA(P->d_lat_row, sizeof(uint16_t) * 1024)
         hipMemcpy(P->d_lat_row, hq_lattice().row_of_local, sizeof(uint16_t) * 1024, hipMemcpyHostToDevice);
-        HQ_PA(P->d_lat_row2, sizeof(uint16_t) * 1024)
-        hipMemcpy(P->d_lat_row2, hq_stencil().row2_of_local, sizeof(uint16_t) * 1024, hipMemcpyHostToDevice);
+    }
+    if (!rg_tab.empty()) {
+        HQ_PA(P->d_rg_tab, sizeof(uint32_t) * rg_tab.size())
+        HQ_PA(P->d_rg_off, sizeof(int64_t) * rg_off.size())
+        {
+            std::vector<double> pco(4 * H.desc.size(), 0.0);
+            for (size_t q = 0; q < H.desc.size(); q++)
+                if (H.desc[q].flags & HQ_PATCH_STENCIL) {
+                    const int32_t e0 = H.pelem[(size_t)H.desc[q].pair_off];
+                    pco[4 * q] = c1[e0]; pco[4 * q + 1] = c2[e0]; pco[4 * q + 2] = beta[e0];
+                }
+            HQ_PA(P->d_pcoef, sizeof(double) * pco.size())
+            hipMemcpy(P->d_pcoef, pco.data(), sizeof(double) * pco.size(), hipMemcpyHostToDevice);
+        }
+        HQ_PA(P->d_E1, sizeof(double) * 576)
+        HQ_PA(P->d_E2, sizeof(double) * 576)
+        hipMemcpy(P->d_rg_tab, rg_tab.data(), sizeof(uint32_t) * rg_tab.size(), hipMemcpyHostToDevice);
+        hipMemcpy(P->d_rg_off, rg_off.data(), sizeof(int64_t) * rg_off.size(), hipMemcpyHostToDevice);
+        hipMemcpy(P->d_E1, hq_stencil().E1, sizeof(double) * 576, hipMemcpyHostToDevice);
+        hipMemcpy(P->d_E2, hq_stencil().E2, sizeof(double) * 576, hipMemcpyHostToDevice);
     }
     if (dn.n > 0) {
         HQ_PA(P->d_ds_ptr, 4 * H.ds_ptr.size())
@@ -1927,7 +2264,7 @@ static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t*
 }
 
 /* slot[n] >= 0 for nodes on the partition interface */
-static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t* bytes)
+static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t nnodes, int64_t* bytes)
 {
     std::vector<int32_t> ptr((size_t)P->npatches + 1, 0), ent;
     for (int32_t p = 0; p < P->npatches; p++) {
@@ -1940,8 +2277,18 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
     if (ent.empty()) return 0;
     /* launch order: patches owning interface nodes first, so their partial forces can travel while the rest of
      * the partition is still being computed; they hand partial forces on, so they take the element form */
+    bool any_st_if = false;
     for (int32_t p = 0; p < P->npatches; p++)
-        if (ptr[p + 1] > ptr[p]) P->h_flags[p] &= ~HQ_PATCH_STENCIL;
+        if (ptr[p + 1] > ptr[p] && (P->h_flags[p] & HQ_PATCH_STENCIL)) {
+            P->h_flags[p] |= HQ_PATCH_RAGGED;                /* hands partial forces on: launched ahead of the exchange */
+            any_st_if = true;
+        }
+    if (P->d_if_slot) { hipFree(P->d_if_slot); P->d_if_slot = nullptr; }
+    if (any_st_if) {
+        if (hipMalloc((void**)&P->d_if_slot, 4 * (size_t)nnodes) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+        *bytes += (int64_t)(4 * (size_t)nnodes);
+        hipMemcpy(P->d_if_slot, slot, 4 * (size_t)nnodes, hipMemcpyHostToDevice);
+    }
     if (hq_patch_build_order(P, ptr.data(), bytes) != 0) return -2;
     if (hipMalloc((void**)&P->d_if_ptr, 4 * ptr.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     if (hipMalloc((void**)&P->d_if_ent, 4 * ent.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
@@ -2080,16 +2427,18 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
         P->hstride);
 }
 
-/* the stencil patches: d_order[nb + ne .. nb + ne + ns) */
-static void hq_patch_launch_stencil(const hq_patch_plan* P, const double* u1, const double* u2, double* un,
-                                    const double* F, double dt2, hipStream_t stream)
+/* the stencil patches: part 0 = those that own interface nodes, d_order[nb + ne .. nb + ne + nr) (they also hand their
+ * pure force to the exchange), part 1 = the others, d_order[nb + ne + nr .. nb + ne + nr + ns) */
+static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const double* u1, const double* u2, double* un,
+                                    const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
-    if (P->ns <= 0) return;
-    const int per_xcd = (P->ns + 7) / 8;
-    hq_k_patch_stencil<<<per_xcd * 8, HQ_ST_THREADS, 0, stream>>>(
-        P->ns, per_xcd, P->d_order + P->nb + P->ne, P->d_desc, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->hstride,
-        u1, u2, un, P->d_nt3, P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_lat_row, P->d_lat_row2,
-        hq_stencil().c);
+    const int32_t count = part == 0 ? P->nr : P->ns;
+    if (count <= 0) return;
+    const int per_xcd = (count + 7) / 8;
+    hq_k_patch_stencil<<<per_xcd * 8, HQ_ST_THREADS, P->nragged > 0 ? HQ_ST_LDS_RAGGED : 0, stream>>>(
+        count, per_xcd, P->d_order + P->nb + P->ne + (part == 0 ? 0 : P->nr), P->d_desc, P->d_pcoef,
+        P->d_halo, P->hstride, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2,
+        P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2, part == 0 ? P->d_if_slot : nullptr, iforce, P->d_lat_row, hq_stencil().c);
 }
 
 #endif /* HQ_PATCH_H */

@@ -37,8 +37,11 @@ def _run(box, variant, u1, u2, nsteps, src=None):
     return out
 
 
-@pytest.mark.parametrize("wl", ["c2", "c3"])
-def test_fullsize_variants_agree_and_step_is_linear(wl):
+@pytest.mark.parametrize("wl", ["c2", "c3", "c2-ragged"])
+def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
+    if wl.endswith("-ragged"):       # the domain-face and far-face patches through hq_k_patch_stencil too
+        monkeypatch.setenv("HQ_PATCH_RAGGED", "1")
+        wl = wl.split("-")[0]
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     box = host.Box(nx, ny, nz, h, dt, freq)
@@ -152,13 +155,16 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap", [("c2", 0), ("c2", 1), ("c3", 1)])
-def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, monkeypatch):
+@pytest.mark.parametrize("wl,overlap,ragged", [("c2", 0, 0), ("c2", 1, 0), ("c2", 1, 1), ("c3", 1, 0)])
+def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
-    single-partition run."""
+    single-partition run.  ragged: the lattice-subset patches (domain faces, partition interfaces) through
+    hq_k_patch_stencil as well (HQ_PATCH_RAGGED=1: its launch ahead of the exchange, forces handed to the interface)."""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
+    if ragged:
+        monkeypatch.setenv("HQ_PATCH_RAGGED", "1")
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3
@@ -177,6 +183,7 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, monkeyp
         maps.append(m)
         solvers.append(b.create_solver(tm1=u[m], tm2=0.999 * u[m]))
         assert solvers[-1].info()["variant"] == ha.HQ_VARIANT_PATCH
+        assert (solvers[-1].info()["ragged_patches"] > 0) == bool(ragged)
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     scale = np.abs(ref1).max()

@@ -760,7 +760,7 @@ def test_create_refuses_a_table_that_is_not_rayleigh_proportional():
         ha.Solver(lnid, et, nt, 1e-3)
 
 
-@pytest.mark.parametrize("pipe", ["0", "4", "6", "4-nostencil", "6-nostencil"])
+@pytest.mark.parametrize("pipe", ["0", "4", "6", "4-nostencil", "6-nostencil", "6-ragged"])
 def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     """The element-form patch kernels -- hq_k_patch_seed (default, HQ_PATCH_PIPE=6), hq_k_patch_pers (4: the form a
     mesh falls back to when three accumulator arrays do not fit LDS) and hq_k_patch_step (0: the form for
@@ -770,6 +770,9 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     single-rank run, and a uniform box with lattice patches, dashpot faces and a point source."""
     from hercules_amd import capi, host
     nostencil = pipe.endswith("-nostencil")      # lattice patches through the element kernels instead of hq_k_patch_stencil
+    ragged = pipe.endswith("-ragged")            # lattice-SUBSET patches (faces, dashpots) through hq_k_patch_stencil too
+    if ragged:
+        monkeypatch.setenv("HQ_PATCH_RAGGED", "1")
     pipe = pipe.split("-")[0]
     monkeypatch.setenv("HQ_PATCH_PIPE", pipe)
     if nostencil:
@@ -786,7 +789,12 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     boxes = [host.OctBox(16, 8, 6, 3, 31.25, ref["dt"], 5.0, rank=r, nranks=nranks) for r in range(nranks)]
     solvers = [b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u1[b.gid], tm2=u2[b.gid]) for b in boxes]
     want = {"0": "hq_k_patch_step", "4": "hq_k_patch_pers", "6": "hq_k_patch_seed"}[pipe]
-    assert solvers[0].dominant_kernel() == want
+    infos = [s.info() for s in solvers]
+    if nostencil:
+        assert all(i["stencil_patches"] == 0 for i in infos)
+    # the partitions of this small mesh are single patches of more than 512 nodes: element form (the stencil kernel's
+    # interface launch is covered by the 8-partition boxes of test_gpu_fullsize.py and by the uniform box below)
+    assert all(s.dominant_kernel() in (want, "hq_k_patch_stencil") for s in solvers)
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     for r, (b, s) in enumerate(zip(boxes, solvers)):
@@ -807,7 +815,11 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     p1, p2 = v2.copy(), v1.copy()
     ho.solver_run(lnid, et, nt, p1, p2, 0, 6, 2e-4, loaded_lnid=loaded, forces=F)
     s = ha.Solver(lnid, et, nt, 2e-4, tm1=v1, tm2=v2, node_xyz=_ticks(node_ijk, 1 << 20), variant=ha.HQ_VARIANT_PATCH)
-    assert s.dominant_kernel() == want              # 8 stencil patches of 64: the element kernel is still the dominant one
+    if ragged:                                      # all 64 patches are lattice subsets (dashpot faces included)
+        assert s.dominant_kernel() == "hq_k_patch_stencil" and s.info()["ragged_patches"] > 0
+        assert s.info()["stencil_patches"] == s.info()["npatches"]
+    else:                                           # 8 stencil patches of 64: the element kernel is still the dominant one
+        assert s.dominant_kernel() == want and s.info()["ragged_patches"] == 0
     s.set_source(loaded, F)
     s.run(6)
     tm1, tm2 = s.download()
