@@ -52,8 +52,8 @@ struct hq_patch_cfg {
     int threads = 512;    /* workgroup size                                          */
     int pmax    = 768;    /* owned nodes per patch (9*9*9 = 729 fits)                */
     int pmerge  = 512;    /* small neighbouring cubes are merged up to this          */
-    int psplit  = 0;      /* a cube with more owned nodes is halved; 0 = pmax, or 512 with HQ_PATCH_RAGGED=1 (the 9-wide
-                           * cubes on the far faces hold 576..729 nodes; hq_k_patch_stencil gives a thread one node)  */
+    int psplit  = 0;      /* a cube with more owned nodes is halved; 0 = pmax (the 9-wide cubes on the far faces hold
+                           * 576..729 nodes)                                                                         */
     int nlmax   = 1024;   /* owned + halo nodes staged in LDS (10*10*10 fits)        */
     int vmax    = 0;      /* extra force accumulators for hanging nodes whose anchors */
                           /* the patch owns (set by the planner when the mesh has any) */
@@ -66,7 +66,7 @@ static hq_patch_cfg hq_patch_cfg_from_env(void)
     c.threads = geti("HQ_PATCH_THREADS", c.threads);
     c.pmax = geti("HQ_PATCH_PMAX", c.pmax);
     c.pmerge = geti("HQ_PATCH_PMERGE", c.pmerge);
-    c.psplit = geti("HQ_PATCH_PSPLIT", hq_patch_want_ragged() ? 512 : 0);
+    c.psplit = geti("HQ_PATCH_PSPLIT", 0);
     c.nlmax = geti("HQ_PATCH_NLMAX", c.nlmax);
     if (c.threads < 64) c.threads = 64;
     if (c.threads > HQ_PATCH_MAX_THREADS) c.threads = HQ_PATCH_MAX_THREADS;
@@ -152,6 +152,7 @@ struct hq_patch_plan {
     uint16_t* d_lat_row = nullptr;   /* [1024] LDS row of thread t's local node in a lattice patch             */
     int32_t  ne = 0, ns = 0, nr = 0; /* d_order = nb interface patches | ne other element-form patches | nr stencil patches with
                                       * interface nodes | ns other stencil patches */
+    int32_t  nr_big = 0, ns_big = 0; /* of the nr / ns: patches of more than 512 owned nodes, at the end of their part */
     int32_t  nragged = 0, nstencil = 0;  /* STENCIL patches (nr + ns entries: two for a patch of more than 512 nodes), RAGGED ones among them */
     uint32_t* d_rg_tab = nullptr;    /* tables of the stencil patches (hq_ragged_match), one per patch shape      */
 #ifdef HQ_ST_TIMING
@@ -472,7 +473,7 @@ static const hq_stencil_tab& hq_stencil(void)
 static bool hq_ragged_match(int32_t base, int32_t nown, const int32_t* lnid, const int32_t* xyz, const int32_t* el,
                             int32_t npairs, const std::vector<int32_t>& h, std::vector<uint32_t>& tab, int32_t* nbnd)
 {
-    if (nown < 1 || nown > 512 || npairs < 1 || npairs > 729 || h.empty() || h.size() > 512 || nown + (int32_t)h.size() > 1000) return false;
+    if (nown < 1 || nown > 729 || npairs < 1 || npairs > 729 || h.empty() || h.size() > (nown > 512 ? 768u : 512u) || nown + (int32_t)h.size() > 1000) return false;
     const int32_t* e0 = lnid + 8 * (int64_t)el[0];
     const int64_t s = (int64_t)xyz[3 * (int64_t)e0[1]] - xyz[3 * (int64_t)e0[0]];
     if (s <= 0) return false;
@@ -1755,7 +1756,8 @@ __device__ unsigned long long* g_hq_st_time = nullptr;
 #define HQ_SCHED_FENCE() do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(HQ_ST_THREADS)
+template <int NT>                /* 512, or 768 for the far-face patches of 513 .. 729 owned nodes (HQ_PATCH_RAGGED=1) */
+__global__ void __launch_bounds__(NT)
 hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order,
                    const hq_patch_desc* __restrict__ desc, const double* __restrict__ pcoef,
                    const int32_t* __restrict__ halo, int32_t hstride, const double* __restrict__ u1g,
@@ -1802,7 +1804,7 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     const uint32_t wJ = blist[j < nbnd ? j : 0];
     /* the element matrix blocks of B (L2-resident, the same for every patch): requested with the first loads */
     double e1a = 0.0, e2a = 0.0, e1b = 0.0, e2b = 0.0;
-    if (nbnd > 0) { e1a = E1[t]; e2a = E2[t]; e1b = E1[512 + (t & 63)]; e2b = E2[512 + (t & 63)]; }
+    if (nbnd > 0) { e1a = E1[t & 511]; e2a = E2[t & 511]; e1b = E1[512 + (t & 63)]; e2b = E2[512 + (t & 63)]; }
     HQ_SCHED_FENCE();
 #pragma unroll
     for (int d = 0; d < 3; d++) { y1[d] = u1g[3 * gB + d]; y2[d] = u2g[3 * gB + d]; }
@@ -1832,7 +1834,7 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     for (int d = 0; d < 3; d++) img[3 * myrow + d] = x1[d] + beta * (x1[d] - x2[d]);
 #pragma unroll
     for (int d = 0; d < 3; d++) img[3 * rowB + d] = y1[d] + beta * (y1[d] - y2[d]);
-    if (nbnd > 0) {
+    if (nbnd > 0 && t < HQ_ST_THREADS) {
         s_E[t] = c1 * e1a + c2 * e2a;
         if (t < 64) s_E[512 + t] = c1 * e1b + c2 * e2b;
     }
@@ -1845,7 +1847,8 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     __syncthreads();
     HQ_ST_STAMP(1);
 
-    if (nbnd > 0) {                                      /* B */
+    if (nbnd > 0) {                                      /* B: the first 512 threads */
+      if (NT == HQ_ST_THREADS || t < HQ_ST_THREADS) {
         const int per = 1 << (sh - 6);
         double g[3] = { 0.0, 0.0, 0.0 };
         const hq_lds_double* __restrict__ Es = (const hq_lds_double*)s_E;
@@ -1869,6 +1872,7 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
         /* partial sums [group][j]; 2 * 256 slots hold 8 x 64, 4 x 128 or 2 x 256 */
         hq_lds_double* fb = (hq_lds_double*)s_fb + 3 * ((grp << sh) + j);
         fb[0] = g[0]; fb[1] = g[1]; fb[2] = g[2];
+      }
         __syncthreads();
     }
     HQ_ST_STAMP(2);
@@ -1998,14 +2002,22 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
     order.reserve((size_t)np);
     auto is_if = [&](int32_t p) { return if_ptr && if_ptr[p + 1] > if_ptr[p]; };
     auto st = [&](int32_t p) { return (P->h_flags[p] & HQ_PATCH_STENCIL) != 0; };
+    P->nr_big = P->ns_big = 0;
     for (int32_t p = 0; p < np; p++) if (is_if(p) && !st(p)) order.push_back(p);
     P->nb = (int32_t)order.size();
     for (int32_t p = 0; p < np; p++) if (!is_if(p) && !st(p)) order.push_back(p);
     P->ne = (int32_t)order.size() - P->nb;
-    for (int32_t p = 0; p < np; p++) if (is_if(p) && st(p)) order.push_back(p);
-    P->nr = (int32_t)order.size() - P->nb - P->ne;
-    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p)) order.push_back(p);
-    P->ns = (int32_t)order.size() - P->nb - P->ne - P->nr;
+    /* stencil patches of more than 512 owned nodes (far faces, HQ_PATCH_RAGGED=1) behind the others of their part:
+     * they are stepped by 768-thread workgroups */
+    auto big = [&](int32_t p) { return P->patch_nown[(size_t)p] > HQ_ST_THREADS; };
+    int32_t mark = (int32_t)order.size();
+    for (int32_t p = 0; p < np; p++) if (is_if(p) && st(p) && !big(p)) order.push_back(p);
+    for (int32_t p = 0; p < np; p++) if (is_if(p) && st(p) && big(p)) { order.push_back(p); P->nr_big++; }
+    P->nr = (int32_t)order.size() - mark;
+    mark = (int32_t)order.size();
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && !big(p)) order.push_back(p);
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && big(p)) { order.push_back(p); P->ns_big++; }
+    P->ns = (int32_t)order.size() - mark;
     P->nragged = P->nstencil = 0;
     for (int32_t p = 0; p < np; p++) {
         P->nragged += (P->h_flags[p] & HQ_PATCH_RAGGED) != 0;
@@ -2432,13 +2444,21 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
 static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const double* u1, const double* u2, double* un,
                                     const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
-    const int32_t count = part == 0 ? P->nr : P->ns;
-    if (count <= 0) return;
-    const int per_xcd = (count + 7) / 8;
-    hq_k_patch_stencil<<<per_xcd * 8, HQ_ST_THREADS, P->nragged > 0 ? HQ_ST_LDS_RAGGED : 0, stream>>>(
-        count, per_xcd, P->d_order + P->nb + P->ne + (part == 0 ? 0 : P->nr), P->d_desc, P->d_pcoef,
-        P->d_halo, P->hstride, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2,
-        P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2, part == 0 ? P->d_if_slot : nullptr, iforce, P->d_lat_row, hq_stencil().c);
+    const int32_t total = part == 0 ? P->nr : P->ns, nbig = part == 0 ? P->nr_big : P->ns_big;
+    const int32_t* ord = P->d_order + P->nb + P->ne + (part == 0 ? 0 : P->nr);
+    const size_t lds = P->nragged > 0 ? HQ_ST_LDS_RAGGED : 0;
+    for (int k = 0; k < 2; k++) {
+        const int32_t count = k == 0 ? total - nbig : nbig;
+        if (count <= 0) continue;
+        const int per_xcd = (count + 7) / 8;
+        const int32_t* o = ord + (k == 0 ? 0 : total - nbig);
+#define HQ_ST_ARGS count, per_xcd, o, P->d_desc, P->d_pcoef, P->d_halo, P->hstride, u1, u2, un, nt, P->d_nt3, P->d_src_ptr,  \
+        P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2,                           \
+        part == 0 ? P->d_if_slot : nullptr, iforce, P->d_lat_row, hq_stencil().c
+        if (k == 0) hq_k_patch_stencil<HQ_ST_THREADS><<<per_xcd * 8, HQ_ST_THREADS, lds, stream>>>(HQ_ST_ARGS);
+        else hq_k_patch_stencil<768><<<per_xcd * 8, 768, lds, stream>>>(HQ_ST_ARGS);
+#undef HQ_ST_ARGS
+    }
 }
 
 #endif /* HQ_PATCH_H */
