@@ -158,6 +158,8 @@ struct hq_patch_plan {
 #ifdef HQ_ST_TIMING
     bool timing_armed = false; unsigned long long* d_timing = nullptr;
 #endif
+    struct hq_st_desc* d_st_desc = nullptr;   /* [nr + ns] the stencil patches' records in launch order (hq_k_stencil_entries) */
+    int2*    d_st_halo = nullptr;    /* [nr + ns][512] (halo node, its LDS word) in launch order                        */
     double*  d_pcoef = nullptr;      /* [P][4] c1, c2, beta of a stencil patch (beside the descriptor: no second hop)  */
     int64_t* d_rg_off = nullptr;     /* [P] offset of a patch's table in d_rg_tab                                  */
     double*  d_E1 = nullptr;         /* [576] element matrix blocks for (c1, c2) = (1, 0) ...                      */
@@ -1719,6 +1721,44 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
 
 
 /*
+ * What a stencil workgroup needs to start, in LAUNCH order (entry k of the stencil part of d_order): the facts of the
+ * patch in one 64-byte record and, per thread, the halo node it loads with the LDS word of that node -- so the
+ * workgroup's first loads depend on nothing but its slot (patch number -> descriptor -> halo list -> rows is two
+ * memory latencies longer).  Built on the device from the plan (hq_k_stencil_entries) whenever the order changes.
+ */
+struct hq_st_desc {
+    int32_t base, nown, nhalo, flags, nbnd, p;
+    int64_t loc_off;                 /* into rg_tab: row, mask, boundary index of the local nodes; then the boundary list */
+    double  c1, c2, beta, pad;
+};
+#define HQ_ST_HSTRIDE 512            /* halo entries per patch: (node, word); past the list: the patch's first node */
+
+__global__ void __launch_bounds__(HQ_ST_HSTRIDE)
+hq_k_stencil_entries(int32_t count, const int32_t* __restrict__ order, const hq_patch_desc* __restrict__ desc,
+                     const double* __restrict__ pcoef, const int64_t* __restrict__ rg_off,
+                     const uint32_t* __restrict__ rg_tab, const int32_t* __restrict__ halo, int32_t hstride,
+                     hq_st_desc* __restrict__ st_desc, int2* __restrict__ st_halo)
+{
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (k >= count) return;
+    const int p = order[k];
+    const hq_patch_desc D = desc[p];
+    const int64_t rgo = rg_off[p];
+    const uint32_t* loc = rg_tab + (rgo & 0xffffffffffll);
+    int2 e;
+    if (t < D.nhalo) { e.x = halo[(int64_t)p * hstride + t]; e.y = (int)loc[D.nown + t]; }
+    else { e.x = D.base; e.y = (int)loc[0]; }
+    st_halo[(int64_t)k * HQ_ST_HSTRIDE + t] = e;
+    if (t == 0) {
+        hq_st_desc q;
+        q.base = D.base; q.nown = D.nown; q.nhalo = D.nhalo; q.flags = D.flags; q.nbnd = (int32_t)(rgo >> 40); q.p = p;
+        q.loc_off = rgo & 0xffffffffffll;
+        q.c1 = pcoef[4 * (int64_t)p]; q.c2 = pcoef[4 * (int64_t)p + 1]; q.beta = pcoef[4 * (int64_t)p + 2]; q.pad = 0.0;
+        st_desc[k] = q;
+    }
+}
+
+/*
  * hq_k_patch_stencil: one step of a STENCIL patch (see hq_stencil and hq_ragged_match): the patch's nodes and elements
  * lie on the 10x10x10 lattice -- all of it (the interior of a uniform region) or a subset (a domain face, a partition
  * interface, the halves of a 9-wide far-face cube: RAGGED).  One 512-thread workgroup per patch, not persistent: few
@@ -1758,13 +1798,12 @@ __device__ unsigned long long* g_hq_st_time = nullptr;
 
 template <int NT>                /* 512, or 768 for the far-face patches of 513 .. 729 owned nodes (HQ_PATCH_RAGGED=1) */
 __global__ void __launch_bounds__(NT)
-hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ order,
-                   const hq_patch_desc* __restrict__ desc, const double* __restrict__ pcoef,
-                   const int32_t* __restrict__ halo, int32_t hstride, const double* __restrict__ u1g,
+hq_k_patch_stencil(int32_t count, int32_t per_xcd, const hq_st_desc* __restrict__ st_desc,
+                   const int2* __restrict__ st_halo, const double* __restrict__ u1g,
                    const double* __restrict__ u2g, double* __restrict__ ung, const double* __restrict__ nt,
                    const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
                    const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
-                   const uint32_t* __restrict__ rg_tab, const int64_t* __restrict__ rg_off,
+                   const uint32_t* __restrict__ rg_tab,
                    const double* __restrict__ E1, const double* __restrict__ E2,
                    const int32_t* __restrict__ if_slot, double* __restrict__ iforce,
                    const uint16_t* __restrict__ lat_row, hq_stencil_coef sc)
@@ -1777,26 +1816,24 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const int32_t* __restrict__ o
     const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (slot >= count) return;
     HQ_ST_STAMP(0);
-    const int p = order[slot];
     const int t = threadIdx.x;
-    const hq_patch_desc D = desc[p];
-    const int64_t rgo = rg_off[p];
-    const int nown = D.nown, nhalo = D.nhalo;
-    const uint32_t* __restrict__ loc = rg_tab + (rgo & 0xffffffffffll);   /* row, mask, boundary index of the local nodes */
-    const int nbnd = (int)(rgo >> 40);
+    const hq_st_desc D = st_desc[slot];
+    const int p = D.p, nown = D.nown, nhalo = D.nhalo, nbnd = D.nbnd;
+    const uint32_t* __restrict__ loc = rg_tab + D.loc_off;                /* row, mask, boundary index of the local nodes */
     const uint32_t* __restrict__ blist = loc + (nown + nhalo);            /* the boundary nodes' words */
-    const double c1 = pcoef[4 * (int64_t)p], c2 = pcoef[4 * (int64_t)p + 1], beta = pcoef[4 * (int64_t)p + 2];
+    const double c1 = D.c1, c2 = D.c2, beta = D.beta;
     hq_lds_double* __restrict__ img = (hq_lds_double*)s_w;
-    /* lanes past a list read its last entry again (same row, same value) */
+    /* halo node t and its LDS word: from the slot alone (past the list: the patch's first node again) */
+    const int2 hw = st_halo[(int64_t)slot * HQ_ST_HSTRIDE + (NT == HQ_ST_THREADS ? t : (t & (HQ_ST_HSTRIDE - 1)))];
+    /* lanes past the owned nodes read the last one again (same row, same value) */
     const bool owner = t < nown;
     const int lA = owner ? t : nown - 1;
     const int64_t gA = (int64_t)D.base + lA;
     double x1[3], x2[3], y1[3], y2[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * gA + d]; x2[d] = u2g[3 * gA + d]; }
-    const int hB = t < nhalo ? t : nhalo - 1;                             /* a stencil patch has a halo */
-    const int64_t gB = (int64_t)halo[(int64_t)p * hstride + hB];
-    const uint32_t wA = loc[lA], wB = loc[nown + hB];
+    const int64_t gB = (int64_t)hw.x;
+    const uint32_t wA = loc[lA], wB = (uint32_t)hw.y;
     /* B's lane (j, group): boundary node j, the group's octants; groups = 512 / (boundary nodes rounded up to 64, 128
      * or 256) = 8, 4 or 2 of 1, 2 or 4 octants: a wave works on ONE octant at a time (uniform E) */
     const int sh = nbnd <= 64 ? 6 : (nbnd <= 128 ? 7 : 8);
@@ -1985,7 +2022,7 @@ static void hq_patch_free(hq_patch_plan* P)
 #endif
     void* ptrs[] = { P->d_desc, P->d_pidx, P->d_pc1, P->d_pc2, P->d_pbeta, P->d_halo, P->d_src_ptr, P->d_src_ent,
                      P->d_if_ptr, P->d_if_ent, P->d_order, P->d_nt3, P->d_ds_ptr, P->d_ds_ent, P->d_tickets, P->d_lat_row,
-                     P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2, P->d_if_slot, P->d_pcoef };
+                     P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2, P->d_if_slot, P->d_pcoef, P->d_st_desc, P->d_st_halo };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_patch_plan();
 }
@@ -2029,6 +2066,18 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
         *bytes += (int64_t)(4 * (size_t)np);
     }
     hipMemcpy(P->d_order, order.data(), 4 * order.size(), hipMemcpyHostToDevice);
+    if (P->nr + P->ns > 0) {                             /* the stencil part's records and halo entries in launch order */
+        const size_t n = (size_t)(P->nr + P->ns);
+        if (!P->d_st_desc) {
+            if (hipMalloc((void**)&P->d_st_desc, sizeof(hq_st_desc) * n) != hipSuccess ||
+                hipMalloc((void**)&P->d_st_halo, sizeof(int2) * HQ_ST_HSTRIDE * n) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+            *bytes += (int64_t)((sizeof(hq_st_desc) + sizeof(int2) * HQ_ST_HSTRIDE) * n);
+        }
+        hq_k_stencil_entries<<<(unsigned)n, HQ_ST_HSTRIDE>>>((int32_t)n, P->d_order + P->nb + P->ne, P->d_desc, P->d_pcoef,
+                                                             P->d_rg_off, P->d_rg_tab, P->d_halo, P->hstride, P->d_st_desc,
+                                                             P->d_st_halo);
+        if (hipDeviceSynchronize() != hipSuccess) { g_patch_err = "building the stencil entries failed"; return -3; }
+    }
 #ifdef HQ_ST_TIMING
     if (!P->timing_armed) hq_st_timing_report(P);
 #endif
@@ -2445,15 +2494,15 @@ static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const doub
                                     const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
     const int32_t total = part == 0 ? P->nr : P->ns, nbig = part == 0 ? P->nr_big : P->ns_big;
-    const int32_t* ord = P->d_order + P->nb + P->ne + (part == 0 ? 0 : P->nr);
+    const int64_t first = part == 0 ? 0 : P->nr;         /* entry of the part's first patch */
     const size_t lds = P->nragged > 0 ? HQ_ST_LDS_RAGGED : 0;
     for (int k = 0; k < 2; k++) {
         const int32_t count = k == 0 ? total - nbig : nbig;
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
-        const int32_t* o = ord + (k == 0 ? 0 : total - nbig);
-#define HQ_ST_ARGS count, per_xcd, o, P->d_desc, P->d_pcoef, P->d_halo, P->hstride, u1, u2, un, nt, P->d_nt3, P->d_src_ptr,  \
-        P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_rg_tab, P->d_rg_off, P->d_E1, P->d_E2,                           \
+        const int64_t e0 = first + (k == 0 ? 0 : total - nbig);
+#define HQ_ST_ARGS count, per_xcd, P->d_st_desc + e0, P->d_st_halo + e0 * HQ_ST_HSTRIDE, u1, u2, un, nt, P->d_nt3, P->d_src_ptr,  \
+        P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_rg_tab, P->d_E1, P->d_E2,                                             \
         part == 0 ? P->d_if_slot : nullptr, iforce, P->d_lat_row, hq_stencil().c
         if (k == 0) hq_k_patch_stencil<HQ_ST_THREADS><<<per_xcd * 8, HQ_ST_THREADS, lds, stream>>>(HQ_ST_ARGS);
         else hq_k_patch_stencil<768><<<per_xcd * 8, 768, lds, stream>>>(HQ_ST_ARGS);
