@@ -39,13 +39,14 @@
 
 /* Tuning knobs (environment overrides HQ_PATCH_THREADS / _PMAX / _PMERGE / _NLMAX are
  * read once per plan; defaults from the sweeps in profiles/). */
-/* HQ_PATCH_RAGGED=1: lattice-SUBSET patches (domain faces, partition interfaces, far-face cubes) go through
- * hq_k_patch_stencil too, not only the full lattices.  Measured equal or slower than the element form:
- * off by default. */
-static inline bool hq_patch_want_ragged(void)
+/* Lattice-SUBSET patches (domain faces, dashpots, far-face cubes, partition interfaces) through hq_k_patch_stencil too,
+ * not only the full lattices?  Measured: on a whole mesh 3 % faster than the element form (64 M box), on
+ * eight in-process partitions 3 % slower -- so the default is yes for a single partition and no on a partitioned mesh;
+ * HQ_PATCH_RAGGED=0/1 overrides.  -> -1 (not set), 0 or 1. */
+static inline int hq_patch_ragged_env(void)
 {
     const char* e = getenv("HQ_PATCH_RAGGED");
-    return e && atoi(e) != 0;
+    return e ? (atoi(e) != 0) : -1;
 }
 
 struct hq_patch_cfg {
@@ -152,6 +153,8 @@ struct hq_patch_plan {
     uint16_t* d_lat_row = nullptr;   /* [1024] LDS row of thread t's local node in a lattice patch             */
     int32_t  ne = 0, ns = 0, nr = 0; /* d_order = nb interface patches | ne other element-form patches | nr stencil patches with
                                       * interface nodes | ns other stencil patches */
+    bool     ragged_default = false; /* set by the caller before hq_patch_build: see hq_patch_ragged_env */
+    int32_t  ns_rg = 0;              /* of the ns: ragged patches of <= 512 nodes, between the full lattices and the big ones */
     int32_t  nr_big = 0, ns_big = 0; /* of the nr / ns: patches of more than 512 owned nodes, at the end of their part */
     int32_t  nragged = 0, nstencil = 0;  /* STENCIL patches (nr + ns entries: two for a patch of more than 512 nodes), RAGGED ones among them */
     uint32_t* d_rg_tab = nullptr;    /* tables of the stencil patches (hq_ragged_match), one per patch shape      */
@@ -2052,7 +2055,11 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
     for (int32_t p = 0; p < np; p++) if (is_if(p) && st(p) && big(p)) { order.push_back(p); P->nr_big++; }
     P->nr = (int32_t)order.size() - mark;
     mark = (int32_t)order.size();
-    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && !big(p)) order.push_back(p);
+    /* part 1: the full lattices (no boundary list: 25 KB of LDS) | the ragged patches of <= 512 nodes | the big ones */
+    auto rg = [&](int32_t p) { return (P->h_flags[p] & HQ_PATCH_RAGGED) != 0; };
+    P->ns_rg = 0;
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && !big(p) && !rg(p)) order.push_back(p);
+    for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && !big(p) && rg(p)) { order.push_back(p); P->ns_rg++; }
     for (int32_t p = 0; p < np; p++) if (!is_if(p) && st(p) && big(p)) { order.push_back(p); P->ns_big++; }
     P->ns = (int32_t)order.size() - mark;
     P->nragged = P->nstencil = 0;
@@ -2167,11 +2174,11 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         }
     }
     /* stencil patches: uniform coefficients, nodes and elements a subset of the lattice, no hanging node's force to
-     * distribute (without HQ_PATCH_RAGGED=1: only the full lattice without dashpot) */
+     * distribute (full_only: only the full lattice without dashpot) */
     std::vector<uint32_t> rg_tab;
     std::vector<int64_t> rg_off(H.desc.size(), 0);       /* table offset + 2^40 x boundary nodes */
     if (hq_stencil().ok && xyz && !getenv("HQ_PATCH_NO_STENCIL")) {
-        const bool full_only = !hq_patch_want_ragged();
+        const bool full_only = !(hq_patch_ragged_env() >= 0 ? hq_patch_ragged_env() != 0 : P->ragged_default);
         std::vector<std::vector<uint32_t>> tabs(H.desc.size());
         std::vector<int32_t> nbnds(H.desc.size(), 0);
 #pragma omp parallel for schedule(dynamic, 64)
@@ -2494,19 +2501,23 @@ static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const doub
                                     const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
     const int32_t total = part == 0 ? P->nr : P->ns, nbig = part == 0 ? P->nr_big : P->ns_big;
+    const int32_t nrg = part == 0 ? total - nbig : P->ns_rg;             /* part 0: every patch hands forces on (ragged) */
     const int64_t first = part == 0 ? 0 : P->nr;         /* entry of the part's first patch */
-    const size_t lds = P->nragged > 0 ? HQ_ST_LDS_RAGGED : 0;
-    for (int k = 0; k < 2; k++) {
-        const int32_t count = k == 0 ? total - nbig : nbig;
+    /* three launches: full lattices (no boundary list, 25 KB of LDS), ragged <= 512 nodes, ragged 513..729 nodes */
+    const int32_t cnt[3] = { total - nbig - nrg, nrg, nbig };
+    int64_t e0 = first;
+    for (int k = 0; k < 3; k++) {
+        const int32_t count = cnt[k];
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
-        const int64_t e0 = first + (k == 0 ? 0 : total - nbig);
+        const size_t lds = k == 0 ? 0 : HQ_ST_LDS_RAGGED;
 #define HQ_ST_ARGS count, per_xcd, P->d_st_desc + e0, P->d_st_halo + e0 * HQ_ST_HSTRIDE, u1, u2, un, nt, P->d_nt3, P->d_src_ptr,  \
         P->d_src_ent, (P->d_src_ptr ? F : nullptr), dt2, P->d_rg_tab, P->d_E1, P->d_E2,                                             \
         part == 0 ? P->d_if_slot : nullptr, iforce, P->d_lat_row, hq_stencil().c
-        if (k == 0) hq_k_patch_stencil<HQ_ST_THREADS><<<per_xcd * 8, HQ_ST_THREADS, lds, stream>>>(HQ_ST_ARGS);
+        if (k < 2) hq_k_patch_stencil<HQ_ST_THREADS><<<per_xcd * 8, HQ_ST_THREADS, lds, stream>>>(HQ_ST_ARGS);
         else hq_k_patch_stencil<768><<<per_xcd * 8, 768, lds, stream>>>(HQ_ST_ARGS);
 #undef HQ_ST_ARGS
+        e0 += count;
     }
 }
 
