@@ -16,7 +16,7 @@ HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
-           "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_check_finite",
+           "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
            "hq_stencil_coefficients"]
 
 
@@ -239,6 +239,16 @@ def plan_check(desc):
     rep = (ctypes.c_int64 * 8)()
     _check(load_library().hq_plan_check(ctypes.byref(desc), rep))
     return dict(zip(PLAN_REPORT, [int(v) for v in rep]))
+
+
+STENCIL_PLAN_REPORT = ("patches", "tables", "full_lattices", "boundary_nodes", "corners_checked", "faults")
+
+
+def stencil_plan_check(desc):
+    """hq_stencil_plan_check on a filled _Desc: the stencil kernel's tables against the mesh (no device needed)."""
+    rep = (ctypes.c_int64 * 6)()
+    _check(load_library().hq_stencil_plan_check(ctypes.byref(desc), rep))
+    return dict(zip(STENCIL_PLAN_REPORT, [int(v) for v in rep]))
 
 
 def comm_unique_id():

@@ -1150,6 +1150,131 @@ extern "C" int hq_stencil_coefficients(double out[16])
     return t.ok ? HQ_OK : hq_fail(HQ_ERR_STATE, "the assembled stencil lacks the cube symmetry%s", "");
 }
 
+/*
+ * Host-only self-check of what hq_k_patch_stencil reads (needs no device).  Plans `desc` as hq_create would; for every
+ * patch whose geometry hq_ragged_match accepts (whatever its coefficients) it checks the shape table against the
+ * mesh: rows distinct and inside the image; the eight nodes of every element of the patch at row(corner 0) + the
+ * lattice offsets of their corner; the element mask of every owned node = the corners it really is in the patch's
+ * elements; the boundary list = the owned nodes with an incomplete mask, in order, with their index.  And once: the
+ * element-matrix blocks E1, E2 of the boundary phase reproduce hq_element_force (the kernels' own arithmetic) for
+ * random displacements and every subset of present octants.
+ * report = {patches, patches with a table, full lattices among them, boundary nodes, element corners checked, faults}
+ */
+extern "C" int hq_stencil_plan_check(const hq_desc* d, int64_t report[6])
+{
+    if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid) || !d->node_xyz)
+        return hq_fail(HQ_ERR_ARG, "inconsistent mesh description (node_xyz is needed)%s", "");
+    const int64_t E = d->lenum, N = d->nharbored;
+    for (int64_t i = 0; i < E * 8; i++)
+        if (d->lnid[i] < 0 || d->lnid[i] >= N) return hq_fail(HQ_ERR_ARG, "lnid out of range%s", "");
+    std::vector<char> shared_dn((size_t)N, 0);
+    for (int32_t i = 0; i < d->dn_sched.s_count; i++)
+        for (int32_t k = 0; k < d->dn_sched.first_s[i].nodecount; k++) shared_dn[d->dn_sched.first_s[i].mapping[k]] = 1;
+    std::vector<int32_t> l_id, l_ptr(1, 0), l_anc;
+    for (int32_t k = 0; k < d->ldnnum; k++) {
+        if (shared_dn[d->dn_ldnid[k]]) continue;
+        l_id.push_back(d->dn_ldnid[k]);
+        for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) l_anc.push_back(d->dn_lanid[a]);
+        l_ptr.push_back((int32_t)l_anc.size());
+    }
+    hq_dangling dn;
+    dn.n = (int32_t)l_id.size(); dn.id = l_id.data(); dn.ptr = l_ptr.data(); dn.anchor = l_anc.data();
+    hq_patch_cfg cfg = hq_patch_cfg_from_env();
+    if (dn.n > 0 && cfg.vmax == 0) cfg.vmax = 384;
+    hq_patch_host H;
+    const bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && cfg.pmax >= HQ_LAT_ACC;
+    if (hq_patch_plan_host(cfg, E, N, d->lnid, d->node_xyz, dn, want_lattice, &H) != 0)
+        return hq_fail(HQ_ERR_ARG, "patch plan: %s", hq_patch_error());
+    int64_t ntab = 0, nfull = 0, nbnd_tot = 0, ncorner = 0, bad = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : ntab, nfull, nbnd_tot, ncorner, bad)
+    for (int64_t p = 0; p < (int64_t)H.desc.size(); p++) {
+        const hq_patch_desc& D = H.desc[(size_t)p];
+        if (D.nacc != D.nown) continue;
+        if (!H.ds_ptr.empty() && H.ds_ptr[(size_t)p + 1] > H.ds_ptr[(size_t)p]) continue;
+        std::vector<int32_t> h(H.halo.begin() + D.halo_off, H.halo.begin() + D.halo_off + D.nhalo);
+        std::vector<uint32_t> tab;
+        int32_t nbnd = 0;
+        if (!hq_ragged_match(D.base, D.nown, d->lnid, d->node_xyz, &H.pelem[(size_t)D.pair_off], D.npairs, h, tab, &nbnd)) continue;
+        ntab++;
+        nbnd_tot += nbnd;
+        if (nbnd == 0 && D.nown == HQ_LAT_NOWN && D.nhalo == HQ_LAT_NHALO && D.npairs == HQ_LAT_NELEM) nfull++;
+        const int32_t nloc = D.nown + D.nhalo;
+        if ((int32_t)tab.size() < nloc + nbnd) { bad++; continue; }
+        std::unordered_map<int32_t, int32_t> local_of;
+        std::vector<char> used(HQ_ST_ROWS, 0);
+        for (int32_t t = 0; t < nloc; t++) {
+            local_of[t < D.nown ? D.base + t : h[(size_t)(t - D.nown)]] = t;
+            const int r = HQ_RG_ROW(tab[(size_t)t]);
+            if (r >= HQ_ST_ROWS || used[(size_t)r]) bad++; else used[(size_t)r] = 1;
+        }
+        std::vector<unsigned> want((size_t)D.nown, 0u);
+        for (int32_t q = 0; q < D.npairs; q++) {
+            const int32_t* id = d->lnid + 8 * (int64_t)H.pelem[(size_t)D.pair_off + q];
+            auto it0 = local_of.find(id[0]);
+            if (it0 == local_of.end()) { bad++; continue; }
+            const int r0 = HQ_RG_ROW(tab[(size_t)it0->second]);
+            for (int c = 0; c < 8; c++) {
+                auto it = local_of.find(id[c]);
+                if (it == local_of.end()) { bad++; continue; }
+                const int r = HQ_RG_ROW(tab[(size_t)it->second]);
+                if (r != r0 + HQ_ST_PX * (c & 1) + HQ_ST_PY * ((c >> 1) & 1) + HQ_ST_PZ * ((c >> 2) & 1)) bad++;
+                if (it->second < D.nown) want[(size_t)it->second] |= 1u << c;
+                ncorner++;
+            }
+        }
+        int32_t nb = 0;
+        for (int32_t t = 0; t < D.nown; t++) {
+            const uint32_t w = tab[(size_t)t];
+            if (HQ_RG_MASK(w) != want[(size_t)t]) bad++;
+            if (want[(size_t)t] != 0xffu) {
+                if (nb >= nbnd || HQ_RG_BIDX(w) != nb) bad++;
+                else {
+                    const uint32_t b = tab[(size_t)(nloc + nb)];
+                    if (HQ_RG_ROW(b) != HQ_RG_ROW(w) || HQ_RG_MASK(b) != want[(size_t)t]) bad++;
+                }
+                nb++;
+            }
+        }
+        if (nb != nbnd) bad++;
+    }
+    /* E1, E2 against the element arithmetic: a node that is corner o of its present elements */
+    {
+        const hq_stencil_tab& T = hq_stencil();
+        if (!T.ok) bad++;
+        uint64_t seed = 88172645463325252ull;
+        auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (double)(seed >> 11) / 9007199254740992.0 - 0.5; };
+        for (int trial = 0; trial < 64; trial++) {
+            const double c1 = 1.0 + rnd(), c2 = 2.0 + rnd();
+            const unsigned mask = (unsigned)(trial * 37 + 1) & 0xffu;
+            double w[27][3];                             /* the 3x3x3 nodes around the node, index (dx+1) + 3 (dy+1) + 9 (dz+1) */
+            for (auto& r : w) for (double& v : r) v = rnd();
+            double ref[3] = { 0, 0, 0 }, got[3] = { 0, 0, 0 };
+            for (int o = 0; o < 8; o++) {
+                if (!((mask >> o) & 1)) continue;
+                double X[8], Y[8], Z[8];
+                for (int m = 0; m < 8; m++) {
+                    const int dx = (m & 1) - (o & 1), dy = ((m >> 1) & 1) - ((o >> 1) & 1), dz = ((m >> 2) & 1) - ((o >> 2) & 1);
+                    const double* q = w[(dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+                    X[m] = q[0]; Y[m] = q[1]; Z[m] = q[2];
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) {
+                            const int k = ((o * 8 + m) * 3 + a) * 3 + b;
+                            got[a] += (c1 * T.E1[k] + c2 * T.E2[k]) * q[b];
+                        }
+                }
+                hq_element_force(X, Y, Z, c1, c2);
+                ref[0] += X[o]; ref[1] += Y[o]; ref[2] += Z[o];
+            }
+            for (int a = 0; a < 3; a++)
+                if (fabs(got[a] - ref[a]) > 1e-12 * (fabs(ref[a]) + 1.0)) bad++;
+        }
+    }
+    report[0] = (int64_t)H.desc.size(); report[1] = ntab; report[2] = nfull; report[3] = nbnd_tot; report[4] = ncorner;
+    report[5] = bad;
+    if (bad) return hq_fail(HQ_ERR_STATE, "stencil table self-check failed%s", "");
+    return HQ_OK;
+}
+
 extern "C" int hq_destroy(hq_ctx* c)
 {
     if (!c) return HQ_OK;

@@ -244,6 +244,14 @@ HQ_API int hq_run_timed(hq_ctx* ctx, int32_t nsteps, double* total_ms, double* k
 HQ_API int hq_plan_check(const hq_desc* desc, int64_t report[8]);
 
 /*
+ * Host-only self-check of what hq_k_patch_stencil reads (needs no device; desc->node_xyz required): every patch-shape
+ * table (lattice rows, element masks, boundary lists) against the mesh's connectivity, and the element-matrix blocks
+ * of the boundary phase against the kernels' own element arithmetic.
+ * report = {patches, patches with a table, full lattices among them, boundary nodes, element corners checked, faults}.
+ */
+HQ_API int hq_stencil_plan_check(const hq_desc* desc, int64_t report[6]);
+
+/*
  * Host-only: the sixteen coefficients {p1[6], p2[6], q1[2], q2[2]} of the assembled 27-point stencil
  * S = c1 S1 + c2 S2 that hq_k_patch_stencil applies on uniform lattice patches -- the same operator
  * -(c1 K1 + c2 K2) that compute_addforce_effective + damping_addforce apply element by element

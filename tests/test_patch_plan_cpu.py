@@ -49,3 +49,35 @@ def test_octree_box_plan(nranks):
             tot[k] += rep[k]
     assert tot["lattice_patches"] > 0.2 * tot["patches"]
     assert tot["pairs"] >= E
+
+
+def test_stencil_tables_match_the_mesh_on_a_uniform_box():
+    """hq_stencil_plan_check: every patch of a uniform box is a lattice subset -- the interior ones full lattices,
+    the others ragged (ring missing at a domain face, 9-wide far-face cubes); their shape tables (rows, element masks,
+    boundary lists) agree with the connectivity, and the element-matrix blocks of the boundary phase reproduce the
+    kernels' element arithmetic for every kind of present-octant set."""
+    b = host.Box(64, 64, 32, 10.0, 2e-4, 50.0)
+    r = b.stencil_plan_check()
+    b.close()
+    assert r["faults"] == 0
+    assert r["patches"] == 8 * 8 * 4 and r["tables"] == r["patches"]
+    assert r["full_lattices"] == 6 * 6 * 2
+    # boundary nodes: the owned nodes on the six domain faces (65 x 65 x 33 nodes)
+    assert r["boundary_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
+    assert r["corners_checked"] > 8 * 64 * 64 * 32
+
+
+@pytest.mark.parametrize("nranks", [1, 4])
+def test_stencil_tables_on_an_octree_box(nranks):
+    """The four-level octree box (hanging nodes), whole and as partitions: patches with hanging-node work keep the
+    element form; every table that IS made agrees with the mesh."""
+    import bench
+    tables = patches = 0
+    for rank in range(nranks):
+        box = bench.make_octbox("o3s", rank, nranks)[0]
+        rep = box.stencil_plan_check()
+        box.close()
+        assert rep["faults"] == 0
+        tables += rep["tables"]
+        patches += rep["patches"]
+    assert 0 < tables < patches
