@@ -392,7 +392,6 @@ struct hq_stencil_coef {
 struct hq_stencil_tab {
     bool ok;
     hq_stencil_coef c;
-    uint16_t row2_of_local[1024];    /* canonical local node of a lattice patch -> stencil-image row */
     double E1[576], E2[576];         /* element matrix for (c1, c2) = (1, 0) / (0, 1): E[((o * 8 + m) * 3 + a) * 3 + b] = force on
                                       * corner o, component a, per unit displacement of corner m, component b */
 };
@@ -402,12 +401,6 @@ static const hq_stencil_tab& hq_stencil(void)
     static const hq_stencil_tab tab = [] {
         hq_stencil_tab t;
         t.ok = true;
-        const hq_lattice_tab& L = hq_lattice();
-        for (int i = 0; i < 1024; i++) t.row2_of_local[i] = 0;
-        for (int K = 0; K < 10; K++)
-            for (int J = 0; J < 10; J++)
-                for (int I = 0; I < 10; I++)
-                    t.row2_of_local[L.local_of_ijk[I + 10 * J + 100 * K]] = (uint16_t)(HQ_ST_PX * I + HQ_ST_PY * J + HQ_ST_PZ * K);
         for (int which = 0; which < 2; which++) {
             /* element matrix E[(n,a)][(m,b)] for (c1, c2) = (1, 0) / (0, 1): columns = forces of unit displacements */
             double E[24][24];

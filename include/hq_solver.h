@@ -112,7 +112,7 @@ typedef struct {
     int32_t nranks;
     int32_t lattice_patches;     /* patch variant: patches with rows and lanes on one lattice (conflict-free LDS) */
     int32_t stencil_patches;     /* patch variant: patches stepped by hq_k_patch_stencil                          */
-    int32_t ragged_patches;      /* patch variant: lattice-subset patches stepped by hq_k_patch_ragged            */
+    int32_t ragged_patches;      /* patch variant: of the stencil patches, the lattice SUBSETS (faces, far-face cubes) */
     int32_t reserved;
 } hq_info;
 
