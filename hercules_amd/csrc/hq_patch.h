@@ -1757,15 +1757,16 @@ hq_k_stencil_entries(int32_t count, const int32_t* __restrict__ order, const hq_
 /*
  * hq_k_patch_stencil: one step of a STENCIL patch (see hq_stencil and hq_ragged_match): the patch's nodes and elements
  * lie on the 10x10x10 lattice -- all of it (the interior of a uniform region) or a subset (a domain face, a partition
- * interface, the halves of a 9-wide far-face cube: RAGGED).  One 512-thread workgroup per patch, not persistent: few
- * registers and 25 KB of LDS (42 KB where the launch has ragged patches), so three workgroups share a CU and the
- * hardware overlaps one patch's loads with another's arithmetic; the patches of a launch are in Z-order, so
- * neighbours' rings meet in the XCD's L2.  (A persistent, software-pipelined form -- next patch's rows requested
- * before this patch's stencil, two images -- was measured and is slower: DESIGN.md s7.)
+ * interface, a 9-wide far-face cube: RAGGED).  One workgroup per patch, not persistent: 512 threads (768 for the
+ * far-face cubes of 513 .. 729 owned nodes), few registers and 25 KB of LDS (42 KB in the launches over ragged
+ * patches), so three workgroups share a CU and the hardware overlaps one patch's loads with another's arithmetic; the
+ * patches of a launch are in Z-order, so neighbours' rings meet in the XCD's L2.  (A persistent, software-pipelined
+ * form -- next patch's rows requested before this patch's stencil, two images -- was measured and is slower, as are
+ * two patches per workgroup and the ragged patches mixed into the full lattices' launch: DESIGN.md s7.)
  * Thread t owns owned node t and loads it and halo node t.  Everything a thread needs is requested up front in the
- * order of the dependency chain (descriptor, table offset and coefficients ride on the patch number alone; the owned
- * rows need the descriptor; the halo rows the halo list); w = u1 + beta (u1 - u2) of both nodes goes to the LDS image,
- * and after ONE barrier
+ * order of the dependency chain: the patch's record and the thread's halo entry ride on the slot alone
+ * (hq_k_stencil_entries), the owned rows and the table words need the record, the halo rows the halo entry;
+ * w = u1 + beta (u1 - u2) of both nodes goes to the LDS image, and after ONE barrier
  *   B: (ragged patches) the owned nodes with an incomplete element mask, <= 256, compacted list of the table: the sum
  *      over their PRESENT elements' blocks, f = sum_o sum_m E[o][m] w(m), E = c1 E1 + c2 E2 built per patch in LDS,
  *      the octants dealt to the waves (partial sums in LDS, added in octant order: no atomics, one summation order),
@@ -1792,7 +1793,7 @@ __device__ unsigned long long* g_hq_st_time = nullptr;
 #define HQ_SCHED_FENCE() do { } while (0)
 #endif
 
-template <int NT>                /* 512, or 768 for the far-face patches of 513 .. 729 owned nodes (HQ_PATCH_RAGGED=1) */
+template <int NT>                /* 512, or 768 for the far-face patches of 513 .. 729 owned nodes */
 __global__ void __launch_bounds__(NT)
 hq_k_patch_stencil(int32_t count, int32_t per_xcd, const hq_st_desc* __restrict__ st_desc,
                    const int2* __restrict__ st_halo, const double* __restrict__ u1g,
