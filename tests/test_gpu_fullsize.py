@@ -163,8 +163,7 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     hq_k_patch_stencil as well (HQ_PATCH_RAGGED=1: its launch ahead of the exchange, forces handed to the interface)."""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
-    if ragged:
-        monkeypatch.setenv("HQ_PATCH_RAGGED", "1")
+    monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")      # (the default on partitions is 0)
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3
