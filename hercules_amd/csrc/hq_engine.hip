@@ -1018,7 +1018,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
                         seed0[n] = 1;
                     }
             }
-        c->plan.ragged_default = c->nranks == 1;
+        c->plan.ragged_default = true;
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
                             dn, seed0.data(), &pb);
         if (rc != 0)

@@ -40,13 +40,13 @@
 /* Tuning knobs (environment overrides HQ_PATCH_THREADS / _PMAX / _PMERGE / _NLMAX are
  * read once per plan; defaults from the sweeps in profiles/). */
 /* Lattice-SUBSET patches (domain faces, dashpots, far-face cubes, partition interfaces) through hq_k_patch_stencil too,
- * not only the full lattices?  Measured: on a whole mesh 3 % faster than the element form (64 M box), on
- * eight in-process partitions 3 % slower -- so the default is yes for a single partition and no on a partitioned mesh;
- * HQ_PATCH_RAGGED=0/1 overrides.  -> -1 (not set), 0 or 1. */
+ * not only the full lattices?  Measured: 2-3 % faster than the element form on the whole 64 M box, 9 % on
+ * its eight in-process partitions -- the default is yes.  HQ_PATCH_RAGGED=0: element form; 2: stencil form except for
+ * patches with partition-interface nodes.  -> -1 (not set) or the value. */
 static inline int hq_patch_ragged_env(void)
 {
     const char* e = getenv("HQ_PATCH_RAGGED");
-    return e ? (atoi(e) != 0) : -1;
+    return e ? atoi(e) : -1;         /* 2: as 1, but patches with partition-interface nodes keep the element form */
 }
 
 struct hq_patch_cfg {
@@ -2342,6 +2342,7 @@ static int hq_patch_set_interface(hq_patch_plan* P, const int32_t* slot, int64_t
     bool any_st_if = false;
     for (int32_t p = 0; p < P->npatches; p++)
         if (ptr[p + 1] > ptr[p] && (P->h_flags[p] & HQ_PATCH_STENCIL)) {
+            if (hq_patch_ragged_env() == 2) { P->h_flags[p] &= ~(HQ_PATCH_STENCIL | HQ_PATCH_RAGGED); continue; }
             P->h_flags[p] |= HQ_PATCH_RAGGED;                /* hands partial forces on: launched ahead of the exchange */
             any_st_if = true;
         }

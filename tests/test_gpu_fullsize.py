@@ -39,7 +39,7 @@ def _run(box, variant, u1, u2, nsteps, src=None):
 
 @pytest.mark.parametrize("wl", ["c2", "c3", "c2-noragged"])
 def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
-    if wl.endswith("-noragged"):     # the domain-face and far-face patches in the element form (the default on partitions)
+    if wl.endswith("-noragged"):     # the domain-face and far-face patches in the element form
         monkeypatch.setenv("HQ_PATCH_RAGGED", "0")
         wl = wl.split("-")[0]
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
@@ -155,7 +155,7 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged", [("c2", 0, 0), ("c2", 1, 0), ("c2", 1, 1), ("c3", 1, 0)])
+@pytest.mark.parametrize("wl,overlap,ragged", [("c2", 0, 1), ("c2", 1, 0), ("c2", 1, 1), ("c3", 1, 1)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
@@ -163,7 +163,7 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     hq_k_patch_stencil as well (HQ_PATCH_RAGGED=1: its launch ahead of the exchange, forces handed to the interface)."""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
-    monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")      # (the default on partitions is 0)
+    monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")      # (the default is 1)
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3

@@ -771,7 +771,7 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     from hercules_amd import capi, host
     nostencil = pipe.endswith("-nostencil")      # lattice patches through the element kernels instead of hq_k_patch_stencil
     ragged = pipe.endswith("-ragged")            # lattice-SUBSET patches (faces, dashpots) through hq_k_patch_stencil too
-    monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")    # (default: on for one partition, off on partitions)
+    monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")    # (the default is on)
     pipe = pipe.split("-")[0]
     monkeypatch.setenv("HQ_PATCH_PIPE", pipe)
     if nostencil:
