@@ -81,3 +81,17 @@ def test_stencil_tables_on_an_octree_box(nranks):
         tables += rep["tables"]
         patches += rep["patches"]
     assert 0 < tables < patches
+
+
+def test_stencil_tables_on_the_partitions_of_a_uniform_box():
+    """Two block partitions of a 64^3 box: every cube patch is a lattice subset with a table (the patches on the
+    partition interface among them: ragged); only the patches made of the interface PLANE's nodes alone -- rank 0
+    harbors them behind its cubes, octor numbers them with the next partition's cells -- are no lattice subsets and
+    keep the element form."""
+    for rank, plane_patches in ((0, 16), (1, 0)):
+        b = host.Box(64, 64, 64, 10.0, 2e-4, 50.0, rank=rank, nranks=2)
+        r = b.stencil_plan_check()
+        b.close()
+        assert r["faults"] == 0
+        assert r["tables"] == 256 and r["patches"] == 256 + plane_patches
+        assert 0 < r["full_lattices"] < r["tables"]
