@@ -17,7 +17,7 @@ EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_ge
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
-           "hq_stencil_coefficients"]
+           "hq_stencil_coefficients", "hq_brick_plan_check"]
 
 
 class HqError(RuntimeError):
@@ -50,7 +50,8 @@ class _Info(ctypes.Structure):
                 ("patch_pairs", ctypes.c_int64), ("device_bytes", ctypes.c_int64),
                 ("step", ctypes.c_int32), ("nranks", ctypes.c_int32),
                 ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32),
-                ("ragged_patches", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("ragged_patches", ctypes.c_int32), ("brick_units", ctypes.c_int32),
+                ("brick_nodes", ctypes.c_int64)]
 
 
 _lib = None
@@ -249,6 +250,17 @@ def stencil_plan_check(desc):
     rep = (ctypes.c_int64 * 6)()
     _check(load_library().hq_stencil_plan_check(ctypes.byref(desc), rep))
     return dict(zip(STENCIL_PLAN_REPORT, [int(v) for v in rep]))
+
+
+BRICK_PLAN_REPORT = ("brick_nodes", "columns", "units", "units_one_nt_row", "levels", "neighbours_checked",
+                     "patch_nodes", "faults")
+
+
+def brick_plan_check(desc):
+    """hq_brick_plan_check on a filled _Desc: the brick planner against the mesh's connectivity (no device needed)."""
+    rep = (ctypes.c_int64 * 8)()
+    _check(load_library().hq_brick_plan_check(ctypes.byref(desc), rep))
+    return dict(zip(BRICK_PLAN_REPORT, [int(v) for v in rep]))
 
 
 def comm_unique_id():

@@ -1,0 +1,578 @@
+/*
+ * hq_brick.h -- BRICKS: the bulk of a uniformly refined, homogeneous region stepped by a z-marching kernel on a
+ * tile-major node layout (round 3).
+ *
+ * Same operator as hq_k_patch_stencil -- the assembled 27-point stencil f = S w, S = c1 S1 + c2 S2 = -(c1 K1 + c2 K2)
+ * summed over the eight elements around a node (compute_addforce_effective stiffness.c:180-237 + damping_addforce
+ * damping.c:29-103 through w = u1 + beta (u1 - u2)), followed by solver_compute_displacement (psolve.c:4072-4114) --
+ * but organised around what the 8x8x8 patches of the Z-ordered node array cannot avoid: a patch loads 488 halo rows
+ * for 512 owned ones, gathered 24 bytes at a time (7.19 GB per step on the 64M box for 4.87 GB compulsory).
+ *
+ *   SIMPLE node   all eight elements around it exist, have one size and one (c1, c2, beta); its n_t row has no
+ *                 dashpot term; it is neither a hanging node, an anchor, nor named in a communication schedule.
+ *   TILE COLUMN   TX x TY (64 x 8) lattice positions, a run of planes along z, ALL of whose nodes are simple.
+ *   LAYOUT        the engine renumbers the nodes (hq_create: a permutation between the caller's ids and the device's):
+ *                 the nodes of a tile column are consecutive, [plane][y][x] -- a plane is one contiguous 12 KB run --
+ *                 and every other node follows in its original (Z-) order, where the patch planner takes over.
+ *   UNIT          one tile column x <= CZ planes = one workgroup of 512 threads, thread (x, y) -> its node of every
+ *                 plane.  The workgroup marches along z: plane p+1 is requested while plane p is worked on; the
+ *                 arriving plane's w goes to one of TWO LDS slots (31 KB in all, one barrier per plane) together with
+ *                 its ring of 2 (nx + 2) + 2 ny neighbours outside the tile (ids from a table: they may be nodes of
+ *                 other columns or non-brick nodes); a thread reduces the 9 rows around its node ONCE to the 22
+ *                 in-plane sums the cube symmetry of S leaves distinct, and those feed the three output planes p-1,
+ *                 p, p+1 (accumulators in registers): 27 LDS reads and ~85 fp64 operations per node instead of 81 and
+ *                 153+, and 72 B + 2 x 48 B x 148/512 = 100 B ... of which the ring rows are L2 hits of the
+ *                 neighbouring columns marching beside this one.
+ * Measured before integration (profiles/micro/march_stencil.hip, 512 x 512 x 256 nodes): 0.98 ms per step against
+ * 0.94 ms for the same loads and stores without the stencil, i.e. the compulsory 72 B per node at 4.9 TB/s.
+ * Summation order differs from the element kernels and from hq_k_patch_stencil (same operator): GPU parity bar 1e-9.
+ */
+#ifndef HQ_BRICK_H
+#define HQ_BRICK_H
+
+#include <map>
+
+#include "hq_patch.h"
+
+#define HQ_BK_TX 64
+#define HQ_BK_TY 8
+#define HQ_BK_THREADS (HQ_BK_TX * HQ_BK_TY)
+#define HQ_BK_PY (HQ_BK_TX + 2)
+#define HQ_BK_PLANE ((HQ_BK_TX + 2) * (HQ_BK_TY + 2))
+#define HQ_BK_NTSAME 1           /* every node of the unit has the same n_t row: it is in the unit's record */
+
+struct hq_brick_unit {
+    int64_t base;                /* device id of node (0, 0) of the unit's first plane; the unit's nodes are
+                                  * base + (plane * ny + y) * nx + x                                            */
+    int64_t tab;                 /* the unit's id table in d_tab: ring ids [np + 2][nr] (planes za - 1 .. za + np,
+                                  * nr = 2 (nx + 2) + 2 ny: row y = -1, row y = ny, column x = -1, column x = nx),
+                                  * then the nodes of plane za - 1 [ny][nx] and of plane za + np [ny][nx]        */
+    int32_t nx, ny, np, flags;
+    double  c1, c2, beta;        /* of the elements around the unit's nodes                                     */
+    double  m0, m2, m1;          /* HQ_BK_NTSAME: mass_simple, mass2_minusaM, mass_minusaM of every node        */
+};
+
+struct hq_brick_cfg {
+    int cz = 32;                 /* planes per unit (HQ_BRICK_CZ)                                                */
+    int minz = 4;                /* shortest run of planes worth a tile column (HQ_BRICK_MINZ)                   */
+    int minnodes = 512;          /* fewest nodes worth a tile column (HQ_BRICK_MINNODES)                         */
+};
+
+static hq_brick_cfg hq_brick_cfg_from_env(void)
+{
+    hq_brick_cfg c;
+    auto geti = [](const char* n, int def) { const char* v = getenv(n); return (v && *v) ? atoi(v) : def; };
+    c.cz = std::max(2, geti("HQ_BRICK_CZ", c.cz));
+    c.minz = std::max(1, geti("HQ_BRICK_MINZ", c.minz));
+    c.minnodes = std::max(1, geti("HQ_BRICK_MINNODES", c.minnodes));
+    return c;
+}
+
+struct hq_brick_host {
+    int64_t nb = 0;                          /* brick nodes: device ids [0, nb)                                  */
+    std::vector<int32_t> perm;               /* caller's node id -> device id (all N nodes); empty: identity      */
+    std::vector<hq_brick_unit> units;        /* launch order: the HQ_BK_NTSAME units first                        */
+    int32_t nsame = 0;                       /* units with HQ_BK_NTSAME                                           */
+    std::vector<int32_t> tab;                /* id tables (device ids)                                            */
+    int32_t ncolumns = 0, nlevels = 0;
+};
+
+struct hq_brick_plan {
+    int64_t nb = 0;
+    int32_t nunits = 0, nsame = 0;
+    hq_brick_unit* d_units = nullptr;
+    int32_t* d_tab = nullptr;
+    int32_t* d_src_ptr = nullptr;            /* [nunits + 1] source entries per unit (hq_brick_set_source)        */
+    int32_t* d_src_ent = nullptr;            /* [n][2] = {node of the unit (plane * ny + y) * nx + x, loaded idx} */
+    std::vector<int64_t> h_base;             /* units' first ids, ascending, and their launch slots: owner lookup */
+    std::vector<int32_t> h_slot;
+    std::vector<int64_t> h_size;
+};
+
+/*
+ * Plan the bricks of a mesh (host only).  excl[n] != 0: node n must stay with the patches (hanging nodes, anchors,
+ * nodes a schedule names).  Leaves B->nb = 0 (and no permutation) where nothing qualifies.
+ * -> 0, or -1 with g_patch_err set (only on inconsistent input: a level whose geometry cannot be understood is
+ * skipped, not refused).
+ */
+static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz, const double* c1,
+                              const double* c2, const double* beta, const double* ntab, const char* excl,
+                              hq_brick_host* B)
+{
+    *B = hq_brick_host();
+    if (!xyz || E <= 0 || N <= 0) return 0;
+    const hq_brick_cfg cfg = hq_brick_cfg_from_env();
+    const int TX = HQ_BK_TX, TY = HQ_BK_TY;
+
+    /* levels: elements by edge length (ticks) */
+    std::vector<int32_t> hs((size_t)E);
+    std::map<int32_t, int64_t> cnt;
+    for (int64_t e = 0; e < E; e++) {
+        const int32_t* id = lnid + 8 * e;
+        const int64_t h = (int64_t)xyz[3 * (int64_t)id[1]] - xyz[3 * (int64_t)id[0]];
+        if (h <= 0 || h > 0x7fffffff) return 0;                  /* not the corner order of octor.c:6444-6470: no bricks */
+        hs[(size_t)e] = (int32_t)h;
+        cnt[(int32_t)h]++;
+    }
+
+    struct level_t {
+        int32_t h;
+        int64_t O[3];
+        int64_t D[3];                        /* cells per axis; nodes per axis = D + 1 */
+        std::vector<int32_t> Ng;             /* node at a lattice position, or -1 */
+        std::vector<int32_t> Eg;             /* element in a lattice cell, or -1 */
+    };
+    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; };
+    std::vector<level_t> levels;
+    std::vector<column_t> cols;
+    std::vector<int32_t> ntx_of_level;
+
+    for (auto& kv : cnt) {
+        const int32_t h = kv.first;
+        if (kv.second < (int64_t)cfg.minnodes) continue;
+        level_t L;
+        L.h = h;
+        int64_t mn[3] = { INT64_MAX, INT64_MAX, INT64_MAX }, mx[3] = { INT64_MIN, INT64_MIN, INT64_MIN };
+        for (int64_t e = 0; e < E; e++) {
+            if (hs[(size_t)e] != h) continue;
+            const int32_t* p = xyz + 3 * (int64_t)lnid[8 * e];
+            for (int d = 0; d < 3; d++) { mn[d] = std::min<int64_t>(mn[d], p[d]); mx[d] = std::max<int64_t>(mx[d], p[d]); }
+        }
+        bool ok = true;
+        for (int d = 0; d < 3; d++) {
+            L.O[d] = mn[d];
+            if ((mx[d] - mn[d]) % h) ok = false;
+            L.D[d] = (mx[d] - mn[d]) / h + 1;
+        }
+        if (!ok) continue;
+        const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1, NZ = L.D[2] + 1;
+        const double vol = (double)NX * (double)NY * (double)NZ;
+        if (vol > 8.0 * (double)kv.second + 65536.0 || vol > 2.0e9) continue;       /* a sparse level: the patches keep it */
+        std::vector<int32_t>& Eg = L.Eg;
+        Eg.assign((size_t)(L.D[0] * L.D[1] * L.D[2]), -1);
+        L.Ng.assign((size_t)(NX * NY * NZ), -1);
+        for (int64_t e = 0; e < E && ok; e++) {
+            if (hs[(size_t)e] != h) continue;
+            const int32_t* id = lnid + 8 * e;
+            int64_t q[3];
+            for (int d = 0; d < 3; d++) {
+                const int64_t v = (int64_t)xyz[3 * (int64_t)id[0] + d] - L.O[d];
+                if (v % h) ok = false;
+                q[d] = v / h;
+            }
+            if (!ok) break;
+            int32_t& cell = Eg[(size_t)((q[2] * L.D[1] + q[1]) * L.D[0] + q[0])];
+            if (cell != -1) { ok = false; break; }
+            cell = (int32_t)e;
+            for (int c = 0; c < 8 && ok; c++) {
+                const int64_t X = q[0] + (c & 1), Y = q[1] + ((c >> 1) & 1), Z = q[2] + ((c >> 2) & 1);
+                const int32_t* p = xyz + 3 * (int64_t)id[c];
+                if (p[0] != L.O[0] + X * h || p[1] != L.O[1] + Y * h || p[2] != L.O[2] + Z * h) { ok = false; break; }
+                int32_t& g = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                if (g == -1) g = id[c];
+                else if (g != id[c]) ok = false;
+            }
+        }
+        if (!ok) continue;
+        /* simple nodes */
+        std::vector<char> S((size_t)(NX * NY * NZ), 0);
+        int64_t sx0 = INT64_MAX, sx1 = -1, sy0 = INT64_MAX, sy1 = -1;
+        int64_t nsimple = 0;
+#pragma omp parallel for schedule(static) reduction(min : sx0, sy0) reduction(max : sx1, sy1) reduction(+ : nsimple)
+        for (int64_t Z = 1; Z < L.D[2]; Z++)
+            for (int64_t Y = 1; Y < L.D[1]; Y++)
+                for (int64_t X = 1; X < L.D[0]; X++) {
+                    const int32_t n = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                    if (n < 0 || (excl && excl[n])) continue;
+                    const double* q = ntab + 7 * (int64_t)n;
+                    if (!((q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]))) continue;
+                    int32_t e0 = -1;
+                    bool s = true;
+                    for (int o = 0; o < 8 && s; o++) {
+                        const int64_t cx = X - (o & 1), cy = Y - ((o >> 1) & 1), cz = Z - ((o >> 2) & 1);
+                        const int32_t e = Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
+                        if (e < 0) { s = false; break; }
+                        if (e0 < 0) e0 = e;
+                        else s = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
+                    }
+                    if (!s) continue;
+                    S[(size_t)((Z * NY + Y) * NX + X)] = 1;
+                    nsimple++;
+                    sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y);
+                }
+        if (nsimple < cfg.minnodes) continue;
+        /* tile columns: footprints on a TX x TY grid from the first simple node; runs of planes all of whose nodes
+         * in the footprint are simple */
+        const int lvl = (int)levels.size();
+        const int32_t ntx = (int32_t)((sx1 - sx0) / TX + 1), nty = (int32_t)((sy1 - sy0) / TY + 1);
+        std::vector<std::vector<column_t>> found((size_t)nty);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int32_t tj = 0; tj < nty; tj++) {
+            const int64_t y0 = sy0 + (int64_t)tj * TY;
+            const int32_t ny = (int32_t)std::min<int64_t>(TY, sy1 - y0 + 1);
+            for (int32_t ti = 0; ti < ntx; ti++) {
+                const int64_t x0 = sx0 + (int64_t)ti * TX;
+                const int32_t nx = (int32_t)std::min<int64_t>(TX, sx1 - x0 + 1);
+                int64_t run0 = -1;
+                for (int64_t Z = 0; Z <= NZ; Z++) {
+                    bool full = Z < NZ;
+                    for (int64_t y = y0; y < y0 + ny && full; y++) {
+                        const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
+                        for (int32_t x = 0; x < nx; x++) if (!row[x]) { full = false; break; }
+                    }
+                    if (full) { if (run0 < 0) run0 = Z; continue; }
+                    if (run0 >= 0) {
+                        const int64_t nz = Z - run0;
+                        if (nz >= cfg.minz && nz * nx * ny >= cfg.minnodes)
+                            found[(size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)run0, (int32_t)nz, ti, tj, 0 });
+                        run0 = -1;
+                    }
+                }
+            }
+        }
+        size_t before = cols.size();
+        for (auto& v : found) cols.insert(cols.end(), v.begin(), v.end());
+        if (cols.size() == before) continue;
+        ntx_of_level.push_back(ntx);
+        levels.push_back(std::move(L));
+    }
+    if (cols.empty()) return 0;
+
+    /* device numbering: tile columns first (plane-major inside a column), everything else behind in its old order */
+    int64_t nb = 0;
+    for (auto& c : cols) { c.base = nb; nb += (int64_t)c.nx * c.ny * c.nz; }
+    if (nb > 0x7fffffff) return 0;
+    B->perm.assign((size_t)N, -1);
+    for (auto& c : cols) {
+        const level_t& L = levels[(size_t)c.lvl];
+        const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
+        for (int32_t z = 0; z < c.nz; z++)
+            for (int32_t y = 0; y < c.ny; y++)
+                for (int32_t x = 0; x < c.nx; x++) {
+                    const int32_t n = L.Ng[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
+                    if (B->perm[(size_t)n] != -1) { g_patch_err = "brick plan: a node lies in two tile columns"; return -1; }
+                    B->perm[(size_t)n] = (int32_t)(c.base + ((int64_t)z * c.ny + y) * c.nx + x);
+                }
+    }
+    {
+        int64_t k = nb;
+        for (int64_t n = 0; n < N; n++) if (B->perm[(size_t)n] < 0) B->perm[(size_t)n] = (int32_t)k++;
+        if (k != N) { g_patch_err = "brick plan: numbering is not a permutation"; return -1; }
+    }
+    B->nb = nb;
+    B->ncolumns = (int32_t)cols.size();
+    B->nlevels = (int32_t)levels.size();
+
+    /* units: a column in chunks of <= cz planes.  Launch order: slabs of tile rows (about 64 tiles per slab and
+     * chunk level: what an XCD keeps resident), inside a slab chunk by chunk -- neighbouring columns march side by
+     * side on one XCD and find each other's ring rows in its L2 */
+    struct unit_t { int col; int32_t za, np; int64_t key; };
+    std::vector<unit_t> us;
+    for (size_t ci = 0; ci < cols.size(); ci++) {
+        const column_t& c = cols[ci];
+        const int32_t nch = (c.nz + cfg.cz - 1) / cfg.cz;
+        const int32_t G = std::max(1, 64 / std::max(1, ntx_of_level[(size_t)c.lvl]));
+        for (int32_t k = 0; k < nch; k++) {
+            const int32_t za = (int32_t)((int64_t)c.nz * k / nch), zb = (int32_t)((int64_t)c.nz * (k + 1) / nch);
+            /* key: level | slab | plane of the chunk's start | tile row | tile column */
+            const int64_t key = ((int64_t)c.lvl << 56) | ((int64_t)(c.tj / G) << 42) | ((int64_t)((c.z0 + za) / cfg.cz) << 28) |
+                                ((int64_t)(c.tj % G) << 20) | (int64_t)c.ti;
+            us.push_back({ (int)ci, c.z0 + za, zb - za, key });
+        }
+    }
+    std::stable_sort(us.begin(), us.end(), [](const unit_t& a, const unit_t& b) { return a.key < b.key; });
+    B->units.resize(us.size());
+    std::vector<int64_t> toff(us.size() + 1, 0);
+    for (size_t u = 0; u < us.size(); u++) {
+        const column_t& c = cols[(size_t)us[u].col];
+        const int64_t nr = 2 * (c.nx + 2) + 2 * c.ny;
+        toff[u + 1] = toff[u] + ((int64_t)(us[u].np + 2) * nr + 2 * (int64_t)c.nx * c.ny + 3) / 4 * 4;
+    }
+    B->tab.assign((size_t)toff[us.size()] + 64, 0);
+    bool fault = false;
+    std::vector<char> same(us.size(), 0);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t u = 0; u < (int64_t)us.size(); u++) {
+        const column_t& c = cols[(size_t)us[(size_t)u].col];
+        const level_t& L = levels[(size_t)c.lvl];
+        const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
+        const int32_t za = us[(size_t)u].za, np = us[(size_t)u].np, nx = c.nx, ny = c.ny, nr = 2 * (nx + 2) + 2 * ny;
+        auto dev = [&](int64_t X, int64_t Y, int64_t Z) -> int32_t {
+            if (X < 0 || Y < 0 || Z < 0 || X > L.D[0] || Y > L.D[1] || Z > L.D[2]) { fault = true; return 0; }
+            const int32_t n = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+            if (n < 0) { fault = true; return 0; }
+            return B->perm[(size_t)n];
+        };
+        int32_t* t = B->tab.data() + toff[(size_t)u];
+        for (int32_t k = 0; k < np + 2; k++) {
+            const int64_t Z = (int64_t)za - 1 + k;
+            int32_t* r = t + (int64_t)k * nr;
+            for (int32_t i = 0; i < nx + 2; i++) { r[i] = dev(c.x0 - 1 + i, c.y0 - 1, Z); r[nx + 2 + i] = dev(c.x0 - 1 + i, c.y0 + ny, Z); }
+            for (int32_t j = 0; j < ny; j++) { r[2 * (nx + 2) + j] = dev(c.x0 - 1, c.y0 + j, Z); r[2 * (nx + 2) + ny + j] = dev(c.x0 + nx, c.y0 + j, Z); }
+        }
+        int32_t* cap = t + (int64_t)(np + 2) * nr;
+        for (int32_t j = 0; j < ny; j++)
+            for (int32_t i = 0; i < nx; i++) {
+                cap[j * nx + i] = dev(c.x0 + i, c.y0 + j, (int64_t)za - 1);
+                cap[nx * ny + j * nx + i] = dev(c.x0 + i, c.y0 + j, (int64_t)za + np);
+            }
+        hq_brick_unit& U = B->units[(size_t)u];
+        U.base = c.base + (int64_t)(za - c.z0) * nx * ny;
+        U.tab = toff[(size_t)u];
+        U.nx = nx; U.ny = ny; U.np = np; U.flags = 0;
+        /* coefficients: those of any element around the first node (all eight are equal: the node is simple) */
+        const int32_t n0 = L.Ng[(size_t)(((int64_t)za * NY + c.y0) * NX + c.x0)];
+        {
+            /* the element whose corner 7 the node is: one cell down on every axis (all eight are equal: the node is simple) */
+            const int32_t e0 = L.Eg[(size_t)((((int64_t)za - 1) * L.D[1] + (c.y0 - 1)) * L.D[0] + (c.x0 - 1))];
+            if (e0 < 0) { fault = true; continue; }
+            U.c1 = c1[e0]; U.c2 = c2[e0]; U.beta = beta[e0];
+        }
+        bool sm = true;
+        const double* q0 = ntab + 7 * (int64_t)n0;
+        for (int32_t z = 0; z < np && sm; z++)
+            for (int32_t y = 0; y < ny && sm; y++)
+                for (int32_t x = 0; x < nx; x++) {
+                    const int32_t n = L.Ng[(size_t)((((int64_t)za + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
+                    const double* q = ntab + 7 * (int64_t)n;
+                    if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) { sm = false; break; }
+                }
+        if (sm && !getenv("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
+        U.m0 = q0[0]; U.m2 = q0[1]; U.m1 = q0[4];
+    }
+    if (fault) { g_patch_err = "brick plan: a neighbour of a simple node is missing"; return -1; }
+    /* the units whose nodes share one n_t row first (their own launch: the row rides in the record) */
+    {
+        std::vector<hq_brick_unit> a, b;
+        for (size_t u = 0; u < us.size(); u++) (same[u] ? a : b).push_back(B->units[u]);
+        B->nsame = (int32_t)a.size();
+        a.insert(a.end(), b.begin(), b.end());
+        B->units.swap(a);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* kernel                                                                   */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * hq_k_brick: one unit per workgroup (see the head of this file).  PERNODE: the nodes' n_t rows differ (read from
+ * the 3-double table with the node); otherwise the row is in the unit's record.
+ * Plane k = 0 .. np + 1 of the march is plane za - 1 + k of the column; plane k completes the output of plane k - 1.
+ *   fA  accumulator of output plane k - 1: contributions of the planes k - 2 and k - 1 and the node's own term
+ *   fB  accumulator of output plane k: contribution of plane k - 1 and the node's own term m2 u1 - m1 u2
+ */
+template <bool PERNODE>
+__global__ void __launch_bounds__(HQ_BK_THREADS)
+hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
+           const double* __restrict__ u1g, const double* __restrict__ u2g, double* __restrict__ ung,
+           const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
+           const double* __restrict__ F, double dt2, hq_stencil_coef sc)
+{
+    __shared__ __align__(16) double s_w[2 * 3 * HQ_BK_PLANE];
+    const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (slot >= count) return;
+    const hq_brick_unit U = units[slot];
+    const int nx = U.nx, ny = U.ny, np = U.np, nxy = nx * ny, nr = 2 * (nx + 2) + 2 * ny;
+    const int t = threadIdx.x, lx = t & (HQ_BK_TX - 1), ly = t >> 6;
+    const bool active = lx < nx && ly < ny;
+    const int sidx = active ? ly * nx + lx : 0;
+    const int myrow = (ly + 1) * HQ_BK_PY + lx + 1;
+    const bool ring = t < nr;
+    int rrow;
+    {
+        int rx, ry;
+        if (t < nx + 2) { rx = t - 1; ry = -1; }
+        else if (t < 2 * (nx + 2)) { rx = t - (nx + 2) - 1; ry = ny; }
+        else if (t < 2 * (nx + 2) + ny) { rx = -1; ry = t - 2 * (nx + 2); }
+        else { rx = nx; ry = t - 2 * (nx + 2) - ny; }
+        rrow = (ry + 1) * HQ_BK_PY + rx + 1;
+    }
+    const int32_t* __restrict__ rtab = tab + U.tab + (ring ? t : 0);
+    const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
+    const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
+    const double beta = U.beta;
+    double P[6], Q[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) P[i] = U.c1 * sc.p1[i] + U.c2 * sc.p2[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) Q[i] = U.c1 * sc.q1[i] + U.c2 * sc.q2[i];
+    const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
+
+    double x1[3], x2[3], y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
+    double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
+    double m0A = U.m0, m0B = U.m0;           /* mass_simple of the output planes k - 1, k */
+    double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
+    int32_t rid = rtab[0];                   /* ring id of the plane to load next */
+
+#define HQ_BK_LOAD(node_)                                                                             \
+    {                                                                                                 \
+        const int64_t a_ = (node_);                                                                   \
+        if (active) {                                                                                 \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
+            if (PERNODE) { _Pragma("unroll") for (int d = 0; d < 3; d++) mn[d] = nt3[3 * a_ + d]; }    \
+        }                                                                                             \
+        if (ring) {                                                                                   \
+            const int64_t b_ = (int64_t)rid;                                                          \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { y1[d] = u1g[3 * b_ + d]; y2[d] = u2g[3 * b_ + d]; } \
+        }                                                                                             \
+    }
+    /* the loaded plane -> LDS slot s_; its nodes' own term m2 u1 - m1 u2 joins the accumulator acc_ */
+#define HQ_BK_PUT(s_, acc_)                                                                           \
+    {                                                                                                 \
+        hq_lds_double* img_ = (hq_lds_double*)s_w + 3 * HQ_BK_PLANE * (s_);                            \
+        if (active) {                                                                                 \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
+                img_[3 * myrow + d] = x1[d] + beta * (x1[d] - x2[d]);                                 \
+                acc_[d] += mn[1] * x1[d] - mn[2] * x2[d];                                             \
+            }                                                                                         \
+        }                                                                                             \
+        if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) img_[3 * rrow + d] = y1[d] + beta * (y1[d] - y2[d]); } \
+    }
+
+    HQ_BK_LOAD(id_lo)
+    rid = rtab[nr];
+    { double dummy[3] = { 0.0, 0.0, 0.0 }; HQ_BK_PUT(0, dummy) }
+    for (int k = 0; k <= np + 1; k++) {
+        if (k <= np) {                       /* request plane k + 1 */
+            HQ_BK_LOAD(k == np ? id_hi : U.base + (int64_t)k * nxy + sidx)
+            if (k < np) rid = rtab[(int64_t)(k + 2) * nr];
+        }
+        __syncthreads();
+        const hq_lds_double* __restrict__ q = (const hq_lds_double*)s_w + 3 * (HQ_BK_PLANE * (k & 1) + myrow);
+        double m[3], g[3], Uo[3];
+        {
+            double C[3], XM[3], XP[3], YM[3], YP[3], MM[3], PM[3], MP[3], PP[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                C[d] = q[d]; XM[d] = q[d - 3]; XP[d] = q[d + 3]; YM[d] = q[d - 3 * HQ_BK_PY]; YP[d] = q[d + 3 * HQ_BK_PY];
+                MM[d] = q[d - 3 * HQ_BK_PY - 3]; PM[d] = q[d - 3 * HQ_BK_PY + 3];
+                MP[d] = q[d + 3 * HQ_BK_PY - 3]; PP[d] = q[d + 3 * HQ_BK_PY + 3];
+            }
+            /* in-plane sums (first sign: x, second: y) */
+            double sx[3], sy[3], dg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { sx[d] = XM[d] + XP[d]; sy[d] = YM[d] + YP[d]; dg[d] = (MM[d] + PP[d]) + (PM[d] + MP[d]); }
+            const double A_x = (PP[0] + MM[0]) - (PM[0] + MP[0]), A_y = (PP[1] + MM[1]) - (PM[1] + MP[1]);
+            const double Bx0_z = XP[2] - XM[2], Bx0_x = XP[0] - XM[0], By0_z = YP[2] - YM[2], By0_y = YP[1] - YM[1];
+            const double Bx1_z = (PP[2] - MP[2]) + (PM[2] - MM[2]), Bx1_x = (PP[0] - MP[0]) + (PM[0] - MM[0]);
+            const double By1_z = (PP[2] - PM[2]) + (MP[2] - MM[2]), By1_y = (PP[1] - PM[1]) + (MP[1] - MM[1]);
+            const double sxy_z = sx[2] + sy[2];
+            /* the plane seen from its own nodes (dz = 0) */
+            m[0] = fma(P[0], C[0], fma(P[1], sx[0], fma(P[2], sy[0], fma(P[3], dg[0], Q[0] * A_y))));
+            m[1] = fma(P[0], C[1], fma(P[1], sy[1], fma(P[2], sx[1], fma(P[3], dg[1], Q[0] * A_x))));
+            m[2] = fma(P[0], C[2], fma(P[2], sxy_z, P[4] * dg[2]));
+            /* seen from the planes below and above (|dz| = 1): the part even in dz ... */
+            g[0] = fma(P[2], C[0], fma(P[3], sx[0], fma(P[4], sy[0], fma(P[5], dg[0], Q[1] * A_y))));
+            g[1] = fma(P[2], C[1], fma(P[3], sy[1], fma(P[4], sx[1], fma(P[5], dg[1], Q[1] * A_x))));
+            g[2] = fma(P[1], C[2], fma(P[3], sxy_z, P[5] * dg[2]));
+            /* ... and the part odd in dz (sign: dz as the output node sees it) */
+            Uo[0] = fma(Q[0], Bx0_z, Q[1] * Bx1_z);
+            Uo[1] = fma(Q[0], By0_z, Q[1] * By1_z);
+            Uo[2] = fma(Q[0], Bx0_x, fma(Q[1], Bx1_x, fma(Q[0], By0_y, Q[1] * By1_y)));
+        }
+        if (k >= 2 && active) {              /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
+            double f[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) f[d] = fA[d] + (g[d] + Uo[d]);
+            const int local = (k - 2) * nxy + sidx;
+            if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
+                for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
+                    if (src_ent[2 * i] == local) {
+                        const int li = src_ent[2 * i + 1];
+                        for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
+                    }
+            }
+            double* out = ung + 3 * (U.base + (int64_t)local);
+#pragma unroll
+            for (int d = 0; d < 3; d++) out[d] = f[d] / m0A;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - Uo[d]; }
+        if (PERNODE) { m0A = m0B; m0B = mn[0]; }
+        if (k <= np) HQ_BK_PUT((k + 1) & 1, fB)
+    }
+#undef HQ_BK_LOAD
+#undef HQ_BK_PUT
+}
+
+/* ------------------------------------------------------------------------ */
+/* device plan                                                              */
+/* ------------------------------------------------------------------------ */
+
+static void hq_brick_free(hq_brick_plan* P)
+{
+    void* ptrs[] = { P->d_units, P->d_tab, P->d_src_ptr, P->d_src_ent };
+    for (void* p : ptrs) if (p) hipFree(p);
+    *P = hq_brick_plan();
+}
+
+static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* bytes)
+{
+    P->nb = B.nb;
+    P->nunits = (int32_t)B.units.size();
+    P->nsame = B.nsame;
+    if (P->nunits == 0) return 0;
+    if (hipMalloc((void**)&P->d_units, sizeof(hq_brick_unit) * B.units.size()) != hipSuccess ||
+        hipMalloc((void**)&P->d_tab, 4 * B.tab.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+    *bytes += (int64_t)(sizeof(hq_brick_unit) * B.units.size() + 4 * B.tab.size());
+    if (hipMemcpy(P->d_units, B.units.data(), sizeof(hq_brick_unit) * B.units.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->d_tab, B.tab.data(), 4 * B.tab.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick table upload failed"; return -3; }
+    /* owner lookup for hq_brick_set_source */
+    std::vector<std::pair<int64_t, int32_t>> by_base;
+    for (int32_t u = 0; u < P->nunits; u++) by_base.push_back({ B.units[(size_t)u].base, u });
+    std::sort(by_base.begin(), by_base.end());
+    for (auto& pr : by_base) {
+        const hq_brick_unit& U = B.units[(size_t)pr.second];
+        P->h_base.push_back(pr.first); P->h_slot.push_back(pr.second); P->h_size.push_back((int64_t)U.nx * U.ny * U.np);
+    }
+    return 0;
+}
+
+/* group the loaded nodes (device ids) that are brick nodes by their unit; the others are the patches' */
+static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t* loaded, int64_t* bytes)
+{
+    if (P->d_src_ptr) { hipFree(P->d_src_ptr); P->d_src_ptr = nullptr; }
+    if (P->d_src_ent) { hipFree(P->d_src_ent); P->d_src_ent = nullptr; }
+    if (nloaded <= 0 || P->nunits == 0) return 0;
+    std::vector<std::array<int32_t, 3>> rec;
+    for (int32_t i = 0; i < nloaded; i++) {
+        if (loaded[i] >= P->nb) continue;
+        const size_t k = (size_t)(std::upper_bound(P->h_base.begin(), P->h_base.end(), (int64_t)loaded[i]) - P->h_base.begin()) - 1;
+        rec.push_back({ P->h_slot[k], (int32_t)(loaded[i] - P->h_base[k]), i });
+    }
+    if (rec.empty()) return 0;
+    std::sort(rec.begin(), rec.end());
+    std::vector<int32_t> ptr((size_t)P->nunits + 1, 0), ent(rec.size() * 2);
+    for (auto& r : rec) ptr[(size_t)r[0] + 1]++;
+    for (int32_t u = 0; u < P->nunits; u++) ptr[(size_t)u + 1] += ptr[(size_t)u];
+    for (size_t k = 0; k < rec.size(); k++) { ent[2 * k] = rec[k][1]; ent[2 * k + 1] = rec[k][2]; }
+    if (hipMalloc((void**)&P->d_src_ptr, 4 * ptr.size()) != hipSuccess) return -2;
+    if (hipMalloc((void**)&P->d_src_ent, 4 * ent.size()) != hipSuccess) return -2;
+    *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
+    hipMemcpy(P->d_src_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice);
+    hipMemcpy(P->d_src_ent, ent.data(), 4 * ent.size(), hipMemcpyHostToDevice);
+    return 0;
+}
+
+/* one step of all units: the HQ_BK_NTSAME units, then (their own launch) the units with per-node n_t rows */
+static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
+                            const double* F, double dt2, hipStream_t stream)
+{
+    const int32_t cnt[2] = { P->nsame, P->nunits - P->nsame };
+    int32_t first = 0;
+    for (int k = 0; k < 2; k++) {
+        const int32_t count = cnt[k];
+        if (count <= 0) continue;
+        const int per_xcd = (count + 7) / 8;
+        const int32_t* sp = P->d_src_ptr ? P->d_src_ptr + first : nullptr;
+#define HQ_BK_ARGS count, per_xcd, P->d_units + first, P->d_tab, u1, u2, un, nt3, sp, P->d_src_ent, (sp ? F : nullptr), dt2, hq_stencil().c
+        if (k == 0) hq_k_brick<false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else hq_k_brick<true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+#undef HQ_BK_ARGS
+        first += count;
+    }
+}
+
+#endif /* HQ_BRICK_H */

@@ -38,6 +38,7 @@
 #include "../../include/hq_solver.h"
 #include "hq_kernels.h"
 #include "hq_patch.h"
+#include "hq_brick.h"
 
 /* ------------------------------------------------------------------------ */
 /* errors                                                                   */
@@ -188,6 +189,10 @@ struct hq_ctx {
     int32_t* d_sd_ent = nullptr;      /* other ranks share: [nSD][3] {src slot, dst slot, deps} */
     /* patch variant */
     hq_patch_plan plan;
+    /* bricks (hq_brick.h): the device numbers the nodes its own way -- tile columns first -- and every entry point
+     * that takes or returns node ids or node-ordered arrays translates; perm empty: identity */
+    hq_brick_plan bricks;
+    std::vector<int32_t> perm;        /* caller's node id -> device id */
     /* HQ_DEBUG_HALO (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) */
     bool debug_halo = false;
     int64_t* d_gkey = nullptr;        /* [N] global identity of every harbored node          */
@@ -657,6 +662,9 @@ static int hq_phase(hq_ctx* c, int ph)
                 hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
                                 c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             }
+            /* the bricks: simple nodes only, never on the interface -- interior work beside the exchange chain */
+            if (c->bricks.nunits > 0)
+                hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2, c->stream);
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -851,6 +859,47 @@ extern "C" int hq_device_count(void)
     return ok;
 }
 
+static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl);
+
+/* a node-ordered field [N][3] between the caller's numbering and the device's (c->perm; empty: the same) */
+static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
+{
+    const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    if (c->perm.empty()) {
+        HQ_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        return HQ_OK;
+    }
+    std::vector<double> tmp;
+    try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
+    const int32_t* pm = c->perm.data();
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)c->N; n++) {
+        const int64_t q = pm[n];
+        tmp[(size_t)(3 * q)] = host[3 * n]; tmp[(size_t)(3 * q + 1)] = host[3 * n + 1]; tmp[(size_t)(3 * q + 2)] = host[3 * n + 2];
+    }
+    HQ_HIP(hipMemcpy(dev, tmp.data(), bytes, hipMemcpyHostToDevice));
+    return HQ_OK;
+}
+
+static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
+{
+    const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    if (c->perm.empty()) {
+        HQ_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+        return HQ_OK;
+    }
+    std::vector<double> tmp;
+    try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
+    HQ_HIP(hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost));
+    const int32_t* pm = c->perm.data();
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)c->N; n++) {
+        const int64_t q = pm[n];
+        host[3 * n] = tmp[(size_t)(3 * q)]; host[3 * n + 1] = tmp[(size_t)(3 * q + 1)]; host[3 * n + 2] = tmp[(size_t)(3 * q + 2)];
+    }
+    return HQ_OK;
+}
+
 extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
 {
     if (!d || !out) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
@@ -899,6 +948,90 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         return bail(hq_fail(HQ_ERR_ARG, "unknown variant%s", ""));
     c->variant = variant;
 
+    /* element coefficients: (c1, c2, beta = c3/c1).  The fused product needs c3/c1 == c4/c2 (Rayleigh:
+     * both are b/dt, psolve.c:3386-3409); a table that applies different ratios to K1 and K2 is refused */
+    std::vector<double> c1(c->E), c2(c->E), beta(c->E);
+    for (int64_t e = 0; e < c->E; e++) {
+        const double* ep = d->eTable + 4 * e;
+        c1[e] = ep[0]; c2[e] = ep[1];
+        beta[e] = (ep[0] != 0.0) ? ep[2] / ep[0] : ((ep[1] != 0.0) ? ep[3] / ep[1] : 0.0);
+        const double lhs = ep[2] * ep[1], rhs = ep[3] * ep[0];
+        if (fabs(lhs - rhs) > 1e-12 * std::max(fabs(lhs), fabs(rhs)))
+            return bail(hq_fail(HQ_ERR_ARG, "eTable is not Rayleigh-proportional (c3/c1 != c4/c2): not the table solver_init builds%s", ""));
+    }
+
+
+    /*
+     * Bricks (hq_brick.h): where the mesh has simple nodes in bulk -- uniformly refined, homogeneous, no dashpot, not
+     * hanging, not on the partition interface -- they are stepped by the z-marching kernel on a tile-major layout.
+     * That needs the nodes renumbered: from here on `d` is the description in DEVICE numbering (c->perm maps the
+     * caller's ids); hq_set_source / hq_gather / hq_download / hq_upload translate.  Needs node_xyz.
+     */
+    hq_desc dd = *d;
+    std::vector<int32_t> p_lnid, p_xyz, p_dn_id, p_dn_anchor;
+    std::vector<double> p_nt;
+    std::vector<int64_t> p_gnid;
+    std::vector<std::vector<int32_t>> p_maps;
+    std::vector<hq_messenger> p_msg[4];
+    hq_brick_host BH;
+    const double *h_tm1 = d->tm1, *h_tm2 = d->tm2;
+    if (variant == HQ_VARIANT_PATCH && d->node_xyz && !(getenv("HQ_NO_BRICKS") && atoi(getenv("HQ_NO_BRICKS")) != 0)) {
+        std::vector<char> excl;
+        if ((rc = hq_brick_excluded(d, excl)) != HQ_OK) return bail(rc);
+        if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH) != 0)
+            return bail(hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error()));
+    }
+    if (BH.nb > 0) {
+        const std::vector<int32_t>& pm = BH.perm;
+        const int64_t N = c->N;
+        p_lnid.resize((size_t)c->E * 8);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)c->E * 8; i++) p_lnid[(size_t)i] = pm[(size_t)d->lnid[i]];
+        p_xyz.resize((size_t)N * 3);
+        p_nt.resize((size_t)N * 7);
+#pragma omp parallel for schedule(static)
+        for (int64_t n = 0; n < N; n++) {
+            const int64_t q = pm[(size_t)n];
+            for (int k = 0; k < 3; k++) p_xyz[(size_t)(3 * q + k)] = d->node_xyz[3 * n + k];
+            for (int k = 0; k < 7; k++) p_nt[(size_t)(7 * q + k)] = d->nTable[7 * n + k];
+        }
+        dd.lnid = p_lnid.data(); dd.node_xyz = p_xyz.data(); dd.nTable = p_nt.data();
+        if (d->node_gnid) {
+            p_gnid.resize((size_t)N);
+            for (int64_t n = 0; n < N; n++) p_gnid[(size_t)pm[(size_t)n]] = d->node_gnid[n];
+            dd.node_gnid = p_gnid.data();
+        }
+        if (c->ldnnum) {
+            const int32_t na = d->dn_ptr[c->ldnnum];
+            p_dn_id.resize((size_t)c->ldnnum); p_dn_anchor.resize((size_t)na);
+            for (int32_t k = 0; k < c->ldnnum; k++) p_dn_id[(size_t)k] = pm[(size_t)d->dn_ldnid[k]];
+            for (int32_t a = 0; a < na; a++) p_dn_anchor[(size_t)a] = pm[(size_t)d->dn_lanid[a]];
+            dd.dn_ldnid = p_dn_id.data(); dd.dn_lanid = p_dn_anchor.data();
+        }
+        {
+            const hq_schedule* in[2] = { &d->an_sched, &d->dn_sched };
+            hq_schedule* out[2] = { &dd.an_sched, &dd.dn_sched };
+            size_t nm = 0;
+            for (int s2 = 0; s2 < 2; s2++) nm += (size_t)in[s2]->c_count + (size_t)in[s2]->s_count;
+            p_maps.reserve(nm);
+            for (int s2 = 0; s2 < 2; s2++)
+                for (int side = 0; side < 2; side++) {
+                    const int32_t cnt = side ? in[s2]->s_count : in[s2]->c_count;
+                    const hq_messenger* list = side ? in[s2]->first_s : in[s2]->first_c;
+                    std::vector<hq_messenger>& v = p_msg[2 * s2 + side];
+                    for (int32_t i = 0; i < cnt; i++) {
+                        p_maps.emplace_back((size_t)list[i].nodecount);
+                        for (int32_t k = 0; k < list[i].nodecount; k++) p_maps.back()[(size_t)k] = pm[(size_t)list[i].mapping[k]];
+                        v.push_back({ list[i].procid, list[i].nodecount, p_maps.back().data() });
+                    }
+                    if (side) out[s2]->first_s = v.data(); else out[s2]->first_c = v.data();
+                }
+        }
+        dd.tm1 = dd.tm2 = nullptr;              /* uploaded through the permutation below */
+        c->perm = BH.perm;
+        d = &dd;
+    }
+
     /* node state */
     size_t n3 = (size_t)c->N * 3;
     int nbuf = (variant == HQ_VARIANT_PATCH) ? 3 : 2;
@@ -909,10 +1042,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     if ((rc = hq_dev_alloc(c, &c->d_nt, (size_t)c->N * 7)) != HQ_OK) return bail(rc);
     if (hipMemcpy(c->d_nt, d->nTable, sizeof(double) * 7 * c->N, hipMemcpyHostToDevice) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
-    if (d->tm1 && hipMemcpy(c->d_u[c->now], d->tm1, sizeof(double) * n3, hipMemcpyHostToDevice) != hipSuccess)
-        return bail(hq_fail(HQ_ERR_DEVICE, "tm1 upload failed%s", ""));
-    if (d->tm2 && hipMemcpy(c->d_u[c->prev], d->tm2, sizeof(double) * n3, hipMemcpyHostToDevice) != hipSuccess)
-        return bail(hq_fail(HQ_ERR_DEVICE, "tm2 upload failed%s", ""));
+    if (h_tm1 && (rc = hq_field_to_device(c, h_tm1, c->d_u[c->now])) != HQ_OK) return bail(rc);
+    if (h_tm2 && (rc = hq_field_to_device(c, h_tm2, c->d_u[c->prev])) != HQ_OK) return bail(rc);
 
     if (c->ldnnum) {
         int32_t na = d->dn_ptr[c->ldnnum];
@@ -947,18 +1078,6 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if (hipMemcpy(c->d_gkey, key.data(), sizeof(int64_t) * (size_t)c->N, hipMemcpyHostToDevice) != hipSuccess)
             return bail(hq_fail(HQ_ERR_DEVICE, "node identity upload failed%s", ""));
         c->debug_halo = true;
-    }
-
-    /* element coefficients: (c1, c2, beta = c3/c1).  The fused product needs c3/c1 == c4/c2 (Rayleigh:
-     * both are b/dt, psolve.c:3386-3409); a table that applies different ratios to K1 and K2 is refused */
-    std::vector<double> c1(c->E), c2(c->E), beta(c->E);
-    for (int64_t e = 0; e < c->E; e++) {
-        const double* ep = d->eTable + 4 * e;
-        c1[e] = ep[0]; c2[e] = ep[1];
-        beta[e] = (ep[0] != 0.0) ? ep[2] / ep[0] : ((ep[1] != 0.0) ? ep[3] / ep[1] : 0.0);
-        const double lhs = ep[2] * ep[1], rhs = ep[3] * ep[0];
-        if (fabs(lhs - rhs) > 1e-12 * std::max(fabs(lhs), fabs(rhs)))
-            return bail(hq_fail(HQ_ERR_ARG, "eTable is not Rayleigh-proportional (c3/c1 != c4/c2): not the table solver_init builds%s", ""));
     }
 
     if (variant == HQ_VARIANT_SCATTER) {
@@ -1020,7 +1139,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             }
         c->plan.ragged_default = true;
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
-                            dn, seed0.data(), &pb);
+                            dn, seed0.data(), &pb, BH.nb);
+        if (rc == 0 && BH.nb > 0) rc = hq_brick_upload(&c->bricks, BH, &pb);
         if (rc != 0)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));
@@ -1275,6 +1395,144 @@ extern "C" int hq_stencil_plan_check(const hq_desc* d, int64_t report[6])
     return HQ_OK;
 }
 
+/* nodes that must stay with the patches: hanging nodes, their anchors, every node a schedule names */
+static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl)
+{
+    excl.assign((size_t)d->nharbored, 0);
+    for (int32_t k = 0; k < d->ldnnum; k++) {
+        excl[d->dn_ldnid[k]] = 1;
+        for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) excl[d->dn_lanid[a]] = 1;
+    }
+    for (const hq_schedule* sc : { &d->an_sched, &d->dn_sched })
+        for (int side = 0; side < 2; side++) {
+            const int32_t cnt = side ? sc->s_count : sc->c_count;
+            const hq_messenger* list = side ? sc->first_s : sc->first_c;
+            for (int32_t i = 0; i < cnt; i++)
+                for (int32_t k = 0; k < list[i].nodecount; k++) {
+                    const int32_t n = list[i].mapping ? list[i].mapping[k] : -1;
+                    if (n < 0 || n >= d->nharbored) return hq_fail(HQ_ERR_ARG, "messenger node id out of range%s", "");
+                    excl[n] = 1;
+                }
+        }
+    return HQ_OK;
+}
+
+/*
+ * Host-only self-check of the brick planner (needs no device; desc->node_xyz required).  Plans the bricks as
+ * hq_create would and verifies, against the mesh's connectivity alone (node -> elements, no coordinates): the
+ * numbering is a permutation; every brick node lies in exactly one unit, is the corner of exactly eight elements
+ * (one per corner) with the unit's (c1, c2, beta), has an n_t row without dashpot terms (the unit's row where the
+ * unit says they are all the same), is neither hanging, an anchor, nor named in a schedule; and each of its 26
+ * neighbours -- found through those eight elements -- is the node the kernel will read at that offset: a node of
+ * the unit, an entry of the unit's ring table or of its first / last plane's id list.
+ * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}
+ */
+extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
+{
+    if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid) || !d->node_xyz || !d->eTable || !d->nTable)
+        return hq_fail(HQ_ERR_ARG, "inconsistent mesh description (node_xyz is needed)%s", "");
+    const int64_t E = d->lenum, N = d->nharbored;
+    for (int64_t i = 0; i < E * 8; i++)
+        if (d->lnid[i] < 0 || d->lnid[i] >= N) return hq_fail(HQ_ERR_ARG, "lnid out of range%s", "");
+    std::vector<double> c1((size_t)E), c2((size_t)E), beta((size_t)E);
+    for (int64_t e = 0; e < E; e++) {
+        const double* ep = d->eTable + 4 * e;
+        c1[(size_t)e] = ep[0]; c2[(size_t)e] = ep[1];
+        beta[(size_t)e] = (ep[0] != 0.0) ? ep[2] / ep[0] : ((ep[1] != 0.0) ? ep[3] / ep[1] : 0.0);
+    }
+    std::vector<char> excl;
+    HQ_TRY(hq_brick_excluded(d, excl));
+    hq_brick_host B;
+    if (hq_brick_plan_host(E, N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &B) != 0)
+        return hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error());
+    int64_t bad = 0, nchecked = 0;
+    for (int k = 0; k < 8; k++) report[k] = 0;
+    report[6] = N;
+    if (B.nb == 0) return HQ_OK;
+    /* permutation and its inverse */
+    std::vector<int32_t> inv((size_t)N, -1);
+    for (int64_t n = 0; n < N; n++) {
+        const int32_t q = B.perm[(size_t)n];
+        if (q < 0 || q >= N || inv[(size_t)q] != -1) { bad++; continue; }
+        inv[(size_t)q] = (int32_t)n;
+    }
+    /* node -> (element, corner) */
+    std::vector<int64_t> aptr((size_t)N + 1, 0);
+    for (int64_t i = 0; i < E * 8; i++) aptr[(size_t)d->lnid[i] + 1]++;
+    for (int64_t n = 0; n < N; n++) aptr[(size_t)n + 1] += aptr[(size_t)n];
+    std::vector<int64_t> adj((size_t)(E * 8));
+    {
+        std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+        for (int64_t i = 0; i < E * 8; i++) adj[(size_t)fill[(size_t)d->lnid[i]]++] = i;
+    }
+    std::vector<int32_t> covered((size_t)B.nb, 0);
+    int64_t nsame = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad, nchecked, nsame)
+    for (int64_t u = 0; u < (int64_t)B.units.size(); u++) {
+        const hq_brick_unit& U = B.units[(size_t)u];
+        const int nx = U.nx, ny = U.ny, np = U.np, nr = 2 * (nx + 2) + 2 * ny;
+        if (nx < 1 || nx > HQ_BK_TX || ny < 1 || ny > HQ_BK_TY || np < 1 || U.base < 0 || U.base + (int64_t)nx * ny * np > B.nb) { bad++; continue; }
+        nsame += (U.flags & HQ_BK_NTSAME) != 0;
+        if (((U.flags & HQ_BK_NTSAME) != 0) != (u < B.nsame)) bad++;
+        const int32_t* ring = B.tab.data() + U.tab;
+        const int32_t* cap = ring + (int64_t)(np + 2) * nr;
+        /* the device id the kernel reads at (x, y) of plane k, k = -1 .. np */
+        auto at = [&](int x, int y, int k) -> int64_t {
+            const bool in = x >= 0 && x < nx && y >= 0 && y < ny;
+            if (in) {
+                if (k >= 0 && k < np) return U.base + ((int64_t)k * ny + y) * nx + x;
+                return cap[(k < 0 ? 0 : nx * ny) + y * nx + x];
+            }
+            const int32_t* r = ring + (int64_t)(k + 1) * nr;
+            if (y == -1) return r[x + 1];
+            if (y == ny) return r[nx + 2 + x + 1];
+            if (x == -1) return r[2 * (nx + 2) + y];
+            return r[2 * (nx + 2) + ny + y];
+        };
+        for (int k = 0; k < np; k++)
+            for (int y = 0; y < ny; y++)
+                for (int x = 0; x < nx; x++) {
+                    const int64_t q = U.base + ((int64_t)k * ny + y) * nx + x;
+#pragma omp atomic
+                    covered[(size_t)q]++;
+                    const int32_t n = inv[(size_t)q];
+                    if (n < 0) { bad++; continue; }
+                    if (excl[(size_t)n]) bad++;
+                    const double* t7 = d->nTable + 7 * (int64_t)n;
+                    if (!((t7[1] == t7[2]) && (t7[1] == t7[3]) && (t7[4] == t7[5]) && (t7[4] == t7[6]))) bad++;
+                    if ((U.flags & HQ_BK_NTSAME) && (t7[0] != U.m0 || t7[1] != U.m2 || t7[4] != U.m1)) bad++;
+                    int64_t el[8];
+                    for (int o = 0; o < 8; o++) el[o] = -1;
+                    if (aptr[(size_t)n + 1] - aptr[(size_t)n] != 8) { bad++; continue; }
+                    bool ok = true;
+                    for (int64_t a = aptr[(size_t)n]; a < aptr[(size_t)n + 1]; a++) {
+                        const int64_t e = adj[(size_t)a] >> 3;
+                        const int o = (int)(adj[(size_t)a] & 7);
+                        if (el[o] != -1) ok = false;
+                        el[o] = e;
+                        if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
+                    }
+                    if (!ok) { bad++; continue; }
+                    for (int dz = -1; dz <= 1; dz++)
+                        for (int dy = -1; dy <= 1; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (!dx && !dy && !dz) continue;
+                                /* the neighbour is corner m of the element whose corner o the node is, m - o = d */
+                                const int o = (dx < 0 ? 1 : 0) | (dy < 0 ? 2 : 0) | (dz < 0 ? 4 : 0);
+                                const int m = (dx > 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dz > 0 ? 4 : 0);
+                                const int32_t nb_abi = d->lnid[8 * el[o] + m];
+                                if (at(x + dx, y + dy, k + dz) != (int64_t)B.perm[(size_t)nb_abi]) bad++;
+                                nchecked++;
+                            }
+                }
+    }
+    for (int64_t q = 0; q < B.nb; q++) if (covered[(size_t)q] != 1) bad++;
+    report[0] = B.nb; report[1] = B.ncolumns; report[2] = (int64_t)B.units.size(); report[3] = nsame;
+    report[4] = B.nlevels; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
+    if (bad) return hq_fail(HQ_ERR_STATE, "brick plan self-check failed%s", "");
+    return HQ_OK;
+}
+
 extern "C" int hq_destroy(hq_ctx* c)
 {
     if (!c) return HQ_OK;
@@ -1307,6 +1565,7 @@ extern "C" int hq_destroy(hq_ctx* c)
         if (!any) delete g;
     }
     hq_patch_free(&c->plan);
+    hq_brick_free(&c->bricks);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (int k = 0; k < 2; k++) if (c->ev_span[k]) hipEventDestroy(c->ev_span[k]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1326,7 +1585,8 @@ extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
     info->lattice_patches = c->plan.nlattice;
     info->stencil_patches = c->plan.nstencil;
     info->ragged_patches = c->plan.nragged;
-    info->reserved = 0;
+    info->brick_units = c->bricks.nunits;
+    info->brick_nodes = c->bricks.nb;
     return HQ_OK;
 }
 
@@ -1424,6 +1684,12 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
     HQ_HIP(hq_quiesce(c));
     for (int32_t i = 0; i < nloaded; i++)
         if (loaded[i] < 0 || loaded[i] >= c->N) return hq_fail(HQ_ERR_ARG, "loaded node id out of range%s", "");
+    std::vector<int32_t> dev_ids;                        /* the loaded nodes in device numbering */
+    if (!c->perm.empty() && nloaded > 0) {
+        dev_ids.resize((size_t)nloaded);
+        for (int32_t i = 0; i < nloaded; i++) dev_ids[(size_t)i] = c->perm[(size_t)loaded[i]];
+        loaded = dev_ids.data();
+    }
     if (c->d_loaded) { hipFree(c->d_loaded); c->d_loaded = nullptr; }
     if (c->d_F) { hipFree(c->d_F); c->d_F = nullptr; }
     c->nloaded = nloaded; c->src_step0 = step0; c->src_nsteps = nsteps;
@@ -1435,6 +1701,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
     }
     if (c->variant == HQ_VARIANT_PATCH) {
         int r = hq_patch_set_source(&c->plan, (nloaded && nsteps) ? nloaded : 0, loaded, &c->bytes);
+        if (r == 0) r = hq_brick_set_source(&c->bricks, (nloaded && nsteps) ? nloaded : 0, loaded, &c->bytes);
         if (r != 0) return hq_fail(HQ_ERR_NOMEM, "source table allocation failed%s", "");
     }
     return HQ_OK;
@@ -1532,6 +1799,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
 extern "C" const char* hq_dominant_kernel(hq_ctx* c)
 {
     if (!c || c->variant != HQ_VARIANT_PATCH) return "hq_k_element_scatter";
+    if (2 * c->bricks.nb > (int64_t)c->N) return "hq_k_brick";
     if (2 * c->plan.nstencil > c->plan.npatches) return "hq_k_patch_stencil";
     if (!hq_patch_uses_pers(&c->plan)) return "hq_k_patch_step";
     return c->plan.seeded ? "hq_k_patch_seed" : "hq_k_patch_pers";
@@ -1564,6 +1832,12 @@ static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1,
     HQ_HIP(hipMalloc((void**)&d_ids, sizeof(int32_t) * n));
     hipError_t e = hipMalloc((void**)&d_o, sizeof(double) * 9 * (size_t)n);
     if (e != hipSuccess) { hipFree(d_ids); return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", ""); }
+    std::vector<int32_t> dev_ids;
+    if (!c->perm.empty()) {
+        dev_ids.resize((size_t)n);
+        for (int32_t i = 0; i < n; i++) dev_ids[(size_t)i] = c->perm[(size_t)lnid[i]];
+        lnid = dev_ids.data();
+    }
     hipMemcpyAsync(d_ids, lnid, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream);
     hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->now], c->d_u[c->prev],
                                                                          d_o, d_o + 3 * (size_t)n);
@@ -1586,9 +1860,8 @@ extern "C" int hq_download(hq_ctx* c, double* tm1, double* tm2)
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
-    size_t bytes = sizeof(double) * 3 * (size_t)c->N;
-    if (tm1) HQ_HIP(hipMemcpy(tm1, c->d_u[c->now], bytes, hipMemcpyDeviceToHost));
-    if (tm2) HQ_HIP(hipMemcpy(tm2, c->d_u[c->prev], bytes, hipMemcpyDeviceToHost));
+    if (tm1) HQ_TRY(hq_field_to_host(c, c->d_u[c->now], tm1));
+    if (tm2) HQ_TRY(hq_field_to_host(c, c->d_u[c->prev], tm2));
     return HQ_OK;
 }
 
@@ -1598,8 +1871,8 @@ extern "C" int hq_upload(hq_ctx* c, const double* tm1, const double* tm2, int32_
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
     size_t bytes = sizeof(double) * 3 * (size_t)c->N;
-    HQ_HIP(hipMemcpy(c->d_u[c->now], tm1, bytes, hipMemcpyHostToDevice));
-    HQ_HIP(hipMemcpy(c->d_u[c->prev], tm2, bytes, hipMemcpyHostToDevice));
+    HQ_TRY(hq_field_to_device(c, tm1, c->d_u[c->now]));
+    HQ_TRY(hq_field_to_device(c, tm2, c->d_u[c->prev]));
     if (c->d_u[2]) HQ_HIP(hipMemset(c->d_u[c->spare], 0, bytes));          /* tm3 after a restart: calloc, psolve.c:3347 */
     c->step = step;
     return HQ_OK;

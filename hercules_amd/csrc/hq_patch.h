@@ -183,6 +183,7 @@ struct hq_patch_plan {
     std::vector<int32_t> h_halo;     /* host copies kept only for meshes with hanging nodes */
     std::vector<int64_t> h_halo_off;
     std::vector<int32_t> h_nvirt;
+    int64_t  n0 = 0;                 /* the nodes [0, n0) are brick nodes (hq_brick.h): no patch owns them */
     std::vector<int32_t> patch_base; /* host copy of desc[].base for lookups */
     std::vector<int32_t> patch_nown;
 };
@@ -539,20 +540,22 @@ static bool hq_ragged_match(int32_t base, int32_t nown, const int32_t* lnid, con
  * Cut [0,N) into runs of consecutive nodes.  With coordinates (node_t.x/y/z,
  * octor.h:133-147) the cuts follow aligned octree cubes holding at most PMAX
  * nodes; without them (or if the numbering is not Z-ordered) fixed runs.
+ * n0: the nodes [0, n0) are brick nodes (hq_brick.h) and belong to no patch.
  */
-static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz, std::vector<int32_t>& cuts)
+static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz, std::vector<int32_t>& cuts, int64_t n0 = 0)
 {
     cuts.clear();
     auto fixed = [&]() {
         cuts.clear();
-        for (int64_t i = 0; i < N; i += cfg.pmerge) cuts.push_back((int32_t)i);
+        for (int64_t i = n0; i < N; i += cfg.pmerge) cuts.push_back((int32_t)i);
         cuts.push_back((int32_t)N);
     };
+    if (n0 >= N) { cuts.push_back((int32_t)N); return; }       /* every node is a brick node: no patch */
     if (!xyz) { fixed(); return; }
 
     uint32_t orall = 0;
     int32_t maxc[3] = { 0, 0, 0 };
-    for (int64_t n = 0; n < N; n++)
+    for (int64_t n = n0; n < N; n++)
         for (int d = 0; d < 3; d++) {
             int32_t v = xyz[3 * n + d];
             if (v < 0) { fixed(); return; }
@@ -569,7 +572,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
     bool sorted = false;
     for (int mask = 7; mask >= 0 && !sorted; mask--) {
         sorted = true;
-        for (int64_t n = 0; n < N && sorted; n++) {
+        for (int64_t n = n0; n < N && sorted; n++) {
             uint64_t q[3];
             for (int d = 0; d < 3; d++) {
                 int32_t v = xyz[3 * n + d];
@@ -578,7 +581,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
                 if (q[d] >> 21) { fixed(); return; }
             }
             key[n] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
-            if (n && key[n] < key[n - 1]) sorted = false;
+            if (n > n0 && key[n] < key[n - 1]) sorted = false;
         }
     }
     if (!sorted) { fixed(); return; }                  /* not Z-ordered */
@@ -589,7 +592,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
     std::vector<std::pair<int32_t, int32_t>> runs;
     struct item { int64_t lo, hi; int bit; };
     std::vector<item> stack;
-    stack.push_back({ 0, N, 63 });
+    stack.push_back({ n0, N, 63 });
     while (!stack.empty()) {
         item it = stack.back();
         stack.pop_back();
@@ -608,7 +611,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
     }
     std::sort(runs.begin(), runs.end());
     /* merge small neighbours (coarse octree regions) */
-    cuts.push_back(0);
+    cuts.push_back((int32_t)n0);
     int32_t cur = 0;
     for (auto& r : runs) {
         int32_t n = r.second - r.first;
@@ -623,10 +626,10 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
  * does not fit LDS is halved and the build repeated.
  */
 static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, const int32_t* lnid,
-                              const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H)
+                              const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H, int64_t n0 = 0)
 {
     std::vector<int32_t> cuts;
-    hq_patch_cuts(cfg, N, xyz, cuts);
+    hq_patch_cuts(cfg, N, xyz, cuts, n0);
     /* hanging nodes: dn_of[n] = index into the dangling table or -1 */
     std::vector<int32_t> dn_of;
     if (dn.n > 0) {
@@ -639,7 +642,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
 
     for (int attempt = 0; attempt < 12; attempt++) {
         int32_t P = (int32_t)cuts.size() - 1;
-        std::vector<int32_t> patch_of((size_t)N);
+        std::vector<int32_t> patch_of((size_t)N, -1);            /* -1: a brick node */
         for (int32_t p = 0; p < P; p++)
             for (int32_t n = cuts[p]; n < cuts[p + 1]; n++) patch_of[n] = p;
 
@@ -650,6 +653,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         auto patches_of_elem = [&](int64_t e, int32_t out[40]) {
             int k = 0;
             auto add = [&](int32_t p) {
+                if (p < 0) return;
                 bool seen = false;
                 for (int t = 0; t < k; t++) seen |= (out[t] == p);
                 if (!seen) out[k++] = p;
@@ -2087,9 +2091,10 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
 
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
                           const double* c1, const double* c2, const double* beta, const double* ntab,
-                          const hq_dangling& dn, const char* seed0, int64_t* bytes)
+                          const hq_dangling& dn, const char* seed0, int64_t* bytes, int64_t n0 = 0)
 {
     hq_patch_host H;
+    P->n0 = n0;
     P->cfg = hq_patch_cfg_from_env();
     P->pipe = hq_patch_kernel_choice();
     if (dn.n > 0 && P->cfg.vmax == 0) {
@@ -2106,7 +2111,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
                         pers_fits(std::max(P->cfg.nlmax, HQ_LAT_ROWS), 0);
     for (;;) {
-        if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H) != 0) return -1 /* HQ_ERR_ARG */;
+        if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H, n0) != 0) return -1 /* HQ_ERR_ARG */;
         int32_t mp = 0, nl = 0;
         for (size_t p = 0; p < H.desc.size(); p++) { mp = std::max(mp, H.desc[p].npairs); nl += H.lattice[p]; }
         P->nlattice = nl;
@@ -2301,6 +2306,7 @@ static int hq_patch_set_source(hq_patch_plan* P, int32_t nloaded, const int32_t*
      * "virtual" accumulator of a loaded hanging node (its force is distributed to their anchors) */
     std::vector<std::array<int32_t, 3>> rec;
     for (int32_t i = 0; i < nloaded; i++) {
+        if (loaded[i] < P->n0) continue;                          /* a brick node: hq_brick_set_source */
         int32_t p = (int32_t)(std::upper_bound(P->patch_base.begin(), P->patch_base.end(), loaded[i]) -
                               P->patch_base.begin()) - 1;
         const int32_t lo = loaded[i] - P->patch_base[p];          /* accumulators are indexed by LDS row */

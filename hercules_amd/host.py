@@ -266,6 +266,14 @@ class Box:
             raise capi.HqError("hqh_box_desc failed: %d" % rc)
         return capi.stencil_plan_check(d)
 
+    def brick_plan_check(self):
+        """The brick planner against this box's connectivity (capi.brick_plan_check, host only)."""
+        d = capi._Desc()
+        rc = self._lib.hqh_box_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_box_desc failed: %d" % rc)
+        return capi.brick_plan_check(d)
+
     def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
         """hq_create on the arrays the C host side built (no copies through Python)."""
         d = capi._Desc()
@@ -515,6 +523,14 @@ class OctBox:
         if rc != 0:
             raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
         return capi.stencil_plan_check(d)
+
+    def brick_plan_check(self):
+        """The brick planner against this box's connectivity (capi.brick_plan_check, host only)."""
+        d = capi._Desc()
+        rc = self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
+        if rc != 0:
+            raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
+        return capi.brick_plan_check(d)
 
     def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
         d = capi._Desc()

@@ -113,7 +113,8 @@ typedef struct {
     int32_t lattice_patches;     /* patch variant: patches with rows and lanes on one lattice (conflict-free LDS) */
     int32_t stencil_patches;     /* patch variant: patches stepped by hq_k_patch_stencil                          */
     int32_t ragged_patches;      /* patch variant: of the stencil patches, the lattice SUBSETS (faces, far-face cubes) */
-    int32_t reserved;
+    int32_t brick_units;         /* patch variant: workgroup units of hq_k_brick (tile column x planes)          */
+    int64_t brick_nodes;         /* patch variant: nodes stepped by hq_k_brick (the rest belongs to the patches)  */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -250,6 +251,15 @@ HQ_API int hq_plan_check(const hq_desc* desc, int64_t report[8]);
  * report = {patches, patches with a table, full lattices among them, boundary nodes, element corners checked, faults}.
  */
 HQ_API int hq_stencil_plan_check(const hq_desc* desc, int64_t report[6]);
+
+/*
+ * Host-only self-check of the brick planner (needs no device; desc->node_xyz required): plans the bricks -- the bulk
+ * of uniformly refined, homogeneous regions, stepped by hq_k_brick on a tile-major node numbering of the device's own
+ * -- as hq_create would and verifies them against the mesh's connectivity alone: permutation, coverage, the eight
+ * equal elements and the dashpot-free n_t row of every brick node, and every neighbour the kernel will read.
+ * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}.
+ */
+HQ_API int hq_brick_plan_check(const hq_desc* desc, int64_t report[8]);
 
 /*
  * Host-only: the sixteen coefficients {p1[6], p2[6], q1[2], q2[2]} of the assembled 27-point stencil
