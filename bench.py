@@ -48,6 +48,11 @@ WORKLOADS = {
     "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0),
     "c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
     "c1": (16, 16, 8, 62.5, 1.0e-3, 5.0),
+    # c3 / c2 / m1 with material that differs from element to element (LATERAL): what solver_init hands over on any
+    # real CVM mesh (psolve.c:3360-3409), and what no uniform-coefficient fast path applies to
+    "c3h": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0),
+    "c2h": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
+    "m1h": (128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0),
     "m1": (128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0),
     # two-level octree box (hanging nodes): nx, ny, nz_fine, h_fine, dt, freq  (+ 96 coarse layers)
     "o1": (512, 512, 64, 1000.0 / 512, 9.0e-5, 200.0),
@@ -55,6 +60,8 @@ WORKLOADS = {
     "o2": (1024, 1024, 128, 1000.0 / 1024, 4.5e-5, 400.0),
 }
 OCT_COARSE_LAYERS = {"o1": 96, "o2": 192}
+# Vp, Vs, rho of an element column (i, j) = the half-space's times a class factor in [0.9, 1.1]; class = hash(i, j) mod 61
+LATERAL = {"c3h": (61, 0.1), "c2h": (61, 0.1), "m1h": (61, 0.1)}
 # layered-basin models meshed by the Vs rule (hqh_layered_column) on several octree levels:
 # name: (nx, ny, finest h [m], dt, freq, points per wavelength, coarsest cell [m], cells in depth,
 #        [(ztop, vp, vs, rho), ...])
@@ -73,6 +80,9 @@ for _k, _v in OCT_LAYERED.items():
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
+                  "c3h": "64M-element box 512x512x256, Vp/Vs/rho of every element column perturbed +-10 % (61 classes by coordinate hash), point double-couple source",
+                  "c2h": "8M-element box 256x256x128, Vp/Vs/rho of every element column perturbed +-10 %",
+                  "m1h": "1M-element box 128x128x64, Vp/Vs/rho of every element column perturbed +-10 %",
                   "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)",
                   "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
                   "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",
@@ -247,7 +257,8 @@ def inproc_diagnostic(args):
                       "nneighbors": len(peers)}
             u1 = seeded_field(b.node_xyz, nx, ny, interfaces)
         else:
-            b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P)
+            ncls, amp = LATERAL.get(args.workload, (0, 0.0))
+            b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P, lateral_classes=ncls, lateral_amp=amp)
             u1 = seeded_field(b.node_ijk, nx, ny)
         solvers.append(b.create_solver(variant=variant, tm1=u1, tm2=u1 * (1.0 - 1e-3)))
         boxes.append(b)
@@ -339,7 +350,8 @@ def build_problem(args, rank, world, device):
         box.info = {"nharbored": box.N, "total_elements": total_e, "lenum": box.E, "total_nodes": total_n}
         box.node_ijk = box.node_xyz
     else:
-        box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
+        ncls, amp = LATERAL.get(args.workload, (0, 0.0))
+        box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world, lateral_classes=ncls, lateral_amp=amp)
     N = box.info["nharbored"]
     # seeded random start: identical on every rank for shared nodes
     # because it is a function of the global node coordinates
@@ -391,7 +403,7 @@ def measure_traffic(args, keep_dir=None):
             d = os.path.join(out_root, counter.lower())
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                    os.path.realpath(sys.executable), os.path.abspath(__file__), "--pmc-child",
-                   "--workload", args.workload, "--variant", args.variant, "--steps", "3", "--warmup", "1"]
+                   "--workload", args.workload, "--variant", args.variant, "--steps", str(PMC_STEPS - 1), "--warmup", "1"]
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -418,24 +430,24 @@ def measure_traffic(args, keep_dir=None):
     return res
 
 
-def traffic_of(pmc, kernel):
-    """(HBM bytes per step of the patch kernels, corrected read bytes, write bytes, steps profiled).  A step
-    launches the dominant kernel once and, where the mesh has patches it does not take (domain faces, hanging
-    nodes), the element-form patch kernel beside it: `kernel_ms` spans both, so do the bytes."""
-    def per_step(counter):
-        steps = tot = 0
-        for k, (n, t) in pmc[counter].items():
-            if kernel in k:
-                steps = n
-            if "hq_k_patch" in k or "hq_k_element" in k or "hq_k_update" in k:
-                tot += t
-        return steps, (tot / steps if steps else None)
-    nf, f = per_step("FETCH_SIZE")
-    nw, w = per_step("WRITE_SIZE")
-    if f is None or w is None:
+PMC_STEPS = 4              # steps a counter pass runs (pmc_child: 1 + 3)
+STEP_KERNELS = ("hq_k_brick", "hq_k_patch", "hq_k_element", "hq_k_update")
+
+
+def traffic_of(pmc, kernel, steps=PMC_STEPS):
+    """(HBM bytes per step of the step's compute kernels, corrected read bytes, write bytes, steps profiled).
+    A step launches the dominant kernel (once, or two to three times: hq_k_patch_stencil has a launch per patch
+    class, hq_k_brick one per n_t form) and the patch kernels for the nodes it does not take (domain faces,
+    hanging nodes): `kernel_ms` spans them all, so do the bytes.  `steps` is the number of steps the counter
+    pass RAN (known from its command line) -- never the dispatch count of some kernel."""
+    if not any(kernel in k for k in pmc["FETCH_SIZE"]) or not any(kernel in k for k in pmc["WRITE_SIZE"]):
         return None
+
+    def per_step(counter):
+        return sum(t for k, (n, t) in pmc[counter].items() if any(name in k for name in STEP_KERNELS)) / steps
+    f, w = per_step("FETCH_SIZE"), per_step("WRITE_SIZE")
     rd, wr = f * 1024.0 * 2.0, w * 1024.0
-    return rd + wr, rd, wr, min(nf, nw)
+    return rd + wr, rd, wr, steps
 
 
 def main():
@@ -556,18 +568,23 @@ def main():
             if got:
                 traffic, rd, wr, nprof = got
                 source = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE passes of this bench.py run, "
-                          "%d steps each: %s and the element-form patch kernel beside it" % (nprof, kernel))
+                          "%d steps each: %s and the patch kernels beside it" % (nprof, kernel))
         elif pmc is not None:
             source = "unmeasured: " + pmc["error"]
         elif world > 1:
             source = "unmeasured: counter passes run at N = 1 only"
         else:
             source = "unmeasured: --no-pmc"
-        basis = traffic if traffic is not None else compulsory
-        achieved = basis / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # frac: the bytes the step HAS to move (72 B per node: read u(t), u(t-dt), write u(t+dt)) over the time
+        # it took, against the peak -- the fraction of the roofline the work needs.  counter_frac: the bytes the
+        # kernels really moved (PMC), waste included.  wasted = the ratio of the two byte counts.
+        achieved = compulsory / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        achieved_counter = traffic / (kernel_ms * 1e-3) / 1e9 if (traffic is not None and kernel_ms > 0) else None
         ideal_ms = compulsory / (HBM_PEAK_GBS * 1e9) * 1e3
         frac = achieved / HBM_PEAK_GBS
+        counter_frac = achieved_counter / HBM_PEAK_GBS if achieved_counter is not None else None
         assert frac <= 1.0, "roofline fraction above 1: the byte count is not this kernel's traffic"
+        assert counter_frac is None or counter_frac <= 1.0, "measured HBM rate above the peak: wrong counter arithmetic"
         out = {
             "metric": "element-updates/sec (whole node) + achieved HBM GB/s, 64M-elem box",
             "value": value,
@@ -596,10 +613,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": frac, "traffic": traffic, "traffic_read_corrected": rd, "traffic_write": wr,
                          "traffic_source": source,
-                         "achieved_basis": "measured HBM bytes" if traffic is not None else "compulsory bytes (lower bound)",
+                         "achieved_basis": "compulsory bytes: 72 B per node and step",
+                         "counter_frac": counter_frac, "achieved_counter": achieved_counter,
+                         "wasted": (traffic / compulsory) if traffic is not None else None,
                          "kernel": kernel, "kernel_ms": kernel_ms,
                          "compulsory_bytes_per_launch": compulsory, "ideal_ms": ideal_ms,
-                         "frac_of_ideal_time": ideal_ms / kernel_ms if kernel_ms > 0 else 0.0,
                          "algorithmic_equiv_GBs": BYTES_PER_ELEMENT_UPDATE * value / 1e9,
                          "limiter": "see DESIGN.md s7"},
         }

@@ -50,7 +50,8 @@ struct hqh_box {
     int32_t* loc;                   /* [Ng] global grid index -> local id or -1 */
     double* etable;                 /* [lenum][4] */
     double* ntable;                 /* [nharbored][7] */
-    /* per-depth-index element constants */
+    /* element constants per material index (depth index x lateral class, mat_index) */
+    int32_t ncls;                   /* lateral classes (1: the material depends on depth only) */
     float *k_vp, *k_vs, *k_rho;
     double *k_c1, *k_c2, *k_c3, *k_c4, *k_a, *k_M;
     /* schedule */
@@ -191,7 +192,32 @@ static void rayleigh_base(double freq, int damping, double* aBase, double* bBase
 }
 
 /*
- * Element constants for depth index k (material depends on depth only):
+ * Lateral classes (hqh_box_params.lateral_classes > 1): the element column (ei, ej) belongs to class
+ * hash(ei, ej) mod ncls and its Vp, Vs, rho are the layer's times a class factor in [1 - amp, 1 + amp] -- a mesh
+ * whose material differs from element to element, as solver_init sees it on any real CVM (psolve.c:3360-3409 reads
+ * every element's own edata_t), while the table of distinct materials stays small.
+ */
+static inline int32_t lateral_class(const hqh_box* b, int32_t ei, int32_t ej)
+{
+    if (b->ncls <= 1) return 0;
+    uint32_t h = (uint32_t)ei * 0x9E3779B1u ^ ((uint32_t)ej * 0x85EBCA77u + 0x165667B1u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (int32_t)(h % (uint32_t)b->ncls);
+}
+
+static inline int64_t mat_index(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek)
+{
+    return (int64_t)ek * b->ncls + lateral_class(b, ei, ej);
+}
+
+static inline float lateral_factor(const hqh_box* b, int32_t cls)
+{
+    if (b->ncls <= 1) return 1.0f;
+    return (float)(1.0 + b->p.lateral_amp * (2.0 * cls / (double)(b->ncls - 1) - 1.0));
+}
+
+/*
+ * Element constants per material index (depth index k, lateral class):
  * mu_and_lambda (psolve.c:3236-3272) + psolve.c:3387-3409, 3436-3437.
  */
 static int depth_constants(hqh_box* b)
@@ -206,7 +232,10 @@ static int depth_constants(hqh_box* b)
         int L = 0;
         for (int l = 0; l < p->nlayers; l++)
             if (p->layer_ztop[l] <= zc) L = l;
-        float Vp = p->layer_vp[L], Vs = p->layer_vs[L], rho = p->layer_rho[L];
+      for (int32_t cls = 0; cls < b->ncls; cls++) {
+        const float fac = lateral_factor(b, cls);
+        float Vp = p->layer_vp[L] * fac, Vs = p->layer_vs[L] * fac, rho = p->layer_rho[L] * fac;
+        const int64_t m = (int64_t)k * b->ncls + cls;
         double mu = rho * Vs * Vs;
         double lambda;
         if (Vp > (Vs * p->threshold_vpvs))
@@ -223,14 +252,15 @@ static int depth_constants(hqh_box* b)
         double zeta = 10 / Vs;
         if (zeta > p->threshold_damping) zeta = p->threshold_damping;
         double a = zeta * aBase, bb = zeta * bBase;
-        b->k_vp[k] = Vp; b->k_vs[k] = Vs; b->k_rho[k] = rho;
-        b->k_c1[k] = dt2 * h * mu / 9;
-        b->k_c2[k] = dt2 * h * lambda / 9;
-        b->k_c3[k] = bb * dt * h * mu / 9;
-        b->k_c4[k] = bb * dt * h * lambda / 9;
-        b->k_a[k] = a;
+        b->k_vp[m] = Vp; b->k_vs[m] = Vs; b->k_rho[m] = rho;
+        b->k_c1[m] = dt2 * h * mu / 9;
+        b->k_c2[m] = dt2 * h * lambda / 9;
+        b->k_c3[m] = bb * dt * h * mu / 9;
+        b->k_c4[m] = bb * dt * h * lambda / 9;
+        b->k_a[m] = a;
         double mass = rho * h * h * h;
-        b->k_M[k] = mass / 8;
+        b->k_M[m] = mass / 8;
+      }
     }
     return 0;
 }
@@ -260,7 +290,8 @@ static int corner_dashpot(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek, 
     }
     out[0] = out[1] = out[2] = 0.0;
     if (!touches) return 0;
-    float size = (float)p->h, Vp = b->k_vp[ek], Vs = b->k_vs[ek], rho = b->k_rho[ek];
+    const int64_t mi = mat_index(b, ei, ej, ek);
+    float size = (float)p->h, Vp = b->k_vp[mi], Vs = b->k_vs[mi], rho = b->k_rho[mi];
     double scale = rho * (size / 2) * (size / 2);
     int nf = (bits & 1) + ((bits >> 1) & 1) + ((bits >> 2) & 1);
     for (int d = 0; d < 3; d++) {
@@ -297,7 +328,8 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, do
     for (int t = 0; t < 7; t++) np[t] = 0.0;
     for (int q = 0; q < cnt; q++) {
         int32_t ek = ee[q][2];
-        double M = b->k_M[ek], a = b->k_a[ek], dash[3];
+        const int64_t mi = mat_index(b, ee[q][0], ee[q][1], ek);
+        double M = b->k_M[mi], a = b->k_a[mi], dash[3];
         int bnd = corner_dashpot(b, ee[q][0], ee[q][1], ek, cn[q], dash);
         np[0] += M;
         for (int ax = 0; ax < 3; ax++) {
@@ -365,7 +397,9 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     if (b->ehi - b->elo > 0x7fffffff / 8) { hqh_box_destroy(b); return HQ_ERR_ARG; }
     b->lenum = (int32_t)(b->ehi - b->elo);
 
-    size_t nz = (size_t)p->nz;
+    b->ncls = p->lateral_classes > 1 ? p->lateral_classes : 1;
+    if (b->ncls > 1 && !(p->lateral_amp >= 0.0 && p->lateral_amp < 1.0)) { hqh_box_destroy(b); return HQ_ERR_ARG; }
+    size_t nz = (size_t)p->nz * (size_t)b->ncls;
     b->k_vp = (float*)malloc(nz * sizeof(float)); b->k_vs = (float*)malloc(nz * sizeof(float));
     b->k_rho = (float*)malloc(nz * sizeof(float));
     b->k_c1 = (double*)malloc(nz * 8); b->k_c2 = (double*)malloc(nz * 8); b->k_c3 = (double*)malloc(nz * 8);
@@ -455,13 +489,29 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
             for (int c = 0; c < 8; c++)
                 b->lnid[8 * le + c] = b->loc[grid_index(b, i + (c & 1), j + ((c >> 1) & 1), k + ((c >> 2) & 1))];
             double* ep = &b->etable[4 * le];
-            ep[0] = b->k_c1[k]; ep[1] = b->k_c2[k]; ep[2] = b->k_c3[k]; ep[3] = b->k_c4[k];
+            const int64_t mi = mat_index(b, i, j, k);
+            ep[0] = b->k_c1[mi]; ep[1] = b->k_c2[mi]; ep[2] = b->k_c3[mi]; ep[3] = b->k_c4[mi];
             z = ((z | ~b->zmask) + 1) & b->zmask;
         }
     }
     int rc = build_schedule(b);
     if (rc != HQ_OK) { hqh_box_destroy(b); return rc; }
     *out = b;
+    return HQ_OK;
+}
+
+/* edata_t of this partition's elements as solver_init reads them (psolve.c:3372-3385): out[lenum][3] = Vp, Vs, rho */
+int hqh_box_material(const hqh_box* b, float* out)
+{
+    if (!b || !out) return HQ_ERR_ARG;
+    uint64_t z = bits_deposit((uint64_t)b->elo, b->zmask);
+    for (int64_t e = b->elo; e < b->ehi; e++) {
+        int32_t i = (int32_t)compact3(z), j = (int32_t)compact3(z >> 1), k = (int32_t)compact3(z >> 2);
+        const int64_t mi = mat_index(b, i, j, k);
+        float* o = out + 3 * (e - b->elo);
+        o[0] = b->k_vp[mi]; o[1] = b->k_vs[mi]; o[2] = b->k_rho[mi];
+        z = ((z | ~b->zmask) + 1) & b->zmask;
+    }
     return HQ_OK;
 }
 

@@ -13,7 +13,7 @@ _LIBPATH = os.environ.get("HQ_HOST_LIB") or os.path.join(_HERE, "csrc", "libhq_h
 
 DAMPING = {"none": 0, "rayleigh": 1, "mass": 2}
 EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_desc", "hqh_box_lnid",
-           "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner",
+           "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner", "hqh_box_material",
            "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
            "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format", "hqh_station_format_derivs",
@@ -28,7 +28,8 @@ class _BoxParams(ctypes.Structure):
                 ("layer_vs", ctypes.c_void_p), ("layer_rho", ctypes.c_void_p),
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("lateral_classes", ctypes.c_int32), ("lateral_amp", ctypes.c_double)]
 
 
 class _BoxInfo(ctypes.Structure):
@@ -202,7 +203,7 @@ class Box:
 
     def __init__(self, nx, ny, nz, h, dt, freq, vp=6000.0, vs=3464.0, rho=2700.0, layers=None,
                  damping="rayleigh", threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True,
-                 rank=0, nranks=1):
+                 rank=0, nranks=1, lateral_classes=0, lateral_amp=0.0):
         lib = load_library()
         if layers is None:
             layers = [(0.0, vp, vs, rho)]
@@ -212,7 +213,7 @@ class Box:
         lrho = np.array([l[3] for l in layers], np.float32)
         p = _BoxParams(nx, ny, nz, h, len(layers), zt.ctypes.data, lvp.ctypes.data, lvs.ctypes.data,
                        lrho.ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
-                       int(halfspace), rank, nranks)
+                       int(halfspace), rank, nranks, int(lateral_classes), float(lateral_amp))
         self._h = ctypes.c_void_p()
         rc = lib.hqh_box_create(ctypes.byref(p), ctypes.byref(self._h))
         if rc != 0:
@@ -238,6 +239,14 @@ class Box:
             self._h = ctypes.c_void_p()
 
     __del__ = close
+
+    def material(self):
+        """[lenum][3] float32 Vp, Vs, rho of this partition's elements (edata_t as solver_init reads it)."""
+        out = np.empty((self.info["lenum"], 3), np.float32)
+        rc = self._lib.hqh_box_material(self._h, out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise capi.HqError("hqh_box_material failed: %d" % rc)
+        return out
 
     def schedule(self):
         """an_sched as {"c": [(procid, mapping)], "s": [...]} (copies)."""

@@ -55,6 +55,11 @@ typedef struct {
     double        threshold_vpvs;    /* the_threshold_Vp_over_Vs                   */
     int32_t       halfspace;         /* 1: z = 0 is a free surface (-DHALFSPACE)   */
     int32_t       rank, nranks;      /* this partition / number of partitions      */
+    int32_t       lateral_classes;   /* > 1: the element column (i, j) belongs to class hash(i, j) mod this and its
+                                      * Vp, Vs, rho are the layer's times 1 + lateral_amp (2 class / (classes - 1) - 1):
+                                      * material that differs from element to element, as on a real CVM mesh
+                                      * (psolve.c:3360-3409 reads every element's own edata_t); 0 | 1: depth only  */
+    double        lateral_amp;       /* 0 <= amp < 1                                                              */
 } hqh_box_params;
 
 typedef struct {
@@ -79,6 +84,8 @@ HQ_API const int32_t* hqh_box_node_ijk(const hqh_box* box);
 HQ_API const double*  hqh_box_etable(const hqh_box* box);
 HQ_API const double*  hqh_box_ntable(const hqh_box* box);
 HQ_API const int32_t* hqh_box_owner(const hqh_box* box);
+/* edata_t of this partition's elements as solver_init reads them (psolve.c:3372-3385): out[lenum][3] = Vp, Vs, rho */
+HQ_API int hqh_box_material(const hqh_box* box, float* out);
 
 /*
  * Double-couple point source at (x,y,z) metres: finds the containing element

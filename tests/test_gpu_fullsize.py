@@ -85,6 +85,41 @@ def test_one_million_elements_against_oracle():
     box.close()
 
 
+def test_one_million_elements_with_lateral_material_against_oracle():
+    """bench.py's m1h (the 1 M-element cut of c3h): every element column has its own Vp, Vs, rho, so every element its
+    own (c1, c2, beta) and every node its own n_t row -- what solver_init builds on a real CVM mesh
+    (psolve.c:3360-3473).  No uniform-coefficient fast path applies; the oracle's loops on the same tables are the
+    reference.  Also: two block partitions of it against the whole."""
+    import bench
+    from hercules_amd import capi
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS["m1h"]
+    ncls, amp = bench.LATERAL["m1h"]
+    box = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
+    assert len(np.unique(box.etable[:, 0])) > 50
+    u = _field(box, 777)
+    nsteps = 3
+    o1, o2 = (0.999 * u).copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, dt)
+    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
+        tm1, tm2 = _run(box, variant, u, 0.999 * u, nsteps)
+        assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    gid = (box.node_ijk[:, 2].astype(np.int64) * (ny + 1) + box.node_ijk[:, 1]) * (nx + 1) + box.node_ijk[:, 0]
+    lut = np.empty(gid.max() + 1, np.int64)
+    lut[gid] = np.arange(len(gid))
+    box.close()
+    parts = [host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp, rank=r, nranks=2) for r in range(2)]
+    maps = [lut[(b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]] for b in parts]
+    solvers = [b.create_solver(tm1=u[m], tm2=0.999 * u[m]) for b, m in zip(parts, maps)]
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for s, m in zip(solvers, maps):
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2[m]) < 1e-9 and H.rel_linf(tm2, o1[m]) < 1e-9
+        s.close()
+    for b in parts:
+        b.close()
+
+
 def test_host_solver_run_with_stations():
     """hqh_solver_run (the C mirror of solver_run): source windows, station
     cadence and interpolation, against the oracle driven the same way."""
@@ -155,8 +190,9 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged", [("c2", 0, 1), ("c2", 1, 0), ("c2", 1, 1), ("c3", 1, 1)])
-def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, monkeypatch):
+@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 0, 1, 0), ("c2", 1, 0, 0), ("c2", 1, 1, 0), ("c2", 1, 1, 1),
+                                                      ("c2", 0, 1, 1), ("c3", 1, 1, 1)])
+def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
     single-partition run.  ragged: the lattice-subset patches (domain faces, partition interfaces) through
@@ -164,6 +200,8 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
     monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")      # (the default is 1)
+    if not bricks:                                                      # the patch kernels take every node
+        monkeypatch.setenv("HQ_NO_BRICKS", "1")
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3
@@ -182,7 +220,10 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
         maps.append(m)
         solvers.append(b.create_solver(tm1=u[m], tm2=0.999 * u[m]))
         assert solvers[-1].info()["variant"] == ha.HQ_VARIANT_PATCH
-        assert (solvers[-1].info()["ragged_patches"] > 0) == bool(ragged)
+        if bricks:
+            assert solvers[-1].dominant_kernel() == "hq_k_brick"
+        else:
+            assert (solvers[-1].info()["ragged_patches"] > 0) == bool(ragged)
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     scale = np.abs(ref1).max()
@@ -344,10 +385,14 @@ def test_full_basin_variants_agree():
     box.close()
 
 
-def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels():
-    """1 M-element box, point source, 1500 steps: hq_k_patch_stencil (+ the element kernel at the faces) against
-    the scatter variant -- two formulations of the same operator (assembled 27-point stencil vs element by
-    element with atomics) -- stay together to rounding over a long run; both stay finite."""
+@pytest.mark.parametrize("path", ["hq_k_brick", "hq_k_patch_stencil"])
+def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels(path, monkeypatch):
+    """1 M-element box, point source, 1500 steps: hq_k_brick (the plane sums of the assembled stencil, marching along
+    z; the patch kernels at the faces) and, with HQ_NO_BRICKS=1, hq_k_patch_stencil (+ the element kernel at the
+    faces) against the scatter variant -- formulations of the same operator (assembled 27-point stencil vs element
+    by element with atomics) -- stay together to rounding over a long run; all stay finite."""
+    if path != "hq_k_brick":
+        monkeypatch.setenv("HQ_NO_BRICKS", "1")
     nx, ny, nz, h, dt, freq = 128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0
     box = host.Box(nx, ny, nz, h, dt, freq)
     L = nx * h
@@ -356,7 +401,7 @@ def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels():
     rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt, source_window=nsteps)
     F = box.source_table(rp, 0, nsteps)
     res = []
-    for variant, kernel in ((ha.HQ_VARIANT_PATCH, "hq_k_patch_stencil"), (ha.HQ_VARIANT_SCATTER, "hq_k_element_scatter")):
+    for variant, kernel in ((ha.HQ_VARIANT_PATCH, path), (ha.HQ_VARIANT_SCATTER, "hq_k_element_scatter")):
         s = box.create_solver(variant=variant)
         assert s.dominant_kernel() == kernel
         s.set_source(loaded, F)

@@ -12,6 +12,19 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-9
+
+
+@pytest.fixture(params=["bricks", "patches-only"], autouse=True)
+def brick_mode(request, monkeypatch):
+    """Every parity case twice: as shipped -- the simple nodes of uniform regions stepped by hq_k_brick on the
+    device's own tile-major numbering, the patches taking the rest -- and with HQ_NO_BRICKS=1, where the patch
+    kernels (stencil and element form) take every node, as on meshes without node coordinates."""
+    if request.param == "patches-only":
+        monkeypatch.setenv("HQ_NO_BRICKS", "1")
+    else:
+        monkeypatch.delenv("HQ_NO_BRICKS", raising=False)
+    return request.param
+
 VARIANTS = [ha.HQ_VARIANT_SCATTER, ha.HQ_VARIANT_PATCH]
 
 
@@ -761,7 +774,7 @@ def test_create_refuses_a_table_that_is_not_rayleigh_proportional():
 
 
 @pytest.mark.parametrize("pipe", ["0", "4", "6", "4-nostencil", "6-nostencil", "6-ragged"])
-def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
+def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch, brick_mode):
     """The element-form patch kernels -- hq_k_patch_seed (default, HQ_PATCH_PIPE=6), hq_k_patch_pers (4: the form a
     mesh falls back to when three accumulator arrays do not fit LDS) and hq_k_patch_step (0: the form for
     patches of more than 1024 elements) -- with and without hq_k_patch_stencil taking the uniform lattice patches
@@ -814,7 +827,9 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch):
     p1, p2 = v2.copy(), v1.copy()
     ho.solver_run(lnid, et, nt, p1, p2, 0, 6, 2e-4, loaded_lnid=loaded, forces=F)
     s = ha.Solver(lnid, et, nt, 2e-4, tm1=v1, tm2=v2, node_xyz=_ticks(node_ijk, 1 << 20), variant=ha.HQ_VARIANT_PATCH)
-    if ragged:                                      # all 64 patches are lattice subsets (dashpot faces included)
+    if brick_mode == "bricks":                      # the 31^3 simple nodes are brick nodes; the patch kernels keep the shell
+        assert s.dominant_kernel() == "hq_k_brick" and s.info()["brick_nodes"] == 31 ** 3
+    elif ragged:                                    # all 64 patches are lattice subsets (dashpot faces included)
         assert s.dominant_kernel() == "hq_k_patch_stencil" and s.info()["ragged_patches"] > 0
         assert s.info()["stencil_patches"] == s.info()["npatches"]
     else:                                           # 8 stencil patches of 64: the element kernel is still the dominant one

@@ -1,0 +1,132 @@
+"""The drop-in boundary exercised by the reference itself: oracle/_ref/psolve_hq is the REAL CMU-Quake/hercules
+psolve -- its main(), mesher (octor on the example's material database), solver_init, source and station code --
+with INTEGRATION.md's stub applied to a scratch copy of psolve.c at build time (oracle/build_ref_hq.sh: hq_attach
+behind solver_init, hq_steps in place of solver_run()'s physics + communication block psolve.c:4286-4316,
+hq_refresh_host where the outputs read tm1 / tm2) and linked against libhq_solver.so.
+
+Run on examples/simple (16 x 16 x 8 elements, 1 rank; mpiexec starts the program before anything touches the GPU):
+* its checkpoints equal the ones the unmodified reference wrote for the golden fixture (steps 400 / 800 of the
+  1000-step run) to the parity bar 1e-9;
+* its station files equal those of the unmodified psolve run beside it on the host cores, line for line to the
+  printed precision;
+* and (20 000 steps) the station traces the reference SHIPS in examples/simple/expected-out.
+Needs the two binaries (built in the build container, they travel with the repo snapshot) and the image's MPICH."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import ref_baseline as rb
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PSOLVE_HQ = os.path.join(ROOT, "oracle", "_ref", "psolve_hq")
+MPI = os.environ.get("HERC_MPI_DIR", "/opt/conda")
+
+
+def _setkey(t, key, val):
+    assert re.search(r"(?m)^%s\s*=.*$" % re.escape(key), t), key
+    return re.sub(r"(?m)^%s\s*=.*$" % re.escape(key), "%s = %s" % (key, val), t)
+
+
+def _params(end_time, ckpt_rate, station_rate):
+    t = rb.PARAMS.format(freq=5.0, dt=0.001, end_time=repr(end_time))
+    t = _setkey(t, "checkpointing_rate", ckpt_rate)
+    t = _setkey(t, "number_output_stations", len(H.C1_STATIONS))
+    t = _setkey(t, "output_stations_print_rate", station_rate)
+    t = t.replace("output_stations =\n500.0 500.0 100.0\n",
+                  "output_stations =\n" + "".join("%.1f %.1f %.5f\n" % s for s in H.C1_STATIONS))
+    return t
+
+
+def _run(binary, params, timeout=900):
+    run = tempfile.mkdtemp(prefix="herc_hq_", dir="/tmp")
+    shutil.copy(os.path.join(rb.INPUTS, "simple_case.e"), run)
+    shutil.copytree(os.path.join(rb.INPUTS, "sourcefiles"), os.path.join(run, "sourcefiles"))
+    for d in ("checkpoints", "planes", "srctmp", "stations"):
+        os.makedirs(os.path.join(run, "out", d))
+    open(os.path.join(run, "parameters.in"), "w").write(params)
+    # the system's libstdc++ (libhq_solver.so needs it) ahead of the older one beside the image's MPICH
+    syslib = "/usr/lib/x86_64-linux-gnu"
+    env = dict(os.environ, LD_LIBRARY_PATH=":".join([syslib, os.path.join(MPI, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
+    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", "1", binary, "parameters.in"], cwd=run, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:]
+    return run, out.stdout
+
+
+def _stations(run, n=5):
+    def one(i):
+        rows = [l.split() for l in open(os.path.join(run, "out", "stations", "station.%d" % i)).read().splitlines()
+                if l.strip() and not l.lstrip().startswith("#")]
+        return np.array([[float(v) for v in r[:4]] for r in rows])
+    return np.stack([one(i) for i in range(n)])
+
+
+def _checkpoints(run):
+    out = {}
+    for k in (0, 1):
+        b = open(os.path.join(run, "out", "checkpoints", "checkpoint.out%d" % k), "rb").read()
+        groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+        assert groupsize == 1
+        tm2 = np.frombuffer(b[12:12 + nmax * 24], "<f8").reshape(nmax, 3)
+        tm1 = np.frombuffer(b[12 + nmax * 24:12 + 2 * nmax * 24], "<f8").reshape(nmax, 3)
+        out[step] = (tm2, tm1)
+    return out
+
+
+needs_binaries = pytest.mark.skipif(
+    not (os.path.exists(PSOLVE_HQ) and rb.available()),
+    reason="oracle/_ref/psolve_hq, oracle/_ref/psolve (oracle/build_ref*.sh, build container) or mpiexec missing")
+
+
+@needs_binaries
+def test_the_reference_program_on_the_library_reproduces_its_own_checkpoints_and_stations():
+    g = H.load("c1_short")
+    params = _params(float(g["end_time"]), 400, 1)
+    run_hq, log = _run(PSOLVE_HQ, params)
+    run_ref, _ = _run(rb.PSOLVE, params)
+    try:
+        assert "Total elements:" in log and int(re.search(r"Total elements:\s+(\d+)", log).group(1)) == 2048
+        ck, ck_ref = _checkpoints(run_hq), _checkpoints(run_ref)
+        assert sorted(ck) == sorted(ck_ref) == [int(s) for s in g["ckpt_steps"]]
+        for k, step in enumerate(g["ckpt_steps"]):
+            tm2, tm1 = ck[int(step)]
+            # the golden fixture (written by the unmodified reference in the build container) ...
+            assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < 1e-9 and H.rel_linf(tm2, g["ckpt_tm2"][k]) < 1e-9
+            # ... and the unmodified reference run just now on this box's host cores
+            assert H.rel_linf(tm1, ck_ref[int(step)][1]) < 1e-9 and H.rel_linf(tm2, ck_ref[int(step)][0]) < 1e-9
+            assert np.abs(tm1).max() > 0
+        st, st_ref = _stations(run_hq), _stations(run_ref)
+        assert st.shape == st_ref.shape == (5, 1000, 4)
+        scale = np.abs(st_ref[:, :, 1:]).max()
+        assert scale > 0 and np.abs(st - st_ref).max() <= 2e-6 * scale           # %e text: 6 digits behind the point
+        assert np.abs(st - g["stations"]).max() <= 2e-6 * scale
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)
+        shutil.rmtree(run_ref, ignore_errors=True)
+
+
+@needs_binaries
+def test_the_reference_program_on_the_library_matches_the_shipped_station_traces():
+    """The whole examples/simple run (20 000 steps) through psolve_hq against the station traces the reference ships
+    (examples/simple/expected-out/stations; every 20th line and the first 400 are in the fixture)."""
+    g = H.load("c1_full")
+    run_hq, _ = _run(PSOLVE_HQ, _params(float(g["end_time"]), 100000000, 1), timeout=1500)
+    try:
+        st = _stations(run_hq)
+        assert st.shape == (5, 20000, 4)
+        exp = g["expected_every20"]
+        mine = st[:, ::20, :][:, :exp.shape[1], :]
+        scale = np.abs(exp[:, :, 1:]).max()
+        assert scale > 1000.0 and np.abs(mine[:, :, 1:] - exp[:, :, 1:]).max() <= 2e-6 * scale
+        head = g["expected_head"]
+        assert np.abs(st[:, :head.shape[1], 1:] - head[:, :, 1:]).max() <= 2e-6 * np.abs(head[:, :, 1:]).max()
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)

@@ -498,3 +498,36 @@ def test_4d_wavefield_files_equal_the_references(tmp_path):
             assert ours[:32] == ref[:32] and ours[48:128] == ref[48:128]     # all but ufid[16] and generation_date
             assert ours[136:] == ref[136:]
     assert np.abs(np.frombuffer(ref[136:], "<f8")).max() > 1e3
+
+
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_laterally_varying_material_tables_equal_the_oracles_bitwise(nranks):
+    """c3h's kind of mesh: hqh_box_params.lateral_classes > 1 gives every element column its own Vp, Vs, rho (a class
+    factor on the layer's values), so neighbouring elements differ as on a real CVM mesh.  From the per-element edata
+    the box reports, the oracle's solver_init (psolve.c:3360-3473: float-evaluated mu / lambda / zeta, dashpots, the
+    nodal sums in element order) builds the same eTable and nTable bit for bit -- whole and on partitions."""
+    nx, ny, nz, h, dt, freq = 16, 16, 8, 62.5, 1e-3, 5.0
+    layers = [(0.0, 3000.0, 1400.0, 2200.0), (200.0, 6000.0, 3464.0, 2700.0)]
+    whole = host.Box(nx, ny, nz, h, dt, freq, layers=layers, lateral_classes=61, lateral_amp=0.1)
+    mat = whole.material()
+    assert len(np.unique(mat[:, 1])) > 40                     # neighbouring element columns differ
+    assert abs(mat[:, 1] / np.where(mat[:, 1] > 2000, 3464.0, 1400.0) - 1).max() <= 0.1 + 1e-6
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    assert np.array_equal(whole.lnid, lnid)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:, 0] = h
+    edata[:, 1:] = mat
+    et, nt = ho.solver_init(lnid, edata, ho.face_bits(elem_ijk, nx, ny, nz), len(node_ijk), dt, freq)
+    assert np.array_equal(whole.etable, et)
+    assert np.array_equal(whole.ntable, nt)
+    gid = {tuple(v): i for i, v in enumerate(whole.node_ijk.tolist())}
+    e0 = 0
+    for r in range(nranks if nranks > 1 else 0):
+        b = host.Box(nx, ny, nz, h, dt, freq, layers=layers, lateral_classes=61, lateral_amp=0.1, rank=r, nranks=nranks)
+        E = b.info["lenum"]
+        assert np.array_equal(b.etable, et[e0:e0 + E]) and np.array_equal(b.material(), mat[e0:e0 + E])
+        g = np.array([gid[tuple(v)] for v in b.node_ijk.tolist()])
+        assert np.array_equal(b.ntable, nt[g])               # every harbored copy is evaluated completely
+        e0 += E
+        b.close()
+    whole.close()
