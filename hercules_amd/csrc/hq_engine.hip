@@ -161,6 +161,8 @@ struct hq_ctx {
     int32_t nloaded = 0, src_step0 = 0, src_nsteps = 0;
     int32_t* d_loaded = nullptr;
     double* d_F = nullptr;
+    std::vector<int32_t> h_loaded;  /* the loaded nodes (device numbering) of the window in place, and the */
+    size_t F_capacity = 0;          /* doubles d_F holds: the next window of the same nodes reuses both    */
     /* hanging nodes */
     int32_t* d_dn_id = nullptr;
     int32_t* d_dn_ptr = nullptr;
@@ -1690,14 +1692,27 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
         for (int32_t i = 0; i < nloaded; i++) dev_ids[(size_t)i] = c->perm[(size_t)loaded[i]];
         loaded = dev_ids.data();
     }
+    /* the next window of the same loaded nodes (a host that steps window by window, or step by step as the stub of
+     * INTEGRATION.md does inside the reference's loop): only the force table travels */
+    const bool same_nodes = nloaded > 0 && nsteps > 0 && c->d_loaded && (int32_t)c->h_loaded.size() == nloaded &&
+                            memcmp(c->h_loaded.data(), loaded, sizeof(int32_t) * (size_t)nloaded) == 0 &&
+                            (size_t)nloaded * 3 * (size_t)nsteps <= c->F_capacity;
+    if (same_nodes) {
+        c->src_step0 = step0; c->src_nsteps = nsteps;
+        HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+        return HQ_OK;
+    }
     if (c->d_loaded) { hipFree(c->d_loaded); c->d_loaded = nullptr; }
     if (c->d_F) { hipFree(c->d_F); c->d_F = nullptr; }
     c->nloaded = nloaded; c->src_step0 = step0; c->src_nsteps = nsteps;
+    c->h_loaded.clear(); c->F_capacity = 0;
     if (nloaded && nsteps) {
         HQ_TRY(hq_dev_alloc(c, &c->d_loaded, (size_t)nloaded));
         HQ_TRY(hq_dev_alloc(c, &c->d_F, (size_t)nloaded * 3 * nsteps));
         HQ_HIP(hipMemcpy(c->d_loaded, loaded, sizeof(int32_t) * nloaded, hipMemcpyHostToDevice));
         HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+        c->h_loaded.assign(loaded, loaded + nloaded);
+        c->F_capacity = (size_t)nloaded * 3 * (size_t)nsteps;
     }
     if (c->variant == HQ_VARIANT_PATCH) {
         int r = hq_patch_set_source(&c->plan, (nloaded && nsteps) ? nloaded : 0, loaded, &c->bytes);

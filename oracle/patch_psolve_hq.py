@@ -15,7 +15,8 @@ blindly):
      (hq_download in the post-swap view), so that checkpoints, stations, planes and the 4D output read
      what they always read;
   4. solver_run(): the block from solver_nonlinear_state() to solver_send_displacement_dangling() becomes
-     hq_steps( step, 1 ); the context is destroyed behind the loop.
+     hq_steps( step, 1 ) between Timer_Start / Timer_Stop of the timers solver_run_collect_timers() reduces;
+     the context is destroyed behind the loop.
 """
 import sys
 
@@ -48,7 +49,17 @@ def main():
     i, j = once(t, a), once(t, b) + len(b)
     if not i < j:
         sys.exit("patch_psolve_hq: the physics block's anchors are out of order")
-    t = t[:i] + '        Timer_Start( "Compute Physics" );\n        hq_steps( step, 1 );\n        Timer_Stop( "Compute Physics" );\n' + t[j:]
+    # solver_run_collect_timers() reduces the timers of the replaced phases: they must exist
+    names = ["Compute Physics", "Communication", "Compute addforces s", "Compute addforces e", "Damping addforce",
+             "1st schedule send data (contribution)", "1st compute adjust (distribution)",
+             "2nd schedule send data (contribution)", "Compute new displacement", "3rd schedule send data (sharing)",
+             "2nd compute adjust (assignment)", "4th schadule send data (sharing)"]
+    for n in names:
+        if '"%s"' % n not in t:
+            sys.exit("patch_psolve_hq: the reference has no timer %r any more" % n)
+    block = "".join('        Timer_Start( "%s" );\n' % n for n in names) + "        hq_steps( step, 1 );\n" + \
+        "".join('        Timer_Stop( "%s" );\n' % n for n in reversed(names))
+    t = t[:i] + block + t[j:]
     a = "    solver_drm_close();\n    solver_output_wavefield_close();\n    solver_run_collect_timers();\n"
     i = once(t, a)
     t = t[:i] + "    hq_sync( theHq );\n    hq_destroy( theHq );\n" + t[i:]
