@@ -293,7 +293,7 @@ def launch_ranks(args, argv):
     if not args.dry_launch:
         import torch                                       # device_count() does not initialise the GPU
         have = torch.cuda.device_count()
-        if have < n:
+        if have < n and not (have >= 1 and os.environ.get("HQ_BENCH_SHARE_GPU")):
             print("bench.py: --gpus %d but this box shows %d GPU(s); nothing launched" % (n, have), file=sys.stderr)
             return 2
     sock = socket.socket()
@@ -308,8 +308,33 @@ def launch_ranks(args, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       universal_newlines=True))
-    out0, _ = procs[0].communicate()
+    # rank 0's stdout is read by a thread; the parent polls ALL children: a rank that dies during set-up or rendezvous
+    # would otherwise leave the others (and this parent) in the rendezvous' 30-minute timeout.  stderr of every rank
+    # is inherited, so the cause is on the parent's stderr.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is not None:
+        print("bench.py: rank %d exited with status %d; stopping the other ranks" % (failed, procs[failed].returncode),
+              file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                              # the exact children started above, nothing else
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
     line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
     for l in (out0 or "").splitlines():
         if not l.startswith("{"):
@@ -518,11 +543,24 @@ def main():
     t_setup = time.perf_counter()
     box, solver, N, octree = build_problem(args, rank, world, device)
     rccl_ranks = 1
-    if world > 1:
+    transport = "none (one rank)"
+    if world > 1 and os.environ.get("HQ_BENCH_TRANSPORT", "rccl") == "host":
+        # the engine's host-staged transport (hq_comm_init_host) over gloo: several ranks may then share one GPU
+        # (HQ_BENCH_SHARE_GPU=1) -- separate processes, contexts and streams as with RCCL, records through pinned memory
+        def gloo_exchange(recvs, sends, tag):
+            reqs = [dist.irecv(torch.from_numpy(buf), src=int(peer), tag=int(tag)) for peer, buf in recvs]
+            reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
+            for r in reqs:
+                r.wait()
+        solver.comm_init_host(gloo_exchange)
+        rccl_ranks = 0
+        transport = "host-staged (pinned buffers + gloo), %d ranks" % world
+    elif world > 1:
         idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(idbuf, src=0)
         solver.comm_init(idbuf[0])
         rccl_ranks = int(solver.info()["nranks"])
+        transport = "RCCL grouped send/recv, %d ranks" % rccl_ranks
         flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
     total_steps = args.warmup + args.steps
     add_source(args, box, solver, octree, total_steps)
@@ -605,6 +643,7 @@ def main():
                        "ragged_patches": int(info["ragged_patches"]),
                        "patch_elements": int(info["patch_pairs"]),
                        "setup_s": round(setup_s, 1), "finite": nonfinite == 0, "rccl_ranks": rccl_ranks,
+                       "transport": transport, "brick_nodes": int(info["brick_nodes"]),
                        "preheat_s": args.preheat},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch
             # time (HIP events on its stream); where the counters are unavailable, the compulsory bytes

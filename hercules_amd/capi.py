@@ -17,11 +17,18 @@ EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_ge
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
-           "hq_stencil_coefficients", "hq_brick_plan_check"]
+           "hq_stencil_coefficients", "hq_brick_plan_check", "hq_comm_init_host"]
 
 
 class HqError(RuntimeError):
     pass
+
+
+# hq_host_exchange_fn (include/hq_solver.h)
+HOST_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                    ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32)
 
 
 class _Messenger(ctypes.Structure):
@@ -169,6 +176,27 @@ class Solver:
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
         _check(self._lib.hq_comm_init(self._h, buf))
+
+    def comm_init_host(self, exchange):
+        """hq_comm_init_host: `exchange(recvs, sends, tag)` is called at every halo exchange with
+        recvs = [(peer, float64 array to fill)], sends = [(peer, float64 array)] -- views of the engine's pinned
+        staging buffers -- and must return when everything has arrived (the caller's MPI / gloo / ...)."""
+        import numpy as np
+
+        def view(ptr, n):
+            return np.ctypeslib.as_array(ctypes.cast(ctypes.c_void_p(ptr), ctypes.POINTER(ctypes.c_double)), shape=(int(n),))
+
+        def trampoline(user, nrecv, rpeer, rcount, rbuf, nsend, speer, scount, sbuf, tag):
+            try:
+                exchange([(rpeer[i], view(rbuf[i], rcount[i])) for i in range(nrecv)],
+                         [(speer[i], view(sbuf[i], scount[i])) for i in range(nsend)], tag)
+                return 0
+            except Exception:                       # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_exchange = HOST_EXCHANGE_FN(trampoline)          # keep the thunk alive with the context
+        _check(self._lib.hq_comm_init_host(self._h, self._host_exchange, None))
 
     def comm_selftest(self, count=1024):
         _check(self._lib.hq_comm_selftest(self._h, ctypes.c_int32(count)))

@@ -134,6 +134,11 @@ struct hq_dev_schedule {
     int64_t* d_c_in_id = nullptr;
     int64_t* d_s_out_id = nullptr;
     int64_t* d_s_in_id = nullptr;
+    /* host-staged transport (hq_comm_init_host): pinned mirrors of the four record buffers */
+    double*  h_c_out = nullptr;
+    double*  h_c_in = nullptr;
+    double*  h_s_out = nullptr;
+    double*  h_s_in = nullptr;
 };
 
 struct hq_ctx {
@@ -170,6 +175,8 @@ struct hq_ctx {
     /* halo */
     hq_dev_schedule an, dn;
     hq_nccl_comm comm = nullptr;
+    hq_host_exchange_fn host_xchg = nullptr; /* host-staged transport (hq_comm_init_host): the caller's MPI, ... */
+    void* host_user = nullptr;
     std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
     bool group_owner = false;
     hipEvent_t ev_sent = nullptr;
@@ -445,7 +452,8 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     double* d_out = contribution ? s->d_c_out : s->d_s_out;
     double* d_in = contribution ? s->d_s_in : s->d_c_in;
     int32_t total = contribution ? s->ctotal : s->stotal;
-    if (!c->comm && !c->group) return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init or hq_group_link%s", "");
+    if (!c->comm && !c->group && !c->host_xchg)
+        return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init, hq_comm_init_host or hq_group_link%s", "");
     if (total)
         hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_out);
     /* HQ_DEBUG_HALO: the global identity of every record's node travels with it (psolve.c:5002-5007) */
@@ -474,6 +482,29 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
             }
         }
         HQ_HIP(hipEventRecord(c->ev_sent, xs));
+    } else if (c->host_xchg) {
+        /* records through pinned host memory and the caller's transport (the MPI_Irecv / MPI_Isend / MPI_Waitall of
+         * schedule_senddata, psolve.c:5013-5033, stay the caller's): pack -> D2H -> callback -> H2D, on the exchange
+         * stream; only that stream is waited for, the interior kernels keep running on the compute stream */
+        if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the host-staged transport%s", "");
+        double** ph_out = contribution ? &s->h_c_out : &s->h_s_out;
+        double** ph_in = contribution ? &s->h_s_in : &s->h_c_in;
+        const int32_t total_in = contribution ? s->stotal : s->ctotal;
+        if (total && !*ph_out) HQ_HIP(hipHostMalloc((void**)ph_out, sizeof(double) * 3 * (size_t)total, hipHostMallocDefault));
+        if (total_in && !*ph_in) HQ_HIP(hipHostMalloc((void**)ph_in, sizeof(double) * 3 * (size_t)total_in, hipHostMallocDefault));
+        if (total) HQ_HIP(hipMemcpyAsync(*ph_out, d_out, sizeof(double) * 3 * (size_t)total, hipMemcpyDeviceToHost, xs));
+        HQ_HIP(hipStreamSynchronize(xs));
+        std::vector<int32_t> rp, sp;
+        std::vector<int64_t> rn, sn;
+        std::vector<double*> rb;
+        std::vector<const double*> sb;
+        for (auto& m : rcv) if (m.nodecount) { rp.push_back(m.procid); rn.push_back(3 * (int64_t)m.nodecount); rb.push_back(*ph_in + 3 * (int64_t)m.offset); }
+        for (auto& m : snd) if (m.nodecount) { sp.push_back(m.procid); sn.push_back(3 * (int64_t)m.nodecount); sb.push_back(*ph_out + 3 * (int64_t)m.offset); }
+        const int32_t tag = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
+        if (c->host_xchg(c->host_user, (int32_t)rp.size(), rp.data(), rn.data(), rb.data(), (int32_t)sp.size(), sp.data(), sn.data(),
+                         sb.data(), tag) != 0)
+            return hq_fail(HQ_ERR_COMM, "the host transport's exchange callback failed%s", "");
+        if (total_in) HQ_HIP(hipMemcpyAsync(d_in, *ph_in, sizeof(double) * 3 * (size_t)total_in, hipMemcpyHostToDevice, xs));
     } else {
         HQ_NCCL(g_rccl.GroupStart());
         for (auto& m : rcv)
@@ -1553,6 +1584,9 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
     if (c->dn.d_cmap_f && c->dn.d_cmap_f != c->dn.d_cmap) hipFree(c->dn.d_cmap_f);
     if (c->dn.d_smap_f && c->dn.d_smap_f != c->dn.d_smap) hipFree(c->dn.d_smap_f);
+    for (hq_dev_schedule* sc : { &c->an, &c->dn })
+        for (double* hp : { sc->h_c_out, sc->h_c_in, sc->h_s_out, sc->h_s_in })
+            if (hp) hipHostFree(hp);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
@@ -1605,7 +1639,7 @@ extern "C" int hq_comm_unique_id(void* id128)
 extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
 {
     if (!c || !id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
-    if (c->comm) return hq_fail(HQ_ERR_STATE, "communicator already initialised%s", "");
+    if (c->comm || c->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     HQ_TRY(hq_rccl_load());
     HQ_HIP(hipSetDevice(c->device));
     hq_nccl_id id;
@@ -1642,13 +1676,24 @@ extern "C" int hq_comm_selftest(hq_ctx* c, int32_t count)
     return HQ_OK;
 }
 
+extern "C" int hq_comm_init_host(hq_ctx* c, hq_host_exchange_fn fn, void* user)
+{
+    if (!c || !fn) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (c->comm || c->group || c->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    c->host_xchg = fn;
+    c->host_user = user;
+    /* as between GPUs: the chain on its own stream, so that the host waits for the exchange stream only */
+    c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
+    return HQ_OK;
+}
+
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
 {
     if (!ctxs || n < 1) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     for (int32_t i = 0; i < n; i++) {
         if (!ctxs[i] || ctxs[i]->rank != i || ctxs[i]->nranks != n)
             return hq_fail(HQ_ERR_ARG, "group member %s must be the context of rank i of n", "i");
-        if (ctxs[i]->group || ctxs[i]->comm) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+        if (ctxs[i]->group || ctxs[i]->comm || ctxs[i]->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     }
     std::vector<hq_ctx*>* g = new (std::nothrow) std::vector<hq_ctx*>(ctxs, ctxs + n);
     if (!g) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");

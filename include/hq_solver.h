@@ -151,6 +151,21 @@ HQ_API int hq_comm_init(hq_ctx* ctx, const void* id128);
 HQ_API int hq_comm_selftest(hq_ctx* ctx, int32_t count);
 
 /*
+ * Host-staged transport: the halo records travel through pinned host memory and the CALLER's transport -- in the
+ * reference's world the MPI_Irecv / MPI_Isend / MPI_Waitall of schedule_senddata (psolve.c:5013-5033) on
+ * comm_solver -- for systems without RCCL between the ranks' GPUs, or several ranks on one GPU.  At each of the (up
+ * to four) exchanges of a step the engine packs on the device, copies the records to the host and calls
+ * `fn(user, nrecv, recv_peer, recv_count, recv_buf, nsend, send_peer, send_count, send_buf, tag)`: counts in
+ * doubles, one entry per neighbour with records, `tag` = 0..3 names the exchange (anchored-node contribution /
+ * sharing, dangling-node contribution / sharing); `fn` must have received everything when it returns 0.
+ * The exchange chain runs on its own stream as with RCCL: only that stream is waited for.
+ */
+typedef int (*hq_host_exchange_fn)(void* user, int32_t nrecv, const int32_t* recv_peer, const int64_t* recv_count,
+                                   double* const* recv_buf, int32_t nsend, const int32_t* send_peer,
+                                   const int64_t* send_count, const double* const* send_buf, int32_t tag);
+HQ_API int hq_comm_init_host(hq_ctx* ctx, hq_host_exchange_fn fn, void* user);
+
+/*
  * In-process transport for hosts that drive several partitions from ONE process
  * (and for tests on a single GPU): ctxs[i] must be the context of rank i of n.
  * The halo records then travel by device-to-device copies ordered with HIP

@@ -1,0 +1,73 @@
+"""Worker of tests/test_gpu_multiprocess.py: ONE RANK of a partitioned run in its own process -- its own HIP
+context, streams and events -- on the GPU all ranks of the test share.  The halo records travel through the
+engine's host-staged transport (hq_comm_init_host) and torch.distributed's gloo, which stands in for the MPI of the
+reference's world (psolve.c:7344-7389 `mpiexec -np N`; schedule_senddata psolve.c:4945-5079).  Everything else is
+the product path: C host side for the partition, hq_create / hq_set_source / hq_run on the device.
+Writes this rank's final fields to <outdir>/rank<r>.npz."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import hercules_amd as ha               # noqa: E402
+from hercules_amd import host           # noqa: E402
+
+
+def gloo_exchange(recvs, sends, tag):
+    """schedule_senddata's MPI_Irecv / MPI_Isend / MPI_Waitall (psolve.c:5013-5033) over gloo."""
+    reqs = [dist.irecv(torch.from_numpy(buf), src=int(peer), tag=int(tag)) for peer, buf in recvs]
+    reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
+    for r in reqs:
+        r.wait()
+
+
+def main():
+    outdir, kind, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(4321)
+    if kind == "box":
+        nx, ny, nz, h, dt, freq = 64, 64, 32, 15.0, 3e-4, 30.0
+        b = host.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world)
+        ijk = b.node_ijk.astype(np.int64)
+        gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+        Ng = (nx + 1) * (ny + 1) * (nz + 1)
+        loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
+        rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
+        F = b.source_table(rp, 0, nsteps) if len(loaded) else None
+    else:                                                   # two-level octree box: all four exchanges of a step
+        from tests import helpers as H
+        ref = H.two_level_mesh(16, 8, 6, 3)
+        b = host.OctBox(16, 8, 6, 3, 31.25, ref["dt"], 5.0, rank=rank, nranks=world)
+        gid, Ng, loaded, F = b.gid.astype(np.int64), ref["N"], np.zeros(0, np.int32), None
+    g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
+    if kind != "box":
+        from oracle import herc_oracle as ho                # (checker-side helper: hanging rows = means of their anchors)
+        ho.compute_adjust(g1, 1, ref["dangling"])
+        ho.compute_adjust(g2, 1, ref["dangling"])
+    s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid])
+    s.comm_init_host(gloo_exchange)
+    if F is not None:
+        s.set_source(loaded, F)
+    dist.barrier()
+    s.run(nsteps)
+    s.sync()
+    tm1, tm2 = s.download()
+    info = s.info()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), gid=gid, tm1=tm1, tm2=tm2, brick_nodes=info["brick_nodes"],
+             kernel=s.dominant_kernel())
+    s.close()
+    b.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

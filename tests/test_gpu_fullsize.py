@@ -412,3 +412,124 @@ def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels(path, monk
     scale = np.abs(res[1]).max()
     assert scale > 0 and np.abs(res[0] - res[1]).max() <= 1e-11 * scale
     box.close()
+
+
+def _cone_windows(nx, ny, nz, src_elem):
+    """Centres (element indices) of the windows: corners, edges, faces (all five dashpot faces and the free surface
+    z = 0), the far-face cubes, the source element, the borders of brick tiles / chunks and of the 8^3 patches, and
+    seeded interior points."""
+    c = []
+    for i in (0, nx - 1):
+        for j in (0, ny - 1):
+            for k in (0, nz - 1):
+                c.append((i, j, k))                                                  # 8 corners
+    mid = (nx // 2 + 3, ny // 2 - 5, nz // 2 + 1)
+    for a in range(3):                                                               # 12 edges, 6 + 6 face points
+        for s1 in (0, 1):
+            for s2 in (0, 1):
+                e = list(mid)
+                o = [d for d in range(3) if d != a]
+                e[o[0]] = 0 if s1 == 0 else (nx, ny, nz)[o[0]] - 1
+                e[o[1]] = 0 if s2 == 0 else (nx, ny, nz)[o[1]] - 1
+                c.append(tuple(e))
+        for s in (0, 1):
+            e = list(mid)
+            e[a] = 0 if s == 0 else (nx, ny, nz)[a] - 1
+            c.append(tuple(e))
+            e2 = [(nx, ny, nz)[d] // 3 + 2 for d in range(3)]
+            e2[a] = 1 if s == 0 else (nx, ny, nz)[a] - 2
+            c.append(tuple(e2))
+    c.append(tuple(src_elem))
+    # brick tiles start at node 1 and are 64 x 8 nodes, chunks 32 planes; round-2 patches are 8^3 node cubes
+    for i in (63, 64, 65, 128):
+        for j in (7, 8, 9, 16):
+            c.append((i, j, nz // 2 + 2))
+    for k in (31, 32, 33, 64):
+        c.append((nx // 2 - 7, ny // 2 + 9, k))
+        c.append((64, 8, k))
+    rng = np.random.default_rng(99)
+    for _ in range(16):
+        c.append((int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))))
+    return c
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_dependency_cone_windows_against_the_oracle(wl):
+    """Oracle parity AT BASELINE sizes: after k steps a node depends on its k-ring only, so a window of the full box
+    -- a block of 4^3 elements and k + 1 more layers around it, with the true eTable / nTable rows and the true start
+    field -- stepped by the oracle's reference loops gives the exact values of the nodes that lie at least k layers
+    inside every CUT face of the window (domain faces are no cuts).  >= 64 windows of the 8 M and the 64 M box (all
+    five dashpot faces, the free surface, edges, corners, the far-face cubes, the source element, tile / chunk /
+    patch borders, seeded interior points) against the GPU's whole-box result: <= 1e-9 of the field's scale."""
+    import bench
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
+    k = 4
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    u = _field(box, 2718)
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt, source_window=k)
+    F = box.source_table(rp, 0, k)
+    s = box.create_solver(tm1=u, tm2=0.999 * u)
+    assert s.dominant_kernel() == "hq_k_brick"
+    s.set_source(loaded, F)
+    s.run(k)
+    ijk = box.node_ijk
+    gid = (ijk[:, 2].astype(np.int64) * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    lut = np.empty((nx + 1) * (ny + 1) * (nz + 1), np.int32)
+    lut[gid] = np.arange(len(gid), dtype=np.int32)
+    e_of = np.full(len(gid), -1, np.int32)                    # element whose corner 0 a node is
+    e_of[box.lnid[:, 0]] = np.arange(len(box.lnid), dtype=np.int32)
+    src_elem = ijk[loaded].min(axis=0)
+    scale = np.abs(u).max()
+    dims = (nx, ny, nz)
+    worst, nwin, nchecked = 0.0, 0, 0
+    for ctr in _cone_windows(nx, ny, nz, src_elem):
+        lo = [max(0, min(ctr[d], dims[d] - 4) - (k + 1)) for d in range(3)]
+        hi = [min(dims[d], lo[d] + 4 + 2 * (k + 1)) for d in range(3)]
+        ei, ej, ek = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), np.arange(lo[2], hi[2]), indexing="ij")
+        e = e_of[lut[(ek.ravel().astype(np.int64) * (ny + 1) + ej.ravel()) * (nx + 1) + ei.ravel()]]
+        assert (e >= 0).all()
+        nodes, inv = np.unique(box.lnid[e], return_inverse=True)
+        lnid_w = inv.reshape(-1, 8).astype(np.int32)
+        o1, o2 = (0.999 * u[nodes]).copy(), u[nodes].copy()
+        pos = {int(n): i for i, n in enumerate(nodes)}
+        lw = [(pos[int(n)], i) for i, n in enumerate(loaded) if int(n) in pos]
+        kw = {}
+        if lw:
+            kw = dict(loaded_lnid=np.array([a for a, _ in lw], np.int32),
+                      forces=np.ascontiguousarray(F[:, [b for _, b in lw], :]))
+        ho.solver_run(lnid_w, box.etable[e].copy(), box.ntable[nodes].copy(), o1, o2, 0, k, dt, **kw)
+        q = ijk[nodes]
+        ok = np.ones(len(nodes), bool)
+        for d in range(3):
+            if lo[d] > 0:
+                ok &= q[:, d] >= lo[d] + k
+            if hi[d] < dims[d]:
+                ok &= q[:, d] <= hi[d] - k
+        assert ok.sum() >= 27
+        tm1, tm2 = s.gather(nodes[ok].astype(np.int32))
+        worst = max(worst, np.abs(tm1 - o2[ok]).max() / scale, np.abs(tm2 - o1[ok]).max() / scale)
+        nwin += 1
+        nchecked += int(ok.sum())
+    s.close()
+    box.close()
+    assert nwin >= 64 and nchecked > 64 * 27
+    assert worst < 1e-9, worst
+
+
+def test_small_basin_against_the_oracle():
+    """BASELINE config 5 in small (o3s: 3.3 M elements on four octree levels, hanging nodes on three interfaces, three
+    materials): the oracle's reference loops with compute_adjust on the WHOLE mesh for two steps against the default
+    path (bricks in every level's uniform interior, patches with hanging-node accumulators around them)."""
+    box, E, N, u = _basin("o3s")
+    nsteps = 2
+    o1, o2 = (0.999 * u).copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling)
+    s = box.create_solver(tm1=u, tm2=0.999 * u)
+    assert s.info()["brick_nodes"] > 0.3 * N
+    s.run(nsteps)
+    tm1, tm2 = s.download()
+    s.close()
+    assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    box.close()

@@ -1,0 +1,82 @@
+"""Separate PROCESSES per rank -- what RCCL ranks are -- on one GPU: every rank has its own HIP context, compute and
+exchange streams and events, and steps its partition with hq_run (not in lockstep from one thread as hq_group_run
+does); the halo records travel through the engine's host-staged transport (hq_comm_init_host: pack on the device,
+pinned host buffers, the caller's transport -- here gloo, standing in for the reference's MPI -- and back), with the
+exchange chain on its own stream beside the interior kernels.  Only ncclSend / ncclRecv themselves stay unexercised
+on a one-GPU box (RCCL refuses two ranks on one device).  Against the oracle's single-rank run."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(tmp_path, world, kind, nsteps, env_extra=None):
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_hq_rank_worker.py"), str(tmp_path), kind, str(nsteps)]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,overlap", [(2, "1"), (4, "1"), (4, "0")])
+def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, overlap):
+    nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 20
+    parts = _launch(tmp_path, world, "box", nsteps, {"HQ_OVERLAP": overlap})
+    from hercules_amd import host
+    b = host.Box(nx, ny, nz, h, dt, freq)
+    ijk = b.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    Ng = (nx + 1) * (ny + 1) * (nz + 1)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
+    loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
+    rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
+    F = b.source_table(rp, 0, nsteps)
+    o1, o2 = g2[gid].copy(), g1[gid].copy()
+    ho.solver_run(b.lnid, b.etable.copy(), b.ntable.copy(), o1, o2, 0, nsteps, dt, loaded_lnid=loaded, forces=F)
+    ref1, ref2 = np.zeros((Ng, 3)), np.zeros((Ng, 3))
+    ref1[gid], ref2[gid] = o2, o1
+    b.close()
+    for z in parts:
+        assert H.rel_linf(z["tm1"], ref1[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], ref2[z["gid"]]) < 1e-9
+        assert int(z["brick_nodes"]) > 0 and str(z["kernel"]) == "hq_k_brick"
+
+
+def test_ranks_in_their_own_processes_on_one_gpu_octree_box(tmp_path):
+    """Three ranks of the two-level octree box: hanging nodes shared between ranks, so all four exchanges of a step
+    (dangling-node and anchored-node contribution and sharing) go through the host-staged transport."""
+    nsteps = 12
+    parts = _launch(tmp_path, 3, "octree", nsteps)
+    ref = H.two_level_mesh(16, 8, 6, 3)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (ref["N"], 3)) * 1e-6
+    ho.compute_adjust(g1, 1, ref["dangling"])
+    ho.compute_adjust(g2, 1, ref["dangling"])
+    o1, o2 = g2.copy(), g1.copy()
+    ho.solver_run(ref["lnid"], ref["etable"], ref["ntable"], o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
+    for z in parts:
+        assert H.rel_linf(z["tm1"], o2[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], o1[z["gid"]]) < 1e-9

@@ -95,3 +95,55 @@ def test_stencil_tables_on_the_partitions_of_a_uniform_box():
         assert r["faults"] == 0
         assert r["tables"] == 256 and r["patches"] == 256 + plane_patches
         assert 0 < r["full_lattices"] < r["tables"]
+
+
+def test_brick_plan_of_a_uniform_box_matches_the_connectivity():
+    """hq_brick_plan_check: the simple nodes of a uniform box -- everything but the six faces -- become tile columns of
+    64 x 8 nodes; every neighbour hq_k_brick will read (unit-internal, ring table, first / last plane lists) is the node
+    the connectivity says, the numbering is a permutation, the patches keep the rest."""
+    b = host.Box(64, 64, 32, 10.0, 2e-4, 50.0)
+    r = b.brick_plan_check()
+    b.close()
+    assert r["faults"] == 0
+    assert r["brick_nodes"] == 63 * 63 * 31 and r["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
+    assert r["columns"] == 8 and r["units"] == 8 and r["units_one_nt_row"] == 8 and r["levels"] == 1
+    assert r["neighbours_checked"] == 26 * r["brick_nodes"]
+
+
+def test_brick_plan_on_partitions_layers_and_lateral_material():
+    """Partitions (interface nodes stay with the patches), a layered box (nodes on the material interface are not
+    simple; the units of each layer carry its coefficients and its n_t row) and a box whose material differs from
+    element to element (no simple node at all: no bricks, no renumbering)."""
+    tot = 0
+    for rank in range(2):
+        b = host.Box(64, 64, 64, 10.0, 2e-4, 50.0, rank=rank, nranks=2)
+        r = b.brick_plan_check()
+        b.close()
+        assert r["faults"] == 0 and r["brick_nodes"] > 0
+        tot += r["brick_nodes"]
+    assert tot == 63 * 63 * (31 + 31)                        # the interface plane z = 32 and the faces are left out
+    layers = [(0.0, 3000.0, 1400.0, 2200.0), (200.0, 6000.0, 3464.0, 2700.0)]
+    b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, layers=layers)
+    r = b.brick_plan_check()
+    b.close()
+    assert r["faults"] == 0 and r["brick_nodes"] == 31 * 31 * (15 + 15) and r["units_one_nt_row"] == r["units"]
+    b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, lateral_classes=61, lateral_amp=0.1)
+    r = b.brick_plan_check()
+    b.close()
+    assert r["faults"] == 0 and r["brick_nodes"] == 0 and r["patch_nodes"] == 33 ** 3
+
+
+@pytest.mark.parametrize("nranks", [1, 4])
+def test_brick_plan_on_an_octree_box(nranks):
+    """The four-level octree box (hanging nodes), whole and as partitions: every level's uniform interior is planned
+    on its own lattice; hanging nodes, anchors and interface nodes stay with the patches."""
+    import bench
+    bricks = nodes = 0
+    for rank in range(nranks):
+        box = bench.make_octbox("o3s", rank, nranks)[0]
+        rep = box.brick_plan_check()
+        box.close()
+        assert rep["faults"] == 0
+        bricks += rep["brick_nodes"]
+        nodes += rep["brick_nodes"] + rep["patch_nodes"]
+    assert bricks > 0.3 * nodes
