@@ -280,7 +280,7 @@ def stencil_plan_check(desc):
     return dict(zip(STENCIL_PLAN_REPORT, [int(v) for v in rep]))
 
 
-BRICK_PLAN_REPORT = ("brick_nodes", "columns", "units", "units_one_nt_row", "levels", "neighbours_checked",
+BRICK_PLAN_REPORT = ("brick_nodes", "columns", "units", "units_one_nt_row", "het_units", "neighbours_checked",
                      "patch_nodes", "faults")
 
 

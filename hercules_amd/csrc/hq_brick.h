@@ -40,6 +40,15 @@
 #define HQ_BK_PY (HQ_BK_TX + 2)
 #define HQ_BK_PLANE ((HQ_BK_TX + 2) * (HQ_BK_TY + 2))
 #define HQ_BK_NTSAME 1           /* every node of the unit has the same n_t row: it is in the unit's record */
+#define HQ_BK_HET 2              /* the elements around the unit's nodes have coefficients of their own: hq_k_brick_het */
+/* tile of a HET unit: 62 x 7 owned nodes -- the 64 x 8 threads of the workgroup each evaluate ONE element of the layer,
+ * the elements around the owned nodes (element (i, j) has its low corner at node (i - 1, j - 1)); the 78 threads that own
+ * no node (row 7, columns 62 and 63) load the <= 142 ring nodes, two each, in the registers the owners use for their node */
+#define HQ_BH_NRT 78
+#define HQ_BH_TX 62
+#define HQ_BH_TY 7
+#define HQ_BH_PY 65
+#define HQ_BH_ROWS (65 * 9)
 
 struct hq_brick_unit {
     int64_t base;                /* device id of node (0, 0) of the unit's first plane; the unit's nodes are
@@ -50,6 +59,9 @@ struct hq_brick_unit {
     int32_t nx, ny, np, flags;
     double  c1, c2, beta;        /* of the elements around the unit's nodes                                     */
     double  m0, m2, m1;          /* HQ_BK_NTSAME: mass_simple, mass2_minusaM, mass_minusaM of every node        */
+    int64_t coef;                /* HQ_BK_HET: the unit's element coefficients in d_coef, [np + 1 layers][8][64]
+                                  * {c1, c2, beta}: layer l lies between the planes za - 1 + l and za + l, element
+                                  * (i, j) has its low corner at node (i - 1, j - 1) of the tile; 0 where there is none */
 };
 
 struct hq_brick_cfg {
@@ -74,14 +86,17 @@ struct hq_brick_host {
     std::vector<hq_brick_unit> units;        /* launch order: the HQ_BK_NTSAME units first                        */
     int32_t nsame = 0;                       /* units with HQ_BK_NTSAME                                           */
     std::vector<int32_t> tab;                /* id tables (device ids)                                            */
+    std::vector<double> coef;                /* element coefficients of the HQ_BK_HET units                       */
+    int32_t nhet = 0;                        /* HQ_BK_HET units: the last of the launch order                     */
     int32_t ncolumns = 0, nlevels = 0;
 };
 
 struct hq_brick_plan {
     int64_t nb = 0;
-    int32_t nunits = 0, nsame = 0;
+    int32_t nunits = 0, nsame = 0, nhet = 0;
     hq_brick_unit* d_units = nullptr;
     int32_t* d_tab = nullptr;
+    double* d_coef = nullptr;
     int32_t* d_src_ptr = nullptr;            /* [nunits + 1] source entries per unit (hq_brick_set_source)        */
     int32_t* d_src_ent = nullptr;            /* [n][2] = {node of the unit (plane * ny + y) * nx + x, loaded idx} */
     std::vector<int64_t> h_base;             /* units' first ids, ascending, and their launch slots: owner lookup */
@@ -103,6 +118,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     if (!xyz || E <= 0 || N <= 0) return 0;
     const hq_brick_cfg cfg = hq_brick_cfg_from_env();
     const int TX = HQ_BK_TX, TY = HQ_BK_TY;
+    const bool want_het = !(getenv("HQ_BRICK_NO_HET") && atoi(getenv("HQ_BRICK_NO_HET")) != 0);
 
     /* levels: elements by edge length (ticks) */
     std::vector<int32_t> hs((size_t)E);
@@ -122,7 +138,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         std::vector<int32_t> Ng;             /* node at a lattice position, or -1 */
         std::vector<int32_t> Eg;             /* element in a lattice cell, or -1 */
     };
-    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; };
+    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; int het; };
     std::vector<level_t> levels;
     std::vector<column_t> cols;
     std::vector<int32_t> ntx_of_level;
@@ -187,49 +203,75 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     const double* q = ntab + 7 * (int64_t)n;
                     if (!((q[1] == q[2]) && (q[1] == q[3]) && (q[4] == q[5]) && (q[4] == q[6]))) continue;
                     int32_t e0 = -1;
-                    bool s = true;
+                    bool s = true, uni = true;
                     for (int o = 0; o < 8 && s; o++) {
                         const int64_t cx = X - (o & 1), cy = Y - ((o >> 1) & 1), cz = Z - ((o >> 2) & 1);
                         const int32_t e = Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
                         if (e < 0) { s = false; break; }
                         if (e0 < 0) e0 = e;
-                        else s = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
+                        else uni = uni && c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
                     }
                     if (!s) continue;
-                    S[(size_t)((Z * NY + Y) * NX + X)] = 1;
+                    if (!uni && !want_het) continue;
+                    S[(size_t)((Z * NY + Y) * NX + X)] = uni ? 2 : 1;   /* 1: all eight elements, coefficients of their own */
                     nsimple++;
                     sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y);
                 }
         if (nsimple < cfg.minnodes) continue;
         /* tile columns: footprints on a TX x TY grid from the first simple node; runs of planes all of whose nodes
-         * in the footprint are simple */
+         * in the footprint are simple.  Two passes: 64 x 8 tiles of nodes whose eight elements share their coefficients
+         * (hq_k_brick), then 63 x 7 tiles of what is left (hq_k_brick_het: per-element coefficients) */
         const int lvl = (int)levels.size();
-        const int32_t ntx = (int32_t)((sx1 - sx0) / TX + 1), nty = (int32_t)((sy1 - sy0) / TY + 1);
-        std::vector<std::vector<column_t>> found((size_t)nty);
+        std::vector<std::vector<column_t>> found;
+        int32_t ntx_lvl = 1;
+        for (int pass = 0; pass < 2; pass++) {
+            const int PTX = pass == 0 ? TX : HQ_BH_TX, PTY = pass == 0 ? TY : HQ_BH_TY;
+            const char want = pass == 0 ? 2 : 1;             /* pass 1: any flag still set (taken nodes are cleared) */
+            if (pass == 1) {
+                sx0 = INT64_MAX; sx1 = -1; sy0 = INT64_MAX; sy1 = -1;
+                for (int64_t Z = 0; Z < NZ; Z++)
+                    for (int64_t Y = 0; Y < NY; Y++)
+                        for (int64_t X = 0; X < NX; X++)
+                            if (S[(size_t)((Z * NY + Y) * NX + X)]) { sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y); }
+                if (sx1 < 0) break;
+            }
+            const int32_t ntx = (int32_t)((sx1 - sx0) / PTX + 1), nty = (int32_t)((sy1 - sy0) / PTY + 1);
+            if (pass == 0) ntx_lvl = ntx;
+            const size_t f0 = found.size();
+            found.resize(f0 + (size_t)nty);
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int32_t tj = 0; tj < nty; tj++) {
-            const int64_t y0 = sy0 + (int64_t)tj * TY;
-            const int32_t ny = (int32_t)std::min<int64_t>(TY, sy1 - y0 + 1);
-            for (int32_t ti = 0; ti < ntx; ti++) {
-                const int64_t x0 = sx0 + (int64_t)ti * TX;
-                const int32_t nx = (int32_t)std::min<int64_t>(TX, sx1 - x0 + 1);
-                int64_t run0 = -1;
-                for (int64_t Z = 0; Z <= NZ; Z++) {
-                    bool full = Z < NZ;
-                    for (int64_t y = y0; y < y0 + ny && full; y++) {
-                        const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
-                        for (int32_t x = 0; x < nx; x++) if (!row[x]) { full = false; break; }
-                    }
-                    if (full) { if (run0 < 0) run0 = Z; continue; }
-                    if (run0 >= 0) {
-                        const int64_t nz = Z - run0;
-                        if (nz >= cfg.minz && nz * nx * ny >= cfg.minnodes)
-                            found[(size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)run0, (int32_t)nz, ti, tj, 0 });
-                        run0 = -1;
+            for (int32_t tj = 0; tj < nty; tj++) {
+                const int64_t y0 = sy0 + (int64_t)tj * PTY;
+                const int32_t ny = (int32_t)std::min<int64_t>(PTY, sy1 - y0 + 1);
+                for (int32_t ti = 0; ti < ntx; ti++) {
+                    const int64_t x0 = sx0 + (int64_t)ti * PTX;
+                    const int32_t nx = (int32_t)std::min<int64_t>(PTX, sx1 - x0 + 1);
+                    int64_t run0 = -1;
+                    for (int64_t Z = 0; Z <= NZ; Z++) {
+                        bool full = Z < NZ;
+                        for (int64_t y = y0; y < y0 + ny && full; y++) {
+                            const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
+                            for (int32_t x = 0; x < nx; x++) if (row[x] < want) { full = false; break; }
+                        }
+                        if (full) { if (run0 < 0) run0 = Z; continue; }
+                        if (run0 >= 0) {
+                            const int64_t nz = Z - run0;
+                            if (nz >= cfg.minz && nz * nx * ny >= cfg.minnodes)
+                                found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)run0, (int32_t)nz, ti, tj, 0, pass });
+                            run0 = -1;
+                        }
                     }
                 }
             }
+            /* the nodes the pass took are gone for the next one */
+            for (size_t f = f0; f < found.size(); f++)
+                for (auto& c : found[f])
+                    for (int32_t z = 0; z < c.nz; z++)
+                        for (int32_t y = 0; y < c.ny; y++)
+                            memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
+            if (!want_het) break;
         }
+        const int32_t ntx = ntx_lvl;
         size_t before = cols.size();
         for (auto& v : found) cols.insert(cols.end(), v.begin(), v.end());
         if (cols.size() == before) continue;
@@ -289,6 +331,10 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         toff[u + 1] = toff[u] + ((int64_t)(us[u].np + 2) * nr + 2 * (int64_t)c.nx * c.ny + 3) / 4 * 4;
     }
     B->tab.assign((size_t)toff[us.size()] + 64, 0);
+    std::vector<int64_t> coff(us.size() + 1, 0);         /* coefficient blocks of the HET units */
+    for (size_t u = 0; u < us.size(); u++)
+        coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BK_THREADS * 3 : 0);
+    B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
     bool fault = false;
     std::vector<char> same(us.size(), 0);
 #pragma omp parallel for schedule(dynamic, 16)
@@ -337,16 +383,37 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     const double* q = ntab + 7 * (int64_t)n;
                     if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) { sm = false; break; }
                 }
-        if (sm && !getenv("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
+        if (sm && !c.het && !getenv("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
         U.m0 = q0[0]; U.m2 = q0[1]; U.m1 = q0[4];
+        U.coef = 0;
+        if (c.het) {
+            U.flags |= HQ_BK_HET;
+            same[(size_t)u] = 2;
+            U.coef = coff[(size_t)u];
+            double* cf = B->coef.data() + coff[(size_t)u];
+            for (int32_t l = 0; l <= np; l++)
+                for (int32_t j = 0; j < HQ_BK_TY; j++)
+                    for (int32_t i = 0; i < HQ_BK_TX; i++) {
+                        const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
+                        double* o = cf + 3 * (((int64_t)l * HQ_BK_TY + j) * HQ_BK_TX + i);
+                        int32_t e = -1;
+                        if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
+                            e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
+                        if (e >= 0) { o[0] = c1[e]; o[1] = c2[e]; o[2] = beta[e]; }
+                        else if (i <= nx && j <= ny) fault = true;       /* an element around an owned node is missing */
+                    }
+        }
     }
     if (fault) { g_patch_err = "brick plan: a neighbour of a simple node is missing"; return -1; }
-    /* the units whose nodes share one n_t row first (their own launch: the row rides in the record) */
+    /* launch order: the units whose nodes share one n_t row (the row rides in the record), then those with per-node
+     * rows, then the HET units -- a launch each */
     {
-        std::vector<hq_brick_unit> a, b;
-        for (size_t u = 0; u < us.size(); u++) (same[u] ? a : b).push_back(B->units[u]);
+        std::vector<hq_brick_unit> a, b, h;
+        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 2 ? h : b)).push_back(B->units[u]);
         B->nsame = (int32_t)a.size();
+        B->nhet = (int32_t)h.size();
         a.insert(a.end(), b.begin(), b.end());
+        a.insert(a.end(), h.begin(), h.end());
         B->units.swap(a);
     }
     return 0;
@@ -364,7 +431,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
  *   fB  accumulator of output plane k: contribution of plane k - 1 and the node's own term m2 u1 - m1 u2
  */
 template <bool PERNODE>
-__global__ void __launch_bounds__(HQ_BK_THREADS)
+__global__ void __launch_bounds__(HQ_BK_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
 hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
            const double* __restrict__ u1g, const double* __restrict__ u2g, double* __restrict__ ung,
            const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
@@ -497,13 +564,196 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
 #undef HQ_BK_PUT
 }
 
+
+/*
+ * hq_k_brick_het: the same march for units whose elements have coefficients of their own (HQ_BK_HET) -- what
+ * solver_init builds on any real CVM mesh (psolve.c:3360-3409): no assembled stencil applies, the force is summed
+ * element by element, f_e = -(c1_e K1 + c2_e K2)(u1 + beta_e (u1 - u2)) (hq_element_force: the butterfly form of
+ * compute_addforce_effective stiffness.c:180-237 + damping_addforce damping.c:29-103).
+ * The tile owns 63 x 7 nodes; its 64 x 8 threads each evaluate ONE element of the layer between the planes l and
+ * l + 1 -- element (i, j) has its low corner at node (i - 1, j - 1) -- from u1 and v = u1 - u2 of the two planes in
+ * LDS (two slots of two fields, 56 KB), and the eight corner forces are summed to the nodes WITHOUT atomics:
+ *   x: thread (i, j) owns node (i, j) = the high-x corners of its own element; the low-x corners of element (i + 1, j)
+ *      come from lane i + 1 by DPP (wave_shl:1; a tile row is one wave);
+ *   y: the low-y corners of row j + 1 come through a 24 KB exchange buffer;
+ *   z: the accumulators of the two unfinished node planes live in registers, as in hq_k_brick.
+ * Two barriers per layer; 2 workgroups per CU (80.7 KB of LDS, <= 128 VGPRs).  Per node and step: 72 B of state +
+ * 24 B of n_t + 24 B x 512 / 441 of coefficients + the ring.
+ */
+#define HQ_BH_LDS (8 * (2 * 2 * 3 * HQ_BH_ROWS + 6 * HQ_BK_THREADS))
+#ifndef HQ_BH_ABL            /* experiment builds only (-DHQ_BH_ABL=n, results wrong by construction): 1 no ring loads,
+                              * 2 no coefficient loads, 3 no element arithmetic, 4 no n_t loads */
+#define HQ_BH_ABL 0
+#endif
+
+static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);     /* wave_shl:1: lane i <- lane i + 1 */
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(HQ_BK_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
+hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
+               const double* __restrict__ coef, const double* __restrict__ u1g, const double* __restrict__ u2g,
+               double* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
+               const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2)
+{
+    extern __shared__ __align__(16) double s_het[];
+    hq_lds_double* const img = (hq_lds_double*)s_het;                  /* [slot][u1 | v][3 x rows] */
+    hq_lds_double* const xch = img + 2 * 2 * 3 * HQ_BH_ROWS;           /* [6][threads] */
+    const int slot = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (slot >= count) return;
+    const hq_brick_unit U = units[slot];
+    const int nx = U.nx, ny = U.ny, np = U.np, nxy = nx * ny, nr = 2 * (nx + 2) + 2 * ny;
+    const int t = threadIdx.x, lx = t & 63, ly = t >> 6;
+    const bool owner = lx < nx && ly < ny;
+    const int sidx = owner ? ly * nx + lx : 0;
+    const int myrow = (ly + 1) * HQ_BH_PY + lx + 1;                    /* node (lx, ly) */
+    const int row0 = ly * HQ_BH_PY + lx;                               /* low corner of element (lx, ly): node (lx - 1, ly - 1) */
+    /* ring threads: the 78 that never own a node (nx <= 62, ny <= 7); thread q loads the ring slots q and q + 78 */
+    const int rq = ly == 7 ? lx : (lx >= 62 ? 64 + 2 * ly + (lx - 62) : -1);
+    const bool ringA = rq >= 0 && rq < nr, ringB = rq >= 0 && rq + HQ_BH_NRT < nr;
+    auto ring_row = [&](int r) {
+        int rx, ry;
+        if (r < nx + 2) { rx = r - 1; ry = -1; }
+        else if (r < 2 * (nx + 2)) { rx = r - (nx + 2) - 1; ry = ny; }
+        else if (r < 2 * (nx + 2) + ny) { rx = -1; ry = r - 2 * (nx + 2); }
+        else { rx = nx; ry = r - 2 * (nx + 2) - ny; }
+        return (ry + 1) * HQ_BH_PY + rx + 1;
+    };
+    const int rrowA = ringA ? ring_row(rq) : 0, rrowB = ringB ? ring_row(rq + HQ_BH_NRT) : 0;
+    const int32_t* __restrict__ rtabA = tab + U.tab + (ringA ? rq : 0);
+    const int32_t* __restrict__ rtabB = tab + U.tab + (ringB ? rq + HQ_BH_NRT : 0);
+    const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
+    const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
+    const double* __restrict__ cf = coef + U.coef + 3 * t;
+    const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
+
+    /* an owner's registers: x1, x2 = u1, u2 of its node of the plane in flight, mn = its n_t row, accA / accB = the
+     * accumulators of its two unfinished planes.  A ring thread's: x1, x2 = u1, u2 of ring node A, mn / accB = u1 / u2
+     * of ring node B (the same registers: a thread is either the one or the other) */
+    double x1[3] = { 0.0, 0.0, 0.0 }, x2[3] = { 0.0, 0.0, 0.0 };
+    double mn[3] = { 1.0, 0.0, 0.0 };
+    double accA[3] = { 0.0, 0.0, 0.0 }, accB[3] = { 0.0, 0.0, 0.0 }, m0A = 1.0, m0B = 1.0;
+    int32_t ridA = rtabA[0], ridB = rtabB[0];
+
+#define HQ_BH_LOAD(node_)                                                                             \
+    {                                                                                                 \
+        if (owner) {                                                                                  \
+            const int64_t a_ = (node_);                                                               \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; if (HQ_BH_ABL != 4) mn[d] = nt3[3 * a_ + d]; } \
+        }                                                                                             \
+        if (ringA && HQ_BH_ABL != 1) {                                                                \
+            const int64_t b_ = (int64_t)ridA;                                                         \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * b_ + d]; x2[d] = u2g[3 * b_ + d]; } \
+        }                                                                                             \
+        if (ringB && HQ_BH_ABL != 1) {                                                                \
+            const int64_t b_ = (int64_t)ridB;                                                         \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { mn[d] = u1g[3 * b_ + d]; accB[d] = u2g[3 * b_ + d]; } \
+        }                                                                                             \
+    }
+    /* the loaded plane -> slot s_; acc_ / m0_: seed m2 u1 - m1 u2 and mass_simple of its owned node */
+#define HQ_BH_PUT(s_, acc_, m0_)                                                                      \
+    {                                                                                                 \
+        hq_lds_double* iu_ = img + (size_t)(s_) * (2 * 3 * HQ_BH_ROWS);                                \
+        hq_lds_double* iv_ = iu_ + 3 * HQ_BH_ROWS;                                                    \
+        if (owner) {                                                                                  \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
+                iu_[3 * myrow + d] = x1[d]; iv_[3 * myrow + d] = x1[d] - x2[d];                       \
+                acc_[d] = mn[1] * x1[d] - mn[2] * x2[d];                                              \
+            }                                                                                         \
+            m0_ = mn[0];                                                                              \
+        }                                                                                             \
+        if (ringA) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowA + d] = x1[d]; iv_[3 * rrowA + d] = x1[d] - x2[d]; } } \
+        if (ringB) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowB + d] = mn[d]; iv_[3 * rrowB + d] = mn[d] - accB[d]; } } \
+    }
+
+    HQ_BH_LOAD(id_lo)
+    ridA = rtabA[nr]; ridB = rtabB[nr];
+    HQ_BH_PUT(0, accA, m0A)
+    HQ_BH_LOAD(U.base + sidx)                    /* plane 1: the unit's first */
+    ridA = rtabA[2 * (int64_t)nr]; ridB = rtabB[2 * (int64_t)nr];
+    HQ_BH_PUT(1, accB, m0B)
+    double c1 = cf[0], c2 = cf[1], beta = cf[2];
+    __syncthreads();
+    for (int l = 0; l <= np; l++) {
+        if (l < np) {                            /* request plane l + 2 and the coefficients of layer l + 1 */
+            HQ_BH_LOAD(l + 1 == np ? id_hi : U.base + (int64_t)(l + 1) * nxy + sidx)
+            if (l + 1 < np) { ridA = rtabA[(int64_t)(l + 3) * nr]; ridB = rtabB[(int64_t)(l + 3) * nr]; }
+        }
+        double nc1 = 0.0, nc2 = 0.0, nbeta = 0.0;
+        if (l < np && HQ_BH_ABL != 2) { const double* q = cf + (int64_t)(l + 1) * (3 * HQ_BK_THREADS); nc1 = q[0]; nc2 = q[1]; nbeta = q[2]; }
+        if (HQ_BH_ABL == 2) { nc1 = c1; nc2 = c2; nbeta = beta; }
+        /* the element between the planes l and l + 1 */
+        double X[8], Y[8], Z[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const hq_lds_double* pu = img + (size_t)((l + (m >> 2)) & 1) * (2 * 3 * HQ_BH_ROWS) + 3 * (row0 + (m & 1) + ((m >> 1) & 1) * HQ_BH_PY);
+            const hq_lds_double* pv = pu + 3 * HQ_BH_ROWS;
+            X[m] = fma(beta, pv[0], pu[0]); Y[m] = fma(beta, pv[1], pu[1]); Z[m] = fma(beta, pv[2], pu[2]);
+        }
+        if (HQ_BH_ABL != 3) hq_element_force(X, Y, Z, c1, c2);
+        /* x: the node's high-x corners are this element's, its low-x corners the next lane's element's */
+        double G[2][2][3];                       /* [y bit][z bit] */
+#pragma unroll
+        for (int yb = 0; yb < 2; yb++)
+#pragma unroll
+            for (int zb = 0; zb < 2; zb++) {
+                const int m1 = 1 + 2 * yb + 4 * zb, m0 = 2 * yb + 4 * zb;
+                G[yb][zb][0] = X[m1] + hq_dpp_from_next_lane(X[m0]);
+                G[yb][zb][1] = Y[m1] + hq_dpp_from_next_lane(Y[m0]);
+                G[yb][zb][2] = Z[m1] + hq_dpp_from_next_lane(Z[m0]);
+            }
+        /* y: the low-y corners belong to the node one row down */
+#pragma unroll
+        for (int zb = 0; zb < 2; zb++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) xch[(3 * zb + d) * HQ_BK_THREADS + t] = G[0][zb][d];
+        __syncthreads();
+        if (owner) {
+            double H0[3], H1[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                H0[d] = G[1][0][d] + xch[d * HQ_BK_THREADS + t + 64];
+                H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BK_THREADS + t + 64];
+            }
+            if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
+                double f[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) f[d] = accA[d] + H0[d];
+                const int local = (l - 1) * nxy + sidx;
+                if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
+                    for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
+                        if (src_ent[2 * i] == local) {
+                            const int li = src_ent[2 * i + 1];
+                            for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
+                        }
+                }
+                double* out = ung + 3 * (U.base + (int64_t)local);
+#pragma unroll
+                for (int d = 0; d < 3; d++) out[d] = f[d] / m0A;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) accA[d] = accB[d] + H1[d];
+            m0A = m0B;
+        }
+        if (l < np) HQ_BH_PUT(l & 1, accB, m0B)
+        __syncthreads();
+        c1 = nc1; c2 = nc2; beta = nbeta;
+    }
+#undef HQ_BH_LOAD
+#undef HQ_BH_PUT
+}
+
 /* ------------------------------------------------------------------------ */
 /* device plan                                                              */
 /* ------------------------------------------------------------------------ */
 
 static void hq_brick_free(hq_brick_plan* P)
 {
-    void* ptrs[] = { P->d_units, P->d_tab, P->d_src_ptr, P->d_src_ent };
+    void* ptrs[] = { P->d_units, P->d_tab, P->d_coef, P->d_src_ptr, P->d_src_ent };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_brick_plan();
 }
@@ -513,7 +763,18 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
     P->nb = B.nb;
     P->nunits = (int32_t)B.units.size();
     P->nsame = B.nsame;
+    P->nhet = B.nhet;
     if (P->nunits == 0) return 0;
+    if (P->nhet > 0) {
+        if (hipMalloc((void**)&P->d_coef, 8 * B.coef.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+        *bytes += (int64_t)(8 * B.coef.size());
+        if (hipMemcpy(P->d_coef, B.coef.data(), 8 * B.coef.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick coefficient upload failed"; return -3; }
+        static bool attr_set = false;            /* 80.7 KB of dynamic LDS per workgroup */
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)hq_k_brick_het, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess) { g_patch_err = "hq_k_brick_het: LDS attribute"; return -3; }
+            attr_set = true;
+        }
+    }
     if (hipMalloc((void**)&P->d_units, sizeof(hq_brick_unit) * B.units.size()) != hipSuccess ||
         hipMalloc((void**)&P->d_tab, 4 * B.tab.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
     *bytes += (int64_t)(sizeof(hq_brick_unit) * B.units.size() + 4 * B.tab.size());
@@ -556,20 +817,22 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
     return 0;
 }
 
-/* one step of all units: the HQ_BK_NTSAME units, then (their own launch) the units with per-node n_t rows */
+/* one step of all units: the HQ_BK_NTSAME units, then (a launch each) the units with per-node n_t rows and the HET units */
 static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
                             const double* F, double dt2, hipStream_t stream)
 {
-    const int32_t cnt[2] = { P->nsame, P->nunits - P->nsame };
+    const int32_t cnt[3] = { P->nsame, P->nunits - P->nsame - P->nhet, P->nhet };
     int32_t first = 0;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         const int32_t count = cnt[k];
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
         const int32_t* sp = P->d_src_ptr ? P->d_src_ptr + first : nullptr;
 #define HQ_BK_ARGS count, per_xcd, P->d_units + first, P->d_tab, u1, u2, un, nt3, sp, P->d_src_ent, (sp ? F : nullptr), dt2, hq_stencil().c
         if (k == 0) hq_k_brick<false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
-        else hq_k_brick<true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 1) hq_k_brick<true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else hq_k_brick_het<<<per_xcd * 8, HQ_BK_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
+                                                                             P->d_src_ent, (sp ? F : nullptr), dt2);
 #undef HQ_BK_ARGS
         first += count;
     }

@@ -905,7 +905,7 @@ static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
     std::vector<double> tmp;
     try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
     const int32_t* pm = c->perm.data();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (c->N > 262144)     /* small fields: a parallel region costs more than the loop */
     for (int64_t n = 0; n < (int64_t)c->N; n++) {
         const int64_t q = pm[n];
         tmp[(size_t)(3 * q)] = host[3 * n]; tmp[(size_t)(3 * q + 1)] = host[3 * n + 1]; tmp[(size_t)(3 * q + 2)] = host[3 * n + 2];
@@ -925,7 +925,7 @@ static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
     try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
     HQ_HIP(hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost));
     const int32_t* pm = c->perm.data();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (c->N > 262144)     /* small fields: a parallel region costs more than the loop */
     for (int64_t n = 0; n < (int64_t)c->N; n++) {
         const int64_t q = pm[n];
         host[3 * n] = tmp[(size_t)(3 * q)]; host[3 * n + 1] = tmp[(size_t)(3 * q + 1)]; host[3 * n + 2] = tmp[(size_t)(3 * q + 2)];
@@ -1504,9 +1504,13 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     for (int64_t u = 0; u < (int64_t)B.units.size(); u++) {
         const hq_brick_unit& U = B.units[(size_t)u];
         const int nx = U.nx, ny = U.ny, np = U.np, nr = 2 * (nx + 2) + 2 * ny;
-        if (nx < 1 || nx > HQ_BK_TX || ny < 1 || ny > HQ_BK_TY || np < 1 || U.base < 0 || U.base + (int64_t)nx * ny * np > B.nb) { bad++; continue; }
+        const bool het = (U.flags & HQ_BK_HET) != 0;
+        if (nx < 1 || nx > (het ? HQ_BH_TX : HQ_BK_TX) || ny < 1 || ny > (het ? HQ_BH_TY : HQ_BK_TY) || np < 1 || U.base < 0 ||
+            U.base + (int64_t)nx * ny * np > B.nb) { bad++; continue; }
         nsame += (U.flags & HQ_BK_NTSAME) != 0;
         if (((U.flags & HQ_BK_NTSAME) != 0) != (u < B.nsame)) bad++;
+        if (het != (u >= (int64_t)B.units.size() - B.nhet)) bad++;
+        if (het && (U.coef < 0 || U.coef + (int64_t)(np + 1) * HQ_BK_THREADS * 3 > (int64_t)B.coef.size())) { bad++; continue; }
         const int32_t* ring = B.tab.data() + U.tab;
         const int32_t* cap = ring + (int64_t)(np + 2) * nr;
         /* the device id the kernel reads at (x, y) of plane k, k = -1 .. np */
@@ -1543,7 +1547,12 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                         const int o = (int)(adj[(size_t)a] & 7);
                         if (el[o] != -1) ok = false;
                         el[o] = e;
-                        if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
+                        if (het) {
+                            /* the element whose corner o the node is: column (x - ox + 1, y - oy + 1) of layer k - oz + 1 */
+                            const int i = x - (o & 1) + 1, j = y - ((o >> 1) & 1) + 1, l = k - ((o >> 2) & 1) + 1;
+                            const double* q = B.coef.data() + U.coef + 3 * (((int64_t)l * HQ_BK_TY + j) * HQ_BK_TX + i);
+                            if (c1[(size_t)e] != q[0] || c2[(size_t)e] != q[1] || beta[(size_t)e] != q[2]) ok = false;
+                        } else if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
                     }
                     if (!ok) { bad++; continue; }
                     for (int dz = -1; dz <= 1; dz++)
@@ -1561,7 +1570,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     }
     for (int64_t q = 0; q < B.nb; q++) if (covered[(size_t)q] != 1) bad++;
     report[0] = B.nb; report[1] = B.ncolumns; report[2] = (int64_t)B.units.size(); report[3] = nsame;
-    report[4] = B.nlevels; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
+    report[4] = B.nhet; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
     if (bad) return hq_fail(HQ_ERR_STATE, "brick plan self-check failed%s", "");
     return HQ_OK;
 }

@@ -272,7 +272,8 @@ HQ_API int hq_stencil_plan_check(const hq_desc* desc, int64_t report[6]);
  * of uniformly refined, homogeneous regions, stepped by hq_k_brick on a tile-major node numbering of the device's own
  * -- as hq_create would and verifies them against the mesh's connectivity alone: permutation, coverage, the eight
  * equal elements and the dashpot-free n_t row of every brick node, and every neighbour the kernel will read.
- * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}.
+ * report = {brick nodes, tile columns, units, units with one n_t row, units with per-element coefficients
+ *           (hq_k_brick_het), neighbours checked, patch nodes, faults}.
  */
 HQ_API int hq_brick_plan_check(const hq_desc* desc, int64_t report[8]);
 

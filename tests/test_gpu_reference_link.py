@@ -54,7 +54,8 @@ def _run(binary, params, timeout=900):
     open(os.path.join(run, "parameters.in"), "w").write(params)
     # the system's libstdc++ (libhq_solver.so needs it) ahead of the older one beside the image's MPICH
     syslib = "/usr/lib/x86_64-linux-gnu"
-    env = dict(os.environ, LD_LIBRARY_PATH=":".join([syslib, os.path.join(MPI, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
+    env = dict(os.environ, OMP_NUM_THREADS="2",
+               LD_LIBRARY_PATH=":".join([syslib, os.path.join(MPI, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
     out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", "1", binary, "parameters.in"], cwd=run, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:]

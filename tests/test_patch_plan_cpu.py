@@ -4,6 +4,8 @@ every element row names the LDS rows of its element's eight nodes, accumulate fl
 hanging nodes on owned anchors, every node owned by exactly one patch.  It also counts the LDS passes
 of the element gathers under the bank rule of MI355X_MICROARCH.md (32-lane groups, 24-byte rows
 conflict iff equal modulo 32): lattice patches must be free of conflicts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -106,14 +108,15 @@ def test_brick_plan_of_a_uniform_box_matches_the_connectivity():
     b.close()
     assert r["faults"] == 0
     assert r["brick_nodes"] == 63 * 63 * 31 and r["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
-    assert r["columns"] == 8 and r["units"] == 8 and r["units_one_nt_row"] == 8 and r["levels"] == 1
+    assert r["columns"] == 8 and r["units"] == 8 and r["units_one_nt_row"] == 8 and r["het_units"] == 0
     assert r["neighbours_checked"] == 26 * r["brick_nodes"]
 
 
 def test_brick_plan_on_partitions_layers_and_lateral_material():
-    """Partitions (interface nodes stay with the patches), a layered box (nodes on the material interface are not
-    simple; the units of each layer carry its coefficients and its n_t row) and a box whose material differs from
-    element to element (no simple node at all: no bricks, no renumbering)."""
+    """Partitions (interface nodes stay with the patches), a layered box (the units of each layer carry its coefficients
+    and its n_t row; the nodes of the interface plane have elements of two materials around them: one plane is too
+    short a run, they stay with the patches) and a box whose material differs from element to element (tiles of
+    63 x 7 nodes for hq_k_brick_het, every unit with its own element coefficients)."""
     tot = 0
     for rank in range(2):
         b = host.Box(64, 64, 64, 10.0, 2e-4, 50.0, rank=rank, nranks=2)
@@ -129,6 +132,12 @@ def test_brick_plan_on_partitions_layers_and_lateral_material():
     assert r["faults"] == 0 and r["brick_nodes"] == 31 * 31 * (15 + 15) and r["units_one_nt_row"] == r["units"]
     b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, lateral_classes=61, lateral_amp=0.1)
     r = b.brick_plan_check()
+    assert r["faults"] == 0 and r["brick_nodes"] == 31 ** 3 and r["het_units"] == r["units"] == 5 and r["units_one_nt_row"] == 0
+    os.environ["HQ_BRICK_NO_HET"] = "1"                       # the uniform-coefficient kernel alone finds nothing here
+    try:
+        r = b.brick_plan_check()
+    finally:
+        del os.environ["HQ_BRICK_NO_HET"]
     b.close()
     assert r["faults"] == 0 and r["brick_nodes"] == 0 and r["patch_nodes"] == 33 ** 3
 
