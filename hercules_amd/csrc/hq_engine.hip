@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/hq_solver.h"
@@ -134,6 +135,10 @@ struct hq_dev_schedule {
     int64_t* d_c_in_id = nullptr;
     int64_t* d_s_out_id = nullptr;
     int64_t* d_s_in_id = nullptr;
+    /* in-process transport (hq_group_link): where every record of the contribution / sharing send lands in its peer's
+     * receive buffer -- the pack kernel writes there directly (one kernel per exchange, no copies) */
+    double** d_c_dst = nullptr;
+    double** d_s_dst = nullptr;
     /* host-staged transport (hq_comm_init_host): pinned mirrors of the four record buffers */
     double*  h_c_out = nullptr;
     double*  h_c_in = nullptr;
@@ -332,6 +337,16 @@ __global__ void hq_k_pack(int32_t count, const int32_t* __restrict__ map,
     out[t] = table[3 * (int64_t)map[i] + d];
 }
 
+/* in-process transport: record i goes where its peer expects it (dst[i]: base of the record in the peer's buffer) */
+__global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
+                                   double* const* __restrict__ dst)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    dst[i][d] = table[3 * (int64_t)map[i] + d];
+}
+
 __global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
                             const double* __restrict__ in, double* __restrict__ table, int add)
 {
@@ -454,6 +469,14 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     int32_t total = contribution ? s->ctotal : s->stotal;
     if (!c->comm && !c->group && !c->host_xchg)
         return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init, hq_comm_init_host or hq_group_link%s", "");
+    double* const* d_dst = contribution ? s->d_c_dst : s->d_s_dst;
+    if (c->group && d_dst && !c->debug_halo) {
+        /* all partitions in one process: the records are written where the peers read them */
+        if (total)
+            hq_k_pack_to_peers<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_dst);
+        HQ_HIP(hipEventRecord(c->ev_sent, xs));
+        return HQ_OK;
+    }
     if (total)
         hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_out);
     /* HQ_DEBUG_HALO: the global identity of every record's node travels with it (psolve.c:5002-5007) */
@@ -673,27 +696,35 @@ static int hq_phase(hq_ctx* c, int ph)
                 /* ONE persistent launch for all element-form patches, the interface patches at the head of its
                  * queue; the exchange chain starts behind it and runs beside the stencil kernel -- the bulk of the
                  * partition, in small workgroups that leave CUs to the chain's kernels as they retire */
-                hq_patch_launch(&c->plan, 0, nb + ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                /* with the chain on its own stream only the patches that own interface nodes go ahead of the event: the
+                 * other element-form patches (all of them on octree or layered partitions) run beside the exchange */
+                const int32_t head = c->overlap ? nb : nb + ne;
+                hq_patch_launch(&c->plan, 0, head, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                                 c->d_iforce, c->stream);
                 hq_patch_launch_stencil(&c->plan, 0, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                                         c->d_iforce, c->stream);      /* the stencil patches on the partition interface */
                 if (c->overlap) {
                     HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                     HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                    hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                    c->d_iforce, c->stream, c->reserve_cus);
                 }
                 hq_patch_launch_stencil(&c->plan, 1, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                                         c->d_iforce, c->stream);
             } else {
                 /* no stencil patches (octree regions, layered material): interface patches first, then the interior
                  * launch, which leaves `reserve_cus` CUs to the chain */
-                hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
-                                c->d_iforce, c->stream);
                 if (c->overlap) {
+                    hq_patch_launch(&c->plan, 0, nb, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
+                                    c->d_iforce, c->stream);
                     HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                     HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                    hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
+                                    c->dt2, c->d_iforce, c->stream, c->reserve_cus);
+                } else {                         /* one stream: one persistent launch over all of them */
+                    hq_patch_launch(&c->plan, 0, nb + ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
+                                    c->dt2, c->d_iforce, c->stream);
                 }
-                hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
-                                c->dt2, c->d_iforce, c->stream, c->overlap ? c->reserve_cus : 0);
             }
             /* the bricks: simple nodes only, never on the interface -- interior work beside the exchange chain */
             if (c->bricks.nunits > 0)
@@ -1000,6 +1031,23 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
      * That needs the nodes renumbered: from here on `d` is the description in DEVICE numbering (c->perm maps the
      * caller's ids); hq_set_source / hq_gather / hq_download / hq_upload translate.  Needs node_xyz.
      */
+    if (variant == HQ_VARIANT_PATCH && !d->node_xyz) {
+        static bool warned = false;
+        if (!warned && !getenv("HQ_QUIET")) {
+            warned = true;
+            fprintf(stderr, "hq_create: hq_desc.node_xyz is NULL -- no bricks, no lattice / stencil patches (fixed runs of the node "
+                            "order, element-form kernels only): expect about a third of the throughput; pass node_t.x/y/z\n");
+        }
+    }
+    /* HQ_PATCH_VERBOSE: where hq_create's time goes */
+    const bool verbose = getenv("HQ_PATCH_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "hq_create: %-34s %7.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     hq_desc dd = *d;
     std::vector<int32_t> p_lnid, p_xyz, p_dn_id, p_dn_anchor;
     std::vector<double> p_nt;
@@ -1013,6 +1061,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_brick_excluded(d, excl)) != HQ_OK) return bail(rc);
         if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH) != 0)
             return bail(hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error()));
+        lap("brick plan");
     }
     if (BH.nb > 0) {
         const std::vector<int32_t>& pm = BH.perm;
@@ -1063,6 +1112,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         dd.tm1 = dd.tm2 = nullptr;              /* uploaded through the permutation below */
         c->perm = BH.perm;
         d = &dd;
+        lap("renumbering");
     }
 
     /* node state */
@@ -1173,7 +1223,9 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         c->plan.ragged_default = true;
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
                             dn, seed0.data(), &pb, BH.nb);
+        lap("state upload + patch plan");
         if (rc == 0 && BH.nb > 0) rc = hq_brick_upload(&c->bricks, BH, &pb);
+        lap("brick upload");
         if (rc != 0)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
                                 hq_patch_error()));
@@ -1593,9 +1645,12 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->an.d_smap_f && c->an.d_smap_f != c->an.d_smap) hipFree(c->an.d_smap_f);
     if (c->dn.d_cmap_f && c->dn.d_cmap_f != c->dn.d_cmap) hipFree(c->dn.d_cmap_f);
     if (c->dn.d_smap_f && c->dn.d_smap_f != c->dn.d_smap) hipFree(c->dn.d_smap_f);
-    for (hq_dev_schedule* sc : { &c->an, &c->dn })
+    for (hq_dev_schedule* sc : { &c->an, &c->dn }) {
         for (double* hp : { sc->h_c_out, sc->h_c_in, sc->h_s_out, sc->h_s_in })
             if (hp) hipHostFree(hp);
+        if (sc->d_c_dst) hipFree(sc->d_c_dst);
+        if (sc->d_s_dst) hipFree(sc->d_s_dst);
+    }
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
@@ -1712,6 +1767,38 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
      * which is how the GPU tests cover that path without a second GPU). */
     const bool ov = getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) != 0;
     for (int32_t i = 0; i < n; i++) { ctxs[i]->group = g; ctxs[i]->overlap = ov && ctxs[i]->can_overlap; }
+    /* destination of every send record in its peer's receive buffer (all contexts on one device: plain pointers) */
+    bool one_device = true;
+    for (int32_t i = 1; i < n; i++) one_device = one_device && ctxs[i]->device == ctxs[0]->device;
+    if (one_device && !getenv("HQ_GROUP_COPIES")) {
+        for (int32_t i = 0; i < n; i++) {
+            hq_ctx* c = ctxs[i];
+            HQ_HIP(hipSetDevice(c->device));
+            for (int which = 0; which < 2; which++) {
+                hq_dev_schedule* s = which ? &c->dn : &c->an;
+                for (int contribution = 0; contribution < 2; contribution++) {
+                    std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
+                    const int32_t total = contribution ? s->ctotal : s->stotal;
+                    if (!total) continue;
+                    std::vector<double*> dst((size_t)total, nullptr);
+                    for (auto& m : snd) {
+                        if (!m.nodecount) continue;
+                        hq_ctx* peer = ctxs[m.procid];
+                        hq_dev_schedule* ps = which ? &peer->dn : &peer->an;
+                        std::vector<hq_dev_messenger>& prcv = contribution ? ps->s : ps->c;
+                        double* p_in = contribution ? ps->d_s_in : ps->d_c_in;
+                        const hq_dev_messenger* pm = nullptr;
+                        for (auto& q : prcv) if (q.procid == c->rank) pm = &q;
+                        if (!pm || pm->nodecount != m.nodecount) return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
+                        for (int32_t k = 0; k < m.nodecount; k++) dst[(size_t)m.offset + k] = p_in + 3 * ((int64_t)pm->offset + k);
+                    }
+                    double*** slot = contribution ? &s->d_c_dst : &s->d_s_dst;
+                    HQ_TRY(hq_dev_alloc(c, slot, (size_t)total));
+                    HQ_HIP(hipMemcpy(*slot, dst.data(), sizeof(double*) * (size_t)total, hipMemcpyHostToDevice));
+                }
+            }
+        }
+    }
     return HQ_OK;
 }
 
@@ -1798,6 +1885,7 @@ extern "C" int hq_sync(hq_ctx* c)
         if (bad) {
             char n[32];
             snprintf(n, sizeof n, "%d", bad);
+            HQ_HIP(hipMemset(c->d_halo_err, 0, sizeof(int32_t)));      /* reported once: later syncs count afresh */
             return hq_fail(HQ_ERR_COMM, "HQ_DEBUG_HALO: %s halo records arrived for another node than the schedule names "
                                         "(global node ids do not match, psolve.c:5058-5069)", n);
         }

@@ -2089,6 +2089,8 @@ static int hq_patch_build_order(hq_patch_plan* P, const int32_t* if_ptr, int64_t
     return 0;
 }
 
+static bool hq_patch_uses_pers(const hq_patch_plan* P);
+
 static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz,
                           const double* c1, const double* c2, const double* beta, const double* ntab,
                           const hq_dangling& dn, const char* seed0, int64_t* bytes, int64_t n0 = 0)
@@ -2127,7 +2129,10 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         P->max_nacc = P->nlattice ? HQ_LAT_ACC : 0;
         for (auto& D : H.desc) { P->max_nacc = std::max(P->max_nacc, D.nacc); mp = std::max(mp, D.npairs); }
         /* hq_k_patch_seed: two images and THREE accumulator arrays must fit the 160 KiB of LDS */
-        P->seeded = P->pipe == 6 && seed0 &&
+        /* (and the persistent form itself must be the one that runs: hq_patch_uses_pers -- the fallback kernel
+         * hq_k_patch_step divides by mass_simple as it stands and must never see a negated one) */
+        P->max_npairs = std::max(P->max_npairs, mp);
+        P->seeded = P->pipe == 6 && seed0 && hq_patch_uses_pers(P) &&
                     P->cfg.nlmax <= HQ_PERS_THREADS && mp <= HQ_PERS_THREADS &&
                     (12 * (size_t)P->nrows + 9 * (size_t)P->max_nacc + 16) * sizeof(double) <= 160 * 1024;
     }
