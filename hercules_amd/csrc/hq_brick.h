@@ -310,14 +310,25 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
      * side on one XCD and find each other's ring rows in its L2 */
     struct unit_t { int col; int32_t za, np; int64_t key; };
     std::vector<unit_t> us;
+    /* planes per unit: 32 where that still gives two units per CU; a small mesh (or a rank's share of one) gets shorter
+     * chunks -- each costs two more planes of loads, but 64 workgroups do not fill 256 CUs (1 M-element box: 0.068 ms
+     * per step with 32 planes per unit, 0.039 with 8; 8 M box: 0.164 / 0.172).  HQ_BRICK_CZ fixes it. */
+    int cz = cfg.cz;
+    if (!getenv("HQ_BRICK_CZ")) {
+        for (cz = 32; cz > 8; cz /= 2) {
+            int64_t n = 0;
+            for (auto& c : cols) n += (c.nz + cz - 1) / cz;
+            if (n >= 512) break;
+        }
+    }
     for (size_t ci = 0; ci < cols.size(); ci++) {
         const column_t& c = cols[ci];
-        const int32_t nch = (c.nz + cfg.cz - 1) / cfg.cz;
+        const int32_t nch = (c.nz + cz - 1) / cz;
         const int32_t G = std::max(1, 64 / std::max(1, ntx_of_level[(size_t)c.lvl]));
         for (int32_t k = 0; k < nch; k++) {
             const int32_t za = (int32_t)((int64_t)c.nz * k / nch), zb = (int32_t)((int64_t)c.nz * (k + 1) / nch);
             /* key: level | slab | plane of the chunk's start | tile row | tile column */
-            const int64_t key = ((int64_t)c.lvl << 56) | ((int64_t)(c.tj / G) << 42) | ((int64_t)((c.z0 + za) / cfg.cz) << 28) |
+            const int64_t key = ((int64_t)c.lvl << 56) | ((int64_t)(c.tj / G) << 42) | ((int64_t)((c.z0 + za) / cz) << 28) |
                                 ((int64_t)(c.tj % G) << 20) | (int64_t)c.ti;
             us.push_back({ (int)ci, c.z0 + za, zb - za, key });
         }

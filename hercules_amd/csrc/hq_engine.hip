@@ -199,8 +199,13 @@ struct hq_ctx {
     int32_t* d_oi_slot = nullptr;
     int32_t* d_oi_ptr = nullptr;      /* [nOI+1] CSR: records of an.d_s_in to add, in       */
     int32_t* d_oi_pos = nullptr;      /*         messenger order (fixed summation order)    */
-    int32_t  nSD = 0;                 /* distribution entries of owned hanging nodes that    */
-    int32_t* d_sd_ent = nullptr;      /* other ranks share: [nSD][3] {src slot, dst slot, deps} */
+    /* compute_adjust DISTRIBUTION grouped by destination (hq_k_distribute): the shared hanging nodes of the patch
+     * variant on the interface table (slots), all hanging nodes of the scatter variant on the force table (nodes) */
+    int32_t  nSD = 0;                 /* destinations (anchors)                              */
+    int32_t* d_sd_dst = nullptr;      /* [nSD]                                               */
+    int32_t* d_sd_ptr = nullptr;      /* [nSD + 1]                                           */
+    int32_t* d_sd_src = nullptr;      /* [entries] hanging node (slot / id)                  */
+    int32_t* d_sd_deps = nullptr;     /* [entries] its number of anchors                     */
     /* patch variant */
     hq_patch_plan plan;
     /* bricks (hq_brick.h): the device numbers the nodes its own way -- tile columns first -- and every entry point
@@ -299,17 +304,23 @@ hq_k_update(int64_t n3, const double* __restrict__ nt, const double* __restrict_
     force[t] = 0.0;
 }
 
-/* compute_adjust DISTRIBUTION (psolve.c:5942-5987) */
-__global__ void hq_k_adjust_distribute(int32_t ldnnum, const int32_t* __restrict__ dn_id,
-                                       const int32_t* __restrict__ dn_ptr,
-                                       const int32_t* __restrict__ dn_anchor, double* __restrict__ table)
+/*
+ * compute_adjust DISTRIBUTION (psolve.c:5942-5987) without atomics and in ONE summation order: the entries are
+ * grouped by the anchor they add to (CSR, host-built), inside an anchor in the order of the reference's loop --
+ * hanging nodes in table order, their anchors in list order -- so an anchor several hanging nodes hang on gets its
+ * parts in the same order on every run.  Anchors are never hanging nodes themselves (hq_create refuses that), so no
+ * row is read and written in the same launch.  ids: node ids (scatter variant, force table) or interface slots.
+ */
+__global__ void hq_k_distribute(int32_t ndst, const int32_t* __restrict__ dst, const int32_t* __restrict__ ptr,
+                                const int32_t* __restrict__ src, const int32_t* __restrict__ deps, double* __restrict__ table)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ldnnum * 3) return;
+    if (t >= ndst * 3) return;
     int k = t / 3, d = t - 3 * k;
-    int32_t lo = dn_ptr[k], hi = dn_ptr[k + 1];
-    double part = table[3 * (int64_t)dn_id[k] + d] / (double)(uint32_t)(hi - lo);
-    for (int32_t p = lo; p < hi; p++) unsafeAtomicAdd(&table[3 * (int64_t)dn_anchor[p] + d], part);
+    double* p = &table[3 * (int64_t)dst[k] + d];
+    double v = *p;
+    for (int32_t q = ptr[k]; q < ptr[k + 1]; q++) v += table[3 * (int64_t)src[q] + d] / (double)(uint32_t)deps[q];
+    *p = v;
 }
 
 /* compute_adjust ASSIGNMENT (psolve.c:5992-6035) */
@@ -637,17 +648,6 @@ static int hq_launch_update(hq_ctx* c)
     return HQ_OK;
 }
 
-/* compute_adjust DISTRIBUTION (psolve.c:5942-5987) for owned hanging nodes that other ranks share,
- * on the interface force table, after their contribution exchange */
-__global__ void hq_k_iface_distribute(int32_t n, const int32_t* __restrict__ ent, double* __restrict__ iforce)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 3) return;
-    int i = t / 3, d = t - 3 * i;
-    double part = iforce[3 * (int64_t)ent[3 * i] + d] / (double)(uint32_t)ent[3 * i + 2];
-    unsafeAtomicAdd(&iforce[3 * (int64_t)ent[3 * i + 1] + d], part);
-}
-
 /*
  * Interface nodes this rank owns: own partial force + the sharers' records
  * (the "+=" unpack of schedule_senddata, psolve.c:5035-5073, in messenger order)
@@ -741,11 +741,11 @@ static int hq_phase(hq_ctx* c, int ph)
         if (patch) {
             /* hanging nodes nobody shares were distributed inside the patches; the shared ones here */
             if (c->nSD)
-                hq_k_iface_distribute<<<hq_blocks(c->nSD * 3, 256), 256, 0, c->overlap ? c->cstream : c->stream>>>(
-                    c->nSD, c->d_sd_ent, c->d_iforce);
-        } else if (c->ldnnum) {                                            /* :4299 */
-            hq_k_adjust_distribute<<<hq_blocks(c->ldnnum * 3, 256), 256, 0, c->stream>>>(
-                c->ldnnum, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor, c->d_force);
+                hq_k_distribute<<<hq_blocks(c->nSD * 3, 256), 256, 0, c->overlap ? c->cstream : c->stream>>>(
+                    c->nSD, c->d_sd_dst, c->d_sd_ptr, c->d_sd_src, c->d_sd_deps, c->d_iforce);
+        } else if (c->nSD) {                                               /* :4299 */
+            hq_k_distribute<<<hq_blocks(c->nSD * 3, 256), 256, 0, c->stream>>>(
+                c->nSD, c->d_sd_dst, c->d_sd_ptr, c->d_sd_src, c->d_sd_deps, c->d_force);
         }
         return HQ_OK;
     case 3: return hq_xchg_send(c, &c->an, ftab, true, true);                        /* :4301 */
@@ -816,6 +816,32 @@ static int hq_step(hq_ctx* c)
  * contribution exchange adds the neighbours' partials to the owner's slot, the
  * owner updates the node (hq_k_interface_update) and shares the result.
  */
+/* {src, dst, deps} entries in the reference's loop order -> the tables of hq_k_distribute */
+static int hq_build_distribution(hq_ctx* c, const std::vector<int32_t>& sd)
+{
+    const size_t n = sd.size() / 3;
+    c->nSD = 0;
+    if (!n) return HQ_OK;
+    std::vector<int32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return sd[3 * (size_t)a + 1] < sd[3 * (size_t)b + 1]; });
+    std::vector<int32_t> dst, ptr(1, 0), src, deps;
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = (size_t)order[k];
+        if (dst.empty() || dst.back() != sd[3 * i + 1]) { if (!dst.empty()) ptr.push_back((int32_t)src.size()); dst.push_back(sd[3 * i + 1]); }
+        src.push_back(sd[3 * i]); deps.push_back(sd[3 * i + 2]);
+    }
+    ptr.push_back((int32_t)src.size());
+    auto up = [&](const std::vector<int32_t>& v, int32_t** p) -> int {
+        HQ_TRY(hq_dev_alloc(c, p, v.size()));
+        HQ_HIP(hipMemcpy(*p, v.data(), 4 * v.size(), hipMemcpyHostToDevice));
+        return HQ_OK;
+    };
+    HQ_TRY(up(dst, &c->d_sd_dst)); HQ_TRY(up(ptr, &c->d_sd_ptr)); HQ_TRY(up(src, &c->d_sd_src)); HQ_TRY(up(deps, &c->d_sd_deps));
+    c->nSD = (int32_t)dst.size();
+    return HQ_OK;
+}
+
 static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
 {
     if (c->an.ctotal == 0 && c->an.stotal == 0 && c->dn.ctotal == 0 && c->dn.stotal == 0) return HQ_OK;
@@ -861,7 +887,6 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         if (slot[n] >= 0 && !nonowned[n]) { oin.push_back(n); ois.push_back(slot[n]); }
     c->nI = nI;
     c->nOI = (int32_t)oin.size();
-    c->nSD = (int32_t)(sd.size() / 3);
     HQ_TRY(hq_dev_alloc(c, &c->d_iforce, (size_t)nI * 3));
     HQ_HIP(hipMemset(c->d_iforce, 0, sizeof(double) * 3 * (size_t)nI));
     auto upload = [&](const std::vector<int32_t>& v, int32_t** dst) -> int {
@@ -874,7 +899,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     HQ_TRY(upload(an_ss, &c->an.d_smap_f));
     HQ_TRY(upload(dn_cs, &c->dn.d_cmap_f));
     HQ_TRY(upload(dn_ss, &c->dn.d_smap_f));
-    HQ_TRY(upload(sd, &c->d_sd_ent));
+    HQ_TRY(hq_build_distribution(c, sd));
     if (c->nOI) {
         /* records of the anchored-node contribution receive buffer per owned interface node,
          * messenger order */
@@ -1005,6 +1030,14 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(HQ_ERR_ARG, "bad dangling-node table%s", ""));
         for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++)
             if (d->dn_lanid[a] < 0 || d->dn_lanid[a] >= c->N) return bail(hq_fail(HQ_ERR_ARG, "bad anchor id%s", ""));
+    }
+    if (c->ldnnum) {
+        /* an anchor must itself be anchored (octor's 2:1 balance guarantees it): the distribution kernels read the
+         * hanging nodes' rows while they add to the anchors' */
+        std::vector<char> is_dn((size_t)c->N, 0);
+        for (int32_t k = 0; k < c->ldnnum; k++) is_dn[d->dn_ldnid[k]] = 1;
+        for (int32_t a = 0; a < d->dn_ptr[c->ldnnum]; a++)
+            if (is_dn[d->dn_lanid[a]]) return bail(hq_fail(HQ_ERR_ARG, "an anchor is itself a hanging node%s", ""));
     }
     if (hipEventCreateWithFlags(&c->ev_sent, hipEventDisableTiming) != hipSuccess)
         return bail(hq_fail(HQ_ERR_DEVICE, "hipEventCreate failed%s", ""));
@@ -1181,6 +1214,14 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(HQ_ERR_DEVICE, "element table upload failed%s", ""));
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
+        if (c->ldnnum) {
+            std::vector<int32_t> sd;                     /* {hanging node, anchor, deps} in the reference's loop order */
+            for (int32_t k = 0; k < c->ldnnum; k++)
+                for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) {
+                    sd.push_back(d->dn_ldnid[k]); sd.push_back(d->dn_lanid[a]); sd.push_back(d->dn_ptr[k + 1] - d->dn_ptr[k]);
+                }
+            if ((rc = hq_build_distribution(c, sd)) != HQ_OK) return bail(rc);
+        }
     } else {
         int64_t pb = 0;
         /* hanging nodes the patches may distribute themselves: owned and not shared with any rank
@@ -1637,7 +1678,7 @@ extern "C" int hq_destroy(hq_ctx* c)
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
-                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_ent,
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_dst, c->d_sd_ptr, c->d_sd_src, c->d_sd_deps,
                      c->d_gkey, c->d_halo_err, c->an.d_c_out_id, c->an.d_c_in_id, c->an.d_s_out_id, c->an.d_s_in_id,
                      c->dn.d_c_out_id, c->dn.d_c_in_id, c->dn.d_s_out_id, c->dn.d_s_in_id };
     for (void* p : ptrs) if (p) hipFree(p);

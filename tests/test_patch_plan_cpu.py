@@ -108,7 +108,7 @@ def test_brick_plan_of_a_uniform_box_matches_the_connectivity():
     b.close()
     assert r["faults"] == 0
     assert r["brick_nodes"] == 63 * 63 * 31 and r["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
-    assert r["columns"] == 8 and r["units"] == 8 and r["units_one_nt_row"] == 8 and r["het_units"] == 0
+    assert r["columns"] == 8 and r["units"] == 8 * 4 and r["units_one_nt_row"] == r["units"] and r["het_units"] == 0   # 31 planes in chunks of 8: a small mesh
     assert r["neighbours_checked"] == 26 * r["brick_nodes"]
 
 
@@ -132,7 +132,7 @@ def test_brick_plan_on_partitions_layers_and_lateral_material():
     assert r["faults"] == 0 and r["brick_nodes"] == 31 * 31 * (15 + 15) and r["units_one_nt_row"] == r["units"]
     b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, lateral_classes=61, lateral_amp=0.1)
     r = b.brick_plan_check()
-    assert r["faults"] == 0 and r["brick_nodes"] == 31 ** 3 and r["het_units"] == r["units"] == 5 and r["units_one_nt_row"] == 0
+    assert r["faults"] == 0 and r["brick_nodes"] == 31 ** 3 and r["columns"] == 5 and r["het_units"] == r["units"] == 5 * 4 and r["units_one_nt_row"] == 0
     os.environ["HQ_BRICK_NO_HET"] = "1"                       # the uniform-coefficient kernel alone finds nothing here
     try:
         r = b.brick_plan_check()
