@@ -190,6 +190,7 @@ struct hq_ctx {
     hipStream_t cstream = nullptr;
     hipEvent_t ev_bnd = nullptr, ev_shared = nullptr, ev_an_shared = nullptr, ev_assigned = nullptr;
     bool overlap = false;             /* exchange chain on cstream beside the interior patches               */
+    bool stream_masked = false;       /* the compute stream leaves reserve_cus CUs to the exchange stream (hq_mask_compute_stream) */
     bool can_overlap = false;         /* the stream and events for it exist (hq_setup_interface)             */
     int reserve_cus = 8;              /* CUs the interior launch leaves to the exchange chain (HQ_RESERVE_CUS) */
     /* patch variant: nodes on the partition interface */
@@ -1731,6 +1732,45 @@ extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
     return HQ_OK;
 }
 
+/*
+ * With the exchange chain on its own stream BETWEEN GPUs the compute stream must leave it somewhere to run: stream
+ * priority does not preempt resident waves, and the brick launch of a partition is one wave of workgroups that fills
+ * every CU's registers until it ends (130 us on an eighth of the 64M box).  So the compute stream is re-created with a
+ * CU mask (hipExtStreamCreateWithCUMask) without `reserve_cus` CUs of the device (one per XCD); pack / RCCL / interface
+ * kernels on the exchange stream find them free at any time.
+ */
+static int hq_mask_compute_stream(hq_ctx* c)
+{
+    if (!c->overlap || c->reserve_cus <= 0 || c->stream_masked) return HQ_OK;
+    /* opt-in (HQ_CU_MASK=1): measured on one rank of an 8-way split of the 64M box alone on the GPU
+     * (profiles/r03/rank_alone_trace.txt), the chain's kernels then do run beside the brick launch, but that launch
+     * -- 512 workgroups for 496 slots -- takes 164 us instead of 122: a second, nearly empty round */
+    if (!(getenv("HQ_CU_MASK") && atoi(getenv("HQ_CU_MASK")) != 0)) return HQ_OK;
+    hipDeviceProp_t prop;
+    HQ_HIP(hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount;
+    if (c->reserve_cus >= ncu) return HQ_OK;
+    /* which CUs: index 33 k (k = 0 .. reserve - 1): one per XCD whether the runtime numbers the CUs XCD by XCD
+     * (33 k / 32 = k) or deals them round-robin (33 k mod 8 = k mod 8) */
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    for (int k = 0; k < c->reserve_cus; k++) {
+        const int i = (33 * k) % ncu;
+        mask[(size_t)i / 32] &= ~(1u << (i % 32));
+    }
+    hipStream_t ns = nullptr;
+    if (hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        return HQ_OK;                            /* no CU masking on this runtime: the exchange waits for free CUs as before */
+    }
+    HQ_HIP(hq_quiesce(c));
+    hipStreamDestroy(c->stream);
+    c->stream = ns;
+    c->stream_masked = true;
+    c->plan.grid_cus = std::max(8, (ncu - c->reserve_cus) & ~7);
+    return HQ_OK;
+}
+
 extern "C" int hq_comm_unique_id(void* id128)
 {
     if (!id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
@@ -1752,7 +1792,7 @@ extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
     HQ_NCCL(g_rccl.CommInitRank(&c->comm, c->nranks, id, c->rank));
     /* between GPUs the exchange is latency the interior patches can hide: run the chain on its own stream */
     c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
-    return HQ_OK;
+    return hq_mask_compute_stream(c);
 }
 
 extern "C" int hq_comm_selftest(hq_ctx* c, int32_t count)
@@ -1789,7 +1829,7 @@ extern "C" int hq_comm_init_host(hq_ctx* c, hq_host_exchange_fn fn, void* user)
     c->host_user = user;
     /* as between GPUs: the chain on its own stream, so that the host waits for the exchange stream only */
     c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
-    return HQ_OK;
+    return hq_mask_compute_stream(c);
 }
 
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
