@@ -152,14 +152,42 @@ static int radix_sort_u64(uint64_t* a, int64_t n, int bits)
     if (!t) return -1;
     uint64_t* src = a;
     uint64_t* dst = t;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = n > (1 << 20) ? omp_get_max_threads() : 1;
+    if (nth > 64) nth = 64;
+#endif
+    int64_t* hist = (int64_t*)malloc(sizeof(int64_t) * 2048 * (size_t)nth);
+    if (!hist) { free(t); return -1; }
     for (int sh = 0; sh < bits; sh += 11) {
-        int64_t cnt[2049];
-        memset(cnt, 0, sizeof cnt);
-        for (int64_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 2047) + 1]++;
-        for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
-        for (int64_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 2047]++] = src[i];
+        /* per-thread histograms over contiguous blocks: a stable parallel counting pass */
+        memset(hist, 0, sizeof(int64_t) * 2048 * (size_t)nth);
+#pragma omp parallel num_threads(nth)
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+            int64_t* h = hist + 2048 * (size_t)tid;
+            for (int64_t i = lo; i < hi; i++) h[(src[i] >> sh) & 2047]++;
+        }
+        int64_t run = 0;
+        for (int d = 0; d < 2048; d++)
+            for (int q = 0; q < nth; q++) { int64_t c = hist[2048 * (size_t)q + d]; hist[2048 * (size_t)q + d] = run; run += c; }
+#pragma omp parallel num_threads(nth)
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+            int64_t* h = hist + 2048 * (size_t)tid;
+            for (int64_t i = lo; i < hi; i++) dst[h[(src[i] >> sh) & 2047]++] = src[i];
+        }
         uint64_t* s = src; src = dst; dst = s;
     }
+    free(hist);
     if (src != a) memcpy(a, src, sizeof(uint64_t) * (size_t)n);
     free(t);
     return 0;
@@ -1336,6 +1364,426 @@ static int face_dashpot(int face, int corner, int halfspace, float size, float V
     return 1;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* per-rank construction of a layered octree box (no whole-box arrays)       */
+/* ------------------------------------------------------------------------ */
+/*
+ * hqh_octbox_create_levels builds the WHOLE box and cuts a rank's part out (octbox_cut): 30 GB and a minute per rank
+ * at 189 M elements.  octbox_local builds the same per-rank tables from the sorted leaf keys alone (the only whole-box
+ * array, 8 B per element): everything a node's row needs is found by locating the leaves around it --
+ *   leaf of a cell            level of its plane, origin = the cell rounded to that level's edge, global element id =
+ *                             position of its key among the sorted leaf keys (octree pre-order = Z-order);
+ *   vertices of a leaf        its eight corners; a node is a vertex of the <= 8 leaves around it whose corner it is;
+ *   owner                     rank of the leaf that contains the (far-boundary adjusted) node (octor.c:5466-5475);
+ *   harbored by               the ranks of the leaves it is a vertex of, its owner, and -- an anchor -- the owners of
+ *                             the hanging nodes on it (indirect sharing, octor.c:5516-6040);
+ *   n_t row                   the elements' contributions in global element order (psolve.c:3436-3471), then the
+ *                             hanging nodes' mass parts in node order (compute_adjust on nTable, psolve.c:3502).
+ * Equal table for table to octbox_cut's output (tests/test_host_partition.py) except gid (the global node index is
+ * not computed: -1).
+ */
+typedef struct { int32_t o[3]; int32_t L; int64_t e; } oct_leaf_t;
+
+#define OCT_BUCKET_BITS 20
+typedef struct {
+    const hqh_octbox* b;
+    const uint64_t* ek;
+    const int64_t* bucket;          /* [2^20 + 1] first leaf whose key's top 20 of 36 bits reach the bucket's */
+    int64_t E;
+    int P;
+    int32_t far[3];
+    const double (*lc)[4];
+    const double *la, *lM;
+    const float *lvp, *lh;
+} oct_ctx_t;
+
+static int oct_leaf_of_cell(const oct_ctx_t* C, int32_t px, int32_t py, int32_t pz, oct_leaf_t* out)
+{
+    if (px < 0 || py < 0 || pz < 0 || px >= C->far[0] || py >= C->far[1] || pz >= C->far[2]) return 0;
+    const int L = octbox_level_at(C->b, pz), s = 1 << L;
+    out->L = L;
+    out->o[0] = px & ~(s - 1); out->o[1] = py & ~(s - 1); out->o[2] = pz & ~(s - 1);
+    const uint64_t key = zvalue((uint32_t)out->o[0], (uint32_t)out->o[1], (uint32_t)out->o[2]);
+    const int64_t bk = (int64_t)(key >> (36 - OCT_BUCKET_BITS));
+    int64_t lo = C->bucket[bk], hi = C->bucket[bk + 1] - 1;
+    if (hi < lo) return 0;
+    while (lo < hi) { int64_t m = (lo + hi) / 2; if (C->ek[m] < key) lo = m + 1; else hi = m; }
+    if (C->ek[lo] != key) return 0;
+    out->e = lo;
+    return 1;
+}
+
+#define OCT_ERANK(C, e) ((int)((((int64_t)(e) + 1) * (C)->P - 1) / (C)->E))      /* octor.c:4939-4944 */
+
+/* the leaves node c is a vertex of, in global element order; corner[k] = which corner of leaf k it is */
+static int oct_leaves_of_node(const oct_ctx_t* C, const int32_t c[3], oct_leaf_t leaf[8], int corner[8])
+{
+    int n = 0;
+    for (int o = 0; o < 8; o++) {
+        oct_leaf_t lf;
+        if (!oct_leaf_of_cell(C, c[0] - (o & 1), c[1] - ((o >> 1) & 1), c[2] - ((o >> 2) & 1), &lf)) continue;
+        const int s = 1 << lf.L;
+        int cb = 0, ok = 1;
+        for (int d = 0; d < 3; d++) {
+            if (c[d] == lf.o[d] + s) cb |= 1 << d;
+            else if (c[d] != lf.o[d]) ok = 0;
+        }
+        if (!ok) continue;
+        int dup = 0;
+        for (int k = 0; k < n; k++) dup |= (leaf[k].e == lf.e);
+        if (dup) continue;
+        int pos = n++;
+        while (pos > 0 && leaf[pos - 1].e > lf.e) { leaf[pos] = leaf[pos - 1]; corner[pos] = corner[pos - 1]; pos--; }
+        leaf[pos] = lf; corner[pos] = cb;
+    }
+    return n;
+}
+
+/* does node c hang?  -> its level (>= 1) and its anchors in octor's list order, or 0 */
+static int oct_node_hangs(const oct_ctx_t* C, const int32_t c[3], int32_t anchor[4][3], int* deps)
+{
+    const hqh_octbox* b = C->b;
+    const int Lh = octbox_level_at(b, c[2] < C->far[2] ? c[2] : C->far[2] - 1);
+    if (Lh < 1 || c[2] != b->ztop[Lh]) return 0;
+    const int32_t m = (1 << Lh) - 1, h = 1 << (Lh - 1);
+    if (!((c[0] & m) || (c[1] & m))) return 0;
+    int na = 0;
+#define OCT_A(dx, dy) { anchor[na][0] = c[0] + (dx); anchor[na][1] = c[1] + (dy); anchor[na][2] = c[2]; na++; }
+    if ((c[0] & m) && (c[1] & m)) { OCT_A(h, h) OCT_A(-h, h) OCT_A(h, -h) OCT_A(-h, -h) }     /* ZFACE */
+    else if (c[0] & m) { OCT_A(h, 0) OCT_A(-h, 0) }                                          /* XEDGE */
+    else { OCT_A(0, h) OCT_A(0, -h) }                                                         /* YEDGE */
+#undef OCT_A
+    *deps = na;
+    return Lh;
+}
+
+static int oct_owner(const oct_ctx_t* C, const int32_t c[3])
+{
+    oct_leaf_t lf;
+    const int32_t a[3] = { c[0] < C->far[0] ? c[0] : C->far[0] - 1, c[1] < C->far[1] ? c[1] : C->far[1] - 1,
+                           c[2] < C->far[2] ? c[2] : C->far[2] - 1 };
+    if (!oct_leaf_of_cell(C, a[0], a[1], a[2], &lf)) return -1;
+    return OCT_ERANK(C, lf.e);
+}
+
+/* the element contributions to node c's n_t row (psolve.c:3436-3471), elements in global order; -> harbor bits of
+ * the elements' ranks */
+static uint64_t oct_node_row(const oct_ctx_t* C, const int32_t c[3], double np[7])
+{
+    const hqh_octbox* b = C->b;
+    oct_leaf_t leaf[8];
+    int corner[8];
+    const int n = oct_leaves_of_node(C, c, leaf, corner);
+    const double dt = b->p.deltaT;
+    uint64_t bits = 0;
+    for (int t = 0; t < 7; t++) np[t] = 0.0;
+    for (int k = 0; k < n; k++) {
+        const int L = leaf[k].L, s = 1 << L;
+        const int32_t q = b->lay0[L] + ((leaf[k].o[2] - b->ztop[L]) >> L);
+        const int face = (leaf[k].o[0] == 0) | ((leaf[k].o[1] == 0) << 1) | ((leaf[k].o[2] == 0) << 2) |
+                         ((leaf[k].o[0] + s == C->far[0]) << 3) | ((leaf[k].o[1] + s == C->far[1]) << 4) |
+                         ((leaf[k].o[2] + s == C->far[2]) << 5);
+        double dash[3];
+        const int bnd = face_dashpot(face, corner[k], b->p.halfspace, C->lh[q], C->lvp[q], b->vs[q], b->rho[q], dash);
+        const double M = C->lM[q], a = C->la[q];
+        np[0] += M;
+        for (int ax = 0; ax < 3; ax++) {
+            np[4 + ax] -= (dt * a * M);
+            np[1 + ax] -= (dt * a * M);
+            if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
+            np[4 + ax] += M;
+            np[1 + ax] += (M * 2);
+        }
+        bits |= 1ull << OCT_ERANK(C, leaf[k].e);
+    }
+    return bits;
+}
+
+static uint64_t oct_node_key(const oct_ctx_t* C, const int32_t c[3])
+{
+    uint32_t d[3];
+    for (int q = 0; q < 3; q++) d[q] = (c[q] == C->far[q]) ? (uint32_t)(2 * c[q] - 1) : (uint32_t)(2 * c[q]);
+    return zvalue(d[0], d[1], d[2]);
+}
+
+static void oct_key_node(const oct_ctx_t* C, uint64_t key, int32_t c[3])
+{
+    const uint32_t d[3] = { compact3(key), compact3(key >> 1), compact3(key >> 2) };
+    for (int q = 0; q < 3; q++) c[q] = (d[q] & 1) ? C->far[q] : (int32_t)(d[q] >> 1);
+}
+
+static int64_t oct_find_key(const uint64_t* keys, int64_t n, uint64_t key)
+{
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) { int64_t m = (lo + hi) / 2; if (keys[m] < key) lo = m + 1; else hi = m; }
+    return (n > 0 && keys[lo] == key) ? lo : -1;
+}
+
+static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const double (*lc)[4], const double* la,
+                        const double* lM, const float* lvp, const float* lh)
+{
+    oct_ctx_t C;
+    C.b = b; C.ek = ek; C.E = b->E; C.P = P;
+    C.far[0] = b->far_q[0]; C.far[1] = b->far_q[1]; C.far[2] = b->far_q[2];
+    C.lc = lc; C.la = la; C.lM = lM; C.lvp = lvp; C.lh = lh;
+    int64_t* bucket = (int64_t*)malloc(sizeof(int64_t) * (((size_t)1 << OCT_BUCKET_BITS) + 1));
+    if (!bucket) return HQ_ERR_NOMEM;
+    {
+        const int64_t nbk = (int64_t)1 << OCT_BUCKET_BITS;
+        int64_t e = 0;
+        for (int64_t k = 0; k <= nbk; k++) {
+            while (e < b->E && (int64_t)(ek[e] >> (36 - OCT_BUCKET_BITS)) < k) e++;
+            bucket[k] = e;
+        }
+    }
+    C.bucket = bucket;
+    const int64_t E = b->E, elo = (int64_t)me * E / P, ehi = (int64_t)(me + 1) * E / P, ne = ehi - elo;
+    int rc = HQ_ERR_NOMEM;
+    uint64_t* keys = NULL;
+    int32_t *lnid = NULL, *xyz = NULL, *own = NULL, *gid = NULL, *dn_id = NULL, *dn_ptr = NULL, *dn_anchor = NULL;
+    double *et = NULL, *nt = NULL;
+    uint64_t* harb = NULL;
+    uint8_t* hang = NULL;
+    /* 1. candidates: the vertices of my elements; the hanging nodes on top of my elements (their containing leaf is
+     *    mine when I own them) and their anchors */
+    int64_t cap = 8 * ne + 64, nk = 8 * ne;
+    keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)cap);
+    if (!keys) goto done;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = elo; e < ehi; e++) {
+        const int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+        const int s = 1 << octbox_level_at(b, k);
+        for (int c = 0; c < 8; c++) {
+            const int32_t p[3] = { i + s * (c & 1), j + s * ((c >> 1) & 1), k + s * ((c >> 2) & 1) };
+            keys[8 * (e - elo) + c] = oct_node_key(&C, p);
+        }
+    }
+    for (int64_t e = elo; e < ehi; e++) {                     /* (the top layers of the coarse slabs only) */
+        const int32_t k = (int32_t)compact3(ek[e] >> 2);
+        const int L = octbox_level_at(b, k), s = 1 << L;
+        if (L < 1 || k != b->ztop[L]) continue;
+        const int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), h = s >> 1;
+        for (int dy = 0; dy <= 2; dy++)
+            for (int dx = 0; dx <= 2; dx++) {
+                const int32_t p[3] = { i + dx * h, j + dy * h, k };
+                int32_t an[4][3];
+                int deps;
+                if (!oct_node_hangs(&C, p, an, &deps) || oct_owner(&C, p) != me) continue;
+                if (nk + 5 > cap) {
+                    cap += cap / 8 + 64;
+                    uint64_t* nw = (uint64_t*)realloc(keys, sizeof(uint64_t) * (size_t)cap);
+                    if (!nw) goto done;
+                    keys = nw;
+                }
+                keys[nk++] = oct_node_key(&C, p);
+                for (int a = 0; a < deps; a++) keys[nk++] = oct_node_key(&C, an[a]);
+            }
+    }
+    if (radix_sort_u64(keys, nk, 36) != 0) goto done;
+    int64_t nh = 0;
+    for (int64_t t = 0; t < nk; t++) if (t == 0 || keys[t] != keys[t - 1]) keys[nh++] = keys[t];
+    {
+        uint64_t* nw = (uint64_t*)realloc(keys, sizeof(uint64_t) * (size_t)(nh ? nh : 1));     /* 8 candidates per node before */
+        if (nw) keys = nw;
+    }
+    /* 2. every harbored node's row */
+    xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(nh ? nh : 1));
+    own = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nh ? nh : 1));
+    gid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nh ? nh : 1));
+    nt = (double*)malloc(sizeof(double) * 7 * (size_t)(nh ? nh : 1));
+    harb = (uint64_t*)calloc((size_t)(nh ? nh : 1), sizeof(uint64_t));
+    hang = (uint8_t*)calloc((size_t)(nh ? nh : 1), 1);
+    lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)(ne ? ne : 1));
+    et = (double*)malloc(sizeof(double) * 4 * (size_t)(ne ? ne : 1));
+    if (!xyz || !own || !gid || !nt || !harb || !hang || !lnid || !et) goto done;
+    int fault = 0;
+    int64_t ndn = 0, nan = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : ndn, nan) reduction(| : fault)
+    for (int64_t l = 0; l < nh; l++) {
+        int32_t c[3];
+        oct_key_node(&C, keys[l], c);
+        memcpy(xyz + 3 * l, c, sizeof c);
+        gid[l] = -1;
+        double* np = nt + 7 * l;
+        uint64_t bits = oct_node_row(&C, c, np);
+        const int o = oct_owner(&C, c);
+        if (o < 0 || !bits) { fault = 1; continue; }
+        own[l] = o;
+        bits |= 1ull << o;
+        int32_t an[4][3];
+        int deps = 0;
+        if (oct_node_hangs(&C, c, an, &deps)) {
+            hang[l] = 1;
+            if (o == me) { ndn++; nan += deps; }
+        } else {
+            /* an anchor?  the hanging nodes around it on its plane, in node order: their mass parts and their owners */
+            const int Lp = octbox_level_at(b, c[2] < C.far[2] ? c[2] : C.far[2] - 1);
+            if (Lp >= 1 && c[2] == b->ztop[Lp]) {
+                const int32_t h = 1 << (Lp - 1);
+                uint64_t hk[8];
+                int32_t hc[8][3];
+                int nhn = 0;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dx && !dy) continue;
+                        const int32_t p[3] = { c[0] + dx * h, c[1] + dy * h, c[2] };
+                        if (p[0] < 0 || p[1] < 0 || p[0] > C.far[0] || p[1] > C.far[1]) continue;
+                        int32_t pa[4][3];
+                        int pd;
+                        if (!oct_node_hangs(&C, p, pa, &pd)) continue;
+                        int mine = 0;
+                        for (int a = 0; a < pd; a++) mine |= (pa[a][0] == c[0] && pa[a][1] == c[1]);
+                        if (!mine) continue;
+                        const uint64_t key = oct_node_key(&C, p);
+                        int pos = nhn++;
+                        while (pos > 0 && hk[pos - 1] > key) { hk[pos] = hk[pos - 1]; memcpy(hc[pos], hc[pos - 1], sizeof hc[0]); pos--; }
+                        hk[pos] = key; memcpy(hc[pos], p, sizeof hc[0]);
+                    }
+                for (int k = 0; k < nhn; k++) {
+                    double hp[7];
+                    int32_t pa[4][3];
+                    int pd;
+                    oct_node_hangs(&C, hc[k], pa, &pd);
+                    oct_node_row(&C, hc[k], hp);
+                    for (int q = 0; q < 7; q++) np[q] += hp[q] / (uint32_t)pd;
+                    const int ho = oct_owner(&C, hc[k]);
+                    if (ho >= 0) bits |= 1ull << ho;                     /* indirect sharing */
+                }
+            }
+        }
+        harb[l] = bits;
+        if (!(bits & (1ull << me))) fault = 1;
+    }
+    if (fault) { rc = HQ_ERR_STATE; goto done; }
+    /* 3. my elements */
+#pragma omp parallel for schedule(static) reduction(| : fault)
+    for (int64_t e = elo; e < ehi; e++) {
+        const int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+        const int L = octbox_level_at(b, k), s = 1 << L;
+        const int32_t q = b->lay0[L] + ((k - b->ztop[L]) >> L);
+        for (int c4 = 0; c4 < 4; c4++) et[4 * (e - elo) + c4] = lc[q][c4];
+        for (int c = 0; c < 8; c++) {
+            const int32_t p[3] = { i + s * (c & 1), j + s * ((c >> 1) & 1), k + s * ((c >> 2) & 1) };
+            const int64_t l = oct_find_key(keys, nh, oct_node_key(&C, p));
+            if (l < 0) fault = 1;
+            lnid[8 * (e - elo) + c] = (int32_t)l;
+        }
+    }
+    if (fault) { rc = HQ_ERR_STATE; goto done; }
+    /* 4. dnodeTable of the hanging nodes I own, node order, anchors in octor's list order */
+    dn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ndn ? ndn : 1));
+    dn_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ndn + 1));
+    dn_anchor = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nan ? nan : 1));
+    if (!dn_id || !dn_ptr || !dn_anchor) goto done;
+    {
+        int32_t kd = 0, na = 0;
+        dn_ptr[0] = 0;
+        for (int64_t l = 0; l < nh; l++) {
+            if (!hang[l] || own[l] != me) continue;
+            int32_t an[4][3];
+            int deps;
+            oct_node_hangs(&C, xyz + 3 * l, an, &deps);
+            dn_id[kd] = (int32_t)l;
+            for (int a = 0; a < deps; a++) {
+                const int64_t al = oct_find_key(keys, nh, oct_node_key(&C, an[a]));
+                if (al < 0) { rc = HQ_ERR_STATE; goto done; }
+                dn_anchor[na++] = (int32_t)al;
+            }
+            dn_ptr[++kd] = na;
+        }
+    }
+    /* 5. schedule_build (psolve.c:4704-4863), as octbox_cut */
+    {
+        const uint64_t mebit = 1ull << me;
+        for (int s = 0; s < 2; s++) {
+            int64_t ccount[64], scount[64], cfill[64], sfill[64];
+            memset(ccount, 0, sizeof ccount); memset(scount, 0, sizeof scount);
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1) {
+                    int64_t ct = 0, st = 0;
+                    for (int r = 0; r < P; r++) { ct += ccount[r]; st += scount[r]; b->nc[s] += ccount[r] > 0; b->ns[s] += scount[r] > 0; }
+                    b->cmap[s] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ct ? ct : 1));
+                    b->smap[s] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(st ? st : 1));
+                    b->mc[s] = (hq_messenger*)calloc((size_t)(b->nc[s] ? b->nc[s] : 1), sizeof(hq_messenger));
+                    b->ms[s] = (hq_messenger*)calloc((size_t)(b->ns[s] ? b->ns[s] : 1), sizeof(hq_messenger));
+                    if (!b->cmap[s] || !b->smap[s] || !b->mc[s] || !b->ms[s]) goto done;
+                    int64_t co = 0, so = 0;
+                    int ic = 0, is = 0;
+                    for (int r = 0; r < P; r++) {
+                        if (ccount[r]) { b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++; }
+                        if (scount[r]) { b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++; }
+                    }
+                }
+                for (int64_t l = 0; l < nh; l++) {
+                    if ((int)hang[l] != s) continue;
+                    if (own[l] != me) {
+                        if (pass == 0) ccount[own[l]]++; else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
+                        continue;
+                    }
+                    uint64_t m = harb[l] & ~mebit;
+                    for (int r = 0; m; r++, m >>= 1)
+                        if (m & 1) { if (pass == 0) scount[r]++; else b->smap[s][sfill[r]++] = (int32_t)l; }
+                }
+            }
+        }
+    }
+    b->lnid = lnid; b->node_xyz = xyz; b->etable = et; b->ntable = nt;
+    b->dn_id = dn_id; b->dn_ptr = dn_ptr; b->dn_anchor = dn_anchor;
+    b->owner = own; b->gid = gid;
+    lnid = xyz = own = gid = dn_id = dn_ptr = dn_anchor = NULL; et = nt = NULL;
+    b->E = ne; b->N = nh; b->ldnnum = (int32_t)ndn;
+    rc = HQ_OK;
+done:
+    free(keys); free(harb); free(hang); free(bucket);
+    free(lnid); free(xyz); free(own); free(gid); free(dn_id); free(dn_ptr); free(dn_anchor); free(et); free(nt);
+    return rc;
+}
+#undef OCT_ERANK
+
+/* element constants per element layer (mu_and_lambda psolve.c:3236-3272 + psolve.c:3387-3409, 3436-3437), as in
+ * hqh_octbox_create_levels; the arrays are the caller's to free */
+static int octbox_layer_constants(const hqh_octbox* b, double (**plc)[4], double** pla, double** plM, float** plvp, float** plh)
+{
+    const hqh_octlevels_params* p = &b->p;
+    const int NL = p->nlevels;
+    const int32_t nlay = b->lay0[NL];
+    double aBase, bBase, dt = p->deltaT, dt2 = dt * dt;
+    rayleigh_base(p->freq, p->damping, &aBase, &bBase);
+    double (*lc)[4] = (double (*)[4])malloc(sizeof(double) * 4 * (size_t)nlay);
+    double* la = (double*)malloc(sizeof(double) * (size_t)nlay);
+    double* lM = (double*)malloc(sizeof(double) * (size_t)nlay);
+    float* lvp = (float*)malloc(sizeof(float) * (size_t)nlay);
+    float* lh = (float*)malloc(sizeof(float) * (size_t)nlay);
+    int rc = HQ_OK;
+    if (!lc || !la || !lM || !lvp || !lh) rc = HQ_ERR_NOMEM;
+    for (int L = 0; L < NL && rc == HQ_OK; L++)
+    for (int32_t q = b->lay0[L]; q < b->lay0[L + 1]; q++) {
+        float Vp = b->vp[q], Vs = b->vs[q], rho = b->rho[q], h = (float)(p->h * (1 << L));
+        lh[q] = h;
+        double mu = rho * Vs * Vs, lambda;
+        if (Vp > (Vs * p->threshold_vpvs)) lambda = rho * Vs * Vs * p->threshold_vpvs * p->threshold_vpvs - 2 * mu;
+        else lambda = rho * Vp * Vp - 2 * mu;
+        if (lambda < 0) {
+            if (Vs < 500) Vp = 2.45 * Vs; else if (Vs < 1200) Vp = 2 * Vs; else Vp = 1.87 * Vs;
+            lambda = rho * Vp * Vp;
+        }
+        if (lambda < 0) { rc = HQ_ERR_ARG; break; }
+        lvp[q] = Vp;
+        double zeta = 10 / Vs;
+        if (zeta > p->threshold_damping) zeta = p->threshold_damping;
+        double a = zeta * aBase, bb = zeta * bBase;
+        lc[q][0] = dt2 * h * mu / 9; lc[q][1] = dt2 * h * lambda / 9;
+        lc[q][2] = bb * dt * h * mu / 9; lc[q][3] = bb * dt * h * lambda / 9;
+        la[q] = a;
+        double mass = rho * h * h * h;
+        lM[q] = mass / 8;
+    }
+    if (rc != HQ_OK) { free(lc); free(la); free(lM); free(lvp); free(lh); return rc; }
+    *plc = lc; *pla = la; *plM = lM; *plvp = lvp; *plh = lh;
+    return HQ_OK;
+}
+
 int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
 {
     if (!p || !out) return HQ_ERR_ARG;
@@ -1377,6 +1825,36 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
     if (nx > 2047 || ny > 2047 || nzt > 2047) { hqh_octbox_destroy(b); return HQ_ERR_ARG; }
     if (E > 0x7fffffff / 8 || N > 0x7fffffff / 8) { hqh_octbox_destroy(b); return HQ_ERR_ARG; }
     b->E = E; b->N = N;
+    {
+        /* partitions of a large box: this rank's tables alone (octbox_local); HQH_OCTBOX_LOCAL = 1 / 0 forces / forbids */
+        const char* le = getenv("HQH_OCTBOX_LOCAL");
+        if (P > 1 && (le ? atoi(le) != 0 : E >= 4000000)) {
+            uint64_t* lek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
+            if (!lek) { hqh_octbox_destroy(b); return HQ_ERR_NOMEM; }
+            int64_t te = 0;
+            for (int L = 0; L < NL; L++) {
+                const int32_t s = 1 << L;
+                const int64_t per = (int64_t)(nx >> L) * (ny >> L);
+#pragma omp parallel for schedule(static)
+                for (int32_t kk = 0; kk < b->layers[L]; kk++) {
+                    const int32_t k = b->ztop[L] + kk * s;
+                    int64_t t2 = te + (int64_t)kk * per;
+                    for (int32_t j = 0; j < ny; j += s)
+                        for (int32_t i = 0; i < nx; i += s) lek[t2++] = zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k);
+                }
+                te += per * b->layers[L];
+            }
+            double (*lc)[4] = NULL;
+            double *la = NULL, *lM = NULL;
+            float *lvp = NULL, *lh = NULL;
+            int rc = radix_sort_u64(lek, E, 36) != 0 ? HQ_ERR_NOMEM : octbox_layer_constants(b, &lc, &la, &lM, &lvp, &lh);
+            if (rc == HQ_OK) rc = octbox_local(b, lek, p->rank, P, (const double (*)[4])lc, la, lM, lvp, lh);
+            free(lc); free(la); free(lM); free(lvp); free(lh); free(lek);
+            if (rc != HQ_OK) { hqh_octbox_destroy(b); return rc; }
+            *out = b;
+            return HQ_OK;
+        }
+    }
     int64_t G = (int64_t)(nx + 1) * (ny + 1) * (nzt + 1);
     uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
     uint64_t* nk = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);

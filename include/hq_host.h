@@ -305,6 +305,9 @@ typedef struct {
 } hqh_octlevels_params;
 
 HQ_API int  hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out);
+/* With nranks > 1 and >= 4 M elements in the whole box (or HQH_OCTBOX_LOCAL=1; =0 forbids) only this rank's tables are
+ * built -- from the sorted leaf keys, no whole-box arrays: equal table for table to the cut of the whole box, except
+ * that the global node index (view 8, `gid`) is then -1 for every node. */
 
 /*
  * The column of leaves the reference's mesher makes of a layered model (material a function of

@@ -531,3 +531,46 @@ def test_laterally_varying_material_tables_equal_the_oracles_bitwise(nranks):
         e0 += E
         b.close()
     whole.close()
+
+
+def _octbox_tables(b):
+    sch = b.schedules()
+    return dict(lnid=b.lnid.copy(), xyz=b.node_xyz.copy(), et=b.etable.copy(), nt=b.ntable.copy(), owner=b.owner.copy(),
+                dn=[np.asarray(x).copy() for x in b.dangling],
+                sch={k: {lst: [(int(pr), np.asarray(m).copy()) for pr, m in sch[k][lst]] for lst in sch[k]} for k in sch})
+
+
+@pytest.mark.parametrize("kind,nranks", [("two_level", 3), ("two_level", 8), ("o3s", 5), ("o3s", 8)])
+def test_per_rank_construction_of_octree_boxes_equals_the_cut_of_the_whole_box(kind, nranks, monkeypatch):
+    """hqh_octbox_create_levels on a partition: built from the sorted leaf keys alone (HQH_OCTBOX_LOCAL=1: what large
+    boxes get -- no whole-box arrays, so that eight ranks of a 189 M-element basin do not each build all of it) against
+    the whole box cut into octor's per-rank tables (octor.c:4939-4944 partition, :5466-5475 ownership, :5516-6040
+    sharing): connectivity, coordinates, eTable, nTable (bit for bit: element order, then the hanging nodes' mass
+    parts), owners, dnodeTable with its anchor order, both schedules."""
+    import bench
+
+    def make(rank):
+        if kind == "o3s":
+            return bench.make_octbox("o3s", rank, nranks)[0]
+        return host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, rank=rank, nranks=nranks)
+    for rank in range(nranks):
+        monkeypatch.setenv("HQH_OCTBOX_LOCAL", "0")
+        whole = make(rank)
+        a = _octbox_tables(whole)
+        assert (whole.gid >= 0).all()
+        whole.close()
+        monkeypatch.setenv("HQH_OCTBOX_LOCAL", "1")
+        loc = make(rank)
+        b = _octbox_tables(loc)
+        assert (loc.gid == -1).all()                          # the global node index is the one thing not computed
+        loc.close()
+        for k in ("lnid", "xyz", "et", "nt", "owner"):
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (rank, k)
+        for x, y in zip(a["dn"], b["dn"]):
+            assert np.array_equal(x, y), (rank, "dangling")
+        assert a["sch"].keys() == b["sch"].keys()
+        for k in a["sch"]:
+            for lst in a["sch"][k]:
+                assert len(a["sch"][k][lst]) == len(b["sch"][k][lst]), (rank, k, lst)
+                for (p1, m1), (p2, m2) in zip(a["sch"][k][lst], b["sch"][k][lst]):
+                    assert p1 == p2 and np.array_equal(m1, m2), (rank, k, lst, p1)
