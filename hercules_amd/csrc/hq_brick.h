@@ -21,8 +21,9 @@
  *                 other columns or non-brick nodes); a thread reduces the 9 rows around its node ONCE to the 22
  *                 in-plane sums the cube symmetry of S leaves distinct, and those feed the three output planes p-1,
  *                 p, p+1 (accumulators in registers): 27 LDS reads and ~85 fp64 operations per node instead of 81 and
- *                 153+, and 72 B + 2 x 48 B x 148/512 = 100 B ... of which the ring rows are L2 hits of the
- *                 neighbouring columns marching beside this one.
+ *                 153+.  HBM: the compulsory 72 B per node + the ring (148 rows of 48 B per 512 nodes, most of them
+ *                 L2 hits of the neighbouring columns marching beside this one) + 2 planes per unit + the id tables:
+ *                 measured 84 B per node on the 64M box (hq_k_patch_stencil: 106).
  * Measured before integration (profiles/micro/march_stencil.hip, 512 x 512 x 256 nodes): 0.98 ms per step against
  * 0.94 ms for the same loads and stores without the stencil, i.e. the compulsory 72 B per node at 4.9 TB/s.
  * Summation order differs from the element kernels and from hq_k_patch_stencil (same operator): GPU parity bar 1e-9.

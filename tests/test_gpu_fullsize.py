@@ -191,7 +191,7 @@ def test_all_c_host_program(tmp_path):
 
 
 @pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 0, 1, 0), ("c2", 1, 0, 0), ("c2", 1, 1, 0), ("c2", 1, 1, 1),
-                                                      ("c2", 0, 1, 1), ("c3", 1, 1, 1)])
+                                                      ("c2", 0, 1, 1), ("c3", 1, 1, 1), ("c2", 0, 1, 2)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
@@ -202,6 +202,8 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     monkeypatch.setenv("HQ_PATCH_RAGGED", "1" if ragged else "0")      # (the default is 1)
     if not bricks:                                                      # the patch kernels take every node
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
+    if bricks == 2:                                                     # the in-process transport with copies instead of
+        monkeypatch.setenv("HQ_GROUP_COPIES", "1")                      # the pack kernel writing into the peers' buffers
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
     nsteps = 3

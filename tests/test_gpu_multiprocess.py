@@ -40,10 +40,12 @@ def _launch(tmp_path, world, kind, nsteps, env_extra=None):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,overlap", [(2, "1"), (4, "1"), (4, "0")])
-def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,cu_mask", [(2, "1", "0"), (4, "1", "0"), (4, "0", "0"), (2, "1", "1")])
+def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, overlap, cu_mask):
+    """cu_mask = 1: the compute stream re-created with a CU mask that leaves HQ_RESERVE_CUS CUs to the exchange stream
+    (HQ_CU_MASK=1, opt-in: DESIGN.md s6)."""
     nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 20
-    parts = _launch(tmp_path, world, "box", nsteps, {"HQ_OVERLAP": overlap})
+    parts = _launch(tmp_path, world, "box", nsteps, {"HQ_OVERLAP": overlap, "HQ_CU_MASK": cu_mask})
     from hercules_amd import host
     b = host.Box(nx, ny, nz, h, dt, freq)
     ijk = b.node_ijk.astype(np.int64)
