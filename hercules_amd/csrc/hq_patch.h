@@ -2114,6 +2114,14 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                         pers_fits(std::max(P->cfg.nlmax, HQ_LAT_ROWS), 0);
     for (;;) {
         if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H, n0) != 0) return -1 /* HQ_ERR_ARG */;
+        /* behind bricks the patches are the shell of the mesh -- a few thousand, 15 per CU on the 64M box: the
+         * persistent kernels' prologue and work queue cost more than they save there, and one workgroup per patch
+         * (hq_k_patch_step, two per CU) fills the device at once: 64M box 1.104 -> 1.060 ms per step, 8M box
+         * 0.159 -> 0.148 on the same box.  HQ_PATCH_PIPE overrides. */
+        if (n0 > 0 && !getenv("HQ_PATCH_PIPE") && P->pipe != 0 && H.desc.size() <= 16384) {
+            P->pipe = 0;
+            if (want_lattice) { want_lattice = false; H = hq_patch_host(); continue; }
+        }
         int32_t mp = 0, nl = 0;
         for (size_t p = 0; p < H.desc.size(); p++) { mp = std::max(mp, H.desc[p].npairs); nl += H.lattice[p]; }
         P->nlattice = nl;
