@@ -124,12 +124,23 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     /* levels: elements by edge length (ticks) */
     std::vector<int32_t> hs((size_t)E);
     std::map<int32_t, int64_t> cnt;
-    for (int64_t e = 0; e < E; e++) {
-        const int32_t* id = lnid + 8 * e;
-        const int64_t h = (int64_t)xyz[3 * (int64_t)id[1]] - xyz[3 * (int64_t)id[0]];
-        if (h <= 0 || h > 0x7fffffff) return 0;                  /* not the corner order of octor.c:6444-6470: no bricks */
-        hs[(size_t)e] = (int32_t)h;
-        cnt[(int32_t)h]++;
+    {
+        bool bad_order = false;
+#pragma omp parallel
+        {
+            std::map<int32_t, int64_t> mine;
+#pragma omp for schedule(static) reduction(|| : bad_order)
+            for (int64_t e = 0; e < E; e++) {
+                const int32_t* id = lnid + 8 * e;
+                const int64_t h = (int64_t)xyz[3 * (int64_t)id[1]] - xyz[3 * (int64_t)id[0]];
+                if (h <= 0 || h > 0x7fffffff) { bad_order = true; hs[(size_t)e] = 0; continue; }
+                hs[(size_t)e] = (int32_t)h;
+                mine[(int32_t)h]++;
+            }
+#pragma omp critical
+            for (auto& kv : mine) cnt[kv.first] += kv.second;
+        }
+        if (bad_order) return 0;                                 /* not the corner order of octor.c:6444-6470: no bricks */
     }
 
     struct level_t {
@@ -150,10 +161,16 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         level_t L;
         L.h = h;
         int64_t mn[3] = { INT64_MAX, INT64_MAX, INT64_MAX }, mx[3] = { INT64_MIN, INT64_MIN, INT64_MIN };
-        for (int64_t e = 0; e < E; e++) {
-            if (hs[(size_t)e] != h) continue;
-            const int32_t* p = xyz + 3 * (int64_t)lnid[8 * e];
-            for (int d = 0; d < 3; d++) { mn[d] = std::min<int64_t>(mn[d], p[d]); mx[d] = std::max<int64_t>(mx[d], p[d]); }
+        {
+            int64_t mn0 = INT64_MAX, mn1 = INT64_MAX, mn2 = INT64_MAX, mx0 = INT64_MIN, mx1 = INT64_MIN, mx2 = INT64_MIN;
+#pragma omp parallel for schedule(static) reduction(min : mn0, mn1, mn2) reduction(max : mx0, mx1, mx2)
+            for (int64_t e = 0; e < E; e++) {
+                if (hs[(size_t)e] != h) continue;
+                const int32_t* p = xyz + 3 * (int64_t)lnid[8 * e];
+                mn0 = std::min<int64_t>(mn0, p[0]); mn1 = std::min<int64_t>(mn1, p[1]); mn2 = std::min<int64_t>(mn2, p[2]);
+                mx0 = std::max<int64_t>(mx0, p[0]); mx1 = std::max<int64_t>(mx1, p[1]); mx2 = std::max<int64_t>(mx2, p[2]);
+            }
+            mn[0] = mn0; mn[1] = mn1; mn[2] = mn2; mx[0] = mx0; mx[1] = mx1; mx[2] = mx2;
         }
         bool ok = true;
         for (int d = 0; d < 3; d++) {
@@ -168,27 +185,33 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         std::vector<int32_t>& Eg = L.Eg;
         Eg.assign((size_t)(L.D[0] * L.D[1] * L.D[2]), -1);
         L.Ng.assign((size_t)(NX * NY * NZ), -1);
-        for (int64_t e = 0; e < E && ok; e++) {
-            if (hs[(size_t)e] != h) continue;
-            const int32_t* id = lnid + 8 * e;
-            int64_t q[3];
-            for (int d = 0; d < 3; d++) {
-                const int64_t v = (int64_t)xyz[3 * (int64_t)id[0] + d] - L.O[d];
-                if (v % h) ok = false;
-                q[d] = v / h;
+        /* fill in parallel (two elements of one cell, or two ids at one position, overwrite each other), then verify:
+         * every element must find itself in its cell and its eight ids at their positions */
+        for (int pass = 0; pass < 2 && ok; pass++) {
+            bool bad = false;
+#pragma omp parallel for schedule(static) reduction(|| : bad)
+            for (int64_t e = 0; e < E; e++) {
+                if (hs[(size_t)e] != h) continue;
+                const int32_t* id = lnid + 8 * e;
+                int64_t q[3];
+                bool good = true;
+                for (int d = 0; d < 3; d++) {
+                    const int64_t v = (int64_t)xyz[3 * (int64_t)id[0] + d] - L.O[d];
+                    if (v % h) good = false;
+                    q[d] = v / h;
+                }
+                if (!good) { bad = true; continue; }
+                int32_t& cell = Eg[(size_t)((q[2] * L.D[1] + q[1]) * L.D[0] + q[0])];
+                if (pass == 0) cell = (int32_t)e; else if (cell != (int32_t)e) bad = true;
+                for (int c = 0; c < 8; c++) {
+                    const int64_t X = q[0] + (c & 1), Y = q[1] + ((c >> 1) & 1), Z = q[2] + ((c >> 2) & 1);
+                    const int32_t* p = xyz + 3 * (int64_t)id[c];
+                    if (p[0] != L.O[0] + X * h || p[1] != L.O[1] + Y * h || p[2] != L.O[2] + Z * h) { bad = true; break; }
+                    int32_t& g = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                    if (pass == 0) g = id[c]; else if (g != id[c]) bad = true;
+                }
             }
-            if (!ok) break;
-            int32_t& cell = Eg[(size_t)((q[2] * L.D[1] + q[1]) * L.D[0] + q[0])];
-            if (cell != -1) { ok = false; break; }
-            cell = (int32_t)e;
-            for (int c = 0; c < 8 && ok; c++) {
-                const int64_t X = q[0] + (c & 1), Y = q[1] + ((c >> 1) & 1), Z = q[2] + ((c >> 2) & 1);
-                const int32_t* p = xyz + 3 * (int64_t)id[c];
-                if (p[0] != L.O[0] + X * h || p[1] != L.O[1] + Y * h || p[2] != L.O[2] + Z * h) { ok = false; break; }
-                int32_t& g = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
-                if (g == -1) g = id[c];
-                else if (g != id[c]) ok = false;
-            }
+            if (bad) ok = false;
         }
         if (!ok) continue;
         /* simple nodes */
