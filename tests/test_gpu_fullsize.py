@@ -190,7 +190,7 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 0, 1, 0), ("c2", 1, 0, 0), ("c2", 1, 1, 0), ("c2", 1, 1, 1),
+@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 1, 0, 0), ("c2", 1, 1, 0), ("c2", 1, 1, 1),
                                                       ("c2", 0, 1, 1), ("c3", 1, 1, 1), ("c2", 0, 1, 2)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
