@@ -12,6 +12,7 @@ import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R02 = os.path.join(ROOT, "profiles", "r02")
+R03 = os.path.join(ROOT, "profiles", "r03")
 
 
 def _per_kernel(path, counter, drop=None):
@@ -43,6 +44,28 @@ def test_traffic_and_fraction_from_the_committed_counter_passes(tag, line_file):
     counter_frac = total / (line["roofline"]["kernel_ms"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBS
     # round 2's lines called this `frac`; since round 3 it is `counter_frac` and `frac` is the compulsory-byte fraction
     assert 0.0 < counter_frac <= 1.0 and abs(counter_frac - line["roofline"]["frac"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag,line_file,kernel", [("v18", "bench_default_v18.json", "hq_k_brick"),
+                                                  ("c3h_v18", "bench_c3h_v18.json", "hq_k_brick")])
+def test_round3_lines_follow_from_their_counter_passes(tag, line_file, kernel):
+    """Round 3's committed lines (bricks: hq_k_brick / hq_k_brick_het + the patch kernel of the faces beside it):
+    `traffic`, `counter_frac`, `wasted` follow from the committed counter CSVs; `frac` is the compulsory-byte fraction."""
+    pmc = {"FETCH_SIZE": _per_kernel(os.path.join(R03, "pmc_%s_fetch_size.csv" % tag), "FETCH_SIZE"),
+           "WRITE_SIZE": _per_kernel(os.path.join(R03, "pmc_%s_write_size.csv" % tag), "WRITE_SIZE")}
+    line = json.load(open(os.path.join(R03, line_file)))
+    r = line["roofline"]
+    assert r["kernel"] == kernel
+    total, rd, wr, steps = bench.traffic_of(pmc, kernel)
+    assert steps == 4 and abs(total - r["traffic"]) <= 1e-6 * total
+    nodes = line["config"]["nodes"]
+    comp = bench.COMPULSORY_BYTES_PER_NODE * nodes
+    assert abs(r["compulsory_bytes_per_launch"] - comp) < 1.0 and total >= 0.99 * comp
+    assert abs(r["wasted"] - total / comp) < 1e-9
+    t = r["kernel_ms"] * 1e-3
+    assert abs(r["frac"] - comp / t / 1e9 / bench.HBM_PEAK_GBS) < 1e-9
+    assert abs(r["counter_frac"] - total / t / 1e9 / bench.HBM_PEAK_GBS) < 1e-9
+    assert 0.0 < r["frac"] <= r["counter_frac"] <= 1.0
 
 
 def test_step_count_does_not_depend_on_which_kernels_a_step_launches():
