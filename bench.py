@@ -544,24 +544,48 @@ def main():
     box, solver, N, octree = build_problem(args, rank, world, device)
     rccl_ranks = 1
     transport = "none (one rank)"
-    if world > 1 and os.environ.get("HQ_BENCH_TRANSPORT", "rccl") == "host":
+
+    def gloo_exchange(recvs, sends, tag):
+        reqs = [dist.irecv(torch.from_numpy(buf), src=int(peer), tag=int(tag)) for peer, buf in recvs]
+        reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
+        for r in reqs:
+            r.wait()
+    use_host = world > 1 and os.environ.get("HQ_BENCH_TRANSPORT", "rccl") == "host"
+    rccl_error = None
+    if world > 1 and not use_host:
+        # RCCL over xGMI.  If the communicator cannot be made on ANY rank (it has never run on more than one GPU),
+        # all ranks fall back together to the host-staged transport and the line says so.
+        ok = 1
+        try:
+            idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
+        except ha.HqError as e:
+            idbuf, ok, rccl_error = [None], 0, str(e)
+        dist.broadcast_object_list(idbuf, src=0)
+        if idbuf[0] is not None:
+            try:
+                solver.comm_init(idbuf[0])
+            except ha.HqError as e:
+                ok, rccl_error = 0, str(e)
+        else:
+            ok = 0
+        t_ok = torch.tensor([float(ok)], dtype=torch.float64)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if float(t_ok[0]) >= 1.0:
+            rccl_ranks = int(solver.info()["nranks"])
+            transport = "RCCL grouped send/recv, %d ranks" % rccl_ranks
+        elif ok:
+            raise SystemExit("bench.py: RCCL came up on rank %d but not everywhere; cannot change the transport of a "
+                             "context that has one" % rank)
+        else:
+            use_host = True
+            print("bench.py rank %d: RCCL unavailable (%s); host-staged transport instead" % (rank, rccl_error), file=sys.stderr)
+        flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
+    if use_host:
         # the engine's host-staged transport (hq_comm_init_host) over gloo: several ranks may then share one GPU
         # (HQ_BENCH_SHARE_GPU=1) -- separate processes, contexts and streams as with RCCL, records through pinned memory
-        def gloo_exchange(recvs, sends, tag):
-            reqs = [dist.irecv(torch.from_numpy(buf), src=int(peer), tag=int(tag)) for peer, buf in recvs]
-            reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
-            for r in reqs:
-                r.wait()
         solver.comm_init_host(gloo_exchange)
         rccl_ranks = 0
-        transport = "host-staged (pinned buffers + gloo), %d ranks" % world
-    elif world > 1:
-        idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(idbuf, src=0)
-        solver.comm_init(idbuf[0])
-        rccl_ranks = int(solver.info()["nranks"])
-        transport = "RCCL grouped send/recv, %d ranks" % rccl_ranks
-        flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
+        transport = "host-staged (pinned buffers + gloo), %d ranks" % world + (" [RCCL failed: %s]" % rccl_error if rccl_error else "")
     total_steps = args.warmup + args.steps
     add_source(args, box, solver, octree, total_steps)
     info = solver.info()
