@@ -45,11 +45,15 @@
 /* tile of a HET unit: 62 x 7 owned nodes -- the 64 x 8 threads of the workgroup each evaluate ONE element of the layer,
  * the elements around the owned nodes (element (i, j) has its low corner at node (i - 1, j - 1)); the 78 threads that own
  * no node (row 7, columns 62 and 63) load the <= 142 ring nodes, two each, in the registers the owners use for their node */
-#define HQ_BH_NRT 78
+#ifndef HQ_BH_WAVES          /* tile rows of threads = waves of a HET workgroup: 8 (two workgroups of 512 per CU) */
+#define HQ_BH_WAVES 8
+#endif
+#define HQ_BH_THREADS (64 * HQ_BH_WAVES)
+#define HQ_BH_NRT (64 + 2 * (HQ_BH_WAVES - 1))
 #define HQ_BH_TX 62
-#define HQ_BH_TY 7
+#define HQ_BH_TY (HQ_BH_WAVES - 1)
 #define HQ_BH_PY 65
-#define HQ_BH_ROWS (65 * 9)
+#define HQ_BH_ROWS (65 * (HQ_BH_WAVES + 1))
 
 struct hq_brick_unit {
     int64_t base;                /* device id of node (0, 0) of the unit's first plane; the unit's nodes are
@@ -368,7 +372,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     B->tab.assign((size_t)toff[us.size()] + 64, 0);
     std::vector<int64_t> coff(us.size() + 1, 0);         /* coefficient blocks of the HET units */
     for (size_t u = 0; u < us.size(); u++)
-        coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BK_THREADS * 3 : 0);
+        coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BH_THREADS * 3 : 0);
     B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
     bool fault = false;
     std::vector<char> same(us.size(), 0);
@@ -427,10 +431,10 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             U.coef = coff[(size_t)u];
             double* cf = B->coef.data() + coff[(size_t)u];
             for (int32_t l = 0; l <= np; l++)
-                for (int32_t j = 0; j < HQ_BK_TY; j++)
-                    for (int32_t i = 0; i < HQ_BK_TX; i++) {
+                for (int32_t j = 0; j < HQ_BH_WAVES; j++)
+                    for (int32_t i = 0; i < 64; i++) {
                         const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
-                        double* o = cf + 3 * (((int64_t)l * HQ_BK_TY + j) * HQ_BK_TX + i);
+                        double* o = cf + 3 * (((int64_t)l * HQ_BH_WAVES + j) * 64 + i);
                         int32_t e = -1;
                         if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
                             e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
@@ -615,7 +619,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
  * Two barriers per layer; 2 workgroups per CU (80.7 KB of LDS, <= 128 VGPRs).  Per node and step: 72 B of state +
  * 24 B of n_t + 24 B x 512 / 441 of coefficients + the ring.
  */
-#define HQ_BH_LDS (8 * (2 * 2 * 3 * HQ_BH_ROWS + 6 * HQ_BK_THREADS))
+#define HQ_BH_LDS (8 * (2 * 2 * 3 * HQ_BH_ROWS + 6 * HQ_BH_THREADS))
 #ifndef HQ_BH_ABL            /* experiment builds only (-DHQ_BH_ABL=n, results wrong by construction): 1 no ring loads,
                               * 2 no coefficient loads, 3 no element arithmetic, 4 no n_t loads */
 #define HQ_BH_ABL 0
@@ -629,7 +633,7 @@ static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(HQ_BK_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
+__global__ void __launch_bounds__(HQ_BH_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
 hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
                const double* __restrict__ coef, const double* __restrict__ u1g, const double* __restrict__ u2g,
                double* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
@@ -648,7 +652,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     const int myrow = (ly + 1) * HQ_BH_PY + lx + 1;                    /* node (lx, ly) */
     const int row0 = ly * HQ_BH_PY + lx;                               /* low corner of element (lx, ly): node (lx - 1, ly - 1) */
     /* ring threads: the 78 that never own a node (nx <= 62, ny <= 7); thread q loads the ring slots q and q + 78 */
-    const int rq = ly == 7 ? lx : (lx >= 62 ? 64 + 2 * ly + (lx - 62) : -1);
+    const int rq = ly == HQ_BH_WAVES - 1 ? lx : (lx >= 62 ? 64 + 2 * ly + (lx - 62) : -1);
     const bool ringA = rq >= 0 && rq < nr, ringB = rq >= 0 && rq + HQ_BH_NRT < nr;
     auto ring_row = [&](int r) {
         int rx, ry;
@@ -719,7 +723,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
             if (l + 1 < np) { ridA = rtabA[(int64_t)(l + 3) * nr]; ridB = rtabB[(int64_t)(l + 3) * nr]; }
         }
         double nc1 = 0.0, nc2 = 0.0, nbeta = 0.0;
-        if (l < np && HQ_BH_ABL != 2) { const double* q = cf + (int64_t)(l + 1) * (3 * HQ_BK_THREADS); nc1 = q[0]; nc2 = q[1]; nbeta = q[2]; }
+        if (l < np && HQ_BH_ABL != 2) { const double* q = cf + (int64_t)(l + 1) * (3 * HQ_BH_THREADS); nc1 = q[0]; nc2 = q[1]; nbeta = q[2]; }
         if (HQ_BH_ABL == 2) { nc1 = c1; nc2 = c2; nbeta = beta; }
         /* the element between the planes l and l + 1 */
         double X[8], Y[8], Z[8];
@@ -745,14 +749,14 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 #pragma unroll
         for (int zb = 0; zb < 2; zb++)
 #pragma unroll
-            for (int d = 0; d < 3; d++) xch[(3 * zb + d) * HQ_BK_THREADS + t] = G[0][zb][d];
+            for (int d = 0; d < 3; d++) xch[(3 * zb + d) * HQ_BH_THREADS + t] = G[0][zb][d];
         __syncthreads();
         if (owner) {
             double H0[3], H1[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                H0[d] = G[1][0][d] + xch[d * HQ_BK_THREADS + t + 64];
-                H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BK_THREADS + t + 64];
+                H0[d] = G[1][0][d] + xch[d * HQ_BH_THREADS + t + 64];
+                H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BH_THREADS + t + 64];
             }
             if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
                 double f[3];
@@ -866,7 +870,7 @@ static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const doub
 #define HQ_BK_ARGS count, per_xcd, P->d_units + first, P->d_tab, u1, u2, un, nt3, sp, P->d_src_ent, (sp ? F : nullptr), dt2, hq_stencil().c
         if (k == 0) hq_k_brick<false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1) hq_k_brick<true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
-        else hq_k_brick_het<<<per_xcd * 8, HQ_BK_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
+        else hq_k_brick_het<<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
                                                                              P->d_src_ent, (sp ? F : nullptr), dt2);
 #undef HQ_BK_ARGS
         first += count;

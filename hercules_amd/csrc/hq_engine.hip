@@ -1604,7 +1604,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
         nsame += (U.flags & HQ_BK_NTSAME) != 0;
         if (((U.flags & HQ_BK_NTSAME) != 0) != (u < B.nsame)) bad++;
         if (het != (u >= (int64_t)B.units.size() - B.nhet)) bad++;
-        if (het && (U.coef < 0 || U.coef + (int64_t)(np + 1) * HQ_BK_THREADS * 3 > (int64_t)B.coef.size())) { bad++; continue; }
+        if (het && (U.coef < 0 || U.coef + (int64_t)(np + 1) * HQ_BH_THREADS * 3 > (int64_t)B.coef.size())) { bad++; continue; }
         const int32_t* ring = B.tab.data() + U.tab;
         const int32_t* cap = ring + (int64_t)(np + 2) * nr;
         /* the device id the kernel reads at (x, y) of plane k, k = -1 .. np */
@@ -1644,7 +1644,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                         if (het) {
                             /* the element whose corner o the node is: column (x - ox + 1, y - oy + 1) of layer k - oz + 1 */
                             const int i = x - (o & 1) + 1, j = y - ((o >> 1) & 1) + 1, l = k - ((o >> 2) & 1) + 1;
-                            const double* q = B.coef.data() + U.coef + 3 * (((int64_t)l * HQ_BK_TY + j) * HQ_BK_TX + i);
+                            const double* q = B.coef.data() + U.coef + 3 * (((int64_t)l * HQ_BH_WAVES + j) * 64 + i);
                             if (c1[(size_t)e] != q[0] || c2[(size_t)e] != q[1] || beta[(size_t)e] != q[2]) ok = false;
                         } else if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
                     }
