@@ -37,10 +37,10 @@ def _run(box, variant, u1, u2, nsteps, src=None):
     return out
 
 
-@pytest.mark.parametrize("wl", ["c2", "c3", "c2-noragged"])
+@pytest.mark.parametrize("wl", ["c2", "c3", "c2-nobricks"])
 def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
-    if wl.endswith("-noragged"):     # the domain-face and far-face patches in the element form
-        monkeypatch.setenv("HQ_PATCH_RAGGED", "0")
+    if wl.endswith("-nobricks"):     # the patch kernels alone (lattice / ragged stencil patches, element form), as without node_xyz
+        monkeypatch.setenv("HQ_NO_BRICKS", "1")
         wl = wl.split("-")[0]
     nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
                                "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
@@ -190,8 +190,8 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 1, 0, 0), ("c2", 1, 1, 0), ("c2", 1, 1, 1),
-                                                      ("c2", 0, 1, 1), ("c3", 1, 1, 1), ("c2", 0, 1, 2)])
+@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 1, 1, 0), ("c2", 1, 1, 1), ("c2", 0, 1, 1), ("c3", 1, 1, 1),
+                                                      ("c2", 0, 1, 2)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
