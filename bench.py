@@ -41,6 +41,9 @@ BYTES_PER_ELEMENT_UPDATE = 336.0
 BYTES_ELEMENT_PHASE = 160.0          # lnid 32 + coefficients 32 + tm1,tm2 48 + force RMW 48
 # what ANY formulation must move per node and step: read u(t), u(t-dt), write u(t+dt)
 COMPULSORY_BYTES_PER_NODE = 72.0
+# a mesh whose material differs from element to element also has to read every node's own n_t row (24 B in the
+# 3-double form) and every element's (c1, c2, beta) (24 B; elements ~ nodes): 120 B per node and step
+COMPULSORY_BYTES_PER_NODE_LATERAL = 120.0
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 WORKLOADS = {
@@ -622,7 +625,8 @@ def main():
         value = E_total * args.steps / elapsed
         is_patch = info["variant"] == ha.HQ_VARIANT_PATCH
         kernel = solver.dominant_kernel()
-        compulsory = COMPULSORY_BYTES_PER_NODE * N         # this rank's nodes: read u(t), u(t-dt), write u(t+dt)
+        per_node = COMPULSORY_BYTES_PER_NODE_LATERAL if args.workload in LATERAL else COMPULSORY_BYTES_PER_NODE
+        compulsory = per_node * N                          # this rank's nodes: read u(t), u(t-dt), write u(t+dt) (+ n_t, coefficients)
         traffic = rd = wr = None
         source = None
         if pmc is not None and "error" not in pmc:
@@ -676,7 +680,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": frac, "traffic": traffic, "traffic_read_corrected": rd, "traffic_write": wr,
                          "traffic_source": source,
-                         "achieved_basis": "compulsory bytes: 72 B per node and step",
+                         "achieved_basis": "compulsory bytes: %d B per node and step" % int(per_node),
                          "counter_frac": counter_frac, "achieved_counter": achieved_counter,
                          "wasted": (traffic / compulsory) if traffic is not None else None,
                          "kernel": kernel, "kernel_ms": kernel_ms,
