@@ -36,7 +36,9 @@
 #include "hq_patch.h"
 
 #define HQ_BK_TX 64
+#ifndef HQ_BK_TY            /* tile rows = waves of a workgroup (experiment builds: -DHQ_BK_TY=16) */
 #define HQ_BK_TY 8
+#endif
 #define HQ_BK_THREADS (HQ_BK_TX * HQ_BK_TY)
 #define HQ_BK_PY (HQ_BK_TX + 2)
 #define HQ_BK_PLANE ((HQ_BK_TX + 2) * (HQ_BK_TY + 2))
@@ -53,6 +55,11 @@
 #define HQ_BH_TX 62
 #define HQ_BH_TY (HQ_BH_WAVES - 1)
 #define HQ_BH_PY 65
+#ifdef HQ_BH_COEF_AOS
+#define HQ_BH_CS 1
+#else
+#define HQ_BH_CS HQ_BH_THREADS            /* stride between c1, c2, beta of an element in a layer's coefficient block */
+#endif
 #define HQ_BH_ROWS (65 * (HQ_BH_WAVES + 1))
 
 struct hq_brick_unit {
@@ -64,8 +71,8 @@ struct hq_brick_unit {
     int32_t nx, ny, np, flags;
     double  c1, c2, beta;        /* of the elements around the unit's nodes                                     */
     double  m0, m2, m1;          /* HQ_BK_NTSAME: mass_simple, mass2_minusaM, mass_minusaM of every node        */
-    int64_t coef;                /* HQ_BK_HET: the unit's element coefficients in d_coef, [np + 1 layers][8][64]
-                                  * {c1, c2, beta}: layer l lies between the planes za - 1 + l and za + l, element
+    int64_t coef;                /* HQ_BK_HET: the unit's element coefficients in d_coef, [np + 1 layers]
+                                  * [c1 | c2 | beta][8][64]: layer l lies between the planes za - 1 + l and za + l, element
                                   * (i, j) has its low corner at node (i - 1, j - 1) of the tile; 0 where there is none */
 };
 
@@ -434,11 +441,15 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 for (int32_t j = 0; j < HQ_BH_WAVES; j++)
                     for (int32_t i = 0; i < 64; i++) {
                         const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
+#ifdef HQ_BH_COEF_AOS
                         double* o = cf + 3 * (((int64_t)l * HQ_BH_WAVES + j) * 64 + i);
+#else
+                        double* o = cf + (int64_t)l * (3 * HQ_BH_THREADS) + (j * 64 + i);      /* [layer][c1 | c2 | beta][thread] */
+#endif
                         int32_t e = -1;
                         if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
                             e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
-                        if (e >= 0) { o[0] = c1[e]; o[1] = c2[e]; o[2] = beta[e]; }
+                        if (e >= 0) { o[0] = c1[e]; o[HQ_BH_CS] = c2[e]; o[2 * HQ_BH_CS] = beta[e]; }
                         else if (i <= nx && j <= ny) fault = true;       /* an element around an owned node is missing */
                     }
         }
@@ -508,7 +519,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
 
     double x1[3], x2[3], y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
-    double m0A = U.m0, m0B = U.m0;           /* mass_simple of the output planes k - 1, k */
+    double m0A = 1.0 / U.m0, m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
     double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
     int32_t rid = rtab[0];                   /* ring id of the plane to load next */
 
@@ -592,11 +603,11 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             }
             double* out = ung + 3 * (U.base + (int64_t)local);
 #pragma unroll
-            for (int d = 0; d < 3; d++) out[d] = f[d] / m0A;
+            for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
         }
 #pragma unroll
         for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - Uo[d]; }
-        if (PERNODE) { m0A = m0B; m0B = mn[0]; }
+        if (PERNODE) { m0A = m0B; m0B = 1.0 / mn[0]; }
         if (k <= np) HQ_BK_PUT((k + 1) & 1, fB)
     }
 #undef HQ_BK_LOAD
@@ -628,12 +639,12 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
 static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);     /* wave_shl:1: lane i <- lane i + 1 */
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);      /* wave_shl:1: lane i <- lane i + 1 (lane 63 <- 0: */
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);      /* bound_ctrl, no old value to set up; never an owner) */
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(HQ_BH_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
+__global__ void __launch_bounds__(HQ_BH_THREADS, HQ_BH_WAVES == 12 ? 3 : 4)   /* 8 waves: 4 per SIMD = two workgroups per CU, <= 128 VGPRs */
 hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
                const double* __restrict__ coef, const double* __restrict__ u1g, const double* __restrict__ u2g,
                double* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
@@ -667,7 +678,11 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     const int32_t* __restrict__ rtabB = tab + U.tab + (ringB ? rq + HQ_BH_NRT : 0);
     const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
     const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
+#ifdef HQ_BH_COEF_AOS
     const double* __restrict__ cf = coef + U.coef + 3 * t;
+#else
+    const double* __restrict__ cf = coef + U.coef + t;                 /* [layer][c1 | c2 | beta][thread] */
+#endif
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
     /* an owner's registers: x1, x2 = u1, u2 of its node of the plane in flight, mn = its n_t row, accA / accB = the
@@ -675,25 +690,30 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
      * of ring node B (the same registers: a thread is either the one or the other) */
     double x1[3] = { 0.0, 0.0, 0.0 }, x2[3] = { 0.0, 0.0, 0.0 };
     double mn[3] = { 1.0, 0.0, 0.0 };
-    double accA[3] = { 0.0, 0.0, 0.0 }, accB[3] = { 0.0, 0.0, 0.0 }, m0A = 1.0, m0B = 1.0;
+    double accA[3] = { 0.0, 0.0, 0.0 }, accB[3] = { 0.0, 0.0, 0.0 }, m0A = 1.0, m0B = 1.0;    /* m0: 1 / mass_simple */
     int32_t ridA = rtabA[0], ridB = rtabB[0];
 
+    /* One load per register for all lanes of a wave, the address chosen per lane -- an owner's node or a ring thread's
+     * ring node A into x1, x2; the owner's n_t row or u1 of ring node B into mn -- and no branch around them: two loads
+     * into one register (an owner's and a ring lane's) would have the second wait for the first, and loads behind a
+     * branch cannot be counted by the compiler, whose waits then drain everything.  Only u2 of ring node B (into accB,
+     * which an owner needs for itself) sits behind a branch, as the last of a request. */
 #define HQ_BH_LOAD(node_)                                                                             \
     {                                                                                                 \
-        if (owner) {                                                                                  \
-            const int64_t a_ = (node_);                                                               \
-            _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; if (HQ_BH_ABL != 4) mn[d] = nt3[3 * a_ + d]; } \
-        }                                                                                             \
-        if (ringA && HQ_BH_ABL != 1) {                                                                \
-            const int64_t b_ = (int64_t)ridA;                                                         \
-            _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * b_ + d]; x2[d] = u2g[3 * b_ + d]; } \
-        }                                                                                             \
+        const int64_t a_ = owner ? (int64_t)(node_) : (int64_t)ridA;                                  \
+        const double* __restrict__ pb_ = owner ? nt3 + 3 * a_ : u1g + 3 * (int64_t)ridB;              \
+        _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
+        if (HQ_BH_ABL != 4) { _Pragma("unroll") for (int d = 0; d < 3; d++) mn[d] = pb_[d]; }          \
+    }
+#define HQ_BH_LOAD_B()                                                                                \
+    {                                                                                                 \
         if (ringB && HQ_BH_ABL != 1) {                                                                \
             const int64_t b_ = (int64_t)ridB;                                                         \
-            _Pragma("unroll") for (int d = 0; d < 3; d++) { mn[d] = u1g[3 * b_ + d]; accB[d] = u2g[3 * b_ + d]; } \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) accB[d] = u2g[3 * b_ + d];                  \
         }                                                                                             \
     }
-    /* the loaded plane -> slot s_; acc_ / m0_: seed m2 u1 - m1 u2 and mass_simple of its owned node */
+    /* the loaded plane -> slot s_; acc_ / m0_: seed m2 u1 - m1 u2 and 1 / mass_simple of its owned node (one division per
+     * node instead of three: the quotient differs from the reference's by <= 1 ulp, as the summation order does) */
 #define HQ_BH_PUT(s_, acc_, m0_)                                                                      \
     {                                                                                                 \
         hq_lds_double* iu_ = img + (size_t)(s_) * (2 * 3 * HQ_BH_ROWS);                                \
@@ -703,28 +723,33 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                 iu_[3 * myrow + d] = x1[d]; iv_[3 * myrow + d] = x1[d] - x2[d];                       \
                 acc_[d] = mn[1] * x1[d] - mn[2] * x2[d];                                              \
             }                                                                                         \
-            m0_ = mn[0];                                                                              \
+            m0_ = 1.0 / mn[0];                                                                        \
         }                                                                                             \
         if (ringA) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowA + d] = x1[d]; iv_[3 * rrowA + d] = x1[d] - x2[d]; } } \
         if (ringB) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowB + d] = mn[d]; iv_[3 * rrowB + d] = mn[d] - accB[d]; } } \
     }
 
+    /* request plane p_ (1 .. np + 1) of the march, the ring ids of the plane after it and the coefficients of layer p_ - 1 */
+    double nc1 = 0.0, nc2 = 0.0, nbeta = 0.0, c1 = 0.0, c2 = 0.0, beta = 0.0;
+#define HQ_BH_REQUEST(p_)                                                                             \
+    {                                                                                                 \
+        const int pp_ = (p_);                                                                         \
+        if (HQ_BH_ABL != 2) { const double* q_ = cf + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nc1 = q_[0]; nc2 = q_[HQ_BH_CS]; nbeta = q_[2 * HQ_BH_CS]; } \
+        HQ_BH_LOAD(pp_ == np + 1 ? id_hi : U.base + (int64_t)(pp_ - 1) * nxy + sidx)                  \
+        HQ_BH_LOAD_B()                                                                                \
+        { const int64_t r_ = (int64_t)(pp_ < np + 1 ? pp_ + 1 : np + 1) * nr; ridA = rtabA[r_]; ridB = rtabB[r_]; } \
+    }
+    if (HQ_BH_ABL == 2) { nc1 = dt2; nc2 = dt2; nbeta = dt2; }
     HQ_BH_LOAD(id_lo)
+    HQ_BH_LOAD_B()
     ridA = rtabA[nr]; ridB = rtabB[nr];
-    HQ_BH_PUT(0, accA, m0A)
-    HQ_BH_LOAD(U.base + sidx)                    /* plane 1: the unit's first */
-    ridA = rtabA[2 * (int64_t)nr]; ridB = rtabB[2 * (int64_t)nr];
-    HQ_BH_PUT(1, accB, m0B)
-    double c1 = cf[0], c2 = cf[1], beta = cf[2];
-    __syncthreads();
-    for (int l = 0; l <= np; l++) {
-        if (l < np) {                            /* request plane l + 2 and the coefficients of layer l + 1 */
-            HQ_BH_LOAD(l + 1 == np ? id_hi : U.base + (int64_t)(l + 1) * nxy + sidx)
-            if (l + 1 < np) { ridA = rtabA[(int64_t)(l + 3) * nr]; ridB = rtabB[(int64_t)(l + 3) * nr]; }
-        }
-        double nc1 = 0.0, nc2 = 0.0, nbeta = 0.0;
-        if (l < np && HQ_BH_ABL != 2) { const double* q = cf + (int64_t)(l + 1) * (3 * HQ_BH_THREADS); nc1 = q[0]; nc2 = q[1]; nbeta = q[2]; }
-        if (HQ_BH_ABL == 2) { nc1 = c1; nc2 = c2; nbeta = beta; }
+    /* The loop starts two steps early: steps -2 and -1 only put the planes 0 and 1 into LDS and request the planes 1
+     * and 2.  ONE request site: a plane and the coefficients of the next layer are requested as soon as the registers
+     * are free -- right behind the PUT of the plane before, ahead of the barrier -- and stay in flight through the
+     * whole element step that follows (a second site ahead of the loop, with registers of its own, had the compiler wait
+     * at the top of every step for loads that only the first step could still have pending). */
+    for (int l = -2; l <= np; l++) {
+        if (l >= 0) {
         /* the element between the planes l and l + 1 */
         double X[8], Y[8], Z[8];
 #pragma unroll
@@ -772,17 +797,25 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                 }
                 double* out = ung + 3 * (U.base + (int64_t)local);
 #pragma unroll
-                for (int d = 0; d < 3; d++) out[d] = f[d] / m0A;
+                for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
             }
 #pragma unroll
             for (int d = 0; d < 3; d++) accA[d] = accB[d] + H1[d];
             m0A = m0B;
         }
+        }
         if (l < np) HQ_BH_PUT(l & 1, accB, m0B)
-        __syncthreads();
         c1 = nc1; c2 = nc2; beta = nbeta;
+        /* the coefficients and the ring ids are taken HERE, behind the PUT that has waited for the loads of their batch: a
+         * wait for them further down would have to drain the loads requested next (the compiler cannot count loads
+         * behind branches) */
+        asm volatile("" : "+v"(c1), "+v"(c2), "+v"(beta), "+v"(ridA), "+v"(ridB));
+        if (l + 1 < np) HQ_BH_REQUEST(l + 3)
+        __syncthreads();
     }
+#undef HQ_BH_REQUEST
 #undef HQ_BH_LOAD
+#undef HQ_BH_LOAD_B
 #undef HQ_BH_PUT
 }
 
