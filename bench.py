@@ -63,7 +63,7 @@ WORKLOADS = {
     "o2": (1024, 1024, 128, 1000.0 / 1024, 4.5e-5, 400.0),
 }
 OCT_COARSE_LAYERS = {"o1": 96, "o2": 192}
-# Vp, Vs, rho of an element column (i, j) = the half-space's times a class factor in [0.9, 1.1]; class = hash(i, j) mod 61
+# Vp, Vs, rho of element (i, j, k) = the half-space's times a class factor in [0.9, 1.1]; class = hash(i, j, k) mod 61
 LATERAL = {"c3h": (61, 0.1), "c2h": (61, 0.1), "m1h": (61, 0.1)}
 # layered-basin models meshed by the Vs rule (hqh_layered_column) on several octree levels:
 # name: (nx, ny, finest h [m], dt, freq, points per wavelength, coarsest cell [m], cells in depth,
@@ -83,9 +83,9 @@ for _k, _v in OCT_LAYERED.items():
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
-                  "c3h": "64M-element box 512x512x256, Vp/Vs/rho of every element column perturbed +-10 % (61 classes by coordinate hash), point double-couple source",
-                  "c2h": "8M-element box 256x256x128, Vp/Vs/rho of every element column perturbed +-10 %",
-                  "m1h": "1M-element box 128x128x64, Vp/Vs/rho of every element column perturbed +-10 %",
+                  "c3h": "64M-element box 512x512x256, Vp/Vs/rho of every element perturbed +-10 % (61 classes by a hash of its three indices), point double-couple source",
+                  "c2h": "8M-element box 256x256x128, Vp/Vs/rho of every element perturbed +-10 %",
+                  "m1h": "1M-element box 128x128x64, Vp/Vs/rho of every element perturbed +-10 %",
                   "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)",
                   "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
                   "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",

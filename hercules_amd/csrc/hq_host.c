@@ -220,22 +220,22 @@ static void rayleigh_base(double freq, int damping, double* aBase, double* bBase
 }
 
 /*
- * Lateral classes (hqh_box_params.lateral_classes > 1): the element column (ei, ej) belongs to class
- * hash(ei, ej) mod ncls and its Vp, Vs, rho are the layer's times a class factor in [1 - amp, 1 + amp] -- a mesh
- * whose material differs from element to element, as solver_init sees it on any real CVM (psolve.c:3360-3409 reads
- * every element's own edata_t), while the table of distinct materials stays small.
+ * Material classes (hqh_box_params.lateral_classes > 1): the element (ei, ej, ek) belongs to class
+ * hash(ei, ej, ek) mod ncls and its Vp, Vs, rho are its layer's times a class factor in [1 - amp, 1 + amp] -- a mesh
+ * whose material differs from element to element in all three directions, as solver_init sees it on any real CVM
+ * (psolve.c:3360-3409 reads every element's own edata_t), while the table of distinct materials stays small.
  */
-static inline int32_t lateral_class(const hqh_box* b, int32_t ei, int32_t ej)
+static inline int32_t lateral_class(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek)
 {
     if (b->ncls <= 1) return 0;
-    uint32_t h = (uint32_t)ei * 0x9E3779B1u ^ ((uint32_t)ej * 0x85EBCA77u + 0x165667B1u);
+    uint32_t h = (uint32_t)ei * 0x9E3779B1u ^ ((uint32_t)ej * 0x85EBCA77u + 0x165667B1u) ^ ((uint32_t)ek * 0xC2B2AE3Du + 0x27D4EB2Fu);
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (int32_t)(h % (uint32_t)b->ncls);
 }
 
 static inline int64_t mat_index(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek)
 {
-    return (int64_t)ek * b->ncls + lateral_class(b, ei, ej);
+    return (int64_t)ek * b->ncls + lateral_class(b, ei, ej, ek);
 }
 
 static inline float lateral_factor(const hqh_box* b, int32_t cls)
