@@ -758,9 +758,9 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
             const hq_lds_double* pv = pu + 3 * HQ_BH_ROWS;
             X[m] = fma(beta, pv[0], pu[0]); Y[m] = fma(beta, pv[1], pu[1]); Z[m] = fma(beta, pv[2], pu[2]);
         }
-        if (HQ_BH_ABL != 3) hq_element_force(X, Y, Z, c1, c2);
+        if (HQ_BH_ABL != 3) hq_element_force<true>(X, Y, Z, c1, c2);      /* X[0..3] = a, X[4..7] = b: f(near z) = a - b, f(far z) = a + b */
         /* x: the node's high-x corners are this element's, its low-x corners the next lane's element's */
-        double G[2][2][3];                       /* [y bit][z bit] */
+        double G[2][2][3];                       /* [y bit][a | b] */
 #pragma unroll
         for (int yb = 0; yb < 2; yb++)
 #pragma unroll
@@ -786,7 +786,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
             if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
                 double f[3];
 #pragma unroll
-                for (int d = 0; d < 3; d++) f[d] = accA[d] + H0[d];
+                for (int d = 0; d < 3; d++) f[d] = accA[d] + (H0[d] - H1[d]);
                 const int local = (l - 1) * nxy + sidx;
                 if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
                     for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
@@ -800,7 +800,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                 for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
             }
 #pragma unroll
-            for (int d = 0; d < 3; d++) accA[d] = accB[d] + H1[d];
+            for (int d = 0; d < 3; d++) accA[d] = accB[d] + (H0[d] + H1[d]);
             m0A = m0B;
         }
         }

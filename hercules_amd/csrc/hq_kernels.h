@@ -60,10 +60,30 @@ __host__ __device__ __forceinline__ void hq_wht_inv(double v[8])
     }
 }
 
+/* the transposed butterfly without its last (z) stage: v[0..3] = a, v[4..7] = b with f[n] = a[n] - b[n] on the near
+ * z side and f[n + 4] = a[n] + b[n] on the far one -- for callers that sum over elements first (hq_k_brick_het: the
+ * x / y reductions act on a and b, 6 values less to expand per element) */
+__host__ __device__ __forceinline__ void hq_wht_inv_xy(double v[8])
+{
+#pragma unroll
+    for (int s = 1; s < 4; s <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (!(i & s)) {
+                double lo = v[i], hi = v[i | s];
+                v[i] = lo - hi;
+                v[i | s] = lo + hi;
+            }
+        }
+    }
+}
+
 /*
- * In: X,Y,Z = w[n][0..2] per node.  Out: X,Y,Z = f_e[n][0..2].
+ * In: X,Y,Z = w[n][0..2] per node.  Out: X,Y,Z = f_e[n][0..2] (ZMODES: the z stage of the transposed butterfly is
+ * left to the caller, see hq_wht_inv_xy).
  * c1, c2 as in e_t (psolve.h:196-198).
  */
+template <bool ZMODES = false>
 __host__ __device__ __forceinline__ void hq_element_force(double X[8], double Y[8], double Z[8],
                                                  double c1, double c2)
 {
@@ -101,9 +121,8 @@ __host__ __device__ __forceinline__ void hq_element_force(double X[8], double Y[
     Y[0] = 0.0; Y[1] = sxy; Y[2] = ny;  Y[3] = gy3; Y[4] = syz; Y[5] = gy5; Y[6] = gy6; Y[7] = a2b9 * Y[7];
     Z[0] = 0.0; Z[1] = sxz; Z[2] = syz; Z[3] = gz3; Z[4] = nz;  Z[5] = gz5; Z[6] = gz6; Z[7] = a2b9 * Z[7];
 
-    hq_wht_inv(X);
-    hq_wht_inv(Y);
-    hq_wht_inv(Z);
+    if (ZMODES) { hq_wht_inv_xy(X); hq_wht_inv_xy(Y); hq_wht_inv_xy(Z); }
+    else { hq_wht_inv(X); hq_wht_inv(Y); hq_wht_inv(Z); }
 }
 
 #endif /* HQ_KERNELS_H */
