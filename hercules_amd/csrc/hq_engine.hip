@@ -163,7 +163,8 @@ struct hq_ctx {
     double* d_c2 = nullptr;
     double* d_beta = nullptr;
     /* node data */
-    double* d_nt = nullptr;         /* [N][7] */
+    double* d_nt = nullptr;         /* [N][7]; behind bricks only the rows of the nodes nt_first .. N - 1 exist (d_nt_rows), */
+    double* d_nt_rows = nullptr;    /* d_nt = d_nt_rows - 7 nt_first: no kernel reads a brick node's 7-double row */
     double* d_u[3] = { nullptr, nullptr, nullptr };
     int now = 0, prev = 1, spare = 2;
     double* d_force = nullptr;
@@ -1156,9 +1157,17 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_dev_alloc(c, &c->d_u[b], n3)) != HQ_OK) return bail(rc);
         if (hipMemset(c->d_u[b], 0, sizeof(double) * n3) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
     }
-    if ((rc = hq_dev_alloc(c, &c->d_nt, (size_t)c->N * 7)) != HQ_OK) return bail(rc);
-    if (hipMemcpy(c->d_nt, d->nTable, sizeof(double) * 7 * c->N, hipMemcpyHostToDevice) != hipSuccess)
-        return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
+    {
+        /* brick nodes are updated from the 3-double rows (plan.d_nt3) or the unit's record: their 7-double rows stay on
+         * the host (189 M-element basin: 10.5 GB less to upload and to hold) */
+        const int64_t nt_first = (variant == HQ_VARIANT_PATCH) ? BH.nb : 0;
+        const size_t rows = (size_t)std::max<int64_t>(c->N - nt_first, 1);
+        if ((rc = hq_dev_alloc(c, &c->d_nt_rows, rows * 7)) != HQ_OK) return bail(rc);
+        if (c->N > nt_first &&
+            hipMemcpy(c->d_nt_rows, d->nTable + 7 * nt_first, sizeof(double) * 7 * (size_t)(c->N - nt_first), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
+        c->d_nt = c->d_nt_rows - 7 * nt_first;
+    }
     if (h_tm1 && (rc = hq_field_to_device(c, h_tm1, c->d_u[c->now])) != HQ_OK) return bail(rc);
     if (h_tm2 && (rc = hq_field_to_device(c, h_tm2, c->d_u[c->prev])) != HQ_OK) return bail(rc);
 
@@ -1679,7 +1688,7 @@ extern "C" int hq_destroy(hq_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hq_quiesce(c);
     if (c->comm && g_rccl.handle) g_rccl.CommDestroy(c->comm);
-    void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt, c->d_u[0], c->d_u[1], c->d_u[2],
+    void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt_rows, c->d_u[0], c->d_u[1], c->d_u[2],
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,

@@ -23,6 +23,12 @@
 #ifndef HQ_PATCH_H
 #define HQ_PATCH_H
 
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static inline int omp_get_num_threads(void) { return 1; }
+static inline int omp_get_thread_num(void) { return 0; }
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -563,7 +569,7 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
             maxc[d] = std::max(maxc[d], v);
         }
     int m = orall ? __builtin_ctz(orall) : 0;          /* common edge granularity 2^m ticks */
-    std::vector<uint64_t> key((size_t)N);
+    std::vector<uint64_t> key((size_t)(N - n0));           /* of the nodes n0 .. N - 1 (the brick nodes below have no patch) */
     /* Nodes on the far boundary of the DOMAIN sort one tick inwards (octor.c:6100-6106).  On a partition
      * the largest coordinate of an axis is the domain's far face only for the partitions that touch it
      * (elsewhere those nodes belong to the next partition's cells and sort there), so: the set of axes
@@ -580,8 +586,8 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
                 q[d] = (uint64_t)(v >> m);
                 if (q[d] >> 21) { fixed(); return; }
             }
-            key[n] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
-            if (n > n0 && key[n] < key[n - 1]) sorted = false;
+            key[n - n0] = hq_spread3(q[0]) | (hq_spread3(q[1]) << 1) | (hq_spread3(q[2]) << 2);
+            if (n > n0 && key[n - n0] < key[n - n0 - 1]) sorted = false;
         }
     }
     if (!sorted) { fixed(); return; }                  /* not Z-ordered */
@@ -604,8 +610,8 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
         }
         int sh = it.bit - 1;
         /* first node whose bit `sh` is set (keys are sorted and share the bits above) */
-        int64_t mid = std::partition_point(key.begin() + it.lo, key.begin() + it.hi,
-                                           [sh](uint64_t k) { return ((k >> sh) & 1) == 0; }) - key.begin();
+        int64_t mid = std::partition_point(key.begin() + (it.lo - n0), key.begin() + (it.hi - n0),
+                                           [sh](uint64_t k) { return ((k >> sh) & 1) == 0; }) - key.begin() + n0;
         if (mid < it.hi) stack.push_back({ mid, it.hi, sh });
         if (mid > it.lo) stack.push_back({ it.lo, mid, sh });
     }
@@ -625,8 +631,38 @@ static void hq_patch_cuts(const hq_patch_cfg& cfg, int64_t N, const int32_t* xyz
  * Pair lists and local numbering for the node runs `cuts`.  A run whose halo
  * does not fit LDS is halved and the build repeated.
  */
+/* the elements a patch can need when the nodes below n0 are brick nodes: those with a corner at or above n0, or a
+ * hanging corner (its anchors' owners evaluate the element too) -- in ascending order.  Behind bricks that is the shell
+ * of the mesh, a few per cent of it. */
+static void hq_patch_candidates(int64_t E, const int32_t* lnid, const hq_dangling& dn, const std::vector<int32_t>& dn_of,
+                                int64_t n0, std::vector<int32_t>& cand)
+{
+    cand.clear();
+    int nth = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        nth = omp_get_num_threads();
+    }
+    std::vector<std::vector<int32_t>> part((size_t)nth);
+#pragma omp parallel num_threads(nth)
+    {
+        const int t = omp_get_thread_num();
+        const int64_t lo = E * t / nth, hi = E * (t + 1) / nth;
+        std::vector<int32_t>& v = part[(size_t)t];
+        for (int64_t e = lo; e < hi; e++) {
+            const int32_t* id = lnid + 8 * e;
+            bool take = false;
+            for (int c = 0; c < 8 && !take; c++) take = id[c] >= n0 || (dn.n > 0 && dn_of[(size_t)id[c]] >= 0);
+            if (take) v.push_back((int32_t)e);
+        }
+    }
+    for (auto& v : part) cand.insert(cand.end(), v.begin(), v.end());
+}
+
 static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, const int32_t* lnid,
-                              const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H, int64_t n0 = 0)
+                              const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H, int64_t n0 = 0,
+                              std::vector<int32_t>* cand_cache = nullptr)
 {
     std::vector<int32_t> cuts;
     hq_patch_cuts(cfg, N, xyz, cuts, n0);
@@ -639,6 +675,16 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             for (int32_t a = dn.ptr[k]; a < dn.ptr[k + 1]; a++)
                 if (dn_of[dn.anchor[a]] >= 0) { g_patch_err = "an anchor is itself a hanging node"; return -1; }
     }
+
+    /* behind bricks only the shell's elements are looked at (every attempt below walks the element list twice) */
+    std::vector<int32_t> cand_own;
+    std::vector<int32_t>* cand = nullptr;
+    if (n0 > 0) {
+        cand = cand_cache ? cand_cache : &cand_own;
+        if (cand->empty()) hq_patch_candidates(E, lnid, dn, dn_of, n0, *cand);
+    }
+    const int64_t NE = cand ? (int64_t)cand->size() : E;
+    auto elem_at = [&](int64_t i) -> int64_t { return cand ? (int64_t)(*cand)[(size_t)i] : i; };
 
     for (int attempt = 0; attempt < 12; attempt++) {
         int32_t P = (int32_t)cuts.size() - 1;
@@ -666,9 +712,9 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             }
             return k;
         };
-        for (int64_t e = 0; e < E; e++) {
+        for (int64_t i = 0; i < NE; i++) {
             int32_t ps[40];
-            int k = patches_of_elem(e, ps);
+            int k = patches_of_elem(elem_at(i), ps);
             for (int t = 0; t < k; t++) off[ps[t] + 1]++;
         }
         for (int32_t p = 0; p < P; p++) off[p + 1] += off[p];
@@ -676,7 +722,8 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         H->pelem.assign((size_t)npairs, 0);
         {
             std::vector<int64_t> fill(off.begin(), off.end() - 1);
-            for (int64_t e = 0; e < E; e++) {
+            for (int64_t i = 0; i < NE; i++) {
+                const int64_t e = elem_at(i);
                 int32_t ps[40];
                 int k = patches_of_elem(e, ps);
                 for (int t = 0; t < k; t++) H->pelem[(size_t)fill[ps[t]]++] = (int32_t)e;
@@ -2112,8 +2159,9 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     };
     bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
                         pers_fits(std::max(P->cfg.nlmax, HQ_LAT_ROWS), 0);
+    std::vector<int32_t> cand;                       /* the shell's elements: found once, used by every plan below */
     for (;;) {
-        if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H, n0) != 0) return -1 /* HQ_ERR_ARG */;
+        if (hq_patch_plan_host(P->cfg, E, N, lnid, xyz, dn, want_lattice, &H, n0, &cand) != 0) return -1 /* HQ_ERR_ARG */;
         /* behind bricks the patches are the shell of the mesh -- a few thousand, 15 per CU on the 64M box: the
          * persistent kernels' prologue and work queue cost more than they save there, and one workgroup per patch
          * (hq_k_patch_step, two per CU) fills the device at once: 64M box 1.104 -> 1.060 ms per step, 8M box
@@ -2147,6 +2195,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
      * for every owned node, i.e. no dashpot touches the patch */
     std::vector<double> nt3((size_t)N * 3);
+#pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; n++) {
         /* hq_k_patch_seed: a negative mass_simple marks a node whose accumulator is seeded with 0 (its update belongs
          * to the interface kernel or to compute_adjust, and its pure force is handed on) */
