@@ -47,7 +47,9 @@ def test_traffic_and_fraction_from_the_committed_counter_passes(tag, line_file):
 
 
 @pytest.mark.parametrize("tag,line_file,kernel", [("v18", "bench_default_v18.json", "hq_k_brick"),
-                                                  ("c3h_v19", "bench_c3h_v19.json", "hq_k_brick")])
+                                                  ("c3h_v19", "bench_c3h_v19.json", "hq_k_brick"),
+                                                  ("v22", "bench_default_v22.json", "hq_k_brick"),
+                                                  ("c3h_v22", "bench_c3h_v22.json", "hq_k_brick")])
 def test_round3_lines_follow_from_their_counter_passes(tag, line_file, kernel):
     """Round 3's committed lines (bricks: hq_k_brick / hq_k_brick_het + the patch kernel of the faces beside it):
     `traffic`, `counter_frac`, `wasted` follow from the committed counter CSVs; `frac` is the compulsory-byte fraction."""
