@@ -1676,6 +1676,60 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                 }
     }
     for (int64_t q = 0; q < B.nb; q++) if (covered[(size_t)q] != 1) bad++;
+    /* the patches behind the bricks: planned on the renumbered mesh as hq_create does it -- walking only the elements
+     * of the shell (hq_patch_candidates) -- and once more walking every element: the two plans must be the same, and
+     * every element around a patch node must be in its patch */
+    {
+        std::vector<int32_t> p_lnid((size_t)E * 8), p_xyz((size_t)N * 3);
+        for (int64_t i = 0; i < E * 8; i++) p_lnid[(size_t)i] = B.perm[(size_t)d->lnid[i]];
+        for (int64_t n = 0; n < N; n++)
+            for (int k = 0; k < 3; k++) p_xyz[(size_t)(3 * (int64_t)B.perm[(size_t)n] + k)] = d->node_xyz[3 * n + k];
+        std::vector<char> shared_dn((size_t)N, 0);
+        for (int32_t i = 0; i < d->dn_sched.s_count; i++)
+            for (int32_t k = 0; k < d->dn_sched.first_s[i].nodecount; k++) shared_dn[(size_t)d->dn_sched.first_s[i].mapping[k]] = 1;
+        std::vector<int32_t> l_id, l_ptr(1, 0), l_anc;
+        for (int32_t k = 0; k < d->ldnnum; k++) {
+            if (shared_dn[(size_t)d->dn_ldnid[k]]) continue;
+            l_id.push_back(B.perm[(size_t)d->dn_ldnid[k]]);
+            for (int32_t a = d->dn_ptr[k]; a < d->dn_ptr[k + 1]; a++) l_anc.push_back(B.perm[(size_t)d->dn_lanid[a]]);
+            l_ptr.push_back((int32_t)l_anc.size());
+        }
+        hq_dangling dn;
+        dn.n = (int32_t)l_id.size(); dn.id = l_id.data(); dn.ptr = l_ptr.data(); dn.anchor = l_anc.data();
+        hq_patch_cfg cfg = hq_patch_cfg_from_env();
+        if (dn.n > 0 && cfg.vmax == 0) cfg.vmax = 384;
+        hq_patch_host Ha, Hb;
+        std::vector<int32_t> all((size_t)E);
+        for (int64_t e = 0; e < E; e++) all[(size_t)e] = (int32_t)e;
+        if (hq_patch_plan_host(cfg, E, N, p_lnid.data(), p_xyz.data(), dn, false, &Ha, B.nb) != 0 ||
+            hq_patch_plan_host(cfg, E, N, p_lnid.data(), p_xyz.data(), dn, false, &Hb, B.nb, &all) != 0)
+            return hq_fail(HQ_ERR_ARG, "patch plan: %s", hq_patch_error());
+        if (Ha.pelem != Hb.pelem || Ha.halo != Hb.halo || Ha.pidx != Hb.pidx || Ha.desc.size() != Hb.desc.size() || Ha.ds_ent != Hb.ds_ent) bad++;
+        for (size_t q = 0; q < Ha.desc.size() && q < Hb.desc.size(); q++)
+            if (Ha.desc[q].base != Hb.desc[q].base || Ha.desc[q].nown != Hb.desc[q].nown || Ha.desc[q].npairs != Hb.desc[q].npairs ||
+                Ha.desc[q].nhalo != Hb.desc[q].nhalo || Ha.desc[q].pair_off != Hb.desc[q].pair_off) bad++;
+        /* every (element, patch node) incidence is in the owner's list */
+        std::vector<int32_t> patch_of((size_t)N, -1);
+        for (size_t q = 0; q < Ha.desc.size(); q++)
+            for (int32_t n = Ha.desc[q].base; n < Ha.desc[q].base + Ha.desc[q].nown; n++) patch_of[(size_t)n] = (int32_t)q;
+        for (int64_t n = B.nb; n < N; n++) if (patch_of[(size_t)n] < 0) bad++;
+        int64_t need = 0, have = 0;
+        for (int64_t e = 0; e < E; e++) {
+            int32_t seen[8]; int ns = 0;
+            for (int c8 = 0; c8 < 8; c8++) {
+                const int32_t q = patch_of[(size_t)p_lnid[(size_t)(8 * e + c8)]];
+                bool dup = q < 0;
+                for (int t = 0; t < ns; t++) dup |= seen[t] == q;
+                if (!dup) seen[ns++] = q;
+            }
+            for (int t = 0; t < ns; t++) {
+                need++;
+                const hq_patch_desc& D = Ha.desc[(size_t)seen[t]];
+                have += std::binary_search(Ha.pelem.begin() + D.pair_off, Ha.pelem.begin() + D.pair_off + D.npairs, (int32_t)e);
+            }
+        }
+        if (have != need) bad++;
+    }
     report[0] = B.nb; report[1] = B.ncolumns; report[2] = (int64_t)B.units.size(); report[3] = nsame;
     report[4] = B.nhet; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
     if (bad) return hq_fail(HQ_ERR_STATE, "brick plan self-check failed%s", "");
