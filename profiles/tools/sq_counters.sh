@@ -18,7 +18,7 @@ tag = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for f in glob.glob('/tmp/sq_%s/p*/**/*counter_collection.csv' % tag, recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
         if not k.startswith('hq_k_'): continue
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] in ('SQ_WAVES', 'SQ_INSTS_VALU'): n[(k, r['Counter_Name'])] += 1
