@@ -455,18 +455,21 @@ def _cone_windows(nx, ny, nz, src_elem):
     return c
 
 
-@pytest.mark.parametrize("wl", ["c2", "c3"])
+@pytest.mark.parametrize("wl", ["c2", "c3", "c3h"])
 def test_dependency_cone_windows_against_the_oracle(wl):
     """Oracle parity AT BASELINE sizes: after k steps a node depends on its k-ring only, so a window of the full box
     -- a block of 4^3 elements and k + 1 more layers around it, with the true eTable / nTable rows and the true start
     field -- stepped by the oracle's reference loops gives the exact values of the nodes that lie at least k layers
     inside every CUT face of the window (domain faces are no cuts).  >= 64 windows of the 8 M and the 64 M box (all
     five dashpot faces, the free surface, edges, corners, the far-face cubes, the source element, tile / chunk /
-    patch borders, seeded interior points) against the GPU's whole-box result: <= 1e-9 of the field's scale."""
+    patch borders, seeded interior points) against the GPU's whole-box result: <= 1e-9 of the field's scale.
+    c3h: the 64 M box whose material differs from element to element (every interior node in hq_k_brick_het, 62 x 7-node
+    tiles: the windows at i = 63..65, 128 and j = 7..9, 16 straddle their borders as well)."""
     import bench
     nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
     k = 4
-    box = host.Box(nx, ny, nz, h, dt, freq)
+    ncls, amp = bench.LATERAL.get(wl, (0, 0.0))
+    box = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
     u = _field(box, 2718)
     L = nx * h
     loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
@@ -474,6 +477,9 @@ def test_dependency_cone_windows_against_the_oracle(wl):
     F = box.source_table(rp, 0, k)
     s = box.create_solver(tm1=u, tm2=0.999 * u)
     assert s.dominant_kernel() == "hq_k_brick"
+    if ncls:
+        rep = box.brick_plan_check() if nx <= 256 else None      # (the 64 M plan is checked by the run itself)
+        assert s.info()["brick_nodes"] > 0.97 * len(u) and (rep is None or rep["het_units"] == rep["units"])
     s.set_source(loaded, F)
     s.run(k)
     ijk = box.node_ijk
