@@ -55,11 +55,7 @@
 #define HQ_BH_TX 62
 #define HQ_BH_TY (HQ_BH_WAVES - 1)
 #define HQ_BH_PY 65
-#ifdef HQ_BH_COEF_AOS
-#define HQ_BH_CS 1
-#else
 #define HQ_BH_CS HQ_BH_THREADS            /* stride between c1, c2, beta of an element in a layer's coefficient block */
-#endif
 #define HQ_BH_ROWS (65 * (HQ_BH_WAVES + 1))
 
 struct hq_brick_unit {
@@ -441,11 +437,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 for (int32_t j = 0; j < HQ_BH_WAVES; j++)
                     for (int32_t i = 0; i < 64; i++) {
                         const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
-#ifdef HQ_BH_COEF_AOS
-                        double* o = cf + 3 * (((int64_t)l * HQ_BH_WAVES + j) * 64 + i);
-#else
                         double* o = cf + (int64_t)l * (3 * HQ_BH_THREADS) + (j * 64 + i);      /* [layer][c1 | c2 | beta][thread] */
-#endif
                         int32_t e = -1;
                         if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
                             e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
@@ -678,11 +670,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     const int32_t* __restrict__ rtabB = tab + U.tab + (ringB ? rq + HQ_BH_NRT : 0);
     const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
     const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
-#ifdef HQ_BH_COEF_AOS
-    const double* __restrict__ cf = coef + U.coef + 3 * t;
-#else
     const double* __restrict__ cf = coef + U.coef + t;                 /* [layer][c1 | c2 | beta][thread] */
-#endif
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
     /* an owner's registers: x1, x2 = u1, u2 of its node of the plane in flight, mn = its n_t row, accA / accB = the

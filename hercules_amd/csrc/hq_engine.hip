@@ -1653,11 +1653,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                         if (het) {
                             /* the element whose corner o the node is: column (x - ox + 1, y - oy + 1) of layer k - oz + 1 */
                             const int i = x - (o & 1) + 1, j = y - ((o >> 1) & 1) + 1, l = k - ((o >> 2) & 1) + 1;
-#ifdef HQ_BH_COEF_AOS
-                            const double* q = B.coef.data() + U.coef + 3 * (((int64_t)l * HQ_BH_WAVES + j) * 64 + i);
-#else
                             const double* q = B.coef.data() + U.coef + (int64_t)l * (3 * HQ_BH_THREADS) + (j * 64 + i);
-#endif
                             if (c1[(size_t)e] != q[0] || c2[(size_t)e] != q[HQ_BH_CS] || beta[(size_t)e] != q[2 * HQ_BH_CS]) ok = false;
                         } else if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
                     }
