@@ -738,59 +738,59 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
      * at the top of every step for loads that only the first step could still have pending). */
     for (int l = -2; l <= np; l++) {
         if (l >= 0) {
-        /* the element between the planes l and l + 1 */
-        double X[8], Y[8], Z[8];
+            /* the element between the planes l and l + 1 */
+            double X[8], Y[8], Z[8];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const hq_lds_double* pu = img + (size_t)((l + (m >> 2)) & 1) * (2 * 3 * HQ_BH_ROWS) + 3 * (row0 + (m & 1) + ((m >> 1) & 1) * HQ_BH_PY);
-            const hq_lds_double* pv = pu + 3 * HQ_BH_ROWS;
-            X[m] = fma(beta, pv[0], pu[0]); Y[m] = fma(beta, pv[1], pu[1]); Z[m] = fma(beta, pv[2], pu[2]);
-        }
-        if (HQ_BH_ABL != 3) hq_element_force<true>(X, Y, Z, c1, c2);      /* X[0..3] = a, X[4..7] = b: f(near z) = a - b, f(far z) = a + b */
-        /* x: the node's high-x corners are this element's, its low-x corners the next lane's element's */
-        double G[2][2][3];                       /* [y bit][a | b] */
-#pragma unroll
-        for (int yb = 0; yb < 2; yb++)
-#pragma unroll
-            for (int zb = 0; zb < 2; zb++) {
-                const int m1 = 1 + 2 * yb + 4 * zb, m0 = 2 * yb + 4 * zb;
-                G[yb][zb][0] = X[m1] + hq_dpp_from_next_lane(X[m0]);
-                G[yb][zb][1] = Y[m1] + hq_dpp_from_next_lane(Y[m0]);
-                G[yb][zb][2] = Z[m1] + hq_dpp_from_next_lane(Z[m0]);
+            for (int m = 0; m < 8; m++) {
+                const hq_lds_double* pu = img + (size_t)((l + (m >> 2)) & 1) * (2 * 3 * HQ_BH_ROWS) + 3 * (row0 + (m & 1) + ((m >> 1) & 1) * HQ_BH_PY);
+                const hq_lds_double* pv = pu + 3 * HQ_BH_ROWS;
+                X[m] = fma(beta, pv[0], pu[0]); Y[m] = fma(beta, pv[1], pu[1]); Z[m] = fma(beta, pv[2], pu[2]);
             }
-        /* y: the low-y corners belong to the node one row down */
+            if (HQ_BH_ABL != 3) hq_element_force<true>(X, Y, Z, c1, c2);      /* X[0..3] = a, X[4..7] = b: f(near z) = a - b, f(far z) = a + b */
+            /* x: the node's high-x corners are this element's, its low-x corners the next lane's element's */
+            double G[2][2][3];                       /* [y bit][a | b] */
 #pragma unroll
-        for (int zb = 0; zb < 2; zb++)
+            for (int yb = 0; yb < 2; yb++)
 #pragma unroll
-            for (int d = 0; d < 3; d++) xch[(3 * zb + d) * HQ_BH_THREADS + t] = G[0][zb][d];
-        __syncthreads();
-        if (owner) {
-            double H0[3], H1[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                H0[d] = G[1][0][d] + xch[d * HQ_BH_THREADS + t + 64];
-                H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BH_THREADS + t + 64];
-            }
-            if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
-                double f[3];
-#pragma unroll
-                for (int d = 0; d < 3; d++) f[d] = accA[d] + (H0[d] - H1[d]);
-                const int local = (l - 1) * nxy + sidx;
-                if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
-                    for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
-                        if (src_ent[2 * i] == local) {
-                            const int li = src_ent[2 * i + 1];
-                            for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
-                        }
+                for (int zb = 0; zb < 2; zb++) {
+                    const int m1 = 1 + 2 * yb + 4 * zb, m0 = 2 * yb + 4 * zb;
+                    G[yb][zb][0] = X[m1] + hq_dpp_from_next_lane(X[m0]);
+                    G[yb][zb][1] = Y[m1] + hq_dpp_from_next_lane(Y[m0]);
+                    G[yb][zb][2] = Z[m1] + hq_dpp_from_next_lane(Z[m0]);
                 }
-                double* out = ung + 3 * (U.base + (int64_t)local);
+            /* y: the low-y corners belong to the node one row down */
 #pragma unroll
-                for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
+            for (int zb = 0; zb < 2; zb++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) xch[(3 * zb + d) * HQ_BH_THREADS + t] = G[0][zb][d];
+            __syncthreads();
+            if (owner) {
+                double H0[3], H1[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    H0[d] = G[1][0][d] + xch[d * HQ_BH_THREADS + t + 64];
+                    H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BH_THREADS + t + 64];
+                }
+                if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
+                    double f[3];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) f[d] = accA[d] + (H0[d] - H1[d]);
+                    const int local = (l - 1) * nxy + sidx;
+                    if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
+                        for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
+                            if (src_ent[2 * i] == local) {
+                                const int li = src_ent[2 * i + 1];
+                                for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
+                            }
+                    }
+                    double* out = ung + 3 * (U.base + (int64_t)local);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) accA[d] = accB[d] + (H0[d] + H1[d]);
+                m0A = m0B;
             }
-#pragma unroll
-            for (int d = 0; d < 3; d++) accA[d] = accB[d] + (H0[d] + H1[d]);
-            m0A = m0B;
-        }
         }
         if (l < np) HQ_BH_PUT(l & 1, accB, m0B)
         c1 = nc1; c2 = nc2; beta = nbeta;
