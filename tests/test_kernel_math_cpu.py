@@ -18,6 +18,7 @@ HARNESS = r"""
 #define HQ_KERNEL_MATH_HOST_CHECK
 #include "hq_kernels.h"
 extern "C" void element_force(double* X, double* Y, double* Z, double c1, double c2) { hq_element_force(X, Y, Z, c1, c2); }
+extern "C" void element_force_zmodes(double* X, double* Y, double* Z, double c1, double c2) { hq_element_force<true>(X, Y, Z, c1, c2); }
 """
 
 
@@ -55,6 +56,26 @@ def test_butterfly_product_equals_the_element_matrices(lib):
         X, Y, Z = [np.ascontiguousarray(w[:, k]) for k in range(3)]
         lib.element_force(X.ctypes.data_as(dp), Y.ctypes.data_as(dp), Z.ctypes.data_as(dp), 2.0, 3.0)
         assert max(np.abs(X).max(), np.abs(Y).max(), np.abs(Z).max()) <= 1e-14
+
+
+def test_z_modes_of_the_transposed_butterfly(lib):
+    """hq_k_brick_het sums the corner forces over elements BEFORE the z stage of the transposed butterfly
+    (hq_element_force<true>: X[0..3] = a, X[4..7] = b): f(near-z corner n) = a[n] - b[n], f(far-z corner n + 4) =
+    a[n] + b[n] must be the full product."""
+    rng = np.random.default_rng(7)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for fn in (lib.element_force, lib.element_force_zmodes):
+        fn.argtypes = [dp, dp, dp, ctypes.c_double, ctypes.c_double]
+    for c1, c2 in [(1.0, 0.0), (0.0, 1.0), (3.7e9, 1.3e10)]:
+        w = rng.uniform(-1, 1, (8, 3))
+        full = [np.ascontiguousarray(w[:, d]) for d in range(3)]
+        modes = [np.ascontiguousarray(w[:, d]) for d in range(3)]
+        lib.element_force(*[a.ctypes.data_as(dp) for a in full], c1, c2)
+        lib.element_force_zmodes(*[a.ctypes.data_as(dp) for a in modes], c1, c2)
+        for f, m in zip(full, modes):
+            scale = np.abs(f).max()
+            assert np.abs((m[:4] - m[4:]) - f[:4]).max() <= 4e-16 * scale
+            assert np.abs((m[:4] + m[4:]) - f[4:]).max() <= 4e-16 * scale
 
 
 def test_assembled_stencil_coefficients_equal_the_assembled_element_matrices():
