@@ -31,6 +31,7 @@
 #ifndef HQ_BRICK_H
 #define HQ_BRICK_H
 
+#include <chrono>
 #include <map>
 
 #include "hq_patch.h"
@@ -125,6 +126,14 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     *B = hq_brick_host();
     if (!xyz || E <= 0 || N <= 0) return 0;
     const hq_brick_cfg cfg = hq_brick_cfg_from_env();
+    const bool verbose = getenv("HQ_PATCH_VERBOSE") && atoi(getenv("HQ_PATCH_VERBOSE")) > 1;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  brick plan: %-36s %6.2f s\n", what, std::chrono::duration<double>(now - t_lap).count());
+        t_lap = now;
+    };
     const int TX = HQ_BK_TX, TY = HQ_BK_TY;
     const bool want_het = !(getenv("HQ_BRICK_NO_HET") && atoi(getenv("HQ_BRICK_NO_HET")) != 0);
 
@@ -149,6 +158,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         }
         if (bad_order) return 0;                                 /* not the corner order of octor.c:6444-6470: no bricks */
     }
+    lap("edge lengths");
 
     struct level_t {
         int32_t h;
@@ -221,6 +231,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             if (bad) ok = false;
         }
         if (!ok) continue;
+        lap("level grids");
         /* simple nodes */
         std::vector<char> S((size_t)(NX * NY * NZ), 0);
         int64_t sx0 = INT64_MAX, sx1 = -1, sy0 = INT64_MAX, sy1 = -1;
@@ -249,6 +260,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y);
                 }
         if (nsimple < cfg.minnodes) continue;
+        lap("simple nodes");
         /* tile columns: footprints on a TX x TY grid from the first simple node; runs of planes all of whose nodes
          * in the footprint are simple.  Two passes: 64 x 8 tiles of nodes whose eight elements share their coefficients
          * (hq_k_brick), then 63 x 7 tiles of what is left (hq_k_brick_het: per-element coefficients) */
@@ -302,6 +314,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                             memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
             if (!want_het) break;
         }
+        lap("tile columns");
         const int32_t ntx = ntx_lvl;
         size_t before = cols.size();
         for (auto& v : found) cols.insert(cols.end(), v.begin(), v.end());
@@ -316,22 +329,52 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     for (auto& c : cols) { c.base = nb; nb += (int64_t)c.nx * c.ny * c.nz; }
     if (nb > 0x7fffffff) return 0;
     B->perm.assign((size_t)N, -1);
-    for (auto& c : cols) {
-        const level_t& L = levels[(size_t)c.lvl];
-        const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
-        for (int32_t z = 0; z < c.nz; z++)
-            for (int32_t y = 0; y < c.ny; y++)
-                for (int32_t x = 0; x < c.nx; x++) {
-                    const int32_t n = L.Ng[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
-                    if (B->perm[(size_t)n] != -1) { g_patch_err = "brick plan: a node lies in two tile columns"; return -1; }
-                    B->perm[(size_t)n] = (int32_t)(c.base + ((int64_t)z * c.ny + y) * c.nx + x);
-                }
+    {
+        /* columns are disjoint (checked: the nodes numbered must come out as nb, and every id below is taken once) */
+        int64_t twice = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : twice)
+        for (int64_t ci = 0; ci < (int64_t)cols.size(); ci++) {
+            const column_t& c = cols[(size_t)ci];
+            const level_t& L = levels[(size_t)c.lvl];
+            const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
+            for (int32_t z = 0; z < c.nz; z++)
+                for (int32_t y = 0; y < c.ny; y++)
+                    for (int32_t x = 0; x < c.nx; x++) {
+                        const int32_t n = L.Ng[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
+                        int32_t& slot = B->perm[(size_t)n];
+                        int32_t was;
+#pragma omp atomic capture
+                        { was = slot; slot = (int32_t)(c.base + ((int64_t)z * c.ny + y) * c.nx + x); }
+                        twice += was != -1;
+                    }
+        }
+        if (twice) { g_patch_err = "brick plan: a node lies in two tile columns"; return -1; }
     }
     {
-        int64_t k = nb;
-        for (int64_t n = 0; n < N; n++) if (B->perm[(size_t)n] < 0) B->perm[(size_t)n] = (int32_t)k++;
-        if (k != N) { g_patch_err = "brick plan: numbering is not a permutation"; return -1; }
+        /* everything else behind, in its old order: a count per chunk of ids, then the fill */
+        int nth = 1;
+#pragma omp parallel
+        {
+#pragma omp single
+            nth = omp_get_num_threads();
+        }
+        std::vector<int64_t> first((size_t)nth + 1, 0);
+#pragma omp parallel num_threads(nth)
+        {
+            const int t = omp_get_thread_num();
+            const int64_t lo = N * t / nth, hi = N * (t + 1) / nth;
+            int64_t cnt = 0;
+            for (int64_t n = lo; n < hi; n++) cnt += B->perm[(size_t)n] < 0;
+            first[(size_t)t + 1] = cnt;
+#pragma omp barrier
+#pragma omp single
+            for (int i = 0; i < nth; i++) first[(size_t)i + 1] += first[(size_t)i];
+            int64_t k = nb + first[(size_t)t];
+            for (int64_t n = lo; n < hi; n++) if (B->perm[(size_t)n] < 0) B->perm[(size_t)n] = (int32_t)k++;
+        }
+        if (nb + first[(size_t)nth] != N) { g_patch_err = "brick plan: numbering is not a permutation"; return -1; }
     }
+    lap("numbering");
     B->nb = nb;
     B->ncolumns = (int32_t)cols.size();
     B->nlevels = (int32_t)levels.size();
@@ -446,6 +489,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     }
         }
     }
+    lap("unit tables");
     if (fault) { g_patch_err = "brick plan: a neighbour of a simple node is missing"; return -1; }
     /* launch order: the units whose nodes share one n_t row (the row rides in the record), then those with per-node
      * rows, then the HET units -- a launch each */
