@@ -553,11 +553,21 @@ def main():
         reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
         for r in reqs:
             r.wait()
-    use_host = world > 1 and os.environ.get("HQ_BENCH_TRANSPORT", "rccl") == "host"
-    rccl_error = None
-    if world > 1 and not use_host:
-        # RCCL over xGMI.  If the communicator cannot be made on ANY rank (it has never run on more than one GPU),
-        # all ranks fall back together to the host-staged transport and the line says so.
+    # Transport between the ranks, in this order of preference (HQ_BENCH_TRANSPORT = rccl | ipc | host picks the first
+    # to try): RCCL grouped send/recv -> the engine's IPC transport (direct peer stores into IPC-exported receive
+    # buffers, epoch flags; works for ranks that share a GPU too) -> host-staged (pinned buffers + gloo).  A transport
+    # counts only if it came up on EVERY rank; the line says which one ran (config.transport).
+    want = os.environ.get("HQ_BENCH_TRANSPORT", "rccl") if world > 1 else "none"
+    if want == "rccl" and world > 1 and torch.cuda.device_count() < world:
+        want = "ipc"                                       # ranks share a device: RCCL refuses duplicate devices
+    rccl_error = ipc_error = None
+
+    def everywhere(ok):
+        t_ok = torch.tensor([float(ok)], dtype=torch.float64)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        return float(t_ok[0]) >= 1.0
+    if want == "rccl":
+        # RCCL over xGMI.  If the communicator cannot be made on ANY rank, all ranks fall back together.
         ok = 1
         try:
             idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
@@ -571,24 +581,48 @@ def main():
                 ok, rccl_error = 0, str(e)
         else:
             ok = 0
-        t_ok = torch.tensor([float(ok)], dtype=torch.float64)
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        if float(t_ok[0]) >= 1.0:
+        if everywhere(ok):
             rccl_ranks = int(solver.info()["nranks"])
             transport = "RCCL grouped send/recv, %d ranks" % rccl_ranks
         elif ok:
             raise SystemExit("bench.py: RCCL came up on rank %d but not everywhere; cannot change the transport of a "
                              "context that has one" % rank)
         else:
-            use_host = True
-            print("bench.py rank %d: RCCL unavailable (%s); host-staged transport instead" % (rank, rccl_error), file=sys.stderr)
+            want = "ipc"
+            print("bench.py rank %d: RCCL unavailable (%s); IPC transport instead" % (rank, rccl_error), file=sys.stderr)
         flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
-    if use_host:
+    if want == "ipc":
+        ok, blobs = 1, None
+        try:
+            mine = torch.frombuffer(bytearray(solver.comm_ipc_export()), dtype=torch.uint8)
+        except ha.HqError as e:
+            ok, ipc_error, mine = 0, str(e), torch.zeros(ha.capi.IPC_BLOB_BYTES, dtype=torch.uint8)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                      # MPI_Allgather on comm_solver in the reference's world
+        if everywhere(ok):
+            try:
+                solver.comm_init_ipc([t.numpy().tobytes() for t in every])
+            except ha.HqError as e:
+                ok, ipc_error = 0, str(e)
+            if everywhere(ok):
+                rccl_ranks = 0
+                transport = "IPC peer stores + epoch flags (hq_comm_init_ipc), %d ranks" % world + \
+                            (" [RCCL failed: %s]" % rccl_error if rccl_error else "")
+            elif ok:
+                raise SystemExit("bench.py: the IPC transport came up on rank %d but not everywhere" % rank)
+            else:
+                want = "host"
+        else:
+            want = "host"
+        if want == "host":
+            print("bench.py rank %d: IPC transport unavailable (%s); host-staged transport instead" % (rank, ipc_error), file=sys.stderr)
+    if want == "host":
         # the engine's host-staged transport (hq_comm_init_host) over gloo: several ranks may then share one GPU
         # (HQ_BENCH_SHARE_GPU=1) -- separate processes, contexts and streams as with RCCL, records through pinned memory
         solver.comm_init_host(gloo_exchange)
         rccl_ranks = 0
-        transport = "host-staged (pinned buffers + gloo), %d ranks" % world + (" [RCCL failed: %s]" % rccl_error if rccl_error else "")
+        transport = "host-staged (pinned buffers + gloo), %d ranks" % world + \
+                    (" [RCCL failed: %s]" % rccl_error if rccl_error else "") + (" [IPC failed: %s]" % ipc_error if ipc_error else "")
     total_steps = args.warmup + args.steps
     add_source(args, box, solver, octree, total_steps)
     info = solver.info()
@@ -625,8 +659,10 @@ def main():
         value = E_total * args.steps / elapsed
         is_patch = info["variant"] == ha.HQ_VARIANT_PATCH
         kernel = solver.dominant_kernel()
-        per_node = COMPULSORY_BYTES_PER_NODE_LATERAL if args.workload in LATERAL else COMPULSORY_BYTES_PER_NODE
-        compulsory = per_node * N                          # this rank's nodes: read u(t), u(t-dt), write u(t+dt) (+ n_t, coefficients)
+        # ONE basis for every workload (round-3 advisor finding): 72 B per node and step.  What a mesh with material of
+        # its own in every element reads on top (24 B n_t row + 24 B coefficients) is reported beside it, not in `frac`.
+        per_node = COMPULSORY_BYTES_PER_NODE
+        compulsory = per_node * N                          # this rank's nodes: read u(t), u(t-dt), write u(t+dt)
         traffic = rd = wr = None
         source = None
         if pmc is not None and "error" not in pmc:
@@ -683,6 +719,8 @@ def main():
                          "achieved_basis": "compulsory bytes: %d B per node and step" % int(per_node),
                          "counter_frac": counter_frac, "achieved_counter": achieved_counter,
                          "wasted": (traffic / compulsory) if traffic is not None else None,
+                         "frac_incl_tables": (COMPULSORY_BYTES_PER_NODE_LATERAL / COMPULSORY_BYTES_PER_NODE * frac)
+                                             if args.workload in LATERAL else None,
                          "kernel": kernel, "kernel_ms": kernel_ms,
                          "compulsory_bytes_per_launch": compulsory, "ideal_ms": ideal_ms,
                          "algorithmic_equiv_GBs": BYTES_PER_ELEMENT_UPDATE * value / 1e9,

@@ -12,12 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
 
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
+IPC_BLOB_BYTES = 4096                   # HQ_IPC_BLOB_BYTES
 
-EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info",
+EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info", "hq_get_info_sized", "hq_abi_version",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
-           "hq_stencil_coefficients", "hq_brick_plan_check", "hq_comm_init_host"]
+           "hq_stencil_coefficients", "hq_brick_plan_check", "hq_comm_init_host",
+           "hq_comm_ipc_export", "hq_comm_init_ipc", "hq_comm_init_loopback"]
 
 
 class HqError(RuntimeError):
@@ -58,7 +60,8 @@ class _Info(ctypes.Structure):
                 ("step", ctypes.c_int32), ("nranks", ctypes.c_int32),
                 ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32),
                 ("ragged_patches", ctypes.c_int32), ("brick_units", ctypes.c_int32),
-                ("brick_nodes", ctypes.c_int64)]
+                ("brick_nodes", ctypes.c_int64), ("brick_units_pernode", ctypes.c_int32),
+                ("brick_units_het", ctypes.c_int32)]
 
 
 _lib = None
@@ -163,7 +166,7 @@ class Solver:
 
     def info(self):
         i = _Info()
-        _check(self._lib.hq_get_info(self._h, ctypes.byref(i)))
+        _check(self._lib.hq_get_info_sized(self._h, ctypes.byref(i), ctypes.c_uint64(ctypes.sizeof(i))))
         return {k: getattr(i, k) for k, _ in _Info._fields_}
 
     def set_source(self, loaded_lnid, forces, step0=0):
@@ -197,6 +200,21 @@ class Solver:
                 return 1
         self._host_exchange = HOST_EXCHANGE_FN(trampoline)          # keep the thunk alive with the context
         _check(self._lib.hq_comm_init_host(self._h, self._host_exchange, None))
+
+    def comm_ipc_export(self):
+        """hq_comm_ipc_export: this rank's HQ_IPC_BLOB_BYTES blob (bytes) for the host to all-gather."""
+        buf = (ctypes.c_char * IPC_BLOB_BYTES)()
+        _check(self._lib.hq_comm_ipc_export(self._h, buf))
+        return bytes(buf)
+
+    def comm_init_ipc(self, blobs):
+        """hq_comm_init_ipc: `blobs` = every rank's export, in rank order (list of bytes or one bytes object)."""
+        raw = blobs if isinstance(blobs, (bytes, bytearray)) else b"".join(blobs)
+        buf = (ctypes.c_char * len(raw)).from_buffer_copy(bytes(raw))
+        _check(self._lib.hq_comm_init_ipc(self._h, buf))
+
+    def comm_init_loopback(self):
+        _check(self._lib.hq_comm_init_loopback(self._h))
 
     def comm_selftest(self, count=1024):
         _check(self._lib.hq_comm_selftest(self._h, ctypes.c_int32(count)))

@@ -43,6 +43,9 @@
 #define HQ_BK_THREADS (HQ_BK_TX * HQ_BK_TY)
 #define HQ_BK_PY (HQ_BK_TX + 2)
 #define HQ_BK_PLANE ((HQ_BK_TX + 2) * (HQ_BK_TY + 2))
+#ifndef HQ_BK_ATTR            /* experiment builds: -DHQ_BK_ATTR='__attribute__((amdgpu_num_vgpr(120)))' */
+#define HQ_BK_ATTR
+#endif
 #define HQ_BK_NTSAME 1           /* every node of the unit has the same n_t row: it is in the unit's record */
 #define HQ_BK_HET 2              /* the elements around the unit's nodes have coefficients of their own: hq_k_brick_het */
 /* tile of a HET unit: 62 x 7 owned nodes -- the 64 x 8 threads of the workgroup each evaluate ONE element of the layer,
@@ -136,6 +139,9 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     };
     const int TX = HQ_BK_TX, TY = HQ_BK_TY;
     const bool want_het = !(getenv("HQ_BRICK_NO_HET") && atoi(getenv("HQ_BRICK_NO_HET")) != 0);
+    /* the uniform units use the assembled stencil's coefficients: without a verified table (hq_stencil().ok, the gate
+     * hq_k_patch_stencil has too) their nodes go to the element-by-element HET units or stay with the patches */
+    const bool stencil_ok = hq_stencil().ok;
 
     /* levels: elements by edge length (ticks) */
     std::vector<int32_t> hs((size_t)E);
@@ -254,6 +260,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         else uni = uni && c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
                     }
                     if (!s) continue;
+                    if (!stencil_ok) uni = false;
                     if (!uni && !want_het) continue;
                     S[(size_t)((Z * NY + Y) * NX + X)] = uni ? 2 : 1;   /* 1: all eight elements, coefficients of their own */
                     nsimple++;
@@ -359,16 +366,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             nth = omp_get_num_threads();
         }
         std::vector<int64_t> first((size_t)nth + 1, 0);
-#pragma omp parallel num_threads(nth)
-        {
-            const int t = omp_get_thread_num();
+        /* slices dealt by worksharing loops: independent of the team the runtime delivers */
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nth; t++) {
             const int64_t lo = N * t / nth, hi = N * (t + 1) / nth;
             int64_t cnt = 0;
             for (int64_t n = lo; n < hi; n++) cnt += B->perm[(size_t)n] < 0;
             first[(size_t)t + 1] = cnt;
-#pragma omp barrier
-#pragma omp single
-            for (int i = 0; i < nth; i++) first[(size_t)i + 1] += first[(size_t)i];
+        }
+        for (int i = 0; i < nth; i++) first[(size_t)i + 1] += first[(size_t)i];
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nth; t++) {
+            const int64_t lo = N * t / nth, hi = N * (t + 1) / nth;
             int64_t k = nb + first[(size_t)t];
             for (int64_t n = lo; n < hi; n++) if (B->perm[(size_t)n] < 0) B->perm[(size_t)n] = (int32_t)k++;
         }
@@ -420,7 +429,11 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     for (size_t u = 0; u < us.size(); u++)
         coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BH_THREADS * 3 : 0);
     B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
-    bool fault = false;
+    int fault = 0;                                       /* written by many threads: atomic writes only */
+    auto set_fault = [&]() {
+#pragma omp atomic write
+        fault = 1;
+    };
     std::vector<char> same(us.size(), 0);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t u = 0; u < (int64_t)us.size(); u++) {
@@ -429,9 +442,9 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
         const int32_t za = us[(size_t)u].za, np = us[(size_t)u].np, nx = c.nx, ny = c.ny, nr = 2 * (nx + 2) + 2 * ny;
         auto dev = [&](int64_t X, int64_t Y, int64_t Z) -> int32_t {
-            if (X < 0 || Y < 0 || Z < 0 || X > L.D[0] || Y > L.D[1] || Z > L.D[2]) { fault = true; return 0; }
+            if (X < 0 || Y < 0 || Z < 0 || X > L.D[0] || Y > L.D[1] || Z > L.D[2]) { set_fault(); return 0; }
             const int32_t n = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
-            if (n < 0) { fault = true; return 0; }
+            if (n < 0) { set_fault(); return 0; }
             return B->perm[(size_t)n];
         };
         int32_t* t = B->tab.data() + toff[(size_t)u];
@@ -456,7 +469,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         {
             /* the element whose corner 7 the node is: one cell down on every axis (all eight are equal: the node is simple) */
             const int32_t e0 = L.Eg[(size_t)((((int64_t)za - 1) * L.D[1] + (c.y0 - 1)) * L.D[0] + (c.x0 - 1))];
-            if (e0 < 0) { fault = true; continue; }
+            if (e0 < 0) { set_fault(); continue; }
             U.c1 = c1[e0]; U.c2 = c2[e0]; U.beta = beta[e0];
         }
         bool sm = true;
@@ -485,7 +498,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
                             e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
                         if (e >= 0) { o[0] = c1[e]; o[HQ_BH_CS] = c2[e]; o[2 * HQ_BH_CS] = beta[e]; }
-                        else if (i <= nx && j <= ny) fault = true;       /* an element around an owned node is missing */
+                        else if (i <= nx && j <= ny) set_fault();       /* an element around an owned node is missing */
                     }
         }
     }
@@ -516,8 +529,12 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
  *   fA  accumulator of output plane k - 1: contributions of the planes k - 2 and k - 1 and the node's own term
  *   fB  accumulator of output plane k: contribution of plane k - 1 and the node's own term m2 u1 - m1 u2
  */
+/* PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds
+ * ten more values per lane -- the plane's n_t row and the reciprocal masses of the two unfinished planes -- than 128
+ * VGPRs have room for (33 spilled, 76 B of scratch in round 3): it takes one workgroup per CU and as many registers
+ * as it needs, no scratch. */
 template <bool PERNODE>
-__global__ void __launch_bounds__(HQ_BK_THREADS, 4)         /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
+__global__ void HQ_BK_ATTR __launch_bounds__(HQ_BK_THREADS, PERNODE ? 2 : 4)   /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
 hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
            const double* __restrict__ u1g, const double* __restrict__ u2g, double* __restrict__ ung,
            const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
@@ -913,11 +930,17 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
     for (auto& r : rec) ptr[(size_t)r[0] + 1]++;
     for (int32_t u = 0; u < P->nunits; u++) ptr[(size_t)u + 1] += ptr[(size_t)u];
     for (size_t k = 0; k < rec.size(); k++) { ent[2 * k] = rec[k][1]; ent[2 * k + 1] = rec[k][2]; }
-    if (hipMalloc((void**)&P->d_src_ptr, 4 * ptr.size()) != hipSuccess) return -2;
-    if (hipMalloc((void**)&P->d_src_ent, 4 * ent.size()) != hipSuccess) return -2;
+    if (hipMalloc((void**)&P->d_src_ptr, 4 * ptr.size()) != hipSuccess) { P->d_src_ptr = nullptr; return -2; }
+    if (hipMalloc((void**)&P->d_src_ent, 4 * ent.size()) != hipSuccess) {
+        hipFree(P->d_src_ptr); P->d_src_ptr = nullptr; P->d_src_ent = nullptr;
+        return -2;
+    }
+    if (hipMemcpy(P->d_src_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->d_src_ent, ent.data(), 4 * ent.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(P->d_src_ptr); hipFree(P->d_src_ent); P->d_src_ptr = nullptr; P->d_src_ent = nullptr;
+        return -3;
+    }
     *bytes += (int64_t)(4 * ptr.size() + 4 * ent.size());
-    hipMemcpy(P->d_src_ptr, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice);
-    hipMemcpy(P->d_src_ent, ent.data(), 4 * ent.size(), hipMemcpyHostToDevice);
     return 0;
 }
 

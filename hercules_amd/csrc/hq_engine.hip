@@ -31,11 +31,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
 #include <vector>
 
+#define HQ_SOLVER_IMPLEMENTATION 1
 #include "../../include/hq_solver.h"
 #include "hq_kernels.h"
 #include "hq_patch.h"
@@ -185,6 +187,7 @@ struct hq_ctx {
     void* host_user = nullptr;
     std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
     bool group_owner = false;
+    struct hq_ipc_state* ipc = nullptr;      /* device-to-device transport between processes (hq_comm_init_ipc) */
     hipEvent_t ev_sent = nullptr;
     /* patch variant with an interface: the exchange chain runs on its own stream
      * beside the interior patches */
@@ -217,7 +220,8 @@ struct hq_ctx {
     /* HQ_DEBUG_HALO (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) */
     bool debug_halo = false;
     int64_t* d_gkey = nullptr;        /* [N] global identity of every harbored node          */
-    int32_t* d_halo_err = nullptr;    /* [2] records whose identity did not match; non-finite values seen by hq_check_finite */
+    int32_t* d_halo_err = nullptr;    /* [4] records whose identity did not match; non-finite values seen by hq_check_finite;
+                                       * [2] IPC waits that timed out */
     /* timing */
     std::vector<hipEvent_t> ev;     /* per-launch marks */
     hipEvent_t ev_span[2] = { nullptr, nullptr };
@@ -236,6 +240,42 @@ static int hq_dev_alloc(hq_ctx* c, T** p, size_t count)
 }
 
 #define HQ_TRY(x) do { int r_ = (x); if (r_ != HQ_OK) return r_; } while (0)
+
+/*
+ * hq_comm_init_ipc: what a rank exports (one fixed-size blob, all-gathered by the caller's transport) and what it keeps.
+ * Exchange x = 0 anchored-node contribution (received in an.d_s_in), 1 anchored-node sharing (an.d_c_in),
+ * 2 dangling-node contribution (dn.d_s_in), 3 dangling-node sharing (dn.d_c_in) -- the `tag` of the host-staged transport.
+ */
+enum { HQ_IPC_MAXNB = 64, HQ_IPC_MAGIC = 0x48514950 /* "HQIP" */ };
+struct hq_ipc_blob {
+    uint32_t magic, version;
+    int32_t rank, nranks, device, pid;
+    int32_t coarse, reserved;                        /* reserved: the arena's dump row (in doubles), loopback only      */
+    char busid[32];                                  /* PCI bus id of the device: device ordinals differ between processes */
+    uint64_t arena_bytes, arena_addr;                /* arena_addr: usable by members of the exporting process only */
+    hipIpcMemHandle_t mem;
+    uint64_t buf_off[4];                             /* receive buffer of exchange x in the arena (bytes)            */
+    uint64_t flag_off;                               /* flags [4][HQ_IPC_MAXNB] uint64 in the arena (bytes)          */
+    int32_t nrecv[4];
+    struct { int32_t procid, offset, count; } recv[4][HQ_IPC_MAXNB];
+};
+static_assert(sizeof(hq_ipc_blob) <= HQ_IPC_BLOB_BYTES, "hq_ipc_blob must fit HQ_IPC_BLOB_BYTES");
+
+struct hq_ipc_state {
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool coarse = false, ready = false, loopback = false;
+    hq_ipc_blob mine;
+    std::vector<void*> opened;                       /* hipIpcOpenMemHandle results to close */
+    unsigned long long* d_flags = nullptr;           /* in the arena */
+    double** d_dst[4] = { nullptr, nullptr, nullptr, nullptr };             /* where every send record of exchange x lands */
+    unsigned long long** d_sig[4] = { nullptr, nullptr, nullptr, nullptr }; /* the flags exchange x raises at its peers     */
+    int32_t nsig[4] = { 0, 0, 0, 0 };
+    unsigned long long wait_mask[4] = { 0, 0, 0, 0 };
+    unsigned long long send_epoch[4] = { 0, 0, 0, 0 }, recv_epoch[4] = { 0, 0, 0, 0 };
+    uint32_t* d_done = nullptr;                      /* [4] last-block counters */
+    unsigned long long timeout_ticks = 2000000000ull; /* 20 s of the 100 MHz clock (HQ_IPC_TIMEOUT_MS) */
+};
 
 /* ------------------------------------------------------------------------ */
 /* kernels: scatter variant                                                 */
@@ -360,6 +400,49 @@ __global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ ma
     dst[i][d] = table[3 * (int64_t)map[i] + d];
 }
 
+/*
+ * Device-to-device transport between PROCESSES (hq_comm_init_ipc): the same direct peer stores, into receive buffers
+ * the peers exported through HIP IPC, ordered by epoch flags in the receivers' arenas instead of HIP events -- an event
+ * cannot order streams of two processes without a host handshake per exchange, a counter in memory can.  The block
+ * that finishes last (a device-scope counter behind a system-scope fence: all records of all blocks are out) stores
+ * the epoch of this exchange to one flag per receiving peer.
+ */
+__global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
+                                       double* const* __restrict__ dst, uint32_t* __restrict__ done, int32_t nsig,
+                                       unsigned long long* const* __restrict__ sig, unsigned long long epoch)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count * 3) {
+        int i = t / 3, d = t - 3 * i;
+        dst[i][d] = table[3 * (int64_t)map[i] + d];
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *done = 0;
+    __threadfence_system();
+    if ((int)threadIdx.x < nsig)
+        __hip_atomic_store(sig[threadIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+/* the receiving side: one lane per sending peer spins (with s_sleep) until that peer's flag has reached this exchange's
+ * epoch; a wait that lasts longer than `timeout_ticks` of the 100 MHz wall clock gives up and counts an error that
+ * hq_sync reports -- a rank that died must not leave its neighbours' GPUs spinning for ever */
+__global__ void hq_k_ipc_wait(const unsigned long long* __restrict__ flags, unsigned long long mask, unsigned long long epoch,
+                              unsigned long long timeout_ticks, int32_t* __restrict__ err)
+{
+    const int j = threadIdx.x;
+    if (!((mask >> j) & 1ull)) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(err, 1); return; }
+    }
+}
+
 __global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
                             const double* __restrict__ in, double* __restrict__ table, int add)
 {
@@ -454,6 +537,10 @@ static int hq_build_schedule(hq_ctx* c, const hq_schedule* in, hq_dev_schedule* 
     return HQ_OK;
 }
 
+static bool hq_ipc_ready(const hq_ctx* c);
+/* a transport that is in place (an IPC arena that was exported but never connected is none: bench.py falls back from it) */
+static bool hq_has_transport(const hq_ctx* c) { return c->comm || c->group || c->host_xchg || hq_ipc_ready(c); }
+
 static hq_dev_schedule* hq_peer_schedule(hq_ctx* peer, hq_ctx* me, hq_dev_schedule* mine)
 {
     return (mine == &me->an) ? &peer->an : &peer->dn;
@@ -480,8 +567,20 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     double* d_out = contribution ? s->d_c_out : s->d_s_out;
     double* d_in = contribution ? s->d_s_in : s->d_c_in;
     int32_t total = contribution ? s->ctotal : s->stotal;
-    if (!c->comm && !c->group && !c->host_xchg)
-        return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init, hq_comm_init_host or hq_group_link%s", "");
+    if (!hq_has_transport(c))
+        return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init, hq_comm_init_ipc, hq_comm_init_host or hq_group_link%s", "");
+    if (hq_ipc_ready(c)) {
+        /* between processes: the records are written where the peers read them, the last block raises the peers' flags */
+        hq_ipc_state* I = c->ipc;
+        if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the IPC transport%s", "");
+        const int x = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
+        if (total) {
+            I->send_epoch[x]++;
+            hq_k_pack_to_peers_sig<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, I->d_dst[x], I->d_done + x,
+                                                                                     I->nsig[x], I->d_sig[x], I->send_epoch[x]);
+        }
+        return HQ_OK;
+    }
     double* const* d_dst = contribution ? s->d_c_dst : s->d_s_dst;
     if (c->group && d_dst && !c->debug_halo) {
         /* all partitions in one process: the records are written where the peers read them */
@@ -575,6 +674,17 @@ static void hq_xchg_check(hq_ctx* c, hq_dev_schedule* s, bool contribution, hipS
                                                               contribution ? s->d_s_in_id : s->d_c_in_id, c->d_halo_err);
 }
 
+/* IPC transport: the exchange stream waits until every sending peer's flag has reached this exchange's epoch */
+static void hq_ipc_wait(hq_ctx* c, hq_dev_schedule* s, bool contribution, hipStream_t xs)
+{
+    hq_ipc_state* I = c->ipc;
+    const int x = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
+    if (!I->wait_mask[x]) return;
+    I->recv_epoch[x]++;
+    hq_k_ipc_wait<<<1, 64, 0, xs>>>(I->d_flags + (size_t)x * HQ_IPC_MAXNB, I->wait_mask[x], I->recv_epoch[x], I->timeout_ticks,
+                                   c->d_halo_err + 2);
+}
+
 static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution, bool force_table)
 {
     hipStream_t xs = c->overlap ? c->cstream : c->stream;
@@ -586,6 +696,7 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     if (c->group)
         for (auto& m : rcv)
             if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+    if (hq_ipc_ready(c)) hq_ipc_wait(c, s, contribution, xs);
     hq_xchg_check(c, s, contribution, xs);
     if (!contribution) {
         /* sharing: every non-owned node has exactly one owner, one launch covers all records */
@@ -757,6 +868,7 @@ static int hq_phase(hq_ctx* c, int ph)
             if (c->group)
                 for (auto& m : c->an.s)
                     if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+            if (hq_ipc_ready(c)) hq_ipc_wait(c, &c->an, true, xs);
             hq_xchg_check(c, &c->an, true, xs);
             if (c->nOI)
                 hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
@@ -1182,8 +1294,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(HQ_ERR_DEVICE, "dangling-node table upload failed%s", ""));
     }
 
-    if ((rc = hq_dev_alloc(c, &c->d_halo_err, 2)) != HQ_OK) return bail(rc);
-    if (hipMemset(c->d_halo_err, 0, 2 * sizeof(int32_t)) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
+    if ((rc = hq_dev_alloc(c, &c->d_halo_err, 4)) != HQ_OK) return bail(rc);
+    if (hipMemset(c->d_halo_err, 0, 4 * sizeof(int32_t)) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
     if (getenv("HQ_DEBUG_HALO") && atoi(getenv("HQ_DEBUG_HALO")) != 0 && c->nranks > 1) {
         /* the reference's -DDEBUG exchange: every halo record carries the global id of its node and the
          * receiver checks it (psolve.c:5002-5007, 5058-5069).  Identity = node_t.gnid where the caller
@@ -1738,6 +1850,20 @@ extern "C" int hq_destroy(hq_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hq_quiesce(c);
     if (c->comm && g_rccl.handle) g_rccl.CommDestroy(c->comm);
+    if (c->ipc) {
+        hq_ipc_state* I = c->ipc;
+        for (int x = 0; x < 4; x++) {                /* the receive buffers live in the arena */
+            hq_dev_schedule* sc = x < 2 ? &c->an : &c->dn;
+            if (x & 1) sc->d_c_in = nullptr; else sc->d_s_in = nullptr;
+            if (I->d_dst[x]) hipFree(I->d_dst[x]);
+            if (I->d_sig[x]) hipFree(I->d_sig[x]);
+        }
+        for (void* p : I->opened) hipIpcCloseMemHandle(p);
+        if (I->d_done) hipFree(I->d_done);
+        if (I->arena) hipFree(I->arena);
+        delete I;
+        c->ipc = nullptr;
+    }
     void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt_rows, c->d_u[0], c->d_u[1], c->d_u[2],
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
@@ -1778,22 +1904,33 @@ extern "C" int hq_destroy(hq_ctx* c)
     return HQ_OK;
 }
 
-extern "C" int hq_get_info(hq_ctx* c, hq_info* info)
+extern "C" int hq_abi_version(void) { return HQ_ABI_VERSION; }
+
+extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
 {
     if (!c || !info) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
-    info->variant = c->variant;
-    info->npatches = c->plan.npatches;
-    info->patch_pairs = c->plan.npairs;
-    info->device_bytes = c->bytes;
-    info->step = c->step;
-    info->nranks = c->nranks;
-    info->lattice_patches = c->plan.nlattice;
-    info->stencil_patches = c->plan.nstencil;
-    info->ragged_patches = c->plan.nragged;
-    info->brick_units = c->bricks.nunits;
-    info->brick_nodes = c->bricks.nb;
+    hq_info v;
+    memset(&v, 0, sizeof(v));
+    v.variant = c->variant;
+    v.npatches = c->plan.npatches;
+    v.patch_pairs = c->plan.npairs;
+    v.device_bytes = c->bytes;
+    v.step = c->step;
+    v.nranks = c->nranks;
+    v.lattice_patches = c->plan.nlattice;
+    v.stencil_patches = c->plan.nstencil;
+    v.ragged_patches = c->plan.nragged;
+    v.brick_units = c->bricks.nunits;
+    v.brick_nodes = c->bricks.nb;
+    v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet;
+    v.brick_units_het = c->bricks.nhet;
+    memset(info, 0, (size_t)size);
+    memcpy(info, &v, (size_t)std::min<uint64_t>(size, sizeof(v)));
     return HQ_OK;
 }
+
+/* the symbol of the rounds before the struct grew: 48 bytes, never more (include/hq_solver.h) */
+extern "C" int hq_get_info(hq_ctx* c, hq_info* info) { return hq_get_info_sized(c, info, 48); }
 
 /*
  * With the exchange chain on its own stream BETWEEN GPUs the compute stream must leave it somewhere to run: stream
@@ -1847,7 +1984,7 @@ extern "C" int hq_comm_unique_id(void* id128)
 extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
 {
     if (!c || !id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
-    if (c->comm || c->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     HQ_TRY(hq_rccl_load());
     HQ_HIP(hipSetDevice(c->device));
     hq_nccl_id id;
@@ -1887,12 +2024,214 @@ extern "C" int hq_comm_selftest(hq_ctx* c, int32_t count)
 extern "C" int hq_comm_init_host(hq_ctx* c, hq_host_exchange_fn fn, void* user)
 {
     if (!c || !fn) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
-    if (c->comm || c->group || c->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     c->host_xchg = fn;
     c->host_user = user;
     /* as between GPUs: the chain on its own stream, so that the host waits for the exchange stream only */
     c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
     return hq_mask_compute_stream(c);
+}
+
+/* ------------------------------------------------------------------------ */
+/* IPC transport (between processes on one node; include/hq_solver.h)       */
+/* ------------------------------------------------------------------------ */
+
+static std::vector<hq_dev_messenger>& hq_ipc_list(hq_ctx* c, int x, bool sending)
+{
+    hq_dev_schedule* s = x < 2 ? &c->an : &c->dn;
+    const bool contribution = !(x & 1);
+    if (sending) return contribution ? s->c : s->s;
+    return contribution ? s->s : s->c;
+}
+
+static double** hq_ipc_inbuf(hq_ctx* c, int x)
+{
+    hq_dev_schedule* s = x < 2 ? &c->an : &c->dn;
+    return (x & 1) ? &s->d_c_in : &s->d_s_in;
+}
+
+static int32_t hq_ipc_total(hq_ctx* c, int x, bool sending)
+{
+    hq_dev_schedule* s = x < 2 ? &c->an : &c->dn;
+    const bool contribution = !(x & 1);
+    if (sending) return contribution ? s->ctotal : s->stotal;
+    return contribution ? s->stotal : s->ctotal;
+}
+
+static bool hq_ipc_ready(const hq_ctx* c) { return c->ipc && c->ipc->ready; }
+
+/* the arena: flags, the four receive buffers (moved here from their own allocations), a dump row */
+static int hq_ipc_prepare(hq_ctx* c)
+{
+    if (c->ipc) return HQ_OK;
+    if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the IPC transport%s", "");
+    for (int x = 0; x < 4; x++)
+        if (hq_ipc_list(c, x, false).size() > HQ_IPC_MAXNB || hq_ipc_list(c, x, true).size() > HQ_IPC_MAXNB)
+            return hq_fail(HQ_ERR_ARG, "IPC transport: more than %s neighbours in one schedule", "64");
+    HQ_HIP(hipSetDevice(c->device));
+    HQ_HIP(hq_quiesce(c));
+    hq_ipc_state* I = new (std::nothrow) hq_ipc_state();
+    if (!I) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");
+    memset(&I->mine, 0, sizeof(I->mine));
+    hq_ipc_blob& B = I->mine;
+    B.magic = HQ_IPC_MAGIC; B.version = HQ_ABI_VERSION;
+    B.rank = c->rank; B.nranks = c->nranks; B.device = c->device; B.pid = (int32_t)getpid();
+    size_t off = sizeof(unsigned long long) * 4 * HQ_IPC_MAXNB;
+    B.flag_off = 0;
+    for (int x = 0; x < 4; x++) {
+        B.buf_off[x] = off;
+        off += ((size_t)hq_ipc_total(c, x, false) * 24 + 255) / 256 * 256;
+    }
+    const size_t dump_off = off;
+    off += 256;
+    I->arena_bytes = off;
+    /* fine-grained device memory: remote stores over xGMI become visible to the local consumer kernels without an L2
+     * flush (what RCCL uses for its buffers); where the runtime cannot export it, coarse-grained memory -- coherent only
+     * between ranks that share the device, which hq_comm_init_ipc checks */
+    bool coarse = getenv("HQ_IPC_COARSE") && atoi(getenv("HQ_IPC_COARSE")) != 0;
+    for (int attempt = coarse ? 1 : 0; attempt < 2; attempt++) {
+        hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&I->arena, I->arena_bytes, hipDeviceMallocFinegrained)
+                                    : hipMalloc(&I->arena, I->arena_bytes);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&B.mem, I->arena);
+        if (e == hipSuccess) { coarse = attempt == 1; break; }
+        (void)hipGetLastError();
+        if (I->arena) { hipFree(I->arena); I->arena = nullptr; }
+        if (attempt == 1) {
+            delete I;
+            return hq_fail(HQ_ERR_DEVICE, "IPC transport: cannot allocate / export the receive arena: %s", hipGetErrorString(e));
+        }
+    }
+    I->coarse = coarse;
+    B.coarse = coarse ? 1 : 0;
+    B.arena_bytes = I->arena_bytes;
+    B.arena_addr = (uint64_t)(uintptr_t)I->arena;
+    if (hipDeviceGetPCIBusId(B.busid, (int)sizeof(B.busid), c->device) != hipSuccess) B.busid[0] = 0;
+    if (hipMemset(I->arena, 0, I->arena_bytes) != hipSuccess) { hipFree(I->arena); delete I; return hq_fail(HQ_ERR_DEVICE, "memset%s", ""); }
+    c->bytes += (int64_t)I->arena_bytes;
+    I->d_flags = (unsigned long long*)I->arena;
+    for (int x = 0; x < 4; x++) {
+        double** pin = hq_ipc_inbuf(c, x);
+        if (*pin) { hipFree(*pin); *pin = nullptr; }
+        if (hq_ipc_total(c, x, false)) *pin = (double*)((char*)I->arena + B.buf_off[x]);
+        std::vector<hq_dev_messenger>& rcv = hq_ipc_list(c, x, false);
+        B.nrecv[x] = (int32_t)rcv.size();
+        for (size_t j = 0; j < rcv.size(); j++) {
+            B.recv[x][j].procid = rcv[j].procid; B.recv[x][j].offset = rcv[j].offset; B.recv[x][j].count = rcv[j].nodecount;
+            if (rcv[j].nodecount) I->wait_mask[x] |= 1ull << j;
+        }
+    }
+    B.reserved = (int32_t)(dump_off / 8);
+    if (hipMalloc((void**)&I->d_done, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(I->d_done, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
+        hipFree(I->arena); delete I;
+        return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", "");
+    }
+    if (getenv("HQ_IPC_TIMEOUT_MS") && atof(getenv("HQ_IPC_TIMEOUT_MS")) > 0)
+        I->timeout_ticks = (unsigned long long)(atof(getenv("HQ_IPC_TIMEOUT_MS")) * 1.0e5);
+    c->ipc = I;
+    return HQ_OK;
+}
+
+extern "C" int hq_comm_ipc_export(hq_ctx* c, void* blob)
+{
+    if (!c || !blob) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_TRY(hq_ipc_prepare(c));
+    memset(blob, 0, HQ_IPC_BLOB_BYTES);
+    memcpy(blob, &c->ipc->mine, sizeof(hq_ipc_blob));
+    return HQ_OK;
+}
+
+/* dst / sig tables of exchange x from (peer arena base, peer blob) pairs; loopback: everything into this rank's own arena */
+static int hq_ipc_connect(hq_ctx* c, const char* blobs)
+{
+    hq_ipc_state* I = c->ipc;
+    const bool loop = blobs == nullptr;
+    std::vector<void*> base((size_t)c->nranks, nullptr);
+    auto peer_base = [&](int32_t r, const hq_ipc_blob** pbo) -> int {
+        const hq_ipc_blob* pb = (const hq_ipc_blob*)(blobs + (size_t)r * HQ_IPC_BLOB_BYTES);
+        *pbo = pb;
+        if (pb->magic != HQ_IPC_MAGIC || pb->version != HQ_ABI_VERSION || pb->rank != r || pb->nranks != c->nranks)
+            return hq_fail(HQ_ERR_ARG, "IPC transport: blob %s is not the export of that rank of this run", "r");
+        if (base[(size_t)r]) return HQ_OK;
+        if ((pb->coarse || I->coarse) && strncmp(pb->busid, I->mine.busid, sizeof(pb->busid)) != 0)
+            return hq_fail(HQ_ERR_DEVICE, "IPC transport: a coarse-grained receive arena is coherent only between ranks of ONE device%s", "");
+        if (pb->pid == I->mine.pid) {
+            base[(size_t)r] = (void*)(uintptr_t)pb->arena_addr;         /* a context of this process: its pointer is ours */
+            if (strncmp(pb->busid, I->mine.busid, sizeof(pb->busid)) != 0) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->device, pb->device) != hipSuccess || !can)
+                    return hq_fail(HQ_ERR_DEVICE, "IPC transport: no peer access between the devices of two contexts%s", "");
+                hipError_t e = hipDeviceEnablePeerAccess(pb->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hq_fail(HQ_ERR_DEVICE, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        } else {
+            void* p = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&p, pb->mem, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+            I->opened.push_back(p);
+            base[(size_t)r] = p;
+        }
+        return HQ_OK;
+    };
+    for (int x = 0; x < 4; x++) {
+        std::vector<hq_dev_messenger>& snd = hq_ipc_list(c, x, true);
+        const int32_t total = hq_ipc_total(c, x, true);
+        std::vector<double*> dst((size_t)total, nullptr);
+        std::vector<unsigned long long*> sig;
+        if (loop) {
+            const int32_t in_total = hq_ipc_total(c, x, false);
+            double* in = *hq_ipc_inbuf(c, x);
+            double* dump = (double*)I->arena + I->mine.reserved;
+            for (int32_t i = 0; i < total; i++) dst[(size_t)i] = in_total ? in + 3 * (int64_t)(i % in_total) : dump;
+            if (!total) I->wait_mask[x] = 0;
+            for (int j = 0; j < HQ_IPC_MAXNB; j++)
+                if ((I->wait_mask[x] >> j) & 1ull) sig.push_back(I->d_flags + (size_t)x * HQ_IPC_MAXNB + j);
+        } else {
+            for (auto& m : snd) {
+                if (!m.nodecount) continue;
+                if (m.procid < 0 || m.procid >= c->nranks) return hq_fail(HQ_ERR_ARG, "IPC transport: a messenger names a rank outside the run%s", "");
+                const hq_ipc_blob* pb = nullptr;
+                HQ_TRY(peer_base(m.procid, &pb));
+                int j = -1;
+                for (int q = 0; q < pb->nrecv[x] && q < HQ_IPC_MAXNB; q++) if (pb->recv[x][q].procid == c->rank) j = q;
+                if (j < 0 || pb->recv[x][j].count != m.nodecount) return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
+                char* pbase = (char*)base[(size_t)m.procid];
+                double* p_in = (double*)(pbase + pb->buf_off[x]);
+                for (int32_t k = 0; k < m.nodecount; k++) dst[(size_t)m.offset + k] = p_in + 3 * ((int64_t)pb->recv[x][j].offset + k);
+                sig.push_back((unsigned long long*)(pbase + pb->flag_off) + (size_t)x * HQ_IPC_MAXNB + j);
+            }
+        }
+        I->nsig[x] = (int32_t)sig.size();
+        if (total) {
+            HQ_TRY(hq_dev_alloc(c, &I->d_dst[x], (size_t)total));
+            HQ_HIP(hipMemcpy(I->d_dst[x], dst.data(), sizeof(double*) * (size_t)total, hipMemcpyHostToDevice));
+            HQ_TRY(hq_dev_alloc(c, &I->d_sig[x], sig.size()));
+            if (!sig.empty()) HQ_HIP(hipMemcpy(I->d_sig[x], sig.data(), sizeof(void*) * sig.size(), hipMemcpyHostToDevice));
+        }
+    }
+    I->ready = true;
+    I->loopback = loop;
+    /* as between GPUs: the chain on its own stream beside the interior work */
+    c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
+    return hq_mask_compute_stream(c);
+}
+
+extern "C" int hq_comm_init_ipc(hq_ctx* c, const void* blobs)
+{
+    if (!c || !blobs) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    if (!c->ipc) return hq_fail(HQ_ERR_STATE, "hq_comm_init_ipc needs the blobs of hq_comm_ipc_export (this rank's among them)%s", "");
+    if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    HQ_HIP(hipSetDevice(c->device));
+    return hq_ipc_connect(c, (const char*)blobs);
+}
+
+extern "C" int hq_comm_init_loopback(hq_ctx* c)
+{
+    if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    HQ_TRY(hq_ipc_prepare(c));
+    if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+    return hq_ipc_connect(c, nullptr);
 }
 
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
@@ -1901,7 +2240,7 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
     for (int32_t i = 0; i < n; i++) {
         if (!ctxs[i] || ctxs[i]->rank != i || ctxs[i]->nranks != n)
             return hq_fail(HQ_ERR_ARG, "group member %s must be the context of rank i of n", "i");
-        if (ctxs[i]->group || ctxs[i]->comm || ctxs[i]->host_xchg) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+        if (hq_has_transport(ctxs[i])) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     }
     std::vector<hq_ctx*>* g = new (std::nothrow) std::vector<hq_ctx*>(ctxs, ctxs + n);
     if (!g) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");
@@ -2023,6 +2362,16 @@ extern "C" int hq_sync(hq_ctx* c)
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
+    if (c->ipc) {
+        int32_t late = 0;
+        HQ_HIP(hipMemcpy(&late, c->d_halo_err + 2, sizeof late, hipMemcpyDeviceToHost));
+        if (late) {
+            char n[32];
+            snprintf(n, sizeof n, "%d", late);
+            HQ_HIP(hipMemset(c->d_halo_err + 2, 0, sizeof(int32_t)));
+            return hq_fail(HQ_ERR_COMM, "IPC transport: %s waits for a neighbour's halo records timed out (HQ_IPC_TIMEOUT_MS)", n);
+        }
+    }
     if (c->debug_halo) {
         int32_t bad = 0;
         HQ_HIP(hipMemcpy(&bad, c->d_halo_err, sizeof bad, hipMemcpyDeviceToHost));

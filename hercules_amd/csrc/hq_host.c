@@ -162,12 +162,9 @@ static int radix_sort_u64(uint64_t* a, int64_t n, int bits)
     for (int sh = 0; sh < bits; sh += 11) {
         /* per-thread histograms over contiguous blocks: a stable parallel counting pass */
         memset(hist, 0, sizeof(int64_t) * 2048 * (size_t)nth);
-#pragma omp parallel num_threads(nth)
-        {
-            int tid = 0;
-#ifdef _OPENMP
-            tid = omp_get_thread_num();
-#endif
+        /* slices dealt by a worksharing loop: independent of the team the runtime delivers */
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+        for (int tid = 0; tid < nth; tid++) {
             const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
             int64_t* h = hist + 2048 * (size_t)tid;
             for (int64_t i = lo; i < hi; i++) h[(src[i] >> sh) & 2047]++;
@@ -175,12 +172,8 @@ static int radix_sort_u64(uint64_t* a, int64_t n, int bits)
         int64_t run = 0;
         for (int d = 0; d < 2048; d++)
             for (int q = 0; q < nth; q++) { int64_t c = hist[2048 * (size_t)q + d]; hist[2048 * (size_t)q + d] = run; run += c; }
-#pragma omp parallel num_threads(nth)
-        {
-            int tid = 0;
-#ifdef _OPENMP
-            tid = omp_get_thread_num();
-#endif
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+        for (int tid = 0; tid < nth; tid++) {
             const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
             int64_t* h = hist + 2048 * (size_t)tid;
             for (int64_t i = lo; i < hi; i++) dst[h[(src[i] >> sh) & 2047]++] = src[i];

@@ -644,10 +644,11 @@ static void hq_patch_candidates(int64_t E, const int32_t* lnid, const hq_danglin
 #pragma omp single
         nth = omp_get_num_threads();
     }
+    /* slices are dealt by a worksharing loop, not by thread number: whatever team the runtime delivers, every slice
+     * is scanned (round-3 advisor finding) */
     std::vector<std::vector<int32_t>> part((size_t)nth);
-#pragma omp parallel num_threads(nth)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nth; t++) {
         const int64_t lo = E * t / nth, hi = E * (t + 1) / nth;
         std::vector<int32_t>& v = part[(size_t)t];
         for (int64_t e = lo; e < hi; e++) {

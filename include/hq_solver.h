@@ -115,6 +115,8 @@ typedef struct {
     int32_t ragged_patches;      /* patch variant: of the stencil patches, the lattice SUBSETS (faces, far-face cubes) */
     int32_t brick_units;         /* patch variant: workgroup units of hq_k_brick (tile column x planes)          */
     int64_t brick_nodes;         /* patch variant: nodes stepped by hq_k_brick (the rest belongs to the patches)  */
+    int32_t brick_units_pernode; /* of brick_units: uniform coefficients, n_t rows of their own (hq_k_brick<true>)  */
+    int32_t brick_units_het;     /* of brick_units: per-element coefficients (hq_k_brick_het)                      */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -135,7 +137,21 @@ HQ_API int hq_create(const hq_desc* desc, int device, hq_ctx** out);
 /* solver_delete (psolve.c:3627-3649). */
 HQ_API int hq_destroy(hq_ctx* ctx);
 
+/*
+ * hq_info carries no size field of its own, so the call does: hq_get_info_sized writes min(size, sizeof(hq_info))
+ * bytes, and the hq_get_info() of this header passes the caller's own sizeof -- a client compiled against an older
+ * (shorter) hq_info is never written past its struct, a newer one gets what this library knows and zeros behind.
+ * The exported SYMBOL hq_get_info is kept for binaries built before round 3 and writes the 48-byte struct of then
+ * (up to and including the field that was `reserved`).  hq_abi_version() == HQ_ABI_VERSION is the check a separately
+ * compiled client makes at start-up.
+ */
+#define HQ_ABI_VERSION 4
+HQ_API int hq_abi_version(void);
+HQ_API int hq_get_info_sized(hq_ctx* ctx, hq_info* info, uint64_t size);
 HQ_API int hq_get_info(hq_ctx* ctx, hq_info* info);
+#ifndef HQ_SOLVER_IMPLEMENTATION
+#define hq_get_info(ctx, info) hq_get_info_sized((ctx), (info), (uint64_t)sizeof(hq_info))
+#endif
 
 /*
  * Multi-GPU: one RCCL communicator over the ranks that hold the partitions.
@@ -164,6 +180,27 @@ typedef int (*hq_host_exchange_fn)(void* user, int32_t nrecv, const int32_t* rec
                                    double* const* recv_buf, int32_t nsend, const int32_t* send_peer,
                                    const int64_t* send_count, const double* const* send_buf, int32_t tag);
 HQ_API int hq_comm_init_host(hq_ctx* ctx, hq_host_exchange_fn fn, void* user);
+
+/*
+ * Device-to-device transport between PROCESSES of one node without RCCL: direct peer stores over xGMI (or inside one
+ * GPU that several ranks share) into receive buffers exported through HIP IPC -- the "direct peer stores" design of
+ * SURVEY s5 for schedule_senddata (psolve.c:4945-5079): pack (psolve.c:4985-5011) writes each record where its
+ * receiver's unpack (:5035-5073) reads it, and the MPI_Waitall (:5033) becomes a wait on one epoch flag per sending
+ * neighbour in the receiver's own memory.  No host hop, no collective, no library between the two GPUs.
+ *   1. every rank: hq_comm_ipc_export(ctx, blob)            blob: HQ_IPC_BLOB_BYTES bytes
+ *   2. the host all-gathers the blobs in rank order          (MPI_Allgather on comm_solver in the reference's world)
+ *   3. every rank: hq_comm_init_ipc(ctx, all_blobs)          all_blobs: nranks x HQ_IPC_BLOB_BYTES
+ * A rank whose neighbour stops sending does not spin for ever: a wait longer than HQ_IPC_TIMEOUT_MS (default 20 000)
+ * gives up, and the next hq_sync returns HQ_ERR_COMM.  HQ_DEBUG_HALO is not carried.
+ */
+#define HQ_IPC_BLOB_BYTES 4096
+HQ_API int hq_comm_ipc_export(hq_ctx* ctx, void* blob);
+HQ_API int hq_comm_init_ipc(hq_ctx* ctx, const void* all_blobs);
+/* Diagnostic (profiles/tools/rank_alone_trace.py): the IPC transport with this rank as its own only peer -- every record
+ * it sends lands in its own receive buffers and raises its own flags.  The displacements of interface nodes are then
+ * WRONG by construction; the step's kernels, streams and waits are exactly those of a rank whose neighbours answer
+ * with zero latency. */
+HQ_API int hq_comm_init_loopback(hq_ctx* ctx);
 
 /*
  * In-process transport for hosts that drive several partitions from ONE process

@@ -1,7 +1,10 @@
 """One rank of an 8-way split of the 64M box ALONE on the GPU, with the exchange chain on its own stream and a
-transport that returns at once (hq_comm_init_host with a callback that zero-fills what it should receive): what a rank
-of an 8-GPU run enqueues per step and WHEN the chain's kernels run relative to its patch and brick launches.
-    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/tools/rank_alone_trace.py [rank] [steps]
+transport of zero latency: what a rank of an 8-GPU run enqueues per step and WHEN the chain's kernels run relative
+to its patch and brick launches.  Transport (HQ_TRACE_TRANSPORT): `loopback` (default; hq_comm_init_loopback: the IPC
+transport's kernels, peer stores and flag waits with the rank as its own peer -- all on the device, no host hop) or
+`host` (hq_comm_init_host with a callback that zero-fills what it should receive: two stream synchronisations and
+two PCIe hops per exchange, the round-3 trace).
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/tools/rank_alone_trace.py [rank] [steps] [workload]
     python3 profiles/tools/rank_alone_trace.py --analyse <kernel_trace.csv>
 (Results of the run are meaningless: the neighbours' records are zeros.)"""
 import csv
@@ -11,11 +14,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def run(rank, steps):
+def run(rank, steps, workload="c3"):
     import numpy as np
     import bench
     from hercules_amd import host
-    nx, ny, nz, h, dt, freq = bench.WORKLOADS["c3"]
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS[workload]
     b = host.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=8)
     u = bench.seeded_field(b.node_ijk, nx, ny)
     s = b.create_solver(tm1=u, tm2=u * 0.999)
@@ -23,7 +26,10 @@ def run(rank, steps):
     def exchange(recvs, sends, tag):
         for _, buf in recvs:
             buf[:] = 0.0
-    s.comm_init_host(exchange)
+    if os.environ.get("HQ_TRACE_TRANSPORT", "loopback") == "host":
+        s.comm_init_host(exchange)
+    else:
+        s.comm_init_loopback()
     s.run(steps)
     s.sync()
     print("rank %d of 8 alone: %s" % (rank, s.info()))
@@ -37,7 +43,7 @@ def analyse(path):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Queue_Id"]))
     rows.sort()
     bricks = [i for i, r in enumerate(rows) if "hq_k_brick" in r[2]]
-    chain_names = ("hq_k_pack", "hq_k_unpack", "hq_k_interface_update", "hq_k_distribute")
+    chain_names = ("hq_k_pack", "hq_k_unpack", "hq_k_interface_update", "hq_k_distribute", "hq_k_ipc_wait", "hq_k_iface")
     # steps: from one brick launch to the next; skip the first few
     stats = []
     for a, b in zip(bricks[5:-1], bricks[6:]):
@@ -70,4 +76,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--analyse":
         analyse(sys.argv[2])
     else:
-        run(int(sys.argv[1]) if len(sys.argv) > 1 else 3, int(sys.argv[2]) if len(sys.argv) > 2 else 30)
+        run(int(sys.argv[1]) if len(sys.argv) > 1 else 3, int(sys.argv[2]) if len(sys.argv) > 2 else 30,
+            sys.argv[3] if len(sys.argv) > 3 else "c3")

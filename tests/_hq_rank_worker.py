@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_multiprocess.py: ONE RANK of a partitioned run in its own process -- its own HIP
 context, streams and events -- on the GPU all ranks of the test share.  The halo records travel through the
-engine's host-staged transport (hq_comm_init_host) and torch.distributed's gloo, which stands in for the MPI of the
-reference's world (psolve.c:7344-7389 `mpiexec -np N`; schedule_senddata psolve.c:4945-5079).  Everything else is
+engine's host-staged transport (hq_comm_init_host) and torch.distributed's gloo, or (HQ_TEST_TRANSPORT=ipc) device to
+device through the IPC transport (hq_comm_ipc_export / hq_comm_init_ipc) with gloo only for the set-up all-gather;
+gloo stands in for the MPI of the reference's world (psolve.c:7344-7389 `mpiexec -np N`; schedule_senddata psolve.c:4945-5079).  Everything else is
 the product path: C host side for the partition, hq_create / hq_set_source / hq_run on the device.
 Writes this rank's final fields to <outdir>/rank<r>.npz."""
 import os
@@ -53,7 +54,14 @@ def main():
         ho.compute_adjust(g1, 1, ref["dangling"])
         ho.compute_adjust(g2, 1, ref["dangling"])
     s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid])
-    s.comm_init_host(gloo_exchange)
+    if os.environ.get("HQ_TEST_TRANSPORT", "host") == "ipc":
+        # device-to-device between the processes: blobs all-gathered over gloo (MPI_Allgather in the reference's world)
+        mine = torch.frombuffer(bytearray(s.comm_ipc_export()), dtype=torch.uint8)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        s.comm_init_ipc([bytes(t.numpy().tobytes()) for t in every])
+    else:
+        s.comm_init_host(gloo_exchange)
     if F is not None:
         s.set_source(loaded, F)
     dist.barrier()

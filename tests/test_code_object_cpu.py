@@ -1,0 +1,55 @@
+"""What hipcc made of the hot kernels, read from the code object inside libhq_solver.so (no GPU): the brick kernels
+must not spill -- a spilled VGPR is scratch traffic behind every load in flight -- and must keep the
+occupancy their launch bounds promise (<= 128 VGPRs: two 512-thread workgroups per CU)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+SO = os.path.join(ROOT, "hercules_amd", "csrc", "libhq_solver.so")
+
+
+def _kernel_notes(tmp_path):
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools) or not os.path.exists(SO):
+        pytest.skip("llvm tools or the built library are not here")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, SO])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           "--input=" + fat, "--output=" + co])
+    txt = subprocess.check_output([tools[2], "--notes", co], universal_newlines=True)
+    kernels = {}
+    for block in txt.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|"
+                                                          r"private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", block)}
+    return kernels
+
+
+def test_brick_kernels_do_not_spill(tmp_path):
+    k = _kernel_notes(tmp_path)
+    found = {}
+    for name, v in k.items():
+        for tag in ("hq_k_brickILb0E", "hq_k_brickILb1E", "hq_k_brick_het"):
+            if tag in name:
+                found[tag] = v
+    assert set(found) == {"hq_k_brickILb0E", "hq_k_brickILb1E", "hq_k_brick_het"}, sorted(k)
+    for tag, v in found.items():
+        assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (tag, v)
+    # two workgroups of 512 threads per CU = 4 waves per SIMD: <= 128 VGPRs (MI355X_MICROARCH.md, register files)
+    assert found["hq_k_brickILb0E"]["vgpr_count"] <= 128 and found["hq_k_brick_het"]["vgpr_count"] <= 128
+    assert found["hq_k_brickILb0E"]["group_segment_fixed_size"] <= 80 * 1024
+
+
+def test_exchange_chain_kernels_are_small(tmp_path):
+    """pack / unpack / interface update / the IPC wait run beside the interior launches: few registers, no scratch."""
+    k = _kernel_notes(tmp_path)
+    seen = 0
+    for name, v in k.items():
+        if any(t in name for t in ("hq_k_pack", "hq_k_unpack", "hq_k_interface_update", "hq_k_ipc_wait")):
+            seen += 1
+            assert v["vgpr_count"] <= 32 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
+    assert seen >= 5

@@ -1,0 +1,96 @@
+"""The brick kernels that no mesh of solver_init reaches by itself, against the oracle (through the C-ABI):
+hq_k_brick<true> -- uniform element coefficients, n_t rows that differ from node to node -- and the planner
+switches around the bricks (HQ_BRICK_CZ / MINZ / MINNODES / NO_HET) on a box small enough for the oracle's whole run.
+Tolerance as everywhere: <= 1e-9 relative L-inf on nodal displacement (psolve.c:4072-4114 + stiffness.c:180-237 +
+damping.c:29-103 in fp64, other summation order)."""
+import numpy as np
+import pytest
+
+import hercules_amd as ha
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def _ticks(node_ijk, edge=1 << 24):
+    return (np.asarray(node_ijk, np.int64) * edge).astype(np.int32)
+
+
+def _box(nx, ny, nz, h=15.0, dt=3e-4, freq=30.0):
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:] = (h, 6000.0, 3464.0, 2700.0)
+    face = ho.face_bits(elem_ijk, nx, ny, nz)
+    et, nt = ho.solver_init(lnid, edata, face, len(node_ijk), dt, freq)
+    return lnid, node_ijk, et, nt, dt
+
+
+def _run_both(lnid, node_ijk, et, nt, dt, nsteps, seed=7):
+    N = len(node_ijk)
+    rng = np.random.default_rng(seed)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (N, 3)) * 1e-6
+    s = ha.Solver(lnid, et, nt, dt, node_xyz=_ticks(node_ijk), tm1=u1, tm2=u2, variant=ha.HQ_VARIANT_PATCH)
+    info = s.info()
+    s.run(nsteps)
+    tm1, tm2 = s.download()
+    s.close()
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(lnid, et.copy(), nt.copy(), o1, o2, 0, nsteps, dt)
+    return info, tm1, tm2, o2, o1
+
+
+def test_brick_units_with_per_node_nt_rows_forced(monkeypatch):
+    """HQ_BRICK_NO_NTSAME=1: every uniform unit reads its nodes' own n_t rows -- hq_k_brick<true> on the 64 x 64 x 32 box."""
+    monkeypatch.setenv("HQ_BRICK_NO_NTSAME", "1")
+    lnid, node_ijk, et, nt, dt = _box(64, 64, 32)
+    info, tm1, tm2, r1, r2 = _run_both(lnid, node_ijk, et, nt, dt, 12)
+    assert info["brick_units"] > 0 and info["brick_units_pernode"] == info["brick_units"] and info["brick_units_het"] == 0
+    assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL
+
+
+def test_brick_units_with_a_callers_per_node_masses():
+    """A caller's nTable whose rows differ from node to node inside a homogeneous region (mass_simple, mass2_minusaM and
+    mass_minusaM each scaled by a factor of the node's own; the three axes equal, so the nodes stay dashpot-free): the
+    planner must give those units per-node rows, and hq_k_brick<true> must reproduce solver_compute_displacement
+    (psolve.c:4078-4106) with them."""
+    lnid, node_ijk, et, nt, dt = _box(64, 64, 32)
+    rng = np.random.default_rng(99)
+    ijk = np.asarray(node_ijk)
+    inside = np.all((ijk > 0) & (ijk < np.array([64, 64, 32])), axis=1)
+    nt = nt.copy()
+    nt[inside, 0] *= rng.uniform(0.8, 1.25, inside.sum())
+    nt[inside, 1:4] *= rng.uniform(0.9, 1.1, inside.sum())[:, None]
+    nt[inside, 4:7] *= rng.uniform(0.9, 1.1, inside.sum())[:, None]
+    info, tm1, tm2, r1, r2 = _run_both(lnid, node_ijk, et, nt, dt, 12)
+    assert info["brick_units_pernode"] > 0 and info["brick_units_pernode"] == info["brick_units"]
+    assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL
+
+
+@pytest.mark.parametrize("env", [{"HQ_BRICK_CZ": "5"}, {"HQ_BRICK_CZ": "64", "HQ_BRICK_MINZ": "9"},
+                                 {"HQ_BRICK_MINNODES": "100000"}, {"HQ_BRICK_NO_HET": "1"}])
+def test_brick_planner_switches(monkeypatch, env):
+    """The planner's switches that no other GPU test sets: odd unit lengths, long minimum runs, a node threshold that
+    leaves everything to the patches, and no HET units on a box with two materials side by side (the nodes of the
+    material interface then stay with the patches)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nx, ny, nz = 64, 32, 24
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:] = (15.0, 6000.0, 3464.0, 2700.0)
+    edata[np.asarray(elem_ijk)[:, 0] >= 40] = (15.0, 5000.0, 2800.0, 2500.0)       # a second material beside the first
+    face = ho.face_bits(elem_ijk, nx, ny, nz)
+    dt = 3e-4
+    et, nt = ho.solver_init(lnid, edata, face, len(node_ijk), dt, 30.0)
+    info, tm1, tm2, r1, r2 = _run_both(lnid, node_ijk, et, nt, dt, 10)
+    if "HQ_BRICK_MINNODES" in env:
+        assert info["brick_units"] == 0
+    else:
+        assert info["brick_units"] > 0
+    if "HQ_BRICK_NO_HET" in env:
+        assert info["brick_units_het"] == 0
+    assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL

@@ -1,7 +1,9 @@
 """Separate PROCESSES per rank -- what RCCL ranks are -- on one GPU: every rank has its own HIP context, compute and
 exchange streams and events, and steps its partition with hq_run (not in lockstep from one thread as hq_group_run
 does); the halo records travel through the engine's host-staged transport (hq_comm_init_host: pack on the device,
-pinned host buffers, the caller's transport -- here gloo, standing in for the reference's MPI -- and back), with the
+pinned host buffers, the caller's transport -- here gloo, standing in for the reference's MPI -- and back) or device
+to device through the IPC transport (hq_comm_init_ipc: the pack kernel stores every record where the receiving
+PROCESS reads it, epoch flags order the two streams), with the
 exchange chain on its own stream beside the interior kernels.  Only ncclSend / ncclRecv themselves stay unexercised
 on a one-GPU box (RCCL refuses two ranks on one device).  Against the oracle's single-rank run."""
 import os
@@ -40,12 +42,15 @@ def _launch(tmp_path, world, kind, nsteps, env_extra=None):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,overlap,cu_mask", [(2, "1", "0"), (4, "1", "0"), (4, "0", "0"), (2, "1", "1")])
-def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, overlap, cu_mask):
+@pytest.mark.parametrize("world,overlap,cu_mask,transport",
+                         [(2, "1", "0", "host"), (4, "0", "0", "host"), (2, "1", "1", "host"),
+                          (2, "1", "0", "ipc"), (4, "1", "0", "ipc"), (4, "0", "0", "ipc")])
+def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, overlap, cu_mask, transport):
     """cu_mask = 1: the compute stream re-created with a CU mask that leaves HQ_RESERVE_CUS CUs to the exchange stream
-    (HQ_CU_MASK=1, opt-in: DESIGN.md s6)."""
+    (HQ_CU_MASK=1, opt-in: DESIGN.md s6).  transport = ipc: device-to-device between the processes (hq_comm_init_ipc:
+    peer stores into IPC-exported receive buffers, epoch flags), no host hop."""
     nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 20
-    parts = _launch(tmp_path, world, "box", nsteps, {"HQ_OVERLAP": overlap, "HQ_CU_MASK": cu_mask})
+    parts = _launch(tmp_path, world, "box", nsteps, {"HQ_OVERLAP": overlap, "HQ_CU_MASK": cu_mask, "HQ_TEST_TRANSPORT": transport})
     from hercules_amd import host
     b = host.Box(nx, ny, nz, h, dt, freq)
     ijk = b.node_ijk.astype(np.int64)
@@ -67,11 +72,12 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
         assert int(z["brick_nodes"]) > 0 and str(z["kernel"]) == "hq_k_brick"
 
 
-def test_ranks_in_their_own_processes_on_one_gpu_octree_box(tmp_path):
+@pytest.mark.parametrize("transport", ["host", "ipc"])
+def test_ranks_in_their_own_processes_on_one_gpu_octree_box(tmp_path, transport):
     """Three ranks of the two-level octree box: hanging nodes shared between ranks, so all four exchanges of a step
-    (dangling-node and anchored-node contribution and sharing) go through the host-staged transport."""
+    (dangling-node and anchored-node contribution and sharing) go through the host-staged / the IPC transport."""
     nsteps = 12
-    parts = _launch(tmp_path, 3, "octree", nsteps)
+    parts = _launch(tmp_path, 3, "octree", nsteps, {"HQ_TEST_TRANSPORT": transport})
     ref = H.two_level_mesh(16, 8, 6, 3)
     rng = np.random.default_rng(4321)
     g1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
