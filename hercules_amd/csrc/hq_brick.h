@@ -529,12 +529,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
  *   fA  accumulator of output plane k - 1: contributions of the planes k - 2 and k - 1 and the node's own term
  *   fB  accumulator of output plane k: contribution of plane k - 1 and the node's own term m2 u1 - m1 u2
  */
-/* PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds
- * ten more values per lane -- the plane's n_t row and the reciprocal masses of the two unfinished planes -- than 128
- * VGPRs have room for (33 spilled, 76 B of scratch in round 3): it takes one workgroup per CU and as many registers
- * as it needs, no scratch. */
+/* a value every lane holds alike, moved to scalar registers */
+static __device__ __forceinline__ double hq_uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 template <bool PERNODE>
-__global__ void HQ_BK_ATTR __launch_bounds__(HQ_BK_THREADS, PERNODE ? 2 : 4)   /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
+/* PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds ten
+ * more values per lane -- the plane's n_t row and the reciprocal masses of the two unfinished planes; with the stencil
+ * numbers in scalar registers it fits 128 VGPRs too (round 3: 33 spilled) */
+__global__ void HQ_BK_ATTR __launch_bounds__(HQ_BK_THREADS, 4)   /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
 hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
            const double* __restrict__ u1g, const double* __restrict__ u2g, double* __restrict__ ung,
            const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
@@ -563,16 +569,21 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
     const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
     const double beta = U.beta;
+    /* the eight stencil numbers are the same for every lane, but fp64 products are vector instructions: without the
+     * readfirstlane their results would sit in 16 VGPRs for the whole march.  In SGPRs (a VALU instruction takes one
+     * scalar operand, and no fma below has two of them) the kernel allocates <= 112 VGPRs instead of 128: 4 waves of it
+     * per SIMD then leave 64 registers per lane to the exchange chain's small kernels, which can become resident on a
+     * CU BESIDE two brick workgroups instead of behind them */
     double P[6], Q[2];
 #pragma unroll
-    for (int i = 0; i < 6; i++) P[i] = U.c1 * sc.p1[i] + U.c2 * sc.p2[i];
+    for (int i = 0; i < 6; i++) P[i] = hq_uniform(U.c1 * sc.p1[i] + U.c2 * sc.p2[i]);
 #pragma unroll
-    for (int i = 0; i < 2; i++) Q[i] = U.c1 * sc.q1[i] + U.c2 * sc.q2[i];
+    for (int i = 0; i < 2; i++) Q[i] = hq_uniform(U.c1 * sc.q1[i] + U.c2 * sc.q2[i]);
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
     double x1[3], x2[3], y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
-    double m0A = 1.0 / U.m0, m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
+    double m0A = hq_uniform(1.0 / U.m0), m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
     double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
     int32_t rid = rtab[0];                   /* ring id of the plane to load next */
 

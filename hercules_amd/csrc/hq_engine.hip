@@ -403,9 +403,14 @@ __global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ ma
 /*
  * Device-to-device transport between PROCESSES (hq_comm_init_ipc): the same direct peer stores, into receive buffers
  * the peers exported through HIP IPC, ordered by epoch flags in the receivers' arenas instead of HIP events -- an event
- * cannot order streams of two processes without a host handshake per exchange, a counter in memory can.  The block
- * that finishes last (a device-scope counter behind a system-scope fence: all records of all blocks are out) stores
- * the epoch of this exchange to one flag per receiving peer.
+ * cannot order streams of two processes without a host handshake per exchange, a counter in memory can.
+ * Hand-off (MI355X_MICROARCH.md, "valid forms"): the records leave as system-scope (sc0 sc1, write-through) stores, every
+ * storing wave waits for its stores (s_waitcnt vmcnt(0)), and behind a workgroup barrier one lane adds to a device-scope
+ * counter; the workgroup whose add comes last stores the epoch of this exchange to one flag per receiving peer.  No
+ * fence: a release fence is an L2 write-back and an acquire an L2 invalidate, per workgroup and per poll -- they halved
+ * the brick launch running beside them (first trace of round 4).  The receiver polls with relaxed system-scope loads
+ * and reads the records in a LATER kernel (its start is the acquire); the arena is fine-grained memory, which no L2
+ * holds stale.
  */
 __global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
                                        double* const* __restrict__ dst, uint32_t* __restrict__ done, int32_t nsig,
@@ -414,31 +419,31 @@ __global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict_
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < count * 3) {
         int i = t / 3, d = t - 3 * i;
-        dst[i][d] = table[3 * (int64_t)map[i] + d];
+        __hip_atomic_store(dst[i] + d, table[3 * (int64_t)map[i] + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int s_last;
-    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    if (threadIdx.x == 0) *done = 0;
-    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)threadIdx.x < nsig)
-        __hip_atomic_store(sig[threadIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(sig[threadIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-/* the receiving side: one lane per sending peer spins (with s_sleep) until that peer's flag has reached this exchange's
- * epoch; a wait that lasts longer than `timeout_ticks` of the 100 MHz wall clock gives up and counts an error that
- * hq_sync reports -- a rank that died must not leave its neighbours' GPUs spinning for ever */
+/* the receiving side: one lane per sending peer polls (relaxed system-scope loads, s_sleep between them) until that
+ * peer's flag has reached this exchange's epoch; a wait that lasts longer than `timeout_ticks` of the 100 MHz wall clock
+ * gives up and counts an error that hq_sync reports -- a rank that died must not leave its neighbours' GPUs spinning
+ * for ever.  The records are read by the kernels enqueued behind this one. */
 __global__ void hq_k_ipc_wait(const unsigned long long* __restrict__ flags, unsigned long long mask, unsigned long long epoch,
                               unsigned long long timeout_ticks, int32_t* __restrict__ err)
 {
     const int j = threadIdx.x;
     if (!((mask >> j) & 1ull)) return;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&flags[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-        __builtin_amdgcn_s_sleep(8);
+    while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        __builtin_amdgcn_s_sleep(16);
         if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(err, 1); return; }
     }
 }

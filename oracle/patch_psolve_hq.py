@@ -11,12 +11,14 @@ Edits (each anchor must occur exactly once, else the script fails -- a changed r
 blindly):
   1. the stub (hq_attach / hq_steps / hq_refresh_host) is included in front of solver_run();
   2. main(): hq_attach() behind output_init(), i.e. after solver_init(), source_init(), stiffness_init();
-  3. solver_run(): behind the tm1/tm2 pointer swap the host arrays are refreshed from the device
-     (hq_download in the post-swap view), so that checkpoints, stations, planes and the 4D output read
-     what they always read;
+  3. solver_run(): behind the tm1/tm2 pointer swap the host arrays are refreshed from the device AT THE
+     REFERENCE'S OWN OUTPUT CADENCE (hq_refresh_for_outputs: the whole field in the post-swap view where a
+     checkpoint, the 4D output or a plane is due, the stations' 8 nodes each where only stations are due,
+     nothing otherwise), so that checkpoints, stations, planes and the 4D output read what they always read;
   4. solver_run(): the block from solver_nonlinear_state() to solver_send_displacement_dangling() becomes
-     hq_steps( step, 1 ) between Timer_Start / Timer_Stop of the timers solver_run_collect_timers() reduces;
-     the context is destroyed behind the loop.
+     hq_steps( step, n ) -- n = hq_batch_length( step ), the steps up to the next due output, enqueued in one
+     go, the loop counter advanced by n - 1 -- between Timer_Start / Timer_Stop of the timers
+     solver_run_collect_timers() reduces; the context is destroyed behind the loop.
 """
 import sys
 
@@ -42,7 +44,7 @@ def main():
     # 3
     a = "        Global.mySolver->tm1 = tmpvector;\n"
     i = once(t, a) + len(a)
-    t = t[:i] + "        hq_refresh_host( step );\n" + t[i:]
+    t = t[:i] + "        hq_refresh_for_outputs( step, startingStep );\n" + t[i:]
     # 4
     a = '        Timer_Start( "Compute Physics" );\n        solver_nonlinear_state('
     b = '        solver_send_displacement_dangling( Global.mySolver );\n        Timer_Stop( "Communication" );\n'
@@ -57,7 +59,8 @@ def main():
     for n in names:
         if '"%s"' % n not in t:
             sys.exit("patch_psolve_hq: the reference has no timer %r any more" % n)
-    block = "".join('        Timer_Start( "%s" );\n' % n for n in names) + "        hq_steps( step, 1 );\n" + \
+    block = "".join('        Timer_Start( "%s" );\n' % n for n in names) + \
+        "        { int hq_n = hq_batch_length( step ); hq_steps( step, hq_n ); step += hq_n - 1; }\n" + \
         "".join('        Timer_Stop( "%s" );\n' % n for n in reversed(names))
     t = t[:i] + block + t[j:]
     a = "    solver_drm_close();\n    solver_output_wavefield_close();\n    solver_run_collect_timers();\n"

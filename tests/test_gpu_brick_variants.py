@@ -82,7 +82,10 @@ def test_brick_planner_switches(monkeypatch, env):
     elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
     edata = np.empty((len(lnid), 4), np.float32)
     edata[:] = (15.0, 6000.0, 3464.0, 2700.0)
-    edata[np.asarray(elem_ijk)[:, 0] >= 40] = (15.0, 5000.0, 2800.0, 2500.0)       # a second material beside the first
+    # a second material beside the first (a vertical interface: the tiles that straddle it become HET units) or, without
+    # HET units, below it (a horizontal interface cuts the tile columns' runs; a vertical one would leave no full tile)
+    axis, cut = (2, 14) if "HQ_BRICK_NO_HET" in env else (0, 40)
+    edata[np.asarray(elem_ijk)[:, axis] >= cut] = (15.0, 5000.0, 2800.0, 2500.0)
     face = ho.face_bits(elem_ijk, nx, ny, nz)
     dt = 3e-4
     et, nt = ho.solver_init(lnid, edata, face, len(node_ijk), dt, 30.0)

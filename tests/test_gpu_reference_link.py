@@ -45,7 +45,7 @@ def _params(end_time, ckpt_rate, station_rate):
     return t
 
 
-def _run(binary, params, timeout=900):
+def _run(binary, params, timeout=900, nranks=1, env_extra=None):
     run = tempfile.mkdtemp(prefix="herc_hq_", dir="/tmp")
     shutil.copy(os.path.join(rb.INPUTS, "simple_case.e"), run)
     shutil.copytree(os.path.join(rb.INPUTS, "sourcefiles"), os.path.join(run, "sourcefiles"))
@@ -54,9 +54,10 @@ def _run(binary, params, timeout=900):
     open(os.path.join(run, "parameters.in"), "w").write(params)
     # the system's libstdc++ (libhq_solver.so needs it) ahead of the older one beside the image's MPICH
     syslib = "/usr/lib/x86_64-linux-gnu"
-    env = dict(os.environ, OMP_NUM_THREADS="2",
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
                LD_LIBRARY_PATH=":".join([syslib, os.path.join(MPI, "lib"), os.environ.get("LD_LIBRARY_PATH", "")]))
-    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", "1", binary, "parameters.in"], cwd=run, env=env,
+    env.update(env_extra or {})
+    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", str(nranks), binary, "parameters.in"], cwd=run, env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:]
     return run, out.stdout
@@ -79,6 +80,21 @@ def _checkpoints(run):
         tm2 = np.frombuffer(b[12:12 + nmax * 24], "<f8").reshape(nmax, 3)
         tm1 = np.frombuffer(b[12 + nmax * 24:12 + 2 * nmax * 24], "<f8").reshape(nmax, 3)
         out[step] = (tm2, tm1)
+    return out
+
+
+def _rank_stripes(run):
+    """{step: [(tm2, tm1) of every rank]} of a multi-rank run's checkpoint files (io_checkpoint.c:76-112)."""
+    out = {}
+    for k in (0, 1):
+        b = open(os.path.join(run, "out", "checkpoints", "checkpoint.out%d" % k), "rb").read()
+        groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+        ranks = []
+        for r in range(groupsize):
+            off = 12 + 2 * r * nmax * 24
+            raw = np.frombuffer(b[off:off + 2 * nmax * 24].ljust(2 * nmax * 24, b"\0"), "<f8")
+            ranks.append((raw[:3 * nmax].reshape(nmax, 3), raw[3 * nmax:].reshape(nmax, 3)))
+        out[step] = ranks
     return out
 
 
@@ -129,5 +145,56 @@ def test_the_reference_program_on_the_library_matches_the_shipped_station_traces
         assert scale > 1000.0 and np.abs(mine[:, :, 1:] - exp[:, :, 1:]).max() <= 2e-6 * scale
         head = g["expected_head"]
         assert np.abs(st[:, :head.shape[1], 1:] - head[:, :, 1:]).max() <= 2e-6 * np.abs(head[:, :, 1:]).max()
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)
+
+
+@needs_binaries
+@pytest.mark.parametrize("transport", ["mpi", "ipc"])
+def test_the_reference_program_on_eight_ranks_shares_one_gpu(transport):
+    """mpiexec -np 8 psolve_hq on examples/simple, all eight ranks on this box's one GPU: the reference's own octor
+    partition, schedule_build messengers (psolve.c:4704-4863) and mpiexec world (psolve.c:7344-7389) feed hq_desc on
+    every rank; the halo records travel on the reference's own MPI_Irecv / MPI_Isend / MPI_Waitall (HQ_TRANSPORT=mpi:
+    hq_comm_init_host with the stub's callback, psolve.c:5013-5033) or device to device between the eight processes
+    (HQ_TRANSPORT=ipc).  Against the per-rank checkpoint stripes and the station traces of the unmodified reference's
+    8-rank run (tests/golden/c1_np8.npz)."""
+    g = H.load("c1_np8")
+    run_hq, log = _run(PSOLVE_HQ, _params(float(g["end_time"]), 400, 1), nranks=8, env_extra={"HQ_TRANSPORT": transport})
+    try:
+        ck = _rank_stripes(run_hq)
+        assert sorted(ck) == [int(s) for s in g["ckpt_steps"]]
+        for step in g["ckpt_steps"]:
+            assert len(ck[int(step)]) == 8
+            for r in range(8):
+                ref2, ref1 = g["ckpt%d_tm2_%d" % (int(step), r)], g["ckpt%d_tm1_%d" % (int(step), r)]
+                tm2, tm1 = ck[int(step)][r]
+                n = len(ref1)
+                scale = max(np.abs(ref1).max(), 1e-300)
+                assert scale > 0 and np.abs(tm1[:n] - ref1).max() <= 1e-9 * scale and np.abs(tm2[:n] - ref2).max() <= 1e-9 * scale
+        st = _stations(run_hq)
+        assert st.shape == g["stations"].shape == (5, 1000, 4)
+        scale = np.abs(g["stations"][:, :, 1:]).max()
+        assert scale > 0 and np.abs(st - g["stations"]).max() <= 2e-6 * scale
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)
+
+
+@needs_binaries
+def test_the_reference_program_reads_the_device_at_its_output_cadence_only():
+    """Stations every 10 steps, a checkpoint every 400: between outputs psolve_hq enqueues whole batches (hq_steps with
+    n = steps to the next due output) and refreshes only what the due output reads (the stations' 8 nodes each through
+    hq_gather; the whole field at checkpoints) -- the station lines and checkpoints must equal the every-step run's."""
+    g = H.load("c1_short")
+    run_hq, _ = _run(PSOLVE_HQ, _params(float(g["end_time"]), 400, 10))
+    try:
+        ck = _checkpoints(run_hq)
+        for k, step in enumerate(g["ckpt_steps"]):
+            tm2, tm1 = ck[int(step)]
+            assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < 1e-9 and H.rel_linf(tm2, g["ckpt_tm2"][k]) < 1e-9
+        st = _stations(run_hq)
+        assert st.shape == (5, 100, 4)
+        ref = g["stations"][:, ::10, :]
+        scale = np.abs(g["stations"][:, :, 1:]).max()
+        assert np.abs(st - ref).max() <= 2e-6 * scale
     finally:
         shutil.rmtree(run_hq, ignore_errors=True)
