@@ -230,16 +230,23 @@ def make_octbox(workload, rank, nranks):
         nzc = OCT_COARSE_LAYERS[workload]
         levels = [(nz, None), (nzc, None)]
         box = hhost.OctBox(nx, ny, nz, nzc, h, dt, freq, rank=rank, nranks=nranks)
+    E, N, interfaces = octbox_counts(nx, ny, [l[0] for l in levels])
+    return box, E, N, interfaces
+
+
+def octbox_counts(nx, ny, layers):
+    """Elements, nodes and level interfaces [(z of the plane, finer edge) in finest-element units] of a layered octree
+    box with layers[L] element layers of edge 2^L."""
     E = N = z = 0
     interfaces = []
-    for L, (n, _) in enumerate(levels):
+    for L, n in enumerate(layers):
         E += (nx >> L) * (ny >> L) * n
         N += ((nx >> L) + 1) * ((ny >> L) + 1) * n
         if L > 0:
             interfaces.append((z, 1 << (L - 1)))
         z += n << L
     N += (nx + 1) * (ny + 1)
-    return box, E, N, interfaces
+    return E, N, interfaces
 
 
 def inproc_diagnostic(args):

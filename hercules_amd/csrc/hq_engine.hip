@@ -187,6 +187,7 @@ struct hq_ctx {
     void* host_user = nullptr;
     std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
     bool group_owner = false;
+    bool share_packed = false;               /* this step's hq_k_interface_update wrote the sharing records as well */
     struct hq_ipc_state* ipc = nullptr;      /* device-to-device transport between processes (hq_comm_init_ipc) */
     hipEvent_t ev_sent = nullptr;
     /* patch variant with an interface: the exchange chain runs on its own stream
@@ -458,6 +459,28 @@ __global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
     *p = add ? (*p + in[t]) : in[t];
 }
 
+/* the sharing unpack of the IPC transport with the wait folded in: every workgroup polls the senders' flags before it
+ * reads a record, and reads the records system-scope (hq_k_interface_update<1> has the reasoning) */
+__global__ void __launch_bounds__(256)
+hq_k_unpack_ipc(int32_t count, const int32_t* __restrict__ map, const double* in, double* __restrict__ table,
+                const unsigned long long* __restrict__ flags, unsigned long long mask, unsigned long long epoch,
+                unsigned long long timeout_ticks, int32_t* __restrict__ err)
+{
+    const int j = threadIdx.x;
+    if (j < 64 && ((mask >> j) & 1ull)) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(err, 1); break; }
+        }
+    }
+    __syncthreads();
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 3) return;
+    int i = t / 3, d = t - 3 * i;
+    table[3 * (int64_t)map[i] + d] = __hip_atomic_load(in + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* HQ_DEBUG_HALO: the sender's node identities beside the records, checked on receipt */
 __global__ void hq_k_pack_id(int32_t count, const int32_t* __restrict__ map, const int64_t* __restrict__ gkey,
                              int64_t* __restrict__ out)
@@ -574,9 +597,13 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     int32_t total = contribution ? s->ctotal : s->stotal;
     if (!hq_has_transport(c))
         return hq_fail(HQ_ERR_STATE, "halo exchange needs hq_comm_init, hq_comm_init_ipc, hq_comm_init_host or hq_group_link%s", "");
+    /* the anchored-node sharing of the patch variant: hq_k_interface_update has written the records already */
+    const bool prepacked = !contribution && s == &c->an && c->share_packed;
+    if (prepacked) c->share_packed = false;
     if (hq_ipc_ready(c)) {
         /* between processes: the records are written where the peers read them, the last block raises the peers' flags */
         hq_ipc_state* I = c->ipc;
+        if (prepacked) return HQ_OK;
         if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the IPC transport%s", "");
         const int x = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
         if (total) {
@@ -589,12 +616,12 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     double* const* d_dst = contribution ? s->d_c_dst : s->d_s_dst;
     if (c->group && d_dst && !c->debug_halo) {
         /* all partitions in one process: the records are written where the peers read them */
-        if (total)
+        if (total && !prepacked)
             hq_k_pack_to_peers<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_dst);
         HQ_HIP(hipEventRecord(c->ev_sent, xs));
         return HQ_OK;
     }
-    if (total)
+    if (total && !prepacked)
         hq_k_pack<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, d_out);
     /* HQ_DEBUG_HALO: the global identity of every record's node travels with it (psolve.c:5002-5007) */
     int64_t* d_out_id = contribution ? s->d_c_out_id : s->d_s_out_id;
@@ -701,6 +728,16 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     if (c->group)
         for (auto& m : rcv)
             if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+    if (hq_ipc_ready(c) && !contribution && s->ctotal) {
+        /* IPC sharing: wait and unpack in one kernel */
+        hq_ipc_state* I = c->ipc;
+        const int x = (s == &c->an ? 0 : 2) + 1;
+        const unsigned long long ep = I->wait_mask[x] ? ++I->recv_epoch[x] : 0;
+        hq_k_unpack_ipc<<<hq_blocks((int64_t)s->ctotal * 3, 256), 256, 0, xs>>>(s->ctotal, d_map, d_in, table,
+            I->d_flags + (size_t)x * HQ_IPC_MAXNB, I->wait_mask[x], ep, I->timeout_ticks, c->d_halo_err + 2);
+        HQ_HIP(hipGetLastError());
+        return HQ_OK;
+    }
     if (hq_ipc_ready(c)) hq_ipc_wait(c, s, contribution, xs);
     hq_xchg_check(c, s, contribution, xs);
     if (!contribution) {
@@ -769,23 +806,78 @@ static int hq_launch_update(hq_ctx* c)
 /*
  * Interface nodes this rank owns: own partial force + the sharers' records
  * (the "+=" unpack of schedule_senddata, psolve.c:5035-5073, in messenger order)
- * + solver_compute_displacement, in one kernel.
+ * + solver_compute_displacement + the PACK of the displacement sharing (psolve.c:4312, :4985-5011), in one kernel:
+ * the records a node receives contributions in and the records its new displacement is shared in are the same
+ * entries of the s-list, so the thread that finishes a node also writes it where the transport takes it from
+ * (s_out: the packed send buffer of RCCL / host-staged / copying transports) or where the sharers read it (s_dst:
+ * direct peer stores of the in-process and IPC transports).
+ * IPC = 1: the IPC transport's wait and signal are folded in -- every workgroup polls the contribution flags before it
+ * reads a record (relaxed system-scope loads, and the records are read system-scope too: no cache holds them stale),
+ * and the workgroup that finishes last raises the sharing flags (see hq_k_pack_to_peers_sig).
  */
-__global__ void hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
-                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos,
-                                      const double* __restrict__ iforce, const double* __restrict__ rec,
-                                      const double* __restrict__ nt, const double* __restrict__ u1,
-                                      const double* __restrict__ u2, double* __restrict__ un)
+struct hq_ipc_args {
+    const unsigned long long* wait_flags;            /* this rank's flags of the contribution exchange */
+    unsigned long long wait_mask, wait_epoch, timeout_ticks;
+    int32_t* err;
+    uint32_t* done;
+    int32_t nsig;
+    unsigned long long* const* sig;
+    unsigned long long sig_epoch;
+};
+
+template <int IPC>
+__global__ void __launch_bounds__(256)
+hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
+                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos,
+                      const double* __restrict__ iforce, const double* rec,
+                      const double* __restrict__ nt, const double* __restrict__ u1,
+                      const double* __restrict__ u2, double* __restrict__ un, double* __restrict__ s_out,
+                      double* const* __restrict__ s_dst, hq_ipc_args ia)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 3) return;
-    int i = t / 3, d = t - 3 * i;
-    int64_t g = node[i];
-    const double* np = nt + 7 * g;
-    double f = iforce[3 * (int64_t)slot[i] + d];
-    for (int32_t k = ptr[i]; k < ptr[i + 1]; k++) f += rec[3 * (int64_t)pos[k] + d];
-    f += (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
-    un[3 * g + d] = f / np[0];
+    if (IPC) {
+        const int j = threadIdx.x;
+        if (j < 64 && ((ia.wait_mask >> j) & 1ull)) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&ia.wait_flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < ia.wait_epoch) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > ia.timeout_ticks) { atomicAdd(ia.err, 1); break; }
+            }
+        }
+        __syncthreads();
+    }
+    if (t < n * 3) {
+        int i = t / 3, d = t - 3 * i;
+        int64_t g = node[i];
+        const double* np = nt + 7 * g;
+        const int32_t k0 = ptr[i], k1 = ptr[i + 1];
+        double f = iforce[3 * (int64_t)slot[i] + d];
+        for (int32_t k = k0; k < k1; k++)
+            f += IPC ? __hip_atomic_load(rec + 3 * (int64_t)pos[k] + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                     : rec[3 * (int64_t)pos[k] + d];
+        f += (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
+        const double v = f / np[0];
+        un[3 * g + d] = v;
+        if (s_dst) {
+            for (int32_t k = k0; k < k1; k++) {
+                if (IPC) __hip_atomic_store(s_dst[pos[k]] + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else s_dst[pos[k]][d] = v;
+            }
+        } else if (s_out) {
+            for (int32_t k = k0; k < k1; k++) s_out[3 * (int64_t)pos[k] + d] = v;
+        }
+    }
+    if (IPC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ia.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) __hip_atomic_store(ia.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)threadIdx.x < ia.nsig)
+            __hip_atomic_store(ia.sig[threadIdx.x], ia.sig_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 /*
@@ -807,7 +899,13 @@ static int hq_phase(hq_ctx* c, int ph)
             int32_t k = c->step - c->src_step0;
             const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
                                   ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
-            const int32_t nb = c->plan.nb, ne = c->plan.ne;
+            int32_t nb = c->plan.nb, ne = c->plan.ne;
+            /* Behind bricks a partition's element-form patches are few: where all of them are ONE round of workgroups
+             * (two per CU) the patches that own no interface node join the interface patches' launch -- they run beside
+             * them on CUs that launch leaves empty, instead of behind it and its 7 us launch gap (rank-alone trace of
+             * round 4: 20 + 8 + 14 us -> one launch) */
+            if (c->overlap && !hq_patch_uses_pers(&c->plan) && nb > 0 && nb + ne <= 2 * c->plan.grid_cus &&
+                !(getenv("HQ_PATCH_SPLIT_LAUNCH") && atoi(getenv("HQ_PATCH_SPLIT_LAUNCH")) != 0)) { nb += ne; ne = 0; }
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             hq_mark(c);
             if (c->plan.ns > 0 || c->plan.nr > 0) {
@@ -873,12 +971,43 @@ static int hq_phase(hq_ctx* c, int ph)
             if (c->group)
                 for (auto& m : c->an.s)
                     if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
-            if (hq_ipc_ready(c)) hq_ipc_wait(c, &c->an, true, xs);
             hq_xchg_check(c, &c->an, true, xs);
-            if (c->nOI)
-                hq_k_interface_update<<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
+            c->share_packed = false;
+            if (c->nOI) {
+                /* the update also packs the displacement sharing (phase 5 then only hands the records on) */
+                hq_ipc_args ia = {};
+                static const bool fuse = !(getenv("HQ_NO_FUSED_SHARE") && atoi(getenv("HQ_NO_FUSED_SHARE")) != 0);
+                double* s_out = fuse ? c->an.d_s_out : nullptr;
+                double* const* s_dst = nullptr;
+                if (fuse && c->group && c->an.d_s_dst && !c->debug_halo) s_dst = c->an.d_s_dst;
+                if (hq_ipc_ready(c)) {
+                    hq_ipc_state* I = c->ipc;
+                    if (fuse) {
+                        s_dst = I->d_dst[1];
+                        ia.wait_flags = I->d_flags;                     /* exchange 0: anchored-node contribution */
+                        ia.wait_mask = I->wait_mask[0];
+                        if (ia.wait_mask) ia.wait_epoch = ++I->recv_epoch[0];
+                        ia.timeout_ticks = I->timeout_ticks;
+                        ia.err = c->d_halo_err + 2;
+                        ia.done = I->d_done + 1;
+                        ia.nsig = I->nsig[1];
+                        ia.sig = I->d_sig[1];
+                        ia.sig_epoch = c->an.stotal ? ++I->send_epoch[1] : 0;
+                        hq_k_interface_update<1><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
+                            c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
+                            c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, nullptr, s_dst, ia);
+                        c->share_packed = true;
+                        return HQ_OK;
+                    }
+                    hq_ipc_wait(c, &c->an, true, xs);
+                }
+                hq_k_interface_update<0><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
                     c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
-                    c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew);
+                    c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, s_dst ? nullptr : s_out, s_dst, ia);
+                c->share_packed = fuse;
+            } else if (hq_ipc_ready(c)) {
+                hq_ipc_wait(c, &c->an, true, xs);
+            }
         } else {
             HQ_TRY(hq_xchg_recv(c, &c->an, ftab, true, true));
             HQ_TRY(hq_launch_update(c));                                   /* :4305 */

@@ -123,3 +123,59 @@ def np8_stripe(g, step, rank, n):
     """(tm2, tm1) of one rank from its raw checkpoint stripe (io_checkpoint.c:93-118)."""
     s = g["ckpt%d_stripe_%d" % (int(step), rank)]
     return s[:3 * n].reshape(n, 3), s[3 * n:6 * n].reshape(n, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# dependency-cone windows of an octree mesh (oracle parity at sizes the oracle cannot run whole)
+# ---------------------------------------------------------------------------------------------
+
+def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin):
+    """The elements of an octree mesh that lie inside the box [lo, hi] (node coordinates, finest-element units; lo / hi
+    must be multiples of the coarsest edge inside, so that no element straddles a face and every hanging node of the
+    window finds its anchors in it), renumbered as a mesh of their own.
+    -> dict(elems, nodes, lnid, dangling (window numbering, table order kept), ok) with ok = the window nodes at least
+    `margin` inside every CUT face (a face of the window that is not a face of the domain): after k steps of
+    solver_run a node depends on nodes within <= 2 k c of it (c the coarsest edge around: one element hop per step plus
+    the hop from a hanging node to its anchors, compute_adjust psolve.c:5936-6039), so with margin >= 2 k c the oracle
+    on the window gives the exact values of those nodes."""
+    lo, hi = np.asarray(lo, np.int64), np.asarray(hi, np.int64)
+    inside = np.ones(len(elem_edge), bool)
+    for d in range(3):
+        inside &= (elem_lo[:, d] >= lo[d]) & (elem_lo[:, d] + elem_edge <= hi[d])
+    elems = np.nonzero(inside)[0]
+    assert len(elems) > 0
+    assert int(elem_edge[elems].astype(np.int64).__pow__(3).sum()) == int(np.prod(hi - lo)), "the window is not filled by whole elements"
+    nodes, inv = np.unique(lnid[elems], return_inverse=True)
+    lnid_w = inv.reshape(-1, 8).astype(np.int32)
+    ids, ptr, anchors = dangling
+    pos = np.full(int(max(nodes.max(), ids.max() if len(ids) else 0)) + 2, -1, np.int64)
+    pos[nodes] = np.arange(len(nodes))
+    sel = np.nonzero(pos[np.minimum(ids, len(pos) - 1)] >= 0)[0] if len(ids) else np.zeros(0, np.int64)
+    w_ids, w_ptr, w_anc = [], [0], []
+    for k in sel:
+        a = anchors[ptr[k]:ptr[k + 1]]
+        la = pos[np.minimum(a, len(pos) - 1)]
+        assert (la >= 0).all(), "a hanging node of the window has an anchor outside it: window not aligned to the coarse grid"
+        w_ids.append(pos[ids[k]])
+        w_anc += [int(v) for v in la]
+        w_ptr.append(len(w_anc))
+    dom_hi = node_xyz.max(axis=0).astype(np.int64)
+    q = node_xyz[nodes].astype(np.int64)
+    ok = np.ones(len(nodes), bool)
+    for d in range(3):
+        if lo[d] > 0:
+            ok &= q[:, d] >= lo[d] + margin
+        if hi[d] < dom_hi[d]:
+            ok &= q[:, d] <= hi[d] - margin
+    return dict(elems=elems, nodes=nodes.astype(np.int32), lnid=lnid_w, ok=ok,
+                dangling=(np.array(w_ids, np.int32), np.array(w_ptr, np.int32), np.array(w_anc, np.int32)))
+
+
+def octree_window_oracle(win, etable, ntable, u1, u2, k, dt):
+    """k steps of the oracle's reference loops (+ compute_adjust) on a window: (tm1, tm2) of the window's nodes,
+    post-swap as hq_download / hq_gather return them."""
+    o2 = u1[win["nodes"]].copy()                                        # the oracle's arrays are pre-swap
+    o1 = u2 * o2 if np.isscalar(u2) else u2[win["nodes"]].copy()        # (u2 a number: u(t - dt) = u2 * u(t))
+    dn = win["dangling"] if len(win["dangling"][0]) else None
+    ho.solver_run(win["lnid"], etable[win["elems"]].copy(), ntable[win["nodes"]].copy(), o1, o2, 0, k, dt, dangling=dn)
+    return o2, o1

@@ -267,12 +267,13 @@ def test_large_two_level_box_variants_agree():
 # BASELINE config 5: the layered basin on four octree levels (bench.py workloads o3s / o3)
 # ---------------------------------------------------------------------------------------------
 
-def _basin(workload, rank=0, nranks=1):
+def _basin(workload, rank=0, nranks=1, want_interfaces=False):
     """(OctBox, total elements, start field of its harbored nodes) of bench.py's layered-basin workloads."""
     import bench
     box, total_e, total_n, interfaces = bench.make_octbox(workload, rank, nranks)
     nx, ny = bench.WORKLOADS[workload][:2]
-    return box, total_e, total_n, bench.seeded_field(box.node_xyz, nx, ny, interfaces)
+    out = (box, total_e, total_n, bench.seeded_field(box.node_xyz, nx, ny, interfaces))
+    return out + (interfaces,) if want_interfaces else out
 
 
 def _run_oct(box, variant, u1, u2, nsteps):
@@ -348,28 +349,70 @@ def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap,
         b.close()
 
 
-def test_full_basin_variants_agree():
-    """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging
-    nodes.  The fused patch kernel against the scatter + compute_adjust kernels (two independent
-    implementations), finiteness, hanging nodes = mean of their anchors, quiescence.  Host memory is
-    kept lean: one field at a time, newest displacement only."""
+def _basin_windows(nx, ny, nzt, interfaces, k):
+    """Windows of the layered basin that straddle each level interface (z0 = its plane, c = the coarser edge there, both
+    in finest-element units): in the interior, at a domain side face and in a domain corner."""
+    out = []
+    for z0, hf in interfaces:
+        c = 2 * hf
+        margin = 2 * k * c
+        W = 2 * margin + 2 * c
+        for x0, y0 in (((nx // 2) // c * c - W // 2 // c * c, (ny // 3) // c * c), (0, (ny // 2) // c * c), (nx - W, ny - W)):
+            lo = [max(0, x0), max(0, y0), max(0, z0 - margin - c)]
+            hi = [min(nx, lo[0] + W), min(ny, lo[1] + W), min(nzt, z0 + margin + c)]
+            out.append((lo, hi, margin))
+    return out
+
+
+def test_full_basin_against_the_oracle_and_in_eight_partitions():
+    """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging nodes.
+    * The fused patch + brick path against the scatter + compute_adjust kernels (two independent implementations),
+      finiteness, hanging nodes = mean of their anchors, quiescence.
+    * ORACLE parity at this size: dependency-cone windows that straddle each of the three level interfaces -- hanging
+      nodes, their anchors, compute_adjust's distribution and assignment (psolve.c:5936-6039) inside the checked region
+      -- in the interior, at a domain face and in a corner, stepped by the oracle's reference loops with the true table
+      rows (tests/helpers.octree_window; the window logic itself is pinned on a whole-mesh oracle run in
+      tests/test_octree_windows_cpu.py): <= 1e-9 of the field's scale.
+    * The basin in 8 partitions, every rank's tables built by that rank alone (octbox_local), in-process transport: all
+      four exchanges of a step on 3-7 neighbours each, against the single-partition run.
+    Host memory is kept lean: one field at a time, newest displacement only."""
     import gc
+    import bench
+    from hercules_amd import capi
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 90 * 2 ** 30:
         pytest.skip("needs ~80 GiB of host memory for the 189M-element mesh tables")
-    box, E, N, u = _basin("o3")
-    assert E > 180e6 and box.ldnnum > 1e6
-    nsteps = 3
+    box, E, N, u, interfaces = _basin("o3", want_interfaces=True)
+    assert E > 180e6 and box.ldnnum > 1e6 and len(interfaces) == 3
+    nsteps = 2
+    scale0 = np.abs(u).max()
     res = []
     for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
         s = box.create_solver(variant=variant, tm1=u, tm2=0.999 * u)
         assert s.info()["variant"] == variant
         s.run(nsteps)
+        if variant == ha.HQ_VARIANT_PATCH:
+            # oracle windows across the level interfaces
+            xyz = box.node_xyz
+            elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
+            elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
+            nx, ny = bench.WORKLOADS["o3"][:2]
+            worst, nchecked, nhang = 0.0, 0, 0
+            for lo, hi, margin in _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps):
+                win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+                g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
+                ok, nodes = win["ok"], win["nodes"]
+                tm1, tm2 = s.gather(nodes[ok])
+                worst = max(worst, np.abs(tm1 - g1[ok]).max() / scale0, np.abs(tm2 - g2[ok]).max() / scale0)
+                nchecked += int(ok.sum())
+                nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
+            del elem_lo, elem_edge
+            assert nchecked > 2000 and nhang > 50
+            assert worst < 1e-9, worst
         tm1, _ = s.download(want_tm2=False)
         s.close()
         res.append(tm1)
         gc.collect()
-    del u
     scale = np.abs(res[0]).max()
     assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
     assert np.abs(res[0] - res[1]).max() <= 1e-11 * scale
@@ -377,14 +420,42 @@ def test_full_basin_variants_agree():
     chk = res[0].copy()
     ho.compute_adjust(chk, 1, box.dangling)
     assert np.abs(chk - res[0]).max() <= 1e-13 * scale
-    del chk, res
+    del chk
     gc.collect()
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH)
     s.run(nsteps)
     tm1, _ = s.gather(np.arange(0, N, 4099, dtype=np.int32))
     assert not tm1.any()
     s.close()
+    # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
+    # of every rank through their coordinates
+    key = lambda xyz: (xyz[:, 2].astype(np.int64) << 42) | (xyz[:, 1].astype(np.int64) << 21) | xyz[:, 0].astype(np.int64)
+    k1 = key(box.node_xyz)
+    order = np.argsort(k1)
+    k1s = k1[order]
+    del k1, u
     box.close()
+    gc.collect()
+    solvers, maps = [], []
+    for r in range(8):
+        b, _, _, ur = _basin("o3", r, 8)
+        kr = key(b.node_xyz)
+        m = order[np.searchsorted(k1s, kr)]
+        assert np.array_equal(k1s[np.searchsorted(k1s, kr)], kr)
+        maps.append(m)
+        solvers.append(b.create_solver(tm1=ur, tm2=0.999 * ur))
+        assert solvers[-1].info()["brick_nodes"] > 0
+        del ur, kr
+        b.close()
+        gc.collect()
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for sv, m in zip(solvers, maps):
+        tm1, _ = sv.download(want_tm2=False)
+        assert np.abs(tm1 - res[0][m]).max() <= 1e-11 * scale
+        sv.close()
+    del res
+    gc.collect()
 
 
 @pytest.mark.parametrize("path", ["hq_k_brick", "hq_k_patch_stencil"])
