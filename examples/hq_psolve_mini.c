@@ -73,6 +73,7 @@ int main(int argc, char** argv)
     hq_desc d;
     hqh_box_desc(box, &d);
     hq_ctx* ctx = NULL;
+    if (hq_abi_version() != HQ_ABI_VERSION) { fprintf(stderr, "libhq_solver.so has another ABI version than this program\n"); return 1; }
     if (hq_create(&d, 0, &ctx) != HQ_OK) { fprintf(stderr, "hq_create: %s\n", hq_last_error()); return 1; }
 
     station_files sf;
@@ -101,6 +102,11 @@ int main(int argc, char** argv)
     hq_info hi;
     hq_get_info(ctx, &hi);
     printf("steps run: %d  kernel variant: %d  device bytes: %lld\n", hi.step, hi.variant, (long long)hi.device_bytes);
+    /* what the run moved over PCIe: source windows in, station rows out at their cadence, one checkpoint at the end */
+    printf("PCIe host->device: %lld bytes, device->host: %lld bytes, of which the final checkpoint %lld; per step between "
+           "outputs: %.1f bytes\n", (long long)hi.pcie_h2d_bytes, (long long)hi.pcie_d2h_bytes,
+           (long long)(48LL * info.nharbored),
+           nsteps > 0 ? (double)(hi.pcie_h2d_bytes + hi.pcie_d2h_bytes - 48LL * info.nharbored) / nsteps : 0.0);
     hq_destroy(ctx);
     hqh_box_destroy(box);
     return 0;

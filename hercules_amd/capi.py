@@ -61,7 +61,8 @@ class _Info(ctypes.Structure):
                 ("lattice_patches", ctypes.c_int32), ("stencil_patches", ctypes.c_int32),
                 ("ragged_patches", ctypes.c_int32), ("brick_units", ctypes.c_int32),
                 ("brick_nodes", ctypes.c_int64), ("brick_units_pernode", ctypes.c_int32),
-                ("brick_units_het", ctypes.c_int32)]
+                ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
+                ("pcie_d2h_bytes", ctypes.c_int64)]
 
 
 _lib = None

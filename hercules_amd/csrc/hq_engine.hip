@@ -157,6 +157,10 @@ struct hq_ctx {
     int32_t rank = 0, nranks = 1;
     double dt = 0, dt2 = 0;
     int64_t bytes = 0;
+    int64_t h2d_bytes = 0, d2h_bytes = 0;    /* what crossed PCIe through the entry points since hq_create returned (hq_info) */
+    int32_t* d_gather_ids = nullptr;         /* hq_gather's scratch */
+    double* d_gather_out = nullptr;
+    int32_t gather_cap = 0;
 
     /* element data, SoA */
     int32_t Epad = 0;
@@ -194,6 +198,10 @@ struct hq_ctx {
      * beside the interior patches */
     hipStream_t cstream = nullptr;
     hipEvent_t ev_bnd = nullptr, ev_shared = nullptr, ev_an_shared = nullptr, ev_assigned = nullptr;
+    /* with the chain on its own stream the bricks get one too (hq_use_brick_stream): within a step they depend on
+     * nothing the patches write, so they start beside them instead of behind their two launches and launch gaps */
+    hipStream_t bstream = nullptr;
+    hipEvent_t ev_patches = nullptr, ev_bricks = nullptr;
     bool overlap = false;             /* exchange chain on cstream beside the interior patches               */
     bool stream_masked = false;       /* the compute stream leaves reserve_cus CUs to the exchange stream (hq_mask_compute_stream) */
     bool can_overlap = false;         /* the stream and events for it exist (hq_setup_interface)             */
@@ -660,6 +668,8 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
         if (total && !*ph_out) HQ_HIP(hipHostMalloc((void**)ph_out, sizeof(double) * 3 * (size_t)total, hipHostMallocDefault));
         if (total_in && !*ph_in) HQ_HIP(hipHostMalloc((void**)ph_in, sizeof(double) * 3 * (size_t)total_in, hipHostMallocDefault));
         if (total) HQ_HIP(hipMemcpyAsync(*ph_out, d_out, sizeof(double) * 3 * (size_t)total, hipMemcpyDeviceToHost, xs));
+        c->d2h_bytes += 24 * (int64_t)total;
+        c->h2d_bytes += 24 * (int64_t)total_in;
         HQ_HIP(hipStreamSynchronize(xs));
         std::vector<int32_t> rp, sp;
         std::vector<int64_t> rn, sn;
@@ -763,6 +773,10 @@ static hipError_t hq_quiesce(hq_ctx* c)
     hipError_t e = hipStreamSynchronize(c->stream);
     if (c->cstream) {
         hipError_t e2 = hipStreamSynchronize(c->cstream);
+        if (e == hipSuccess) e = e2;
+    }
+    if (c->bstream) {
+        hipError_t e2 = hipStreamSynchronize(c->bstream);
         if (e == hipSuccess) e = e2;
     }
     return e;
@@ -888,6 +902,25 @@ hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t
  */
 enum { HQ_NPHASE = 9 };
 
+/* the bricks on a stream of their own?  Only where the exchange chain has one (between GPUs / processes, or
+ * HQ_OVERLAP=1 in a group) and there are patches to run beside; HQ_BRICK_STREAM=0 keeps them behind the patches. */
+static bool hq_use_brick_stream(hq_ctx* c)
+{
+    static const bool off = getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) == 0;
+    if (off || !c->overlap || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
+    if (!c->bstream) {
+        int prio_lo = 0, prio_hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return false;
+        if (hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, prio_lo) != hipSuccess) { c->bstream = nullptr; return false; }
+        if (hipEventCreateWithFlags(&c->ev_patches, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_bricks, hipEventDisableTiming) != hipSuccess) return false;
+        /* everything enqueued so far is on the compute stream: the first brick launch goes behind it */
+        hipEventRecord(c->ev_patches, c->stream);
+        hipEventRecord(c->ev_bricks, c->stream);
+    }
+    return true;
+}
+
 static int hq_phase(hq_ctx* c, int ph)
 {
     const bool patch = (c->variant == HQ_VARIANT_PATCH);
@@ -906,7 +939,16 @@ static int hq_phase(hq_ctx* c, int ph)
              * round 4: 20 + 8 + 14 us -> one launch) */
             if (c->overlap && !hq_patch_uses_pers(&c->plan) && nb > 0 && nb + ne <= 2 * c->plan.grid_cus &&
                 !(getenv("HQ_PATCH_SPLIT_LAUNCH") && atoi(getenv("HQ_PATCH_SPLIT_LAUNCH")) != 0)) { nb += ne; ne = 0; }
+            const bool bs = hq_use_brick_stream(c);
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
+            if (bs) {
+                HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));               /* ... and its bricks */
+                /* the bricks' own stream: behind the last step's chain (they read shared nodes in their rings and overwrite
+                 * the buffer its interface update read) and the last step's patches (ring rows; the buffer those read as
+                 * u(t - dt)) -- ev_patches still names THAT record here, this step's comes below */
+                HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_shared, 0));
+                HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_patches, 0));
+            }
             hq_mark(c);
             if (c->plan.ns > 0 || c->plan.nr > 0) {
                 /* ONE persistent launch for all element-form patches, the interface patches at the head of its
@@ -943,8 +985,14 @@ static int hq_phase(hq_ctx* c, int ph)
                 }
             }
             /* the bricks: simple nodes only, never on the interface -- interior work beside the exchange chain */
+            if (bs) HQ_HIP(hipEventRecord(c->ev_patches, c->stream));
             if (c->bricks.nunits > 0)
-                hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2, c->stream);
+                hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2,
+                                bs ? c->bstream : c->stream);
+            if (bs) {
+                HQ_HIP(hipEventRecord(c->ev_bricks, c->bstream));
+                if (c->timing) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));   /* the mark below closes the step's kernels */
+            }
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -1202,6 +1250,7 @@ static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl);
 static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
 {
     const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    c->h2d_bytes += (int64_t)bytes;
     if (c->perm.empty()) {
         HQ_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
         return HQ_OK;
@@ -1221,6 +1270,7 @@ static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
 static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
 {
     const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    c->d2h_bytes += (int64_t)bytes;
     if (c->perm.empty()) {
         HQ_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return HQ_OK;
@@ -1534,6 +1584,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
+    c->h2d_bytes = c->d2h_bytes = 0;          /* the counters of hq_info start with the first call behind hq_create */
     *out = c;
     return HQ_OK;
 }
@@ -1998,7 +2049,7 @@ extern "C" int hq_destroy(hq_ctx* c)
         delete I;
         c->ipc = nullptr;
     }
-    void* ptrs[] = { c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt_rows, c->d_u[0], c->d_u[1], c->d_u[2],
+    void* ptrs[] = { c->d_gather_ids, c->d_gather_out, c->d_lnid, c->d_c1, c->d_c2, c->d_beta, c->d_nt_rows, c->d_u[0], c->d_u[1], c->d_u[2],
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
@@ -2018,6 +2069,9 @@ extern "C" int hq_destroy(hq_ctx* c)
     }
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
+    if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
+    if (c->ev_patches) hipEventDestroy(c->ev_patches);
+    if (c->ev_bricks) hipEventDestroy(c->ev_bricks);
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
     if (c->ev_shared) hipEventDestroy(c->ev_shared);
     if (c->ev_an_shared) hipEventDestroy(c->ev_an_shared);
@@ -2058,6 +2112,8 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.brick_nodes = c->bricks.nb;
     v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet;
     v.brick_units_het = c->bricks.nhet;
+    v.pcie_h2d_bytes = c->h2d_bytes;
+    v.pcie_d2h_bytes = c->d2h_bytes;
     memset(info, 0, (size_t)size);
     memcpy(info, &v, (size_t)std::min<uint64_t>(size, sizeof(v)));
     return HQ_OK;
@@ -2458,6 +2514,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
     if (same_nodes) {
         c->src_step0 = step0; c->src_nsteps = nsteps;
         HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+        c->h2d_bytes += 24 * (int64_t)nloaded * nsteps;
         return HQ_OK;
     }
     if (c->d_loaded) { hipFree(c->d_loaded); c->d_loaded = nullptr; }
@@ -2469,6 +2526,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
         HQ_TRY(hq_dev_alloc(c, &c->d_F, (size_t)nloaded * 3 * nsteps));
         HQ_HIP(hipMemcpy(c->d_loaded, loaded, sizeof(int32_t) * nloaded, hipMemcpyHostToDevice));
         HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+        c->h2d_bytes += 4 * (int64_t)nloaded + 24 * (int64_t)nloaded * nsteps;
         c->h_loaded.assign(loaded, loaded + nloaded);
         c->F_capacity = (size_t)nloaded * 3 * (size_t)nsteps;
     }
@@ -2560,6 +2618,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
     for (int32_t s = 0; s < nsteps && rc == HQ_OK; s++) rc = hq_step(c);
     c->timing = false;
     if (c->overlap) hipStreamWaitEvent(c->stream, c->ev_shared, 0);
+    if (c->bstream) hipStreamWaitEvent(c->stream, c->ev_bricks, 0);
     hipEventRecord(c->ev_span[1], c->stream);
     hipError_t he = hq_quiesce(c);
     double tot = 0, ker = 0;
@@ -2611,11 +2670,25 @@ static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1,
     HQ_HIP(hq_quiesce(c));
     for (int32_t i = 0; i < n; i++)
         if (lnid[i] < 0 || lnid[i] >= c->N) return hq_fail(HQ_ERR_ARG, "node id out of range%s", "");
-    int32_t* d_ids = nullptr;
-    double* d_o = nullptr;
-    HQ_HIP(hipMalloc((void**)&d_ids, sizeof(int32_t) * n));
-    hipError_t e = hipMalloc((void**)&d_o, sizeof(double) * 9 * (size_t)n);
-    if (e != hipSuccess) { hipFree(d_ids); return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", ""); }
+    /* scratch kept with the context: a host that prints stations every few steps (psolve.c:6679-6790) must not pay a
+     * hipMalloc / hipFree pair per call */
+    if (n > c->gather_cap) {
+        if (c->d_gather_ids) { hipFree(c->d_gather_ids); c->d_gather_ids = nullptr; }
+        if (c->d_gather_out) { hipFree(c->d_gather_out); c->d_gather_out = nullptr; }
+        c->gather_cap = 0;
+        const int32_t cap = std::max(n, 1024);
+        HQ_HIP(hipMalloc((void**)&c->d_gather_ids, sizeof(int32_t) * (size_t)cap));
+        if (hipMalloc((void**)&c->d_gather_out, sizeof(double) * 9 * (size_t)cap) != hipSuccess) {
+            hipFree(c->d_gather_ids); c->d_gather_ids = nullptr;
+            return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", "");
+        }
+        c->gather_cap = cap;
+    }
+    int32_t* d_ids = c->d_gather_ids;
+    double* d_o = c->d_gather_out;
+    hipError_t e;
+    c->h2d_bytes += 4 * (int64_t)n;
+    c->d2h_bytes += 24 * (int64_t)n * ((o1 ? 1 : 0) + (o2 ? 1 : 0) + (o3 ? 1 : 0));
     std::vector<int32_t> dev_ids;
     if (!c->perm.empty()) {
         dev_ids.resize((size_t)n);
@@ -2633,8 +2706,6 @@ static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1,
         hipMemcpyAsync(o3, d_o + 6 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
     }
     e = hq_quiesce(c);
-    hipFree(d_ids);
-    hipFree(d_o);
     if (e != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "gather failed: %s", hipGetErrorString(e));
     return HQ_OK;
 }

@@ -117,6 +117,9 @@ typedef struct {
     int64_t brick_nodes;         /* patch variant: nodes stepped by hq_k_brick (the rest belongs to the patches)  */
     int32_t brick_units_pernode; /* of brick_units: uniform coefficients, n_t rows of their own (hq_k_brick<true>)  */
     int32_t brick_units_het;     /* of brick_units: per-element coefficients (hq_k_brick_het)                      */
+    int64_t pcie_h2d_bytes;      /* bytes the entry points moved host -> device since hq_create returned (source   */
+    int64_t pcie_d2h_bytes;      /* windows, gather ids, uploads, host-staged halos) and device -> host (gathers,   */
+                                 /* downloads, host-staged halos): what a run costs on PCIe between outputs         */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */

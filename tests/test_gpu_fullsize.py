@@ -67,8 +67,9 @@ def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
     pw = _run(box, ha.HQ_VARIANT_PATCH, w1, w2, nsteps, (loaded, (a + 2.0 * b) * F))
     lin = a * pu[0] + b * pv[0]
     assert np.abs(pw[0] - lin).max() <= 1e-11 * np.abs(lin).max()
-    z = _run(box, ha.HQ_VARIANT_PATCH, np.zeros_like(u), np.zeros_like(u), nsteps)
-    assert not z[0].any() and not z[1].any()
+    if wl != "c3":                                       # (quiescence at 8M; the 64M box has its cone windows)
+        z = _run(box, ha.HQ_VARIANT_PATCH, np.zeros_like(u), np.zeros_like(u), nsteps)
+        assert not z[0].any() and not z[1].any()
     box.close()
 
 
@@ -190,12 +191,13 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("c2", 1, 1, 0), ("c2", 1, 1, 1), ("c2", 0, 1, 1), ("c3", 1, 1, 1),
-                                                      ("c2", 0, 1, 2)])
+@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("m1", 1, 1, 0), ("c2", 1, 1, 1), ("m1", 0, 1, 1), ("c3", 1, 1, 1),
+                                                      ("m1", 0, 1, 2), ("c2h", 1, 1, 1)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
-    single-partition run.  ragged: the lattice-subset patches (domain faces, partition interfaces) through
+    single-partition run (the switches that differ only in a launch or transport detail on the 1M box; c2h: the 8M box
+    with material of its own in every element, the het kernel on every partition and at every interface).  ragged: the lattice-subset patches (domain faces, partition interfaces) through
     hq_k_patch_stencil as well (HQ_PATCH_RAGGED=1: its launch ahead of the exchange, forces handed to the interface)."""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
@@ -204,17 +206,18 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
     if bricks == 2:                                                     # the in-process transport with copies instead of
         monkeypatch.setenv("HQ_GROUP_COPIES", "1")                      # the pack kernel writing into the peers' buffers
-    nx, ny, nz, h, dt, freq = {"c2": (256, 256, 128, 1000.0 / 256, 1.8e-4, 100.0),
-                               "c3": (512, 512, 256, 1000.0 / 512, 9.0e-5, 200.0)}[wl]
+    import bench
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
+    ncls, amp = bench.LATERAL.get(wl, (0, 0.0))        # c2h: material of its own in every element (hq_k_brick_het in every partition)
     nsteps = 3
-    one = host.Box(nx, ny, nz, h, dt, freq)
+    one = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
     u = _field(one, 31337)
     ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
     gid_one = (one.node_ijk[:, 2].astype(np.int64) * (ny + 1) + one.node_ijk[:, 1]) * (nx + 1) + one.node_ijk[:, 0]
     lut = np.empty(gid_one.max() + 1, np.int64)
     lut[gid_one] = np.arange(len(gid_one))
     one.close()
-    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8) for r in range(8)]
+    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, lateral_classes=ncls, lateral_amp=amp) for r in range(8)]
     solvers, maps = [], []
     for b in boxes:
         g = (b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]
@@ -224,6 +227,8 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
         assert solvers[-1].info()["variant"] == ha.HQ_VARIANT_PATCH
         if bricks:
             assert solvers[-1].dominant_kernel() == "hq_k_brick"
+            if ncls:
+                assert solvers[-1].info()["brick_units_het"] == solvers[-1].info()["brick_units"] > 0
         else:
             assert (solvers[-1].info()["ragged_patches"] > 0) == bool(ragged)
     capi.group_link(solvers)
@@ -312,7 +317,7 @@ def test_small_basin_variants_agree_and_step_is_linear():
     box.close()
 
 
-@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 0), (ha.HQ_VARIANT_PATCH, 1), (ha.HQ_VARIANT_SCATTER, 0)])
+@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 1), (ha.HQ_VARIANT_SCATTER, 0)])
 def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap, monkeypatch):
     """o3s cut into octor's 8 partitions by the C host (hanging nodes and their anchors on partition
     interfaces: all four exchanges of a step, psolve.c:4298-4315), in-process transport, against the
@@ -366,8 +371,7 @@ def _basin_windows(nx, ny, nzt, interfaces, k):
 
 def test_full_basin_against_the_oracle_and_in_eight_partitions():
     """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging nodes.
-    * The fused patch + brick path against the scatter + compute_adjust kernels (two independent implementations),
-      finiteness, hanging nodes = mean of their anchors, quiescence.
+    * Finiteness, hanging nodes = mean of their anchors (the scatter kernels and quiescence are compared on o3s).
     * ORACLE parity at this size: dependency-cone windows that straddle each of the three level interfaces -- hanging
       nodes, their anchors, compute_adjust's distribution and assignment (psolve.c:5936-6039) inside the checked region
       -- in the interior, at a domain face and in a corner, stepped by the oracle's reference loops with the true table
@@ -387,46 +391,37 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     nsteps = 2
     scale0 = np.abs(u).max()
     res = []
-    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
-        s = box.create_solver(variant=variant, tm1=u, tm2=0.999 * u)
-        assert s.info()["variant"] == variant
-        s.run(nsteps)
-        if variant == ha.HQ_VARIANT_PATCH:
-            # oracle windows across the level interfaces
-            xyz = box.node_xyz
-            elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
-            elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
-            nx, ny = bench.WORKLOADS["o3"][:2]
-            worst, nchecked, nhang = 0.0, 0, 0
-            for lo, hi, margin in _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps):
-                win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
-                g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
-                ok, nodes = win["ok"], win["nodes"]
-                tm1, tm2 = s.gather(nodes[ok])
-                worst = max(worst, np.abs(tm1 - g1[ok]).max() / scale0, np.abs(tm2 - g2[ok]).max() / scale0)
-                nchecked += int(ok.sum())
-                nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
-            del elem_lo, elem_edge
-            assert nchecked > 2000 and nhang > 50
-            assert worst < 1e-9, worst
-        tm1, _ = s.download(want_tm2=False)
-        s.close()
-        res.append(tm1)
-        gc.collect()
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
+    assert s.info()["variant"] == ha.HQ_VARIANT_PATCH and s.info()["brick_nodes"] > 0.9 * N
+    s.run(nsteps)
+    # oracle windows across the level interfaces
+    xyz = box.node_xyz
+    elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
+    elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
+    nx, ny = bench.WORKLOADS["o3"][:2]
+    worst, nchecked, nhang = 0.0, 0, 0
+    for lo, hi, margin in _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps):
+        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+        g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
+        ok, nodes = win["ok"], win["nodes"]
+        tm1, tm2 = s.gather(nodes[ok])
+        worst = max(worst, np.abs(tm1 - g1[ok]).max() / scale0, np.abs(tm2 - g2[ok]).max() / scale0)
+        nchecked += int(ok.sum())
+        nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
+    del elem_lo, elem_edge
+    assert nchecked > 2000 and nhang > 50
+    assert worst < 1e-9, worst
+    tm1, _ = s.download(want_tm2=False)
+    s.close()
+    res.append(tm1)
+    gc.collect()
     scale = np.abs(res[0]).max()
     assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
-    assert np.abs(res[0] - res[1]).max() <= 1e-11 * scale
-    del res[1]
     chk = res[0].copy()
-    ho.compute_adjust(chk, 1, box.dangling)
+    ho.compute_adjust(chk, 1, box.dangling)              # hanging nodes = mean of their anchors (psolve.c:5992-6035)
     assert np.abs(chk - res[0]).max() <= 1e-13 * scale
     del chk
     gc.collect()
-    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH)
-    s.run(nsteps)
-    tm1, _ = s.gather(np.arange(0, N, 4099, dtype=np.int32))
-    assert not tm1.any()
-    s.close()
     # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
     # of every rank through their coordinates
     key = lambda xyz: (xyz[:, 2].astype(np.int64) << 42) | (xyz[:, 1].astype(np.int64) << 21) | xyz[:, 0].astype(np.int64)
