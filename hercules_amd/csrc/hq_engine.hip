@@ -198,8 +198,7 @@ struct hq_ctx {
      * beside the interior patches */
     hipStream_t cstream = nullptr;
     hipEvent_t ev_bnd = nullptr, ev_shared = nullptr, ev_an_shared = nullptr, ev_assigned = nullptr;
-    /* with the chain on its own stream the bricks get one too (hq_use_brick_stream): within a step they depend on
-     * nothing the patches write, so they start beside them instead of behind their two launches and launch gaps */
+    /* HQ_BRICK_STREAM=1: the bricks on a stream of their own beside the patches (hq_use_brick_stream; opt-in) */
     hipStream_t bstream = nullptr;
     hipEvent_t ev_patches = nullptr, ev_bricks = nullptr;
     bool overlap = false;             /* exchange chain on cstream beside the interior patches               */
@@ -902,11 +901,14 @@ hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t
  */
 enum { HQ_NPHASE = 9 };
 
-/* the bricks on a stream of their own?  Only where the exchange chain has one (between GPUs / processes, or
- * HQ_OVERLAP=1 in a group) and there are patches to run beside; HQ_BRICK_STREAM=0 keeps them behind the patches. */
+/* the bricks on a stream of their own (HQ_BRICK_STREAM=1, opt-in)?  Within a step they depend on nothing the patches
+ * write, so they could start beside them.  Measured on a rank of 8 alone (profiles/r04/rank_alone_trace.txt): 187 us
+ * per step against 172 with the bricks behind the patches -- the patches that own no interface node then queue for
+ * slots the resident brick workgroups hold (their launch stretches from 14 to 110 us) and the chain's kernels with
+ * them.  Kept for boxes where the shell is larger than one round of workgroups; parity-tested (HQ_OVERLAP=1 tests). */
 static bool hq_use_brick_stream(hq_ctx* c)
 {
-    static const bool off = getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) == 0;
+    static const bool off = !(getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) != 0);
     if (off || !c->overlap || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
     if (!c->bstream) {
         int prio_lo = 0, prio_hi = 0;
