@@ -2433,29 +2433,48 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
         if (!ctxs[i] || ctxs[i]->rank != i || ctxs[i]->nranks != n)
             return hq_fail(HQ_ERR_ARG, "group member %s must be the context of rank i of n", "i");
         if (hq_has_transport(ctxs[i])) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
+        for (hq_dev_schedule* sc : { &ctxs[i]->an, &ctxs[i]->dn })
+            for (auto* lst : { &sc->c, &sc->s })
+                for (auto& m : *lst)
+                    if (m.procid < 0 || m.procid >= n) return hq_fail(HQ_ERR_ARG, "a messenger names a rank outside the group%s", "");
     }
-    std::vector<hq_ctx*>* g = new (std::nothrow) std::vector<hq_ctx*>(ctxs, ctxs + n);
-    if (!g) return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", "");
-    /* Partitions that share ONE GPU gain nothing from a second stream -- the other partitions' patches fill
-     * the device anyway -- and pay for its events: the 64M box in 8 in-process partitions steps in 2.54 ms
-     * on one stream per partition against 3.28 ms with the chain on a second one (HQ_OVERLAP=1 forces it,
-     * which is how the GPU tests cover that path without a second GPU). */
-    const bool ov = getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) != 0;
-    for (int32_t i = 0; i < n; i++) { ctxs[i]->group = g; ctxs[i]->overlap = ov && ctxs[i]->can_overlap; }
-    /* destination of every send record in its peer's receive buffer (all contexts on one device: plain pointers) */
+    /* members on DIFFERENT devices: the records travel by peer stores / peer copies, which need peer access both ways
+     * (checked and enabled here, not discovered by a failing copy in the middle of a step) */
     bool one_device = true;
     for (int32_t i = 1; i < n; i++) one_device = one_device && ctxs[i]->device == ctxs[0]->device;
-    if (one_device && !getenv("HQ_GROUP_COPIES")) {
+    if (!one_device) {
+        for (int32_t i = 0; i < n; i++)
+            for (int32_t j = 0; j < n; j++) {
+                if (ctxs[i]->device == ctxs[j]->device) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, ctxs[j]->device) != hipSuccess || !can)
+                    return hq_fail(HQ_ERR_DEVICE, "hq_group_link: no peer access between the devices of two members%s", "");
+                HQ_HIP(hipSetDevice(ctxs[i]->device));
+                hipError_t e = hipDeviceEnablePeerAccess(ctxs[j]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return hq_fail(HQ_ERR_DEVICE, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+    }
+    /* Everything that can fail is built FIRST, in tables of this call; the contexts are touched only when all of it
+     * exists (round-3 advisor: a failure half-way used to leave members linked to a group without its tables). */
+    struct dst_table { hq_ctx* c; int which, contribution; std::vector<double*> dst; };
+    std::vector<dst_table> tables;
+    /* members of ONE device: the pack kernel writes where the peers read.  Across devices the records go through peer
+     * COPIES (hipMemcpyAsync), whose coherence with the destination device's L2 the runtime answers for -- plain peer
+     * stores into coarse-grained memory do not have it; the IPC transport with its fine-grained arena is the
+     * peer-store path between devices */
+    const bool direct = one_device && !getenv("HQ_GROUP_COPIES");
+    if (direct) {
         for (int32_t i = 0; i < n; i++) {
             hq_ctx* c = ctxs[i];
-            HQ_HIP(hipSetDevice(c->device));
             for (int which = 0; which < 2; which++) {
                 hq_dev_schedule* s = which ? &c->dn : &c->an;
                 for (int contribution = 0; contribution < 2; contribution++) {
                     std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
                     const int32_t total = contribution ? s->ctotal : s->stotal;
                     if (!total) continue;
-                    std::vector<double*> dst((size_t)total, nullptr);
+                    dst_table T{ c, which, contribution, std::vector<double*>((size_t)total, nullptr) };
                     for (auto& m : snd) {
                         if (!m.nodecount) continue;
                         hq_ctx* peer = ctxs[m.procid];
@@ -2465,14 +2484,38 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
                         const hq_dev_messenger* pm = nullptr;
                         for (auto& q : prcv) if (q.procid == c->rank) pm = &q;
                         if (!pm || pm->nodecount != m.nodecount) return hq_fail(HQ_ERR_ARG, "neighbour schedules do not match%s", "");
-                        for (int32_t k = 0; k < m.nodecount; k++) dst[(size_t)m.offset + k] = p_in + 3 * ((int64_t)pm->offset + k);
+                        for (int32_t k = 0; k < m.nodecount; k++) T.dst[(size_t)m.offset + k] = p_in + 3 * ((int64_t)pm->offset + k);
                     }
-                    double*** slot = contribution ? &s->d_c_dst : &s->d_s_dst;
-                    HQ_TRY(hq_dev_alloc(c, slot, (size_t)total));
-                    HQ_HIP(hipMemcpy(*slot, dst.data(), sizeof(double*) * (size_t)total, hipMemcpyHostToDevice));
+                    tables.push_back(std::move(T));
                 }
             }
         }
+    }
+    std::vector<double**> uploaded;
+    auto undo = [&]() { for (double** p : uploaded) hipFree(p); };
+    for (auto& T : tables) {
+        double** d = nullptr;
+        hipSetDevice(T.c->device);
+        if (hipMalloc((void**)&d, sizeof(double*) * T.dst.size()) != hipSuccess ||
+            hipMemcpy(d, T.dst.data(), sizeof(double*) * T.dst.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            if (d) hipFree(d);
+            undo();
+            return hq_fail(HQ_ERR_NOMEM, "hq_group_link: destination tables%s", "");
+        }
+        uploaded.push_back(d);
+    }
+    std::vector<hq_ctx*>* g = new (std::nothrow) std::vector<hq_ctx*>(ctxs, ctxs + n);
+    if (!g) { undo(); return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
+    /* publish.  Partitions that share ONE GPU gain nothing from a second stream -- the other partitions' patches fill
+     * the device anyway -- and pay for its events: the 64M box in 8 in-process partitions steps in 2.54 ms on one
+     * stream per partition against 3.28 ms with the chain on a second one (round 2; HQ_OVERLAP=1 forces it, which is
+     * how the GPU tests cover that path without a second GPU). */
+    const bool ov = getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) != 0;
+    for (int32_t i = 0; i < n; i++) { ctxs[i]->group = g; ctxs[i]->overlap = ov && ctxs[i]->can_overlap; }
+    for (size_t k = 0; k < tables.size(); k++) {
+        hq_dev_schedule* s = tables[k].which ? &tables[k].c->dn : &tables[k].c->an;
+        (tables[k].contribution ? s->d_c_dst : s->d_s_dst) = uploaded[k];
+        tables[k].c->bytes += (int64_t)(sizeof(double*) * tables[k].dst.size());
     }
     return HQ_OK;
 }
@@ -2481,8 +2524,12 @@ extern "C" int hq_group_run(hq_ctx** ctxs, int32_t n, int32_t nsteps)
 {
     if (!ctxs || n < 1 || nsteps < 0) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     for (int32_t i = 0; i < n; i++)
-        if (!ctxs[i] || !ctxs[i]->group || (*ctxs[i]->group)[i] != ctxs[i])
+        if (!ctxs[i] || !ctxs[i]->group || (int32_t)ctxs[i]->group->size() != n || (*ctxs[i]->group)[i] != ctxs[i])
             return hq_fail(HQ_ERR_STATE, "contexts are not linked (hq_group_link)%s", "");
+    /* a destroyed member leaves a hole in the group's table: its neighbours' pack kernels would write into freed receive
+     * buffers, so a group steps complete or not at all */
+    for (hq_ctx* m : *ctxs[0]->group)
+        if (!m) return hq_fail(HQ_ERR_STATE, "a member of the group has been destroyed: the others cannot step any more%s", "");
     for (int32_t s = 0; s < nsteps; s++)
         for (int ph = 0; ph < HQ_NPHASE; ph++)
             for (int32_t i = 0; i < n; i++) {

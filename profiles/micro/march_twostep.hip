@@ -206,6 +206,134 @@ k_ts(const double* __restrict__ A, const double* __restrict__ B, double* __restr
     }
 }
 
+// Variant 2: the two stages on DIFFERENT waves of one workgroup (wave specialisation).  Waves 0 .. TY-1 are the stage-1
+// region as above (loads, w(t) images, u(t + dt), store C) and hand w(t + dt) and the own term m2 u(t+dt) - m1 u(t) of
+// every region node to LDS; waves TY .. 2 TY - 3 (one per inner row) march stage 2 one plane behind from those images
+// (store D).  ONE barrier per plane; each role's registers hold only its own accumulators.
+template <int TX, int TY, int ABL>
+__global__ void __launch_bounds__(TX * TY + TX * (TY - 2), 4)
+k_ts2(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, double* __restrict__ D, int NX, int NY,
+      int NZ, int CZ, int units_per_xcd, int nunits, coef cin)
+{
+    constexpr int OX = TX - 2, OY = TY - 2;
+    constexpr int P1Y = TX + 2, PLANE1 = (TX + 2) * (TY + 2);
+    constexpr int P2Y = TX, PLANE2 = TX * TY;
+    constexpr int NR2 = 2 * (TX + 2) + 2 * TY;
+    constexpr int NS1 = TX * TY;
+    __shared__ __align__(16) double s_w1[3 * PLANE1 * 2];
+    __shared__ __align__(16) double s_w2[6 * PLANE2 * 2];           // per slot: w(t + dt) [3 PLANE2] | own term [3 PLANE2]
+    const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
+    if (unit >= nunits) return;
+    double P[6], Q[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) P[i] = uni(cin.P[i]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) Q[i] = uni(cin.Q[i]);
+    const double beta = cin.beta, m0i = uni(1.0 / cin.m0), m1 = cin.m1, m2 = cin.m2;
+    const int ntx = NX / OX, nty = NY / OY, ntiles = ntx * nty;
+    const int tiles_per_xcd = ntiles / 8;
+    const int xcd = unit / units_per_xcd, u = unit - xcd * units_per_xcd;
+    const int chunk = u / tiles_per_xcd, tl = xcd * tiles_per_xcd + u % tiles_per_xcd;
+    const int tx = tl % ntx, ty = tl / ntx;
+    const int z0 = chunk * CZ, z1 = min(z0 + CZ, NZ);
+    const int t = threadIdx.x;
+    const bool s1 = t < NS1;
+    const int tt = s1 ? t : t - NS1;
+    const int lx = tt % TX, ly = s1 ? tt / TX : 1 + tt / TX;
+    const bool inner = lx >= 1 && lx <= OX && ly >= 1 && ly <= OY;
+    const int gx = min(max(tx * OX + lx - 1, 0), NX - 1), gy = min(max(ty * OY + ly - 1, 0), NY - 1);
+    const int64_t own_base = node_addr<OX, OY>(gx, gy, 0, NX, NY, NZ);
+    const int row1 = (ly + 1) * P1Y + (lx + 1), row2 = ly * P2Y + lx;
+    constexpr int ZS = OX * OY;
+    if (s1) {
+        int rx = 0, ry = 0;
+        if (t < TX + 2) { rx = t - 1; ry = -1; }
+        else if (t < 2 * (TX + 2)) { rx = t - (TX + 2) - 1; ry = TY; }
+        else if (t < 2 * (TX + 2) + TY) { rx = -1; ry = t - 2 * (TX + 2); }
+        else if (t < NR2) { rx = TX; ry = t - 2 * (TX + 2) - TY; }
+        const bool ring = t < NR2;
+        const int rrow = (ry + 1) * P1Y + (rx + 1);
+        const int rgx = min(max(tx * OX + rx - 1, 0), NX - 1), rgy = min(max(ty * OY + ry - 1, 0), NY - 1);
+        const int64_t ring_base = node_addr<OX, OY>(rgx, rgy, 0, NX, NY, NZ);
+        double x1[3], x2[3], y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
+        double aP[3] = { 0, 0, 0 }, aQ[3] = { 0, 0, 0 };
+        double fA[3] = { 0, 0, 0 }, fB[3] = { 0, 0, 0 };
+        auto load = [&](int z) {
+            const int zc = min(max(z, 0), NZ - 1);
+            const int64_t a = own_base + (int64_t)zc * ZS;
+#pragma unroll
+            for (int d = 0; d < 3; d++) { x1[d] = A[3 * a + d]; x2[d] = B[3 * a + d]; }
+            if (ring) {
+                const int64_t b = ring_base + (int64_t)zc * ZS;
+#pragma unroll
+                for (int d = 0; d < 3; d++) { y1[d] = A[3 * b + d]; y2[d] = B[3 * b + d]; }
+            }
+        };
+        auto put = [&](int z, double rs[3]) {
+            double* img = s_w1 + 3 * PLANE1 * (z & 1);
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                img[3 * row1 + d] = x1[d] + beta * (x1[d] - x2[d]);
+                rs[d] += m2 * x1[d] - m1 * x2[d];
+                aP[d] = aQ[d]; aQ[d] = x1[d];
+            }
+            if (ring) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) img[3 * rrow + d] = y1[d] + beta * (y1[d] - y2[d]);
+            }
+        };
+        double dummy[3] = { 0, 0, 0 };
+        load(z0 - 2); put(z0 - 2, dummy);
+        for (int p = z0 - 2; p <= z1 + 2; p++) {
+            if (p <= z1) load(p + 1);
+            __syncthreads();
+            if (p <= z1 + 1) {
+                double m[3], g[3], U[3];
+                if (ABL == 0) plane_sums<P1Y>(s_w1 + 3 * (PLANE1 * (p & 1) + row1), P, Q, m, g, U);
+                else { const double* q = s_w1 + 3 * (PLANE1 * (p & 1) + row1); for (int d = 0; d < 3; d++) { m[d] = q[d]; g[d] = 0; U[d] = 0; } }
+                double un1[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) un1[d] = (fA[d] + (g[d] + U[d])) * m0i;
+                if (inner && p - 1 >= z0 && p - 1 < z1) {
+                    const int64_t a = own_base + (int64_t)(p - 1) * ZS;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) C[3 * a + d] = un1[d];
+                }
+                double* img2 = s_w2 + 6 * PLANE2 * ((p - 1) & 1);
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    img2[3 * row2 + d] = un1[d] + beta * (un1[d] - aP[d]);
+                    img2[3 * PLANE2 + 3 * row2 + d] = m2 * un1[d] - m1 * aP[d];
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - U[d]; }
+                if (p <= z1) put(p + 1, fB);
+            }
+        }
+    } else {
+        double gA[3] = { 0, 0, 0 }, gB[3] = { 0, 0, 0 };
+        for (int p = z0 - 2; p <= z1 + 2; p++) {
+            __syncthreads();
+            const int r = p - 2;                                     // the plane of w(t + dt) stage 1 wrote in the last iteration
+            if (inner && r >= z0 - 1) {
+                const double* img2 = s_w2 + 6 * PLANE2 * (r & 1);
+                double m_[3], g_[3], U_[3];
+                if (ABL == 0) plane_sums<P2Y>(img2 + 3 * row2, P, Q, m_, g_, U_);
+                else { for (int d = 0; d < 3; d++) { m_[d] = img2[3 * row2 + d]; g_[d] = 0; U_[d] = 0; } }
+#pragma unroll
+                for (int d = 0; d < 3; d++) gB[d] += img2[3 * PLANE2 + 3 * row2 + d];
+                if (r - 1 >= z0 && r - 1 < z1) {
+                    const int64_t a = own_base + (int64_t)(r - 1) * ZS;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) D[3 * a + d] = (gA[d] + (g_[d] + U_[d])) * m0i;
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) { gA[d] = gB[d] + m_[d]; gB[d] = g_[d] - U_[d]; }
+            }
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int NZ = argc > 1 ? atoi(argv[1]) : 256;
@@ -261,15 +389,59 @@ int main(int argc, char** argv)
                0.5 * ms / reps * 67634433.0 / N);                                                                      \
         hipFree(A); hipFree(B); hipFree(C); hipFree(D); hipFree(R1); hipFree(R2);                                      \
     }
+#define RUNTS2(TX_, TY_, MINW_, CZ_, ABL_, NTX_, NTY_)                                                                  \
+    {                                                                                                                  \
+        constexpr int OX = TX_ - 2, OY = TY_ - 2;                                                                      \
+        const int NX = OX * NTX_, NY = OY * NTY_;                                                                      \
+        const int64_t N = (int64_t)NX * NY * NZ;                                                                       \
+        double *A, *B, *C, *D, *R1, *R2;                                                                               \
+        CK(hipMalloc(&A, N * 24)); CK(hipMalloc(&B, N * 24)); CK(hipMalloc(&C, N * 24)); CK(hipMalloc(&D, N * 24));    \
+        CK(hipMalloc(&R1, N * 24)); CK(hipMalloc(&R2, N * 24));                                                        \
+        {                                                                                                              \
+            std::vector<double> h((size_t)N * 3);                                                                      \
+            uint64_t s = 88172645463325252ull;                                                                         \
+            for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; } \
+            CK(hipMemcpy(A, h.data(), N * 24, hipMemcpyHostToDevice));                                                 \
+            for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; } \
+            CK(hipMemcpy(B, h.data(), N * 24, hipMemcpyHostToDevice));                                                 \
+        }                                                                                                              \
+        const int ntiles = NTX_ * NTY_, nch = (NZ + CZ_ - 1) / CZ_, nunits = ntiles * nch, upx = (nunits + 7) / 8;     \
+        k_ref<OX, OY><<<(unsigned)((N + 255) / 256), 256>>>(A, B, R1, NX, NY, NZ, c);                                   \
+        k_ref<OX, OY><<<(unsigned)((N + 255) / 256), 256>>>(R1, A, R2, NX, NY, NZ, c);                                  \
+        CK(hipMemset(C, 0, N * 24)); CK(hipMemset(D, 0, N * 24));                                                      \
+        k_ts2<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_ + TX_ * (TY_ - 2)>>>(A, B, C, D, NX, NY, NZ, CZ_, upx, nunits, c);                \
+        CK(hipDeviceSynchronize());                                                                                    \
+        {                                                                                                              \
+            std::vector<double> hc((size_t)N * 3), hd((size_t)N * 3), r1((size_t)N * 3), r2((size_t)N * 3);            \
+            CK(hipMemcpy(hc.data(), C, N * 24, hipMemcpyDeviceToHost)); CK(hipMemcpy(hd.data(), D, N * 24, hipMemcpyDeviceToHost)); \
+            CK(hipMemcpy(r1.data(), R1, N * 24, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), R2, N * 24, hipMemcpyDeviceToHost)); \
+            double w1 = 0, w2 = 0, sc = 0;                                                                             \
+            for (int z = 3; z < NZ - 3; z += 7)                                                                        \
+                for (int y = 3; y < NY - 3; y++)                                                                       \
+                    for (int x = 3; x < NX - 3; x++) {                                                                 \
+                        const int64_t a = node_addr<OX, OY>(x, y, z, NX, NY, NZ);                                      \
+                        for (int d = 0; d < 3; d++) {                                                                  \
+                            w1 = fmax(w1, fabs(hc[3 * a + d] - r1[3 * a + d])); w2 = fmax(w2, fabs(hd[3 * a + d] - r2[3 * a + d])); \
+                            sc = fmax(sc, fabs(r2[3 * a + d]));                                                        \
+                        }                                                                                              \
+                    }                                                                                                  \
+            printf("two-step, stages on different waves: region %2dx%-2d (outputs %dx%d, %d waves/SIMD min) chunk %3d abl %d  grid %dx%dx%d  max err step1 %.1e step2 %.1e (scale %.1e)  ", \
+                   TX_, TY_, OX, OY, MINW_, CZ_, ABL_, NX, NY, NZ, w1, w2, sc);                                        \
+        }                                                                                                              \
+        CK(hipEventRecord(e0));                                                                                        \
+        for (int r = 0; r < reps; r++) k_ts2<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_ + TX_ * (TY_ - 2)>>>(A, B, C, D, NX, NY, NZ, CZ_, upx, nunits, c); \
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));                     \
+        printf("%7.3f ms per PASS of two steps = %.3f ms per step on the 67.6M-node box (one-step kernel: 0.98)\n", ms / reps, \
+               0.5 * ms / reps * 67634433.0 / N);                                                                      \
+        hipFree(A); hipFree(B); hipFree(C); hipFree(D); hipFree(R1); hipFree(R2);                                      \
+    }
     // grids of about 512 x 512 nodes: 62 x 8 = 496, 6 x 86 = 516; 10 x 51 = 510; 14 x 36 = 504
-    RUNTS(64, 8, 2, 32, 0, 8, 86)
+    RUNTS2(64, 8, 4, 32, 0, 8, 86)
+    RUNTS2(64, 8, 4, 64, 0, 8, 86)
+    RUNTS2(64, 8, 4, 128, 0, 8, 86)
+    RUNTS2(64, 8, 4, 64, 1, 8, 86)
     RUNTS(64, 8, 2, 64, 0, 8, 86)
-    RUNTS(64, 8, 4, 32, 0, 8, 86)
-    RUNTS(64, 8, 4, 64, 0, 8, 86)
-    RUNTS(64, 12, 3, 32, 0, 8, 51)
     RUNTS(64, 12, 3, 64, 0, 8, 51)
-    RUNTS(64, 16, 4, 64, 0, 8, 36)
-    RUNTS(64, 16, 2, 64, 0, 8, 36)
     RUNTS(64, 8, 2, 64, 1, 8, 86)
     RUNTS(64, 12, 3, 64, 1, 8, 51)
     return 0;

@@ -97,3 +97,45 @@ def test_brick_planner_switches(monkeypatch, env):
     if "HQ_BRICK_NO_HET" in env:
         assert info["brick_units_het"] == 0
     assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL
+
+
+@pytest.mark.parametrize("env", [{"HQ_PATCH_PSPLIT": "128", "HQ_PATCH_PMERGE": "128"}, {"HQ_PATCH_THREADS": "256"},
+                                 {"HQ_PATCH_NLMAX": "640", "HQ_PATCH_PMAX": "256"}, {"HQ_PATCH_PIPE": "0"}])
+def test_patch_planner_switches(monkeypatch, env):
+    """The patch planner's tuning switches that no other GPU test sets (profiles/sweep_patch_cfg.sh uses them): smaller
+    patches, 256-thread workgroups, a smaller LDS image, the one-patch kernel forced -- with and without bricks -- on a
+    two-level octree box (hanging nodes: element-form patches with extra accumulators) against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ref = H.two_level_mesh(32, 16, 6, 5)
+    rng = np.random.default_rng(11)
+    u1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
+    u2 = u1 + rng.uniform(-1, 1, (ref["N"], 3)) * 1e-6
+    ho.compute_adjust(u1, 1, ref["dangling"])
+    ho.compute_adjust(u2, 1, ref["dangling"])
+    nsteps = 8
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(ref["lnid"], ref["etable"].copy(), ref["ntable"].copy(), o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
+    for nobricks in ("0", "1"):
+        monkeypatch.setenv("HQ_NO_BRICKS", nobricks)
+        s = ha.Solver(ref["lnid"], ref["etable"], ref["ntable"], ref["dt"], dangling=ref["dangling"],
+                      node_xyz=ref["node_q"], tm1=u1, tm2=u2, variant=ha.HQ_VARIANT_PATCH)
+        s.run(nsteps)
+        tm1, tm2 = s.download()
+        s.close()
+        assert H.rel_linf(tm1, o2) < TOL and H.rel_linf(tm2, o1) < TOL
+
+
+def test_a_group_with_a_destroyed_member_refuses_to_step():
+    """hq_group_run on a group one of whose members was destroyed: HQ_ERR_STATE, not stores into freed buffers."""
+    from hercules_amd import capi, host
+    boxes = [host.Box(32, 32, 16, 15.0, 3e-4, 30.0, rank=r, nranks=2) for r in range(2)]
+    solvers = [b.create_solver() for b in boxes]
+    capi.group_link(solvers)
+    capi.group_run(solvers, 2)
+    solvers[1].close()
+    with pytest.raises(ha.HqError):
+        capi.group_run(solvers[:1], 1)
+    solvers[0].close()
+    for b in boxes:
+        b.close()
