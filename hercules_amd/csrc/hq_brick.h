@@ -565,9 +565,10 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         else { rx = nx; ry = t - 2 * (nx + 2) - ny; }
         rrow = (ry + 1) * HQ_BK_PY + rx + 1;
     }
-    const int32_t* __restrict__ rtab = tab + U.tab + (ring ? t : 0);
-    const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
-    const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
+    const int32_t* __restrict__ utab = tab + U.tab;                  /* uniform: scalar registers */
+    const int rofs = ring ? t : 0;
+    const int32_t* __restrict__ cap = utab + (int64_t)(np + 2) * nr;
+    const int32_t id_lo = cap[sidx];
     const double beta = U.beta;
     /* the eight stencil numbers are the same for every lane, but fp64 products are vector instructions: without the
      * readfirstlane their results would sit in 16 VGPRs for the whole march.  In SGPRs (a VALU instruction takes one
@@ -585,7 +586,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
     double m0A = hq_uniform(1.0 / U.m0), m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
     double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
-    int32_t rid = rtab[0];                   /* ring id of the plane to load next */
+    int32_t rid = utab[rofs];                /* ring id of the plane to load next */
 
 #define HQ_BK_LOAD(node_)                                                                             \
     {                                                                                                 \
@@ -612,13 +613,13 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) img_[3 * rrow + d] = y1[d] + beta * (y1[d] - y2[d]); } \
     }
 
-    HQ_BK_LOAD(id_lo)
-    rid = rtab[nr];
+    HQ_BK_LOAD((int64_t)id_lo)
+    rid = utab[nr + rofs];
     { double dummy[3] = { 0.0, 0.0, 0.0 }; HQ_BK_PUT(0, dummy) }
     for (int k = 0; k <= np + 1; k++) {
         if (k <= np) {                       /* request plane k + 1 */
-            HQ_BK_LOAD(k == np ? id_hi : U.base + (int64_t)k * nxy + sidx)
-            if (k < np) rid = rtab[(int64_t)(k + 2) * nr];
+            HQ_BK_LOAD(k == np ? (int64_t)cap[nxy + sidx] : U.base + (int64_t)k * nxy + sidx)
+            if (k < np) rid = utab[(k + 2) * nr + rofs];
         }
         __syncthreads();
         const hq_lds_double* __restrict__ q = (const hq_lds_double*)s_w + 3 * (HQ_BK_PLANE * (k & 1) + myrow);

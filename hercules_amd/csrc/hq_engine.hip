@@ -935,11 +935,12 @@ static int hq_phase(hq_ctx* c, int ph)
             const double* F = (c->nloaded > 0 && k >= 0 && k < c->src_nsteps)
                                   ? c->d_F + (int64_t)k * c->nloaded * 3 : nullptr;
             int32_t nb = c->plan.nb, ne = c->plan.ne;
-            /* Behind bricks a partition's element-form patches are few: where all of them are ONE round of workgroups
-             * (two per CU; HQ_PATCH_MERGE_ROUNDS rounds) the patches that own no interface node join the interface
-             * patches' launch -- they run beside them on CUs that launch leaves empty, instead of behind it and its 7 us
-             * launch gap.  (An eighth of the 64M box has 964 patches: two rounds, two launches by default.) */
-            static const int merge_rounds = getenv("HQ_PATCH_MERGE_ROUNDS") ? atoi(getenv("HQ_PATCH_MERGE_ROUNDS")) : 1;
+            /* Behind bricks a partition's element-form patches are few: where all of them are at most TWO rounds of
+             * workgroups (two per CU; HQ_PATCH_MERGE_ROUNDS) the patches that own no interface node join the interface
+             * patches' launch instead of following it behind a 7 us launch gap -- an eighth of the 64M box has 964
+             * patches: 20 + 7 + 14 us in two launches, 27 us in one (rank-alone trace: 175.5 -> 170.7 us per step; the
+             * chain then starts 7 us later and still ends 20 us before the brick launch does) */
+            static const int merge_rounds = getenv("HQ_PATCH_MERGE_ROUNDS") ? atoi(getenv("HQ_PATCH_MERGE_ROUNDS")) : 2;
             if (c->overlap && !hq_patch_uses_pers(&c->plan) && nb > 0 && nb + ne <= 2 * merge_rounds * c->plan.grid_cus) { nb += ne; ne = 0; }
             const bool bs = hq_use_brick_stream(c);
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
