@@ -234,6 +234,19 @@ def make_octbox(workload, rank, nranks):
     return box, E, N, interfaces
 
 
+def make_octbox_interfaces(workload):
+    """The level interfaces of an octree workload for seeded_field (what make_octbox returns as its fourth value)."""
+    from hercules_amd import host as hhost
+    nx, ny, nz, h, dt, freq = WORKLOADS[workload]
+    if workload in OCT_LAYERED:
+        _, _, _, _, _, ppw, h0, ncoarse, model = OCT_LAYERED[workload]
+        _, levels = hhost.levels_from_column(hhost.layered_column(model, h0, ncoarse, freq * ppw))
+        layers = [l[0] for l in levels]
+    else:
+        layers = [nz, OCT_COARSE_LAYERS[workload]]
+    return octbox_counts(nx, ny, layers)[2]
+
+
 def octbox_counts(nx, ny, layers):
     """Elements, nodes and level interfaces [(z of the plane, finer edge) in finest-element units] of a layered octree
     box with layers[L] element layers of edge 2^L."""
@@ -564,76 +577,141 @@ def main():
         reqs += [dist.isend(torch.from_numpy(buf), dst=int(peer), tag=int(tag)) for peer, buf in sends]
         for r in reqs:
             r.wait()
-    # Transport between the ranks, in this order of preference (HQ_BENCH_TRANSPORT = rccl | ipc | host picks the first
-    # to try): RCCL grouped send/recv -> the engine's IPC transport (direct peer stores into IPC-exported receive
-    # buffers, epoch flags; works for ranks that share a GPU too) -> host-staged (pinned buffers + gloo).  A transport
-    # counts only if it came up on EVERY rank; the line says which one ran (config.transport).
-    want = os.environ.get("HQ_BENCH_TRANSPORT", "rccl") if world > 1 else "none"
-    if want == "rccl" and world > 1 and torch.cuda.device_count() < world:
+    # Transport between the ranks (HQ_BENCH_TRANSPORT = auto | rccl | ipc | host; default auto).
+    #   rccl  RCCL grouped send/recv over xGMI (hq_comm_init)
+    #   ipc   the engine's IPC transport: peer stores into IPC-exported receive buffers + epoch flags (hq_comm_init_ipc);
+    #         also what ranks that share a GPU use (RCCL refuses duplicate devices)
+    #   host  pinned host buffers + gloo (hq_comm_init_host): the last resort
+    #   auto  bring up RCCL and IPC on a solver context each, time 10 steps of both, keep the faster one -- neither has
+    #         ever met more than one GPU before the driver's scaling run, and their kernels differ in what they need
+    #         beside the interior launch (RCCL's send/recv kernels want registers the brick workgroups hold; the IPC
+    #         transport's pack / update / unpack kernels fit beside them).  A transport counts only if it
+    #         came up on EVERY rank; config.transport names the one that ran, config.transport_trials what was measured.
+    want = os.environ.get("HQ_BENCH_TRANSPORT", "auto") if world > 1 else "none"
+    if world > 1 and torch.cuda.device_count() < world and want == "rccl":
         want = "ipc"                                       # ranks share a device: RCCL refuses duplicate devices
-    rccl_error = ipc_error = None
+    os.environ.setdefault("HQ_IPC_TIMEOUT_MS", "5000")
+    errors, trials = {}, {}
 
     def everywhere(ok):
         t_ok = torch.tensor([float(ok)], dtype=torch.float64)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         return float(t_ok[0]) >= 1.0
-    if want == "rccl":
-        # RCCL over xGMI.  If the communicator cannot be made on ANY rank, all ranks fall back together.
+
+    def new_solver():
+        variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+        nx_, ny_ = WORKLOADS[args.workload][:2]
+        interfaces = make_octbox_interfaces(args.workload) if octree else ()
+        u1 = seeded_field(box.node_ijk, nx_, ny_, interfaces)
+        return box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3))
+
+    def bring_up(kind, sv):
+        """-> True if `kind` is in place on every rank's `sv`."""
+        ok = 1
+        if kind == "rccl":
+            try:
+                idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
+            except ha.HqError as e:
+                idbuf, ok, errors[kind] = [None], 0, str(e)
+            dist.broadcast_object_list(idbuf, src=0)
+            if idbuf[0] is not None:
+                try:
+                    sv.comm_init(idbuf[0])
+                except ha.HqError as e:
+                    ok, errors[kind] = 0, str(e)
+            else:
+                ok = 0
+            flush_c_stdio()  # RCCL prints a version banner through C stdio: out now, not after the JSON line
+        elif kind == "ipc":
+            try:
+                mine = torch.frombuffer(bytearray(sv.comm_ipc_export()), dtype=torch.uint8)
+            except ha.HqError as e:
+                ok, errors[kind], mine = 0, str(e), torch.zeros(ha.capi.IPC_BLOB_BYTES, dtype=torch.uint8)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)                  # MPI_Allgather on comm_solver in the reference's world
+            if everywhere(ok):
+                try:
+                    sv.comm_init_ipc([t.numpy().tobytes() for t in every])
+                except ha.HqError as e:
+                    ok, errors[kind] = 0, str(e)
+            else:
+                ok = 0
+        else:
+            sv.comm_init_host(gloo_exchange)
+        up = everywhere(ok)
+        if ok and not up:
+            errors.setdefault(kind, "did not come up on every rank")
+        return up
+
+    def trial(sv, n=10):
+        """ms per step of n steps (max over ranks), or None if the run failed anywhere."""
         ok = 1
         try:
-            idbuf = [ha.capi.comm_unique_id() if rank == 0 else None]
+            sv.run(3)
+            sv.sync()
+            dist.barrier()
+            t0_ = time.perf_counter()
+            sv.run(n)
+            sv.sync()
+            dist.barrier()
+            ms = (time.perf_counter() - t0_) / n * 1e3
         except ha.HqError as e:
-            idbuf, ok, rccl_error = [None], 0, str(e)
-        dist.broadcast_object_list(idbuf, src=0)
-        if idbuf[0] is not None:
-            try:
-                solver.comm_init(idbuf[0])
-            except ha.HqError as e:
-                ok, rccl_error = 0, str(e)
-        else:
-            ok = 0
-        if everywhere(ok):
-            rccl_ranks = int(solver.info()["nranks"])
-            transport = "RCCL grouped send/recv, %d ranks" % rccl_ranks
-        elif ok:
-            raise SystemExit("bench.py: RCCL came up on rank %d but not everywhere; cannot change the transport of a "
-                             "context that has one" % rank)
-        else:
-            want = "ipc"
-            print("bench.py rank %d: RCCL unavailable (%s); IPC transport instead" % (rank, rccl_error), file=sys.stderr)
-        flush_c_stdio()      # RCCL prints a version banner through C stdio: out now, not after the JSON line
-    if want == "ipc":
-        ok, blobs = 1, None
-        try:
-            mine = torch.frombuffer(bytearray(solver.comm_ipc_export()), dtype=torch.uint8)
-        except ha.HqError as e:
-            ok, ipc_error, mine = 0, str(e), torch.zeros(ha.capi.IPC_BLOB_BYTES, dtype=torch.uint8)
-        every = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)                      # MPI_Allgather on comm_solver in the reference's world
-        if everywhere(ok):
-            try:
-                solver.comm_init_ipc([t.numpy().tobytes() for t in every])
-            except ha.HqError as e:
-                ok, ipc_error = 0, str(e)
-            if everywhere(ok):
-                rccl_ranks = 0
-                transport = "IPC peer stores + epoch flags (hq_comm_init_ipc), %d ranks" % world + \
-                            (" [RCCL failed: %s]" % rccl_error if rccl_error else "")
-            elif ok:
-                raise SystemExit("bench.py: the IPC transport came up on rank %d but not everywhere" % rank)
+            ok, ms = 0, 0.0
+            errors["trial"] = str(e)
+        good = everywhere(ok)
+        t_ms = torch.tensor([ms], dtype=torch.float64)
+        dist.all_reduce(t_ms, op=dist.ReduceOp.MAX)
+        return float(t_ms[0]) if good else None
+
+    if world > 1:
+        names = {"rccl": "RCCL grouped send/recv", "ipc": "IPC peer stores + epoch flags (hq_comm_init_ipc)",
+                 "host": "host-staged (pinned buffers + gloo)"}
+        chosen = None
+        if want == "auto":
+            up = {}
+            for kind in ("rccl", "ipc"):
+                sv = solver if kind == "rccl" else new_solver()
+                if bring_up(kind, sv):
+                    up[kind] = sv
+                else:
+                    sv.close()                            # a context whose bring-up failed half-way is not reused
+            if len(up) == 2:
+                for kind, sv in up.items():
+                    trials[kind] = trial(sv)
+                alive = {k: v for k, v in trials.items() if v is not None}
+                chosen = min(alive, key=alive.get) if alive else None
+            elif up:
+                chosen = next(iter(up))
+            for kind, sv in up.items():
+                if kind != chosen:
+                    sv.close()
+            if chosen:
+                solver = up[chosen]
             else:
+                solver = new_solver()
                 want = "host"
-        else:
-            want = "host"
+        if want in ("rccl", "ipc"):
+            if bring_up(want, solver):
+                chosen = want
+            else:
+                other = "ipc" if want == "rccl" else None
+                if other:
+                    solver.close()
+                    solver = new_solver()
+                    if bring_up(other, solver):
+                        chosen = other
+                if not chosen:
+                    solver.close()
+                    solver = new_solver()
+                    want = "host"
         if want == "host":
-            print("bench.py rank %d: IPC transport unavailable (%s); host-staged transport instead" % (rank, ipc_error), file=sys.stderr)
-    if want == "host":
-        # the engine's host-staged transport (hq_comm_init_host) over gloo: several ranks may then share one GPU
-        # (HQ_BENCH_SHARE_GPU=1) -- separate processes, contexts and streams as with RCCL, records through pinned memory
-        solver.comm_init_host(gloo_exchange)
-        rccl_ranks = 0
-        transport = "host-staged (pinned buffers + gloo), %d ranks" % world + \
-                    (" [RCCL failed: %s]" % rccl_error if rccl_error else "") + (" [IPC failed: %s]" % ipc_error if ipc_error else "")
+            bring_up("host", solver)
+            chosen = "host"
+        rccl_ranks = int(solver.info()["nranks"]) if chosen == "rccl" else 0
+        transport = "%s, %d ranks" % (names[chosen], world) + \
+                    "".join(" [%s failed: %s]" % (k, v) for k, v in errors.items())
+        if rank == 0 and errors:
+            print("bench.py: transport bring-up: %s" % errors, file=sys.stderr)
     total_steps = args.warmup + args.steps
     add_source(args, box, solver, octree, total_steps)
     info = solver.info()
@@ -718,7 +796,8 @@ def main():
                        "ragged_patches": int(info["ragged_patches"]),
                        "patch_elements": int(info["patch_pairs"]),
                        "setup_s": round(setup_s, 1), "finite": nonfinite == 0, "rccl_ranks": rccl_ranks,
-                       "transport": transport, "brick_nodes": int(info["brick_nodes"]),
+                       "transport": transport, "transport_trials_ms_per_step": trials or None,
+                       "brick_nodes": int(info["brick_nodes"]),
                        "preheat_s": args.preheat},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch
             # time (HIP events on its stream); where the counters are unavailable, the compulsory bytes

@@ -192,6 +192,10 @@ struct hq_ctx {
     std::vector<hq_ctx*>* group = nullptr;   /* in-process transport (hq_group_link) */
     bool group_owner = false;
     bool share_packed = false;               /* this step's hq_k_interface_update wrote the sharing records as well */
+    /* switches read at hq_create (per context, so that a host -- or a test process -- can differ between contexts) */
+    bool opt_brick_stream = false;           /* HQ_BRICK_STREAM=1 */
+    bool opt_fused_share = true;             /* HQ_NO_FUSED_SHARE=1 clears it */
+    int opt_merge_rounds = 2;                /* HQ_PATCH_MERGE_ROUNDS */
     struct hq_ipc_state* ipc = nullptr;      /* device-to-device transport between processes (hq_comm_init_ipc) */
     hipEvent_t ev_sent = nullptr;
     /* patch variant with an interface: the exchange chain runs on its own stream
@@ -908,8 +912,7 @@ enum { HQ_NPHASE = 9 };
  * them.  Kept for boxes where the shell is larger than one round of workgroups; parity-tested (HQ_OVERLAP=1 tests). */
 static bool hq_use_brick_stream(hq_ctx* c)
 {
-    static const bool off = !(getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) != 0);
-    if (off || !c->overlap || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
+    if (!c->opt_brick_stream || !c->overlap || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
     if (!c->bstream) {
         int prio_lo = 0, prio_hi = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return false;
@@ -940,8 +943,7 @@ static int hq_phase(hq_ctx* c, int ph)
              * patches' launch instead of following it behind a 7 us launch gap -- an eighth of the 64M box has 964
              * patches: 20 + 7 + 14 us in two launches, 27 us in one (rank-alone trace: 175.5 -> 170.7 us per step; the
              * chain then starts 7 us later and still ends 20 us before the brick launch does) */
-            static const int merge_rounds = getenv("HQ_PATCH_MERGE_ROUNDS") ? atoi(getenv("HQ_PATCH_MERGE_ROUNDS")) : 2;
-            if (c->overlap && !hq_patch_uses_pers(&c->plan) && nb > 0 && nb + ne <= 2 * merge_rounds * c->plan.grid_cus) { nb += ne; ne = 0; }
+            if (c->overlap && !hq_patch_uses_pers(&c->plan) && nb > 0 && nb + ne <= 2 * c->opt_merge_rounds * c->plan.grid_cus) { nb += ne; ne = 0; }
             const bool bs = hq_use_brick_stream(c);
             if (c->overlap) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_shared, 0));   /* last step's shared displacements */
             if (bs) {
@@ -1027,7 +1029,7 @@ static int hq_phase(hq_ctx* c, int ph)
             if (c->nOI) {
                 /* the update also packs the displacement sharing (phase 5 then only hands the records on) */
                 hq_ipc_args ia = {};
-                static const bool fuse = !(getenv("HQ_NO_FUSED_SHARE") && atoi(getenv("HQ_NO_FUSED_SHARE")) != 0);
+                const bool fuse = c->opt_fused_share;
                 double* s_out = fuse ? c->an.d_s_out : nullptr;
                 double* const* s_dst = nullptr;
                 if (fuse && c->group && c->an.d_s_dst && !c->debug_halo) s_dst = c->an.d_s_dst;
@@ -1587,6 +1589,9 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
+    c->opt_brick_stream = getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) != 0;
+    c->opt_fused_share = !(getenv("HQ_NO_FUSED_SHARE") && atoi(getenv("HQ_NO_FUSED_SHARE")) != 0);
+    if (getenv("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, atoi(getenv("HQ_PATCH_MERGE_ROUNDS")));
     c->h2d_bytes = c->d2h_bytes = 0;          /* the counters of hq_info start with the first call behind hq_create */
     *out = c;
     return HQ_OK;
