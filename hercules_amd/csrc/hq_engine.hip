@@ -287,6 +287,7 @@ struct hq_ipc_state {
     unsigned long long send_epoch[4] = { 0, 0, 0, 0 }, recv_epoch[4] = { 0, 0, 0, 0 };
     uint32_t* d_done = nullptr;                      /* [4] last-block counters */
     unsigned long long timeout_ticks = 2000000000ull; /* 20 s of the 100 MHz clock (HQ_IPC_TIMEOUT_MS) */
+    unsigned long long delay_ticks = 0;              /* loopback only: flags raised this late (HQ_LOOPBACK_DELAY_US) */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -424,9 +425,19 @@ __global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ ma
  * and reads the records in a LATER kernel (its start is the acquire); the arena is fine-grained memory, which no L2
  * holds stale.
  */
+/* loopback diagnostic only (HQ_LOOPBACK_DELAY_US): the flags are raised `ticks` of the 100 MHz clock late, as if the
+ * records had a link to cross -- how much transport latency does a rank's step hide? */
+static __device__ __forceinline__ void hq_ipc_delay(unsigned long long ticks)
+{
+    if (!ticks) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((unsigned long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 __global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
                                        double* const* __restrict__ dst, uint32_t* __restrict__ done, int32_t nsig,
-                                       unsigned long long* const* __restrict__ sig, unsigned long long epoch)
+                                       unsigned long long* const* __restrict__ sig, unsigned long long epoch,
+                                       unsigned long long delay_ticks)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < count * 3) {
@@ -440,8 +451,10 @@ __global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict_
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)threadIdx.x < nsig)
+    if ((int)threadIdx.x < nsig) {
+        hq_ipc_delay(delay_ticks);
         __hip_atomic_store(sig[threadIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 /* the receiving side: one lane per sending peer polls (relaxed system-scope loads, s_sleep between them) until that
@@ -620,7 +633,7 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
         if (total) {
             I->send_epoch[x]++;
             hq_k_pack_to_peers_sig<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, I->d_dst[x], I->d_done + x,
-                                                                                     I->nsig[x], I->d_sig[x], I->send_epoch[x]);
+                                                                                     I->nsig[x], I->d_sig[x], I->send_epoch[x], I->delay_ticks);
         }
         return HQ_OK;
     }
@@ -840,6 +853,7 @@ struct hq_ipc_args {
     int32_t nsig;
     unsigned long long* const* sig;
     unsigned long long sig_epoch;
+    unsigned long long delay_ticks;                  /* loopback diagnostic: HQ_LOOPBACK_DELAY_US */
 };
 
 template <int IPC>
@@ -892,8 +906,10 @@ hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t
         __syncthreads();
         if (!s_last) return;
         if (threadIdx.x == 0) __hip_atomic_store(ia.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)threadIdx.x < ia.nsig)
+        if ((int)threadIdx.x < ia.nsig) {
+            hq_ipc_delay(ia.delay_ticks);
             __hip_atomic_store(ia.sig[threadIdx.x], ia.sig_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1046,6 +1062,7 @@ static int hq_phase(hq_ctx* c, int ph)
                         ia.nsig = I->nsig[1];
                         ia.sig = I->d_sig[1];
                         ia.sig_epoch = c->an.stotal ? ++I->send_epoch[1] : 0;
+                        ia.delay_ticks = I->delay_ticks;
                         hq_k_interface_update<1><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
                             c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
                             c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, nullptr, s_dst, ia);
@@ -2410,6 +2427,7 @@ static int hq_ipc_connect(hq_ctx* c, const char* blobs)
     }
     I->ready = true;
     I->loopback = loop;
+    if (loop && getenv("HQ_LOOPBACK_DELAY_US")) I->delay_ticks = (unsigned long long)(atof(getenv("HQ_LOOPBACK_DELAY_US")) * 100.0);
     /* as between GPUs: the chain on its own stream beside the interior work */
     c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
     return hq_mask_compute_stream(c);
