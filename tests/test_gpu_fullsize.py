@@ -37,7 +37,7 @@ def _run(box, variant, u1, u2, nsteps, src=None):
     return out
 
 
-@pytest.mark.parametrize("wl", ["c2", "c3", "c2-nobricks"])
+@pytest.mark.parametrize("wl", ["c2", "c2-nobricks"])     # (the 64M box: 75 oracle cone windows below, and 8 partitions against one)
 def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
     if wl.endswith("-nobricks"):     # the patch kernels alone (lattice / ragged stencil patches, element form), as without node_xyz
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
@@ -191,7 +191,7 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
-@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("m1", 1, 1, 0), ("c2", 1, 1, 1), ("m1", 0, 1, 1), ("c3", 1, 1, 1),
+@pytest.mark.parametrize("wl,overlap,ragged,bricks", [("m1", 1, 1, 0), ("m1", 0, 1, 1), ("c3", 1, 1, 1),
                                                       ("m1", 0, 1, 2), ("c2h", 1, 1, 1), ("m1", 1, 1, 3)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
