@@ -624,6 +624,44 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         __syncthreads();
         const hq_lds_double* __restrict__ q = (const hq_lds_double*)s_w + 3 * (HQ_BK_PLANE * (k & 1) + myrow);
         double m[3], g[3], Uo[3];
+#ifdef HQ_BK_BY_COMPONENT
+        /* experiment (-DHQ_BK_BY_COMPONENT): the plane sums component by component behind scheduling barriers -- 9 LDS
+         * values live at a time instead of 27 */
+        {
+            double A_x, A_y;
+            {   /* z */
+                const double C = q[2], XM = q[2 - 3], XP = q[2 + 3], YM = q[2 - 3 * HQ_BK_PY], YP = q[2 + 3 * HQ_BK_PY];
+                const double MM = q[2 - 3 * HQ_BK_PY - 3], PM = q[2 - 3 * HQ_BK_PY + 3], MP = q[2 + 3 * HQ_BK_PY - 3], PP = q[2 + 3 * HQ_BK_PY + 3];
+                const double sxy = (XM + XP) + (YM + YP), dg = (MM + PP) + (PM + MP);
+                m[2] = fma(P[0], C, fma(P[2], sxy, P[4] * dg));
+                g[2] = fma(P[1], C, fma(P[3], sxy, P[5] * dg));
+                Uo[0] = fma(Q[0], XP - XM, Q[1] * ((PP - MP) + (PM - MM)));
+                Uo[1] = fma(Q[0], YP - YM, Q[1] * ((PP - PM) + (MP - MM)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   /* x */
+                const double C = q[0], XM = q[0 - 3], XP = q[0 + 3], YM = q[0 - 3 * HQ_BK_PY], YP = q[0 + 3 * HQ_BK_PY];
+                const double MM = q[0 - 3 * HQ_BK_PY - 3], PM = q[0 - 3 * HQ_BK_PY + 3], MP = q[0 + 3 * HQ_BK_PY - 3], PP = q[0 + 3 * HQ_BK_PY + 3];
+                const double sx = XM + XP, sy = YM + YP, dg = (MM + PP) + (PM + MP);
+                A_x = (PP + MM) - (PM + MP);
+                m[0] = fma(P[0], C, fma(P[1], sx, fma(P[2], sy, P[3] * dg)));
+                g[0] = fma(P[2], C, fma(P[3], sx, fma(P[4], sy, P[5] * dg)));
+                Uo[2] = fma(Q[0], XP - XM, Q[1] * ((PP - MP) + (PM - MM)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   /* y */
+                const double C = q[1], XM = q[1 - 3], XP = q[1 + 3], YM = q[1 - 3 * HQ_BK_PY], YP = q[1 + 3 * HQ_BK_PY];
+                const double MM = q[1 - 3 * HQ_BK_PY - 3], PM = q[1 - 3 * HQ_BK_PY + 3], MP = q[1 + 3 * HQ_BK_PY - 3], PP = q[1 + 3 * HQ_BK_PY + 3];
+                const double sx = XM + XP, sy = YM + YP, dg = (MM + PP) + (PM + MP);
+                A_y = (PP + MM) - (PM + MP);
+                m[1] = fma(P[0], C, fma(P[1], sy, fma(P[2], sx, fma(P[3], dg, Q[0] * A_x))));
+                g[1] = fma(P[2], C, fma(P[3], sy, fma(P[4], sx, fma(P[5], dg, Q[1] * A_x))));
+                Uo[2] += fma(Q[0], YP - YM, Q[1] * ((PP - PM) + (MP - MM)));
+            }
+            m[0] = fma(Q[0], A_y, m[0]);
+            g[0] = fma(Q[1], A_y, g[0]);
+        }
+#else
         {
             double C[3], XM[3], XP[3], YM[3], YP[3], MM[3], PM[3], MP[3], PP[3];
 #pragma unroll
@@ -654,6 +692,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             Uo[1] = fma(Q[0], By0_z, Q[1] * By1_z);
             Uo[2] = fma(Q[0], Bx0_x, fma(Q[1], Bx1_x, fma(Q[0], By0_y, Q[1] * By1_y)));
         }
+#endif
         if (k >= 2 && active) {              /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
             double f[3];
 #pragma unroll

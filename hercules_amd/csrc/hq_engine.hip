@@ -216,6 +216,7 @@ struct hq_ctx {
     int32_t* d_oi_slot = nullptr;
     int32_t* d_oi_ptr = nullptr;      /* [nOI+1] CSR: records of an.d_s_in to add, in       */
     int32_t* d_oi_pos = nullptr;      /*         messenger order (fixed summation order)    */
+    int32_t* d_oi_fc = nullptr;       /* [nOI] first record | number of records << 24       */
     /* compute_adjust DISTRIBUTION grouped by destination (hq_k_distribute): the shared hanging nodes of the patch
      * variant on the interface table (slots), all hanging nodes of the scatter variant on the force table (nodes) */
     int32_t  nSD = 0;                 /* destinations (anchors)                              */
@@ -859,7 +860,7 @@ struct hq_ipc_args {
 template <int IPC>
 __global__ void __launch_bounds__(256)
 hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
-                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos,
+                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos, const int32_t* __restrict__ fcv,
                       const double* __restrict__ iforce, const double* rec,
                       const double* __restrict__ nt, const double* __restrict__ u1,
                       const double* __restrict__ u2, double* __restrict__ un, double* __restrict__ s_out,
@@ -879,23 +880,38 @@ hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t
     }
     if (t < n * 3) {
         int i = t / 3, d = t - 3 * i;
+        /* fcv[i] = the node's FIRST record (low 24 bits: almost every interface node has exactly one sharer) and its
+         * number of records (high 8): record and destination are then loads of the second level, beside n_t, u1, u2 and
+         * the own partial force, instead of a third one behind ptr -> pos -- this kernel runs one workgroup per CU beside
+         * the brick launch, where every level of dependent loads costs microseconds */
         int64_t g = node[i];
+        const int32_t fc = fcv[i];
+        const int32_t first = fc & 0xffffff, cnt = (int32_t)((uint32_t)fc >> 24);
         const double* np = nt + 7 * g;
-        const int32_t k0 = ptr[i], k1 = ptr[i + 1];
         double f = iforce[3 * (int64_t)slot[i] + d];
-        for (int32_t k = k0; k < k1; k++)
-            f += IPC ? __hip_atomic_load(rec + 3 * (int64_t)pos[k] + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                     : rec[3 * (int64_t)pos[k] + d];
+        double* p0 = (s_dst && cnt) ? s_dst[first] : nullptr;
+        if (cnt)
+            f += IPC ? __hip_atomic_load(rec + 3 * (int64_t)first + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                     : rec[3 * (int64_t)first + d];
+        const int32_t k0 = cnt > 1 ? ptr[i] : 0;
+        for (int32_t k = 1; k < cnt; k++)                            /* messenger order: pos[k0] == first */
+            f += IPC ? __hip_atomic_load(rec + 3 * (int64_t)pos[k0 + k] + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                     : rec[3 * (int64_t)pos[k0 + k] + d];
         f += (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
         const double v = f / np[0];
         un[3 * g + d] = v;
         if (s_dst) {
-            for (int32_t k = k0; k < k1; k++) {
-                if (IPC) __hip_atomic_store(s_dst[pos[k]] + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                else s_dst[pos[k]][d] = v;
+            if (cnt) {
+                if (IPC) __hip_atomic_store(p0 + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else p0[d] = v;
+            }
+            for (int32_t k = 1; k < cnt; k++) {
+                if (IPC) __hip_atomic_store(s_dst[pos[k0 + k]] + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else s_dst[pos[k0 + k]][d] = v;
             }
         } else if (s_out) {
-            for (int32_t k = k0; k < k1; k++) s_out[3 * (int64_t)pos[k] + d] = v;
+            if (cnt) s_out[3 * (int64_t)first + d] = v;
+            for (int32_t k = 1; k < cnt; k++) s_out[3 * (int64_t)pos[k0 + k] + d] = v;
         }
     }
     if (IPC) {
@@ -1064,7 +1080,7 @@ static int hq_phase(hq_ctx* c, int ph)
                         ia.sig_epoch = c->an.stotal ? ++I->send_epoch[1] : 0;
                         ia.delay_ticks = I->delay_ticks;
                         hq_k_interface_update<1><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
-                            c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
+                            c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_oi_fc, c->d_iforce, c->an.d_s_in,
                             c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, nullptr, s_dst, ia);
                         c->share_packed = true;
                         return HQ_OK;
@@ -1072,7 +1088,7 @@ static int hq_phase(hq_ctx* c, int ph)
                     hq_ipc_wait(c, &c->an, true, xs);
                 }
                 hq_k_interface_update<0><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
-                    c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_iforce, c->an.d_s_in,
+                    c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_oi_fc, c->d_iforce, c->an.d_s_in,
                     c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, s_dst ? nullptr : s_out, s_dst, ia);
                 c->share_packed = fuse;
             } else if (hq_ipc_ready(c)) {
@@ -1227,7 +1243,15 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         for (int32_t i = 0; i < c->nOI; i++) ptr[i + 1] += ptr[i];
         std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
         for (size_t r = 0; r < an_ss.size(); r++) pos[fill[oi_index[an_ss[r]]]++] = (int32_t)r;
+        if (an_ss.size() >= (size_t)1 << 24) return hq_fail(HQ_ERR_ARG, "more than 16M records in the anchored-node s-lists%s", "");
+        std::vector<int32_t> fc((size_t)c->nOI, 0);
+        for (int32_t i = 0; i < c->nOI; i++) {
+            const int32_t cnt = ptr[(size_t)i + 1] - ptr[(size_t)i];
+            if (cnt > 255) return hq_fail(HQ_ERR_ARG, "a node is shared by more than 255 ranks%s", "");
+            fc[(size_t)i] = cnt ? (int32_t)(((uint32_t)cnt << 24) | (uint32_t)pos[(size_t)ptr[(size_t)i]]) : 0;
+        }
         if (pos.empty()) pos.push_back(0);
+        HQ_TRY(upload(fc, &c->d_oi_fc));
         HQ_TRY(upload(oin, &c->d_oi_node));
         HQ_TRY(upload(ois, &c->d_oi_slot));
         HQ_TRY(upload(ptr, &c->d_oi_ptr));
@@ -2078,7 +2102,7 @@ extern "C" int hq_destroy(hq_ctx* c)
                      c->d_force, c->d_loaded, c->d_F, c->d_dn_id, c->d_dn_ptr, c->d_dn_anchor,
                      c->an.d_cmap, c->an.d_smap, c->an.d_c_out, c->an.d_c_in, c->an.d_s_out, c->an.d_s_in,
                      c->dn.d_cmap, c->dn.d_smap, c->dn.d_c_out, c->dn.d_c_in, c->dn.d_s_out, c->dn.d_s_in,
-                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_sd_dst, c->d_sd_ptr, c->d_sd_src, c->d_sd_deps,
+                     c->d_iforce, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_oi_fc, c->d_sd_dst, c->d_sd_ptr, c->d_sd_src, c->d_sd_deps,
                      c->d_gkey, c->d_halo_err, c->an.d_c_out_id, c->an.d_c_in_id, c->an.d_s_out_id, c->an.d_s_in_id,
                      c->dn.d_c_out_id, c->dn.d_c_in_id, c->dn.d_s_out_id, c->dn.d_s_in_id };
     for (void* p : ptrs) if (p) hipFree(p);
