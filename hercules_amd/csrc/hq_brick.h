@@ -536,7 +536,7 @@ static __device__ __forceinline__ double hq_uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
-template <bool PERNODE>
+template <bool PERNODE, bool BYCOMP>
 /* PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds ten
  * more values per lane -- the plane's n_t row and the reciprocal masses of the two unfinished planes; with the stencil
  * numbers in scalar registers it fits 128 VGPRs too (round 3: 33 spilled) */
@@ -624,10 +624,14 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         __syncthreads();
         const hq_lds_double* __restrict__ q = (const hq_lds_double*)s_w + 3 * (HQ_BK_PLANE * (k & 1) + myrow);
         double m[3], g[3], Uo[3];
-#ifdef HQ_BK_BY_COMPONENT
-        /* experiment (-DHQ_BK_BY_COMPONENT): the plane sums component by component behind scheduling barriers -- 9 LDS
-         * values live at a time instead of 27 */
-        {
+        /* BYCOMP: the plane sums component by component behind scheduling barriers -- 9 LDS values live at a time instead
+         * of 27: 100 VGPRs instead of 118.  On one GPU that is 1.6 % slower (64M box 1.112 against 1.095 ms, same box);
+         * on a PARTITION, where the exchange chain's kernels must find room on CUs two brick workgroups occupy, four waves
+         * of 104 registers leave 96 per lane instead of 32 -- three chain workgroups per CU instead of one: the interface
+         * update beside the bricks takes 38 instead of 65 us, and a rank's step keeps its 180 us with 20 us of transport
+         * latency per exchange where the 118-register kernel goes to 205 (profiles/r04/rank_alone_latency.txt).  The
+         * launcher picks it for contexts with a transport. */
+        if (BYCOMP) {
             double A_x, A_y;
             {   /* z */
                 const double C = q[2], XM = q[2 - 3], XP = q[2 + 3], YM = q[2 - 3 * HQ_BK_PY], YP = q[2 + 3 * HQ_BK_PY];
@@ -660,9 +664,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             }
             m[0] = fma(Q[0], A_y, m[0]);
             g[0] = fma(Q[1], A_y, g[0]);
-        }
-#else
-        {
+        } else {
             double C[3], XM[3], XP[3], YM[3], YP[3], MM[3], PM[3], MP[3], PP[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
@@ -692,7 +694,6 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             Uo[1] = fma(Q[0], By0_z, Q[1] * By1_z);
             Uo[2] = fma(Q[0], Bx0_x, fma(Q[1], Bx1_x, fma(Q[0], By0_y, Q[1] * By1_y)));
         }
-#endif
         if (k >= 2 && active) {              /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
             double f[3];
 #pragma unroll
@@ -997,7 +998,7 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
 
 /* one step of all units: the HQ_BK_NTSAME units, then (a launch each) the units with per-node n_t rows and the HET units */
 static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
-                            const double* F, double dt2, hipStream_t stream)
+                            const double* F, double dt2, hipStream_t stream, bool light = false)
 {
     const int32_t cnt[3] = { P->nsame, P->nunits - P->nsame - P->nhet, P->nhet };
     int32_t first = 0;
@@ -1007,8 +1008,10 @@ static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const doub
         const int per_xcd = (count + 7) / 8;
         const int32_t* sp = P->d_src_ptr ? P->d_src_ptr + first : nullptr;
 #define HQ_BK_ARGS count, per_xcd, P->d_units + first, P->d_tab, u1, u2, un, nt3, sp, P->d_src_ent, (sp ? F : nullptr), dt2, hq_stencil().c
-        if (k == 0) hq_k_brick<false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
-        else if (k == 1) hq_k_brick<true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        if (k == 0 && light) hq_k_brick<false, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 0) hq_k_brick<false, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 1 && light) hq_k_brick<true, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 1) hq_k_brick<true, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else hq_k_brick_het<<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
                                                                              P->d_src_ent, (sp ? F : nullptr), dt2);
 #undef HQ_BK_ARGS

@@ -196,6 +196,7 @@ struct hq_ctx {
     bool opt_brick_stream = false;           /* HQ_BRICK_STREAM=1 */
     bool opt_fused_share = true;             /* HQ_NO_FUSED_SHARE=1 clears it */
     int opt_merge_rounds = 2;                /* HQ_PATCH_MERGE_ROUNDS */
+    int opt_brick_light = -1;                /* HQ_BRICK_BY_COMPONENT: 0 / 1; default (-1): where the chain has its own stream */
     struct hq_ipc_state* ipc = nullptr;      /* device-to-device transport between processes (hq_comm_init_ipc) */
     hipEvent_t ev_sent = nullptr;
     /* patch variant with an interface: the exchange chain runs on its own stream
@@ -1025,7 +1026,7 @@ static int hq_phase(hq_ctx* c, int ph)
             if (bs) HQ_HIP(hipEventRecord(c->ev_patches, c->stream));
             if (c->bricks.nunits > 0)
                 hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2,
-                                bs ? c->bstream : c->stream);
+                                bs ? c->bstream : c->stream, c->opt_brick_light < 0 ? c->overlap : c->opt_brick_light != 0);
             if (bs) {
                 HQ_HIP(hipEventRecord(c->ev_bricks, c->bstream));
                 if (c->timing) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));   /* the mark below closes the step's kernels */
@@ -1633,6 +1634,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     c->opt_brick_stream = getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) != 0;
     c->opt_fused_share = !(getenv("HQ_NO_FUSED_SHARE") && atoi(getenv("HQ_NO_FUSED_SHARE")) != 0);
     if (getenv("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, atoi(getenv("HQ_PATCH_MERGE_ROUNDS")));
+    if (getenv("HQ_BRICK_BY_COMPONENT")) c->opt_brick_light = atoi(getenv("HQ_BRICK_BY_COMPONENT")) != 0;
     c->h2d_bytes = c->d2h_bytes = 0;          /* the counters of hq_info start with the first call behind hq_create */
     *out = c;
     return HQ_OK;

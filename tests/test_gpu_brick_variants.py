@@ -139,3 +139,16 @@ def test_a_group_with_a_destroyed_member_refuses_to_step():
     solvers[0].close()
     for b in boxes:
         b.close()
+
+
+@pytest.mark.parametrize("pernode", [False, True])
+def test_brick_kernel_in_the_form_partitions_launch(monkeypatch, pernode):
+    """hq_k_brick<PERNODE, BYCOMP = true>: the plane sums component by component (100 / 108 VGPRs: room for the exchange
+    chain beside it) -- what every context with a transport launches -- forced on a single context against the oracle."""
+    monkeypatch.setenv("HQ_BRICK_BY_COMPONENT", "1")
+    if pernode:
+        monkeypatch.setenv("HQ_BRICK_NO_NTSAME", "1")
+    lnid, node_ijk, et, nt, dt = _box(64, 64, 32)
+    info, tm1, tm2, r1, r2 = _run_both(lnid, node_ijk, et, nt, dt, 12, seed=3)
+    assert info["brick_units"] > 0 and (info["brick_units_pernode"] == info["brick_units"]) == pernode
+    assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL
