@@ -708,6 +708,8 @@ def main():
             bring_up("host", solver)
             chosen = "host"
         rccl_ranks = int(solver.info()["nranks"]) if chosen == "rccl" else 0
+        if chosen == "ipc":
+            names["ipc"] += ", %s-grained receive arena" % ("coarse" if solver.info()["ipc_arena_coarse"] else "fine")
         transport = "%s, %d ranks" % (names[chosen], world) + \
                     "".join(" [%s failed: %s]" % (k, v) for k, v in errors.items())
         if rank == 0 and errors:

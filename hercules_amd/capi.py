@@ -62,7 +62,7 @@ class _Info(ctypes.Structure):
                 ("ragged_patches", ctypes.c_int32), ("brick_units", ctypes.c_int32),
                 ("brick_nodes", ctypes.c_int64), ("brick_units_pernode", ctypes.c_int32),
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
-                ("pcie_d2h_bytes", ctypes.c_int64)]
+                ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32)]
 
 
 _lib = None

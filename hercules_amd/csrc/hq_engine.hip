@@ -2165,6 +2165,8 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.brick_units_het = c->bricks.nhet;
     v.pcie_h2d_bytes = c->h2d_bytes;
     v.pcie_d2h_bytes = c->d2h_bytes;
+    v.transport = c->comm ? 1 : (hq_ipc_ready(c) ? (c->ipc->loopback ? 5 : 2) : (c->host_xchg ? 3 : (c->group ? 4 : 0)));
+    v.ipc_arena_coarse = (c->ipc && c->ipc->coarse) ? 1 : 0;
     memset(info, 0, (size_t)size);
     memcpy(info, &v, (size_t)std::min<uint64_t>(size, sizeof(v)));
     return HQ_OK;

@@ -120,6 +120,8 @@ typedef struct {
     int64_t pcie_h2d_bytes;      /* bytes the entry points moved host -> device since hq_create returned (source   */
     int64_t pcie_d2h_bytes;      /* windows, gather ids, uploads, host-staged halos) and device -> host (gathers,   */
                                  /* downloads, host-staged halos): what a run costs on PCIe between outputs         */
+    int32_t transport;           /* 0 none, 1 RCCL, 2 IPC, 3 host-staged, 4 in-process group, 5 loopback (diagnostic)  */
+    int32_t ipc_arena_coarse;    /* IPC: 1 if the receive arena had to be coarse-grained memory (ranks of one device only) */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
