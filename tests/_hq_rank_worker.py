@@ -70,7 +70,7 @@ def main():
     tm1, tm2 = s.download()
     info = s.info()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), gid=gid, tm1=tm1, tm2=tm2, brick_nodes=info["brick_nodes"],
-             kernel=s.dominant_kernel())
+             kernel=s.dominant_kernel(), transport=info["transport"], ipc_arena_coarse=info["ipc_arena_coarse"])
     s.close()
     b.close()
     dist.barrier()

@@ -70,6 +70,9 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
     for z in parts:
         assert H.rel_linf(z["tm1"], ref1[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], ref2[z["gid"]]) < 1e-9
         assert int(z["brick_nodes"]) > 0 and str(z["kernel"]) == "hq_k_brick"
+        assert int(z["transport"]) == (2 if transport == "ipc" else 3)       # hq_info.transport: IPC / host-staged
+    if transport == "ipc":
+        print("IPC receive arena:", "coarse-grained" if int(parts[0]["ipc_arena_coarse"]) else "fine-grained")
 
 
 @pytest.mark.parametrize("transport", ["host", "ipc"])
