@@ -60,6 +60,8 @@ def analyse(path):
         print("no steps found")
         return
     mean = [sum(s[k] for s in stats) / n / 1e3 for k in (0, 1, 2, 3, 6)]
+    per_step = sorted(s[6] / 1e3 for s in stats)
+    print("step length over %d steps: min %.1f  median %.1f  max %.1f us" % (n, per_step[0], per_step[n // 2], per_step[-1]))
     print("%d steps of %.1f us: brick launch %.1f us; the chain's %d kernels take %.1f us in all (its critical path on the "
           "device); first start -> last end %.1f us, longest gap between two of them %.1f us (the transport's round trip); "
           "%.1f of them start while the brick launch is in flight"
