@@ -32,6 +32,14 @@ def run(rank, steps, workload="c3"):
         s.comm_init_loopback()
     s.run(steps)
     s.sync()
+    if os.environ.get("HQ_TRACE_TIME_STEPS"):          # wall clock per step without a profiler attached
+        import time
+        n = int(os.environ["HQ_TRACE_TIME_STEPS"])
+        for rep in range(3):
+            t0 = time.perf_counter()
+            s.run(n)
+            s.sync()
+            print("wall clock, %d steps: %.1f us per step" % (n, (time.perf_counter() - t0) / n * 1e6))
     print("rank %d of 8 alone: %s" % (rank, s.info()))
     s.close()
     b.close()
