@@ -75,6 +75,39 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
         print("IPC receive arena:", "coarse-grained" if int(parts[0]["ipc_arena_coarse"]) else "fine-grained")
 
 
+@pytest.mark.parametrize("transport,env", [("ipc", {"HQ_NO_FUSED_SHARE": "1"}), ("host", {"HQ_NO_FUSED_SHARE": "1"}),
+                                           ("ipc", {"HQ_PATCH_MERGE_ROUNDS": "0"}), ("ipc", {"HQ_IPC_COARSE": "1"}),
+                                           ("ipc", {"HQ_BRICK_BY_COMPONENT": "0", "HQ_BRICK_STREAM": "1"})])
+def test_exchange_chain_switches_between_processes(tmp_path, transport, env):
+    """The chain's switches that only traces set otherwise: the displacement sharing packed by its own kernel instead of
+    by hq_k_interface_update; two patch launches instead of one; a coarse-grained IPC arena (ranks of one device); the
+    118-register brick kernel with the bricks on a stream of their own -- two ranks as processes against the oracle."""
+    nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 20
+    e = {"HQ_OVERLAP": "1", "HQ_CU_MASK": "0", "HQ_TEST_TRANSPORT": transport}
+    e.update(env)
+    parts = _launch(tmp_path, 2, "box", nsteps, e)
+    from hercules_amd import host
+    b = host.Box(nx, ny, nz, h, dt, freq)
+    ijk = b.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    Ng = (nx + 1) * (ny + 1) * (nz + 1)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
+    loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
+    rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
+    F = b.source_table(rp, 0, nsteps)
+    o1, o2 = g2[gid].copy(), g1[gid].copy()
+    ho.solver_run(b.lnid, b.etable.copy(), b.ntable.copy(), o1, o2, 0, nsteps, dt, loaded_lnid=loaded, forces=F)
+    ref1, ref2 = np.zeros((Ng, 3)), np.zeros((Ng, 3))
+    ref1[gid], ref2[gid] = o2, o1
+    b.close()
+    for z in parts:
+        assert H.rel_linf(z["tm1"], ref1[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], ref2[z["gid"]]) < 1e-9
+        if "HQ_IPC_COARSE" in env:
+            assert int(z["ipc_arena_coarse"]) == 1
+
+
 @pytest.mark.parametrize("transport", ["host", "ipc"])
 def test_ranks_in_their_own_processes_on_one_gpu_octree_box(tmp_path, transport):
     """Three ranks of the two-level octree box: hanging nodes shared between ranks, so all four exchanges of a step
