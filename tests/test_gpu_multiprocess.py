@@ -75,8 +75,8 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
         print("IPC receive arena:", "coarse-grained" if int(parts[0]["ipc_arena_coarse"]) else "fine-grained")
 
 
-@pytest.mark.parametrize("transport,env", [("ipc", {"HQ_NO_FUSED_SHARE": "1"}), ("host", {"HQ_NO_FUSED_SHARE": "1"}),
-                                           ("ipc", {"HQ_PATCH_MERGE_ROUNDS": "0"}), ("ipc", {"HQ_IPC_COARSE": "1"}),
+@pytest.mark.parametrize("transport,env", [("ipc", {"HQ_NO_FUSED_SHARE": "1", "HQ_PATCH_MERGE_ROUNDS": "0"}),
+                                           ("host", {"HQ_NO_FUSED_SHARE": "1"}), ("ipc", {"HQ_IPC_COARSE": "1"}),
                                            ("ipc", {"HQ_BRICK_BY_COMPONENT": "0", "HQ_BRICK_STREAM": "1"})])
 def test_exchange_chain_switches_between_processes(tmp_path, transport, env):
     """The chain's switches that only traces set otherwise: the displacement sharing packed by its own kernel instead of
