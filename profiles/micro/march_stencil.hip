@@ -261,6 +261,161 @@ k_march2(const double* __restrict__ u1, const double* __restrict__ u2, double* _
     }
 }
 
+// Round 4: the plane-sum march with the loads TWO planes ahead (two register sets, the loop unrolled by two) and the plane
+// sums component by component (9 LDS values live at a time: the registers the second set needs).  All loads
+// unconditional (lanes without a ring node re-read their own row), so that the compiler can count them.
+template <int TX, int TY, int BYCOMP>
+__global__ void __launch_bounds__(TX * TY, 4)
+k_march3(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ un, int NX, int NY, int NZ, int CZ,
+         int units_per_xcd, int nunits, coef cin)
+{
+    constexpr int PY = TX + 2, PLANE = (TX + 2) * (TY + 2);
+    constexpr int NRING = 2 * (TX + 2) + 2 * TY;
+    __shared__ __align__(16) double s_w[3 * PLANE * 2];
+    const int unit = (int)(blockIdx.x & 7) * units_per_xcd + (int)(blockIdx.x >> 3);
+    if (unit >= nunits) return;
+    auto uni = [](double v) {
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
+    double P[6], Q[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) P[i] = uni(cin.P[i]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) Q[i] = uni(cin.Q[i]);
+    const double beta = cin.beta, m0i = uni(1.0 / cin.m0), m1 = cin.m1, m2 = cin.m2;
+    const int ntx = NX / TX, nty = NY / TY, ntiles = ntx * nty;
+    const int tiles_per_xcd = ntiles / 8;
+    const int xcd = unit / units_per_xcd, u = unit - xcd * units_per_xcd;
+    const int chunk = u / tiles_per_xcd, tl = xcd * tiles_per_xcd + u % tiles_per_xcd;
+    const int tx = tl % ntx, ty = tl / ntx;
+    const int z0 = chunk * CZ, z1 = min(z0 + CZ, NZ);
+    const int t = threadIdx.x, lx = t % TX, ly = t / TX;
+    const int64_t tile_base = ((int64_t)ty * ntx + tx) * NZ * (TX * TY);
+    const int myrow = (ly + 1) * PY + (lx + 1);
+    int rx = lx, ry = ly;
+    if (t < TX + 2) { rx = t - 1; ry = -1; }
+    else if (t < 2 * (TX + 2)) { rx = t - (TX + 2) - 1; ry = TY; }
+    else if (t < 2 * (TX + 2) + TY) { rx = -1; ry = t - 2 * (TX + 2); }
+    else if (t < NRING) { rx = TX; ry = t - 2 * (TX + 2) - TY; }
+    const bool ring = t < NRING;
+    const int rrow = ring ? (ry + 1) * PY + (rx + 1) : myrow;
+    const int rgx = min(max(tx * TX + rx, 0), NX - 1), rgy = min(max(ty * TY + ry, 0), NY - 1);
+    const int rtile = (rgy / TY) * ntx + rgx / TX;
+    const int64_t ring_base = (int64_t)rtile * NZ * (TX * TY) + (rgy % TY) * TX + (rgx % TX);
+    constexpr int ZS = TX * TY;
+
+    double a1[3], a2[3], c1[3], c2[3];          // the own node's u1, u2: two sets, loaded two planes ahead
+    double b1[3], b2[3];                        // the ring node's: one set, loaded one plane ahead (mostly L2 hits)
+    double fA[3] = { 0, 0, 0 }, fB[3] = { 0, 0, 0 };
+#define LOADOWN(z_, x1_, x2_)                                                                      \
+    {                                                                                              \
+        const int zc_ = min(max((z_), 0), NZ - 1);                                                 \
+        const int64_t a_ = tile_base + (int64_t)zc_ * ZS + t;                                      \
+        _Pragma("unroll") for (int d = 0; d < 3; d++) { x1_[d] = u1[3 * a_ + d]; x2_[d] = u2[3 * a_ + d]; } \
+    }
+#define LOADRING(z_)                                                                               \
+    {                                                                                              \
+        const int zc_ = min(max((z_), 0), NZ - 1);                                                 \
+        const int64_t b_ = ring_base + (int64_t)zc_ * ZS;                                          \
+        _Pragma("unroll") for (int d = 0; d < 3; d++) { b1[d] = u1[3 * b_ + d]; b2[d] = u2[3 * b_ + d]; } \
+    }
+#define PUTSET(z_, rs_, x1_, x2_)                                                        \
+    {                                                                                              \
+        double* img_ = s_w + 3 * PLANE * ((z_) & 1);                                               \
+        _Pragma("unroll") for (int d = 0; d < 3; d++) {                                            \
+            img_[3 * myrow + d] = x1_[d] + beta * (x1_[d] - x2_[d]);                               \
+            rs_[d] += m2 * x1_[d] - m1 * x2_[d];                                                   \
+        }                                                                                          \
+        if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) img_[3 * rrow + d] = b1[d] + beta * (b1[d] - b2[d]); } \
+    }
+#define STEP(p_, x1_, x2_)   /* consume plane p_ from LDS; PUT plane p_+1 from the given set; reload it with p_+3 */ \
+    {                                                                                              \
+        __syncthreads();                                                                           \
+        const double* q = s_w + 3 * (PLANE * ((p_) & 1) + myrow);                                  \
+        double m[3], g[3], U[3];                                                                   \
+        if (BYCOMP) {                                                                              \
+            double A_x, A_y;                                                                       \
+            {                                                                                      \
+                const double C = q[2], XM = q[2 - 3], XP = q[2 + 3], YM = q[2 - 3 * PY], YP = q[2 + 3 * PY];                      \
+                const double MM = q[2 - 3 * PY - 3], PM = q[2 - 3 * PY + 3], MP = q[2 + 3 * PY - 3], PP = q[2 + 3 * PY + 3];      \
+                const double sxy = (XM + XP) + (YM + YP), dg = (MM + PP) + (PM + MP);              \
+                m[2] = fma(P[0], C, fma(P[2], sxy, P[4] * dg));                                    \
+                g[2] = fma(P[1], C, fma(P[3], sxy, P[5] * dg));                                    \
+                U[0] = fma(Q[0], XP - XM, Q[1] * ((PP - MP) + (PM - MM)));                         \
+                U[1] = fma(Q[0], YP - YM, Q[1] * ((PP - PM) + (MP - MM)));                         \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            {                                                                                      \
+                const double C = q[0], XM = q[0 - 3], XP = q[0 + 3], YM = q[0 - 3 * PY], YP = q[0 + 3 * PY];                      \
+                const double MM = q[0 - 3 * PY - 3], PM = q[0 - 3 * PY + 3], MP = q[0 + 3 * PY - 3], PP = q[0 + 3 * PY + 3];      \
+                const double sx = XM + XP, sy = YM + YP, dg = (MM + PP) + (PM + MP);               \
+                A_x = (PP + MM) - (PM + MP);                                                       \
+                m[0] = fma(P[0], C, fma(P[1], sx, fma(P[2], sy, P[3] * dg)));                      \
+                g[0] = fma(P[2], C, fma(P[3], sx, fma(P[4], sy, P[5] * dg)));                      \
+                U[2] = fma(Q[0], XP - XM, Q[1] * ((PP - MP) + (PM - MM)));                         \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            {                                                                                      \
+                const double C = q[1], XM = q[1 - 3], XP = q[1 + 3], YM = q[1 - 3 * PY], YP = q[1 + 3 * PY];                      \
+                const double MM = q[1 - 3 * PY - 3], PM = q[1 - 3 * PY + 3], MP = q[1 + 3 * PY - 3], PP = q[1 + 3 * PY + 3];      \
+                const double sx = XM + XP, sy = YM + YP, dg = (MM + PP) + (PM + MP);               \
+                A_y = (PP + MM) - (PM + MP);                                                       \
+                m[1] = fma(P[0], C, fma(P[1], sy, fma(P[2], sx, fma(P[3], dg, Q[0] * A_x))));      \
+                g[1] = fma(P[2], C, fma(P[3], sy, fma(P[4], sx, fma(P[5], dg, Q[1] * A_x))));      \
+                U[2] += fma(Q[0], YP - YM, Q[1] * ((PP - PM) + (MP - MM)));                        \
+            }                                                                                      \
+            m[0] = fma(Q[0], A_y, m[0]);                                                           \
+            g[0] = fma(Q[1], A_y, g[0]);                                                           \
+        } else {                                                                                   \
+            double C[3], XM[3], XP[3], YM[3], YP[3], MM[3], PM[3], MP[3], PP[3];                   \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) {                                        \
+                C[d] = q[d]; XM[d] = q[d - 3]; XP[d] = q[d + 3]; YM[d] = q[d - 3 * PY]; YP[d] = q[d + 3 * PY];                   \
+                MM[d] = q[d - 3 * PY - 3]; PM[d] = q[d - 3 * PY + 3]; MP[d] = q[d + 3 * PY - 3]; PP[d] = q[d + 3 * PY + 3];      \
+            }                                                                                      \
+            double sx[3], sy[3], dg[3];                                                            \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { sx[d] = XM[d] + XP[d]; sy[d] = YM[d] + YP[d]; dg[d] = (MM[d] + PP[d]) + (PM[d] + MP[d]); } \
+            const double A_x = (PP[0] + MM[0]) - (PM[0] + MP[0]), A_y = (PP[1] + MM[1]) - (PM[1] + MP[1]);                        \
+            const double sxy_z = sx[2] + sy[2];                                                    \
+            m[0] = fma(P[0], C[0], fma(P[1], sx[0], fma(P[2], sy[0], fma(P[3], dg[0], Q[0] * A_y))));  \
+            m[1] = fma(P[0], C[1], fma(P[1], sy[1], fma(P[2], sx[1], fma(P[3], dg[1], Q[0] * A_x))));  \
+            m[2] = fma(P[0], C[2], fma(P[2], sxy_z, P[4] * dg[2]));                                \
+            g[0] = fma(P[2], C[0], fma(P[3], sx[0], fma(P[4], sy[0], fma(P[5], dg[0], Q[1] * A_y))));  \
+            g[1] = fma(P[2], C[1], fma(P[3], sy[1], fma(P[4], sx[1], fma(P[5], dg[1], Q[1] * A_x))));  \
+            g[2] = fma(P[1], C[2], fma(P[3], sxy_z, P[5] * dg[2]));                                \
+            U[0] = fma(Q[0], XP[2] - XM[2], Q[1] * ((PP[2] - MP[2]) + (PM[2] - MM[2])));           \
+            U[1] = fma(Q[0], YP[2] - YM[2], Q[1] * ((PP[2] - PM[2]) + (MP[2] - MM[2])));           \
+            U[2] = fma(Q[0], XP[0] - XM[0], fma(Q[1], (PP[0] - MP[0]) + (PM[0] - MM[0]), fma(Q[0], YP[1] - YM[1], Q[1] * ((PP[1] - PM[1]) + (MP[1] - MM[1]))))); \
+        }                                                                                          \
+        {   /* unconditional (a store behind a branch makes the compiler drain every load in flight): the first,      \
+             * incomplete result goes to plane z0 too and is overwritten by the right one two steps later */         \
+            const int64_t a_ = tile_base + (int64_t)max((p_) - 1, z0) * ZS + t;                    \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) un[3 * a_ + d] = (fA[d] + (g[d] + U[d])) * m0i; \
+        }                                                                                          \
+        _Pragma("unroll") for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - U[d]; } \
+        PUTSET((p_) + 1, fB, x1_, x2_)                                                             \
+        LOADRING((p_) + 2)                                                                         \
+        LOADOWN((p_) + 3, x1_, x2_)                                                                \
+    }
+    // planes z0-1 .. z1 are consumed; the own rows of plane p + 1 and p + 2 and the ring rows of plane p + 1 are in flight
+    // when plane p is consumed
+    double dummy[3] = { 0, 0, 0 };
+    LOADOWN(z0 - 1, a1, a2)
+    LOADRING(z0 - 1)
+    PUTSET(z0 - 1, dummy, a1, a2)
+    LOADOWN(z0, c1, c2)
+    LOADRING(z0)
+    LOADOWN(z0 + 1, a1, a2)
+    for (int p = z0 - 1; p <= z1; p += 2) {     // (z1 - z0 + 2 planes: an even number for even chunks)
+        STEP(p, c1, c2)                          // consumes plane p, PUTs plane p + 1 (c), requests ring p + 2 and own p + 3 (c)
+        STEP(p + 1, a1, a2)
+    }
+#undef LOADOWN
+#undef LOADRING
+#undef PUTSET
+#undef STEP
+}
+
 int main(int argc, char** argv)
 {
     const int NX = 512, NY = 512, NZ = argc > 1 ? atoi(argv[1]) : 256;
@@ -327,6 +482,36 @@ int main(int argc, char** argv)
         printf("%7.3f ms  (%.0f GB/s of the compulsory 72 B/node; 67.6M-node box: %.3f ms)\n", ms / reps,              \
                72.0 * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
     }
+#define RUN3(TX_, TY_, CZ_, ABL_)                                                                                    \
+    {                                                                                                                  \
+        const int ntiles = (NX / TX_) * (NY / TY_), nch = (NZ + CZ_ - 1) / CZ_, nunits = ntiles * nch, upx = nunits / 8; \
+        k_ref<TX_, TY_><<<(unsigned)((N + 255) / 256), 256>>>(u1, u2, ur, NX, NY, NZ, c);                                \
+        CK(hipMemset(un, 0, N * 24));                                                                                  \
+        k_march3<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c);                   \
+        CK(hipDeviceSynchronize());                                                                                    \
+        {                                                                                                              \
+            std::vector<double> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
+            double worst = 0;                                                                                          \
+            for (int64_t off : { (int64_t)0, N * 3 / 2, N * 3 - ((int64_t)1 << 22) }) {                                \
+                CK(hipMemcpy(a.data(), un + off, a.size() * 8, hipMemcpyDeviceToHost));                                \
+                CK(hipMemcpy(b.data(), ur + off, b.size() * 8, hipMemcpyDeviceToHost));                                \
+                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs(a[i] - b[i]));                          \
+            }                                                                                                          \
+            printf("plane sums, loads two planes ahead (bycomp = abl): tile %2dx%-2d chunk %3d abl %d  max|march - ref| = %.2e  ", TX_, TY_, CZ_, ABL_, worst); \
+        }                                                                                                              \
+        CK(hipEventRecord(e0));                                                                                        \
+        for (int r = 0; r < reps; r++) k_march3<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c); \
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));                     \
+        printf("%7.3f ms  (%.0f GB/s of the compulsory 72 B/node; 67.6M-node box: %.3f ms)\n", ms / reps,              \
+               72.0 * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
+    }
+    RUN3(64, 8, 32, 1)
+    RUN3(64, 8, 64, 1)
+    RUN3(64, 8, 32, 0)
+    RUN3(64, 8, 64, 0)
+    RUN2(64, 8, 32, 0)
+    RUN2(64, 8, 64, 0)
+    return 0;
     RUN2(64, 8, 32, 0)
     RUN2(64, 8, 64, 0)
     RUN2(64, 8, 256, 0)
