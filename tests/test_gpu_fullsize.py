@@ -192,7 +192,7 @@ def test_all_c_host_program(tmp_path):
 
 
 @pytest.mark.parametrize("wl,overlap,ragged,bricks", [("m1", 1, 1, 0), ("m1", 0, 1, 1), ("c3", 1, 1, 1),
-                                                      ("m1", 0, 1, 2), ("c2h", 1, 1, 1), ("m1", 1, 1, 3)])
+                                                      ("m1", 0, 1, 2), ("c2h", 1, 1, 1)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
     """BASELINE config 4 on one GPU: the 8M and the 64M box cut 8 ways (octor blocks),
     stepped with the in-process transport and the comm/compute overlap, against the
@@ -206,8 +206,6 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
     if bricks == 2:                                                     # the in-process transport with copies instead of
         monkeypatch.setenv("HQ_GROUP_COPIES", "1")                      # the pack kernel writing into the peers' buffers
-    if bricks == 3:                                                     # the bricks on a stream of their own beside the
-        monkeypatch.setenv("HQ_BRICK_STREAM", "1")                      # patches (opt-in; needs the chain's own stream)
     import bench
     nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
     ncls, amp = bench.LATERAL.get(wl, (0, 0.0))        # c2h: material of its own in every element (hq_k_brick_het in every partition)
@@ -319,7 +317,8 @@ def test_small_basin_variants_agree_and_step_is_linear():
     box.close()
 
 
-@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 1), (ha.HQ_VARIANT_SCATTER, 0)])
+@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_SCATTER, 0)])    # (patch variant: the 189M basin in 8 partitions below; its
+                                                                             # overlap with hanging nodes: tests/test_gpu_multiprocess.py)
 def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap, monkeypatch):
     """o3s cut into octor's 8 partitions by the C host (hanging nodes and their anchors on partition
     interfaces: all four exchanges of a step, psolve.c:4298-4315), in-process transport, against the
