@@ -265,7 +265,10 @@ def octbox_counts(nx, ny, layers):
 def inproc_diagnostic(args):
     # HIP multiplexes a process's streams onto 4 hardware queues by default: eight partitions' streams then wait for each
     # other two by two.  One queue per partition (measured, 8 partitions of the 64M box: 1.77 -> 1.61 ms per step).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (Not with the chain on a second stream per partition: 16-24 streams with cross-stream events on 16-32 hardware
+    # queues took 1.7 SECONDS per step -- the runtime resolves those waits on the host.)
+    if os.environ.get("HQ_OVERLAP", "0") in ("", "0"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import hercules_amd as ha
     from hercules_amd import capi, host as hhost
     nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
