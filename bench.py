@@ -304,6 +304,51 @@ def inproc_diagnostic(args):
                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "overlap": os.environ.get("HQ_OVERLAP", "0")}))
 
 
+def select_transport(want, solver, new_solver, bring_up, trial, trials):
+    """Which transport carries the halo records of an N > 1 run.  Pure control flow (tests/test_bench_roofline_cpu.py
+    drives it with stand-ins): `solver` is the context built so far, `new_solver()` builds another one on the same mesh,
+    `bring_up(kind, solver)` -> True if transport `kind` is in place on EVERY rank, `trial(solver)` -> ms per step or None.
+    want = auto: RCCL and IPC are both brought up (a context each), both timed, the faster kept; one of them alone if the
+    other does not come up; host-staged if neither does.  want = rccl / ipc: that one, else the other device-side one
+    (rccl -> ipc), else host-staged.  A context whose bring-up failed is closed, never reused.
+    -> (solver that carries the chosen transport, its name); `trials` is filled with what was measured."""
+    chosen = None
+    if want == "auto":
+        up = {}
+        for kind in ("rccl", "ipc"):
+            sv = solver if kind == "rccl" else new_solver()
+            if bring_up(kind, sv):
+                up[kind] = sv
+            else:
+                sv.close()
+        if len(up) == 2:
+            for kind, sv in up.items():
+                trials[kind] = trial(sv)
+            alive = {k: v for k, v in trials.items() if v is not None}
+            chosen = min(alive, key=alive.get) if alive else None
+        elif up:
+            chosen = next(iter(up))
+        for kind, sv in up.items():
+            if kind != chosen:
+                sv.close()
+        if chosen:
+            return up[chosen], chosen
+        solver = new_solver()
+        want = "host"
+    if want in ("rccl", "ipc"):
+        if bring_up(want, solver):
+            return solver, want
+        solver.close()
+        if want == "rccl":
+            solver = new_solver()
+            if bring_up("ipc", solver):
+                return solver, "ipc"
+            solver.close()
+        solver = new_solver()
+    bring_up("host", solver)
+    return solver, "host"
+
+
 def flush_c_stdio():
     """fflush(NULL): libraries that printf (RCCL's banner) must not leave text in a C buffer that
     would reach stdout after this script's one JSON line."""
@@ -669,47 +714,7 @@ def main():
     if world > 1:
         names = {"rccl": "RCCL grouped send/recv", "ipc": "IPC peer stores + epoch flags (hq_comm_init_ipc)",
                  "host": "host-staged (pinned buffers + gloo)"}
-        chosen = None
-        if want == "auto":
-            up = {}
-            for kind in ("rccl", "ipc"):
-                sv = solver if kind == "rccl" else new_solver()
-                if bring_up(kind, sv):
-                    up[kind] = sv
-                else:
-                    sv.close()                            # a context whose bring-up failed half-way is not reused
-            if len(up) == 2:
-                for kind, sv in up.items():
-                    trials[kind] = trial(sv)
-                alive = {k: v for k, v in trials.items() if v is not None}
-                chosen = min(alive, key=alive.get) if alive else None
-            elif up:
-                chosen = next(iter(up))
-            for kind, sv in up.items():
-                if kind != chosen:
-                    sv.close()
-            if chosen:
-                solver = up[chosen]
-            else:
-                solver = new_solver()
-                want = "host"
-        if want in ("rccl", "ipc"):
-            if bring_up(want, solver):
-                chosen = want
-            else:
-                other = "ipc" if want == "rccl" else None
-                if other:
-                    solver.close()
-                    solver = new_solver()
-                    if bring_up(other, solver):
-                        chosen = other
-                if not chosen:
-                    solver.close()
-                    solver = new_solver()
-                    want = "host"
-        if want == "host":
-            bring_up("host", solver)
-            chosen = "host"
+        solver, chosen = select_transport(want, solver, new_solver, bring_up, trial, trials)
         rccl_ranks = int(solver.info()["nranks"]) if chosen == "rccl" else 0
         if chosen == "ipc":
             names["ipc"] += ", %s-grained receive arena" % ("coarse" if solver.info()["ipc_arena_coarse"] else "fine")

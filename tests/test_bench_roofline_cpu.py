@@ -91,3 +91,64 @@ def test_step_count_does_not_depend_on_which_kernels_a_step_launches():
     synth = {c: {"hq_k_brick<false>": [4, 4000.0], "hq_k_patch_seed": [4, 400.0], "hq_k_pack": [8, 99.0]} for c in ("FETCH_SIZE", "WRITE_SIZE")}
     tot, rd, wr, steps = bench.traffic_of(synth, "hq_k_brick")
     assert steps == 4 and rd == 1100.0 * 1024 * 2 and wr == 1100.0 * 1024 and tot == rd + wr
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N: which transport carries the halo records (control flow only; no GPU, no ranks)
+# ---------------------------------------------------------------------------------------------
+
+class _FakeSolver:
+    made = 0
+
+    def __init__(self):
+        _FakeSolver.made += 1
+        self.id, self.closed, self.transport = _FakeSolver.made, False, None
+
+    def close(self):
+        assert not self.closed
+        self.closed = True
+
+
+def _select(want, comes_up, ms):
+    """comes_up: {kind: bool}; ms: {kind: ms per step or None (the trial failed)}."""
+    _FakeSolver.made = 0
+    first = _FakeSolver()
+    made = [first]
+
+    def new_solver():
+        made.append(_FakeSolver())
+        return made[-1]
+
+    def bring_up(kind, sv):
+        assert not sv.closed and sv.transport is None          # never a second transport on a context, never a closed one
+        if comes_up.get(kind, kind == "host"):
+            sv.transport = kind
+            return True
+        sv.transport = "broken:" + kind
+        return False
+
+    trials = {}
+    solver, chosen = bench.select_transport(want, first, new_solver, bring_up, lambda sv: ms[sv.transport], trials)
+    alive = [s for s in made if not s.closed]
+    assert alive == [solver] and solver.transport == chosen    # exactly the chosen context survives, and it carries it
+    return chosen, trials
+
+
+def test_transport_selection_of_a_multi_gpu_bench_run():
+    # both device-side transports come up: both are timed, the faster one is kept
+    assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.30, "ipc": 0.21}) == ("ipc", {"rccl": 0.30, "ipc": 0.21})
+    assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.18, "ipc": 0.21})[0] == "rccl"
+    # a trial that fails (timeouts, a device error) takes its transport out
+    assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": None, "ipc": 0.4})[0] == "ipc"
+    assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": None, "ipc": None})[0] == "host"
+    # only one comes up (ranks that share a GPU: RCCL refuses duplicate devices): no trial
+    assert _select("auto", {"rccl": False, "ipc": True}, {}) == ("ipc", {})
+    assert _select("auto", {"rccl": True, "ipc": False}, {}) == ("rccl", {})
+    assert _select("auto", {"rccl": False, "ipc": False}, {}) == ("host", {})
+    # explicit choices and their fall-backs
+    assert _select("rccl", {"rccl": True}, {})[0] == "rccl"
+    assert _select("rccl", {"rccl": False, "ipc": True}, {})[0] == "ipc"
+    assert _select("rccl", {"rccl": False, "ipc": False}, {})[0] == "host"
+    assert _select("ipc", {"ipc": True}, {})[0] == "ipc"
+    assert _select("ipc", {"ipc": False}, {})[0] == "host"
+    assert _select("host", {}, {})[0] == "host"
