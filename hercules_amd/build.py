@@ -42,7 +42,8 @@ def build_host(force=False):
     src = os.path.join(CSRC, "hq_host.c")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(ROOT, "include", "hq_host.h"), os.path.join(ROOT, "include", "hq_solver.h")]
+    deps = [src, os.path.join(CSRC, "hq_mesher.h"), os.path.join(ROOT, "include", "hq_host.h"),
+            os.path.join(ROOT, "include", "hq_solver.h")]
     if force or _newer(HOST_LIB, deps):
         cmd = ["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp",
                "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB, src,

@@ -2359,6 +2359,8 @@ int hqh_layered_column(const hqh_layered_model* m, double h0, int32_t ncoarse, d
     return HQ_OK;
 }
 
+#include "hq_mesher.h"
+
 /* the two-level box: nz_fine layers of edge h over nz_coarse layers of edge 2h */
 int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
 {

@@ -561,6 +561,44 @@ class OctBox:
         return s
 
 
+class _GridModel(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nz", ctypes.c_int32), ("cell", ctypes.c_double),
+                ("vp", ctypes.c_void_p), ("vs", ctypes.c_void_p), ("rho", ctypes.c_void_p)]
+
+
+class _MesherParams(ctypes.Structure):
+    _fields_ = [("domain", ctypes.c_double * 3), ("factor", ctypes.c_double), ("vscut", ctypes.c_double),
+                ("max_level", ctypes.c_int32)]
+
+
+def octree_generate(vp, vs, rho, cell, domain, factor, vscut=0.0, max_level=0):
+    """hqh_octree_generate: the leaves the reference's mesher makes of a material model given on a regular grid
+    (vp / vs / rho [nz][ny][nx] in the MESH's axes, cell edge in metres): Vs rule on the 27-sample record + 2:1
+    balancing.  -> elem_ticks [E,3] uint32, elem_edge [E] uint32, edata [E,4] float32, far_ticks (3,), ticksize."""
+    lib = load_library()
+    vp, vs, rho = [np.ascontiguousarray(a, np.float32) for a in (vp, vs, rho)]
+    assert vp.ndim == 3 and vp.shape == vs.shape == rho.shape
+    m = _GridModel(vp.shape[2], vp.shape[1], vp.shape[0], float(cell), vp.ctypes.data, vs.ctypes.data, rho.ctypes.data)
+    p = _MesherParams((ctypes.c_double * 3)(*[float(v) for v in domain]), float(factor), float(vscut), int(max_level))
+    E = ctypes.c_int64()
+    t, e, d = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    far = (ctypes.c_uint32 * 3)()
+    ts = ctypes.c_double()
+    lib.hqh_free.restype = None
+    lib.hqh_free.argtypes = [ctypes.c_void_p]
+    rc = lib.hqh_octree_generate(ctypes.byref(m), ctypes.byref(p), ctypes.byref(E), ctypes.byref(t), ctypes.byref(e),
+                                 ctypes.byref(d), far, ctypes.byref(ts))
+    if rc != 0:
+        raise capi.HqError("hqh_octree_generate failed: %d" % rc)
+    n = E.value
+    ticks = np.ctypeslib.as_array(ctypes.cast(t, ctypes.POINTER(ctypes.c_uint32)), (n, 3)).copy()
+    edge = np.ctypeslib.as_array(ctypes.cast(e, ctypes.POINTER(ctypes.c_uint32)), (n,)).copy()
+    edata = np.ctypeslib.as_array(ctypes.cast(d, ctypes.POINTER(ctypes.c_float)), (n, 4)).copy()
+    for q in (t, e, d):
+        lib.hqh_free(q)
+    return ticks, edge, edata, tuple(int(v) for v in far), ts.value
+
+
 def etree_read(path):
     """Leaves of an etree file in key order (hqh_etree_read): ticks [n,3] uint32, level [n],
     raw payloads [n, value_size] uint8."""

@@ -374,6 +374,33 @@ typedef struct {
 HQ_API int hqh_mesh_from_leaves(int64_t E, const uint32_t* elem_ticks, const uint32_t* elem_edge, const float* edata,
                                 const uint32_t far_ticks[3], const hqh_init_params* ip, hqh_octbox** out);
 
+/*
+ * The leaves the reference's mesher makes of a LATERALLY varying material model (BASELINE config 5's mesh class):
+ * octor_newtree + octor_refinetree (toexpand = vsrule on setrec's 27-sample minimum-Vs record, psolve.c:1307-1397,
+ * 2185-2210, quake_util.c:215-225) + octor_balancetree (2:1 across faces and edges, octor.c:4398-4775), for a model
+ * given on a regular grid -- what a CVM etree whose leaves share one level is to cvm_query (cvm.c:266-311).  Pinned on
+ * the mesh the real reference made of such a model (tests/golden/c5_basin).  Output: E leaves in octree pre-order --
+ * elem_ticks [E][3], elem_edge [E] (octor ticks: the root cube is 2^30), edata [E][4] (edgesize, Vp, Vs, rho) --
+ * malloc'ed, release with hqh_free; far_ticks[3] the domain's far end point, *ticksize metres per tick.  Feed them to
+ * hqh_mesh_from_leaves.
+ */
+typedef struct {
+    int32_t      nx, ny, nz;     /* cells along the mesh's x (north), y (east) and z (depth) */
+    double       cell;           /* cell edge, metres */
+    const float *vp, *vs, *rho;  /* [nz][ny][nx] */
+} hqh_grid_model;
+
+typedef struct {
+    double  domain[3];           /* metres: Param.theDomainX / Y / Z (region_length_north / east, depth) */
+    double  factor;              /* simulation_wave_max_freq_hz x simulation_node_per_wavelength */
+    double  vscut;               /* simulation_shear_velocity_min */
+    int32_t max_level;           /* refuse to refine below this octree level (0: 16) */
+} hqh_mesher_params;
+
+HQ_API int  hqh_octree_generate(const hqh_grid_model* m, const hqh_mesher_params* p, int64_t* E, uint32_t** elem_ticks,
+                                uint32_t** elem_edge, float** edata, uint32_t far_ticks[3], double* ticksize);
+HQ_API void hqh_free(void* p);
+
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);
 

@@ -14,6 +14,14 @@
  *
  * usage: make_cvm out.e nsoft Vp_soft Vs_soft rho_soft Vp Vs rho
  *    or: make_cvm out.e layers n  k0 Vp Vs rho  k1 Vp Vs rho ...   (layer i starts at octant layer k_i)
+ *    or: make_cvm out.e regions L  Vp Vs rho  n  <region> ...
+ *        a LATERALLY varying model ("basin"): database octants of level L (2^L x 2^L x 2^(L-1) of them); the
+ *        background material, then n regions, later ones overriding earlier ones:
+ *          box i0 i1 j0 j1 k0 k1 Vp Vs rho     octants with i0 <= i < i1, j0 <= j < j1, k0 <= k < k1
+ *          dip a b c Vp Vs rho                 octants whose centre lies above the plane
+ *                                              k + 0.5 < a + b (i + 0.5) + c (j + 0.5)     (a sediment wedge)
+ *        The reference's Vs rule then refines wherever the soft material is (psolve.c:1308 setrec, :2185 toexpand,
+ *        quake_util.c:215 vsrule), so refinement interfaces get x-, y- and z-normal faces and staircase corners.
  */
 #include <fcntl.h>
 #include <stdio.h>
@@ -34,7 +42,33 @@ int main(int argc, char** argv)
 {
     int nlay = 0, kstart[8];
     cvmpayload_t lay[8];
-    if (argc >= 4 && strcmp(argv[2], "layers") == 0) {
+    int level = 4;
+    enum { MAXREG = 16 };
+    int nreg = -1, reg_kind[MAXREG], reg_box[MAXREG][6];
+    double reg_dip[MAXREG][3];
+    cvmpayload_t reg_mat[MAXREG], background;
+    if (argc >= 8 && strcmp(argv[2], "regions") == 0) {
+        level = atoi(argv[3]);
+        if (level < 3 || level > 7) { fprintf(stderr, "bad level\n"); return 2; }
+        background.Vp = (float)atof(argv[4]); background.Vs = (float)atof(argv[5]); background.rho = (float)atof(argv[6]);
+        nreg = atoi(argv[7]);
+        if (nreg < 0 || nreg > MAXREG) { fprintf(stderr, "bad region count\n"); return 2; }
+        int a = 8;
+        for (int r = 0; r < nreg; r++) {
+            if (a < argc && strcmp(argv[a], "box") == 0 && a + 10 <= argc) {
+                reg_kind[r] = 0;
+                for (int q = 0; q < 6; q++) reg_box[r][q] = atoi(argv[a + 1 + q]);
+                a += 7;
+            } else if (a < argc && strcmp(argv[a], "dip") == 0 && a + 7 <= argc) {
+                reg_kind[r] = 1;
+                for (int q = 0; q < 3; q++) reg_dip[r][q] = atof(argv[a + 1 + q]);
+                a += 4;
+            } else { fprintf(stderr, "bad region %d\n", r); return 2; }
+            reg_mat[r].Vp = (float)atof(argv[a]); reg_mat[r].Vs = (float)atof(argv[a + 1]); reg_mat[r].rho = (float)atof(argv[a + 2]);
+            a += 3;
+        }
+        if (a != argc) { fprintf(stderr, "trailing arguments\n"); return 2; }
+    } else if (argc >= 4 && strcmp(argv[2], "layers") == 0) {
         nlay = atoi(argv[3]);
         if (nlay < 1 || nlay > 8 || argc != 4 + 4 * nlay) { fprintf(stderr, "bad layer list\n"); return 2; }
         for (int l = 0; l < nlay; l++) {
@@ -51,7 +85,7 @@ int main(int argc, char** argv)
         fprintf(stderr, "usage: %s out.e nsoft Vp_s Vs_s rho_s Vp Vs rho | out.e layers n k Vp Vs rho ...\n", argv[0]);
         return 2;
     }
-    const int level = 4, nx = 16, ny = 16, nz = 8;
+    const int nx = 1 << level, ny = 1 << level, nz = 1 << (level - 1);
     const etree_tick_t edge = (etree_tick_t)1 << (31 - level);
 
     etree_t* ep = etree_open(argv[1], O_CREAT | O_TRUNC | O_RDWR, 0, sizeof(cvmpayload_t), 3);
@@ -71,7 +105,20 @@ int main(int argc, char** argv)
         a.type = ETREE_LEAF;
         int L = 0;
         for (int l = 0; l < nlay; l++) if ((int)k >= kstart[l]) L = l;
-        if (etree_append(ep, a, &lay[L]) != 0) {
+        const cvmpayload_t* mat = &lay[L];
+        if (nreg >= 0) {
+            mat = &background;
+            for (int r = 0; r < nreg; r++) {
+                int in;
+                if (reg_kind[r] == 0)
+                    in = (int)i >= reg_box[r][0] && (int)i < reg_box[r][1] && (int)j >= reg_box[r][2] && (int)j < reg_box[r][3] &&
+                         (int)k >= reg_box[r][4] && (int)k < reg_box[r][5];
+                else
+                    in = k + 0.5 < reg_dip[r][0] + reg_dip[r][1] * (i + 0.5) + reg_dip[r][2] * (j + 0.5);
+                if (in) mat = &reg_mat[r];
+            }
+        }
+        if (etree_append(ep, a, mat) != 0) {
             fprintf(stderr, "append: %s\n", etree_strerror(etree_errno(ep))); return 1;
         }
     }

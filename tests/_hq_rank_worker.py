@@ -42,6 +42,23 @@ def main():
         loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
         rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
         F = b.source_table(rp, 0, nsteps) if len(loaded) else None
+    elif kind == "basin":
+        # the reference's laterally refined basin as it ran it on `world` MPI ranks (tests/golden/c5_basin_np<world>):
+        # this rank's partition built by the C host from the leaves alone, the reference's own per-rank force file,
+        # zero start -- the parent compares with the reference's per-rank checkpoint stripes
+        from tests import helpers as H
+        g, base = H.load("c5_basin_np%d" % world), H.load("c5_basin")
+        et = base["elem_ticks"]
+        edge = et[:, 7, 0] - et[:, 0, 0]
+        mat = base["mat_vs_vp_rho"]
+        edata = np.empty((len(et), 4), np.float32)
+        edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+        edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+        b = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(base["freq"]), rank=rank, nranks=world)
+        gid, Ng = b.gid.astype(np.int64), int(base["total_nodes"])
+        loaded, F = g["loaded_lnid_%d" % rank], g["forces_%d" % rank]
+        if len(loaded) == 0:
+            F = None
     else:                                                   # two-level octree box: all four exchanges of a step
         from tests import helpers as H
         ref = H.two_level_mesh(16, 8, 6, 3)
@@ -49,7 +66,9 @@ def main():
         gid, Ng, loaded, F = b.gid.astype(np.int64), ref["N"], np.zeros(0, np.int32), None
     g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
     g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
-    if kind != "box":
+    if kind == "basin":
+        g1[:], g2[:] = 0.0, 0.0
+    elif kind != "box":
         from oracle import herc_oracle as ho                # (checker-side helper: hanging rows = means of their anchors)
         ho.compute_adjust(g1, 1, ref["dangling"])
         ho.compute_adjust(g2, 1, ref["dangling"])

@@ -384,6 +384,21 @@ def case_layered():
                  keep_mesh_etree=True)
 
 
+BASIN_CVM = ["regions", 4, 6000, 3464, 2700, 2,
+             "dip", 3.2, -0.3, -0.12, 3000, 1732, 2200,          # a sediment wedge thinning towards +x, +y
+             "box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800]        # a soft box at the surface against the far-x face
+
+
+def case_basin():
+    """A LATERALLY refined octree (BASELINE config 5's "basin" in miniature): the material varies with
+    (i, j, k) -- a dipping sediment wedge and a soft box against a domain face -- so the reference's Vs rule
+    (psolve.c:1308 setrec, :2185 toexpand, quake_util.c:215 vsrule) and 2:1 balancing (octor.c:4398) leave
+    refinement interfaces with x-, y- and z-normal faces, staircase corners and hanging nodes of every
+    orientation (X/Y/ZEDGE, XY/XZ/YZ faces, on domain faces too: node_setproperty octor.c:3294).
+    5429 elements on three levels, 1196 hanging nodes."""
+    _octree_case("c5_basin", "0.3", 100, BASIN_CVM, 100, 5.0)
+
+
 def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq):
     """The same octree models on `nranks` MPI ranks: per-rank element dumps, force files and
     checkpoint stripes pin octor's multi-rank tables (block partition, ownership by containing
@@ -458,6 +473,9 @@ CASES = {
     "c5_layered": case_layered,
     "c5_two_level_np8": lambda: case_octree_np("c5_two_level_np8", "c5_two_level", 8, "0.5", 200,
                                                [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
+    "c5_basin": case_basin,
+    "c5_basin_np8": lambda: case_octree_np("c5_basin_np8", "c5_basin", 8, "0.3", 100, BASIN_CVM, 100, 5.0),
+    "c5_basin_np5": lambda: case_octree_np("c5_basin_np5", "c5_basin", 5, "0.3", 100, BASIN_CVM, 100, 5.0),
     # (a 5-rank run of the three-level mesh was tried and is NOT a fixture: on 5 ranks the
     #  reference's mesher refines that model uniformly, so it pins nothing the others do not)
 }

@@ -96,15 +96,17 @@ def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), ha
                 N=N, E=E, dt=dt, emin=1, mesh=m)
 
 
-def c5_np8_problem():
-    """The reference's two-level octree mesh on 8 MPI ranks: octor's per-rank tables restated
+def c5_np8_problem(name="c5_two_level_np8"):
+    """One of the reference's octree meshes on several MPI ranks (c5_two_level_np8; c5_basin_np8 /
+    c5_basin_np5: the laterally refined basin): octor's per-rank tables restated
     from the global view (ho.octree_partition), per-rank eTable / nTable after the mass
     exchange, the reference's per-rank force files and checkpoint stripes."""
-    g = load("c5_two_level_np8")
-    base = load("c5_two_level")
+    g = load(name)
+    base = load(str(g["base"]))
+    nranks = int(g["nranks"])
     m = ho.octree_mesh_from_elem_ticks(base["elem_ticks"], C1_FAR_TICKS)
     far_q = [f // m["emin"] for f in C1_FAR_TICKS]
-    parts = ho.octree_partition(m, 8, far_q)
+    parts = ho.octree_partition(m, nranks, far_q)
     mat = base["mat_vs_vp_rho"]
     tick = 1000.0 / 2 ** 30
     E = len(m["lnid"])
@@ -113,10 +115,46 @@ def c5_np8_problem():
     edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
     eds = [np.ascontiguousarray(edata[p["elems"]]) for p in parts]
     fcs = [np.ascontiguousarray(m["face"][p["elems"]]) for p in parts]
-    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, 5.0)
-    return dict(golden=g, base=base, mesh=m, parts=parts, ets=ets, nts=nts, dt=1e-3,
-                loaded=[g["loaded_lnid_%d" % r] for r in range(8)],
-                forces=[g["forces_%d" % r] for r in range(8)])
+    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, float(base["freq"]))
+    return dict(golden=g, base=base, mesh=m, parts=parts, ets=ets, nts=nts, dt=1e-3, nranks=nranks, edata=edata,
+                loaded=[g["loaded_lnid_%d" % r] for r in range(nranks)],
+                forces=[g["forces_%d" % r] for r in range(nranks)])
+
+
+# the material databases tests/golden/make_golden.py wrote with oracle/make_cvm (level-4 octants of 62.5 m), as grids in the
+# MESH's axes [k][y][x]: cvm_query(east = y, north = x) (psolve.c:1352), so make_cvm's octant index i runs along mesh y
+CVM_MODELS = {
+    "c5_two_level": dict(layers=[(0, 3000, 1732, 2200), (2, 6000, 3464, 2700)], vscut=500, freq=5.0),
+    "c5_three_level": dict(layers=[(0, 1500, 150, 1800), (2, 2500, 2000, 2300), (4, 6000, 3464, 2700)], vscut=100, freq=0.25),
+    "c5_layered": dict(layers=[(0, 800, 200, 1700), (1, 1500, 450, 2000), (3, 2600, 1200, 2300)], vscut=100, freq=0.5),
+    "c5_basin": dict(background=(6000, 3464, 2700), vscut=100, freq=5.0,
+                     regions=[("dip", 3.2, -0.3, -0.12, 3000, 1732, 2200), ("box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800)]),
+}
+
+
+def cvm_grid(name, level=4):
+    """-> vp, vs, rho [nz][ny][nx] float32 (mesh axes), cell edge in metres."""
+    spec = CVM_MODELS[name]
+    n, nz = 1 << level, 1 << (level - 1)
+    k, i, j = np.meshgrid(np.arange(nz), np.arange(n), np.arange(n), indexing="ij")     # [k][mesh y = i][mesh x = j]
+    out = [np.zeros((nz, n, n), np.float32) for _ in range(3)]
+    if "layers" in spec:
+        for k0, vp, vs, rho in spec["layers"]:
+            for a, v in zip(out, (vp, vs, rho)):
+                a[k >= k0] = v
+    else:
+        for a, v in zip(out, spec["background"]):
+            a[:] = v
+        for r in spec["regions"]:
+            if r[0] == "box":
+                sel = (i >= r[1]) & (i < r[2]) & (j >= r[3]) & (j < r[4]) & (k >= r[5]) & (k < r[6])
+                mat = r[7:]
+            else:
+                sel = k + 0.5 < r[1] + r[2] * (i + 0.5) + r[3] * (j + 0.5)
+                mat = r[4:]
+            for a, v in zip(out, mat):
+                a[sel] = v
+    return out[0], out[1], out[2], 1000.0 / n
 
 
 def np8_stripe(g, step, rank, n):

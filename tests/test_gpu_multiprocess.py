@@ -124,3 +124,24 @@ def test_ranks_in_their_own_processes_on_one_gpu_octree_box(tmp_path, transport)
     ho.solver_run(ref["lnid"], ref["etable"], ref["ntable"], o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
     for z in parts:
         assert H.rel_linf(z["tm1"], o2[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], o1[z["gid"]]) < 1e-9
+
+
+@pytest.mark.parametrize("transport", ["ipc", "host"])
+def test_the_references_basin_on_five_processes_against_its_own_stripes(tmp_path, transport):
+    """BASELINE config 5's mesh class between PROCESSES: the laterally refined basin exactly as the real reference ran
+    it on 5 MPI ranks (tests/golden/c5_basin_np5) -- every process builds its partition with the C host from the
+    leaves alone, reads the reference's per-rank force file and steps with hq_run; hanging nodes whose anchors live on
+    other ranks across x- and y-normal level interfaces, all four exchanges of a step over the IPC / the host-staged
+    transport -- against the reference's own per-rank checkpoint stripe of step 100."""
+    g = H.load("c5_basin_np5")
+    step = int(g["ckpt_steps"][0])
+    parts = _launch(tmp_path, 5, "basin", step, {"HQ_TEST_TRANSPORT": transport})
+    worst = 0.0
+    for r, z in enumerate(parts):
+        n = len(z["gid"])
+        ref2, ref1 = H.np8_stripe(g, step, r, n)
+        scale = max(np.abs(ref1).max(), 1.0)
+        worst = max(worst, np.abs(z["tm1"] - ref1).max() / scale, np.abs(z["tm2"] - ref2).max() / scale)
+        assert int(z["transport"]) == (2 if transport == "ipc" else 3)
+    assert worst < 1e-9
+    assert max(np.abs(z["tm1"]).max() for z in parts) > 100.0

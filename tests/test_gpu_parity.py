@@ -299,13 +299,15 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     s.close(); s2.close(); box.close()
 
 
-@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level", "c5_layered"])
+@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level", "c5_layered", "c5_basin"])
 @pytest.mark.parametrize("variant", VARIANTS + [ha.HQ_VARIANT_AUTO])
 def test_two_level_mesh_with_hanging_nodes_against_reference(variant, mesh):
     """compute_adjust on the reference's own two-level mesh (800 hanging nodes): scatter
     kernels + adjust kernels, and the patch kernel (hanging-node forces accumulated by the
     patches that own their anchors, assignment kernel after), against the checkpoints the
-    real reference wrote (also its three-level, three-material mesh)."""
+    real reference wrote (also its three-level, three-material mesh, and c5_basin: the LATERALLY
+    refined mesh -- level interfaces with x-, y- and z-normal faces, staircase corners, hanging
+    nodes of every orientation, on domain faces too)."""
     p = H.c5_problem(mesh)
     g = p["golden"]
     s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"], variant=variant,
@@ -347,21 +349,24 @@ def test_larger_two_level_meshes_against_oracle(variant, shape):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_octree_mesh_on_eight_partitions_against_reference(variant):
+@pytest.mark.parametrize("name", ["c5_two_level_np8", "c5_basin_np8", "c5_basin_np5"])
+def test_octree_mesh_on_eight_partitions_against_reference(variant, name):
     """The reference's 8-rank run of its two-level mesh: hanging nodes shared between
     ranks (dn_sched), anchors harbored indirectly, the four exchanges of a step and both
     compute_adjust passes -- eight contexts stepped in one process on one GPU against the
     reference's per-rank checkpoint stripes.  Scatter kernels, and the patch kernel with the
-    interface table carrying shared hanging nodes and their anchors."""
+    interface table carrying shared hanging nodes and their anchors.  c5_basin_np8 / _np5: the
+    laterally refined basin as the reference ran it on 8 and on 5 ranks (hanging nodes with anchors
+    on other ranks across x- and y-normal level interfaces)."""
     from hercules_amd import capi
-    pr = H.c5_np8_problem()
+    pr = H.c5_np8_problem(name)
     g, parts = pr["golden"], pr["parts"]
     mesh = pr["mesh"]
     solvers = []
     for p in parts:
         r = p["rank"]
         s = ha.Solver(p["lnid"], pr["ets"][r], pr["nts"][r], pr["dt"], dangling=p["dangling"],
-                      an_sched=p["an_sched"], dn_sched=p["dn_sched"], rank=r, nranks=8, variant=variant,
+                      an_sched=p["an_sched"], dn_sched=p["dn_sched"], rank=r, nranks=pr["nranks"], variant=variant,
                       node_xyz=mesh["node_q"][p["nodes"]])
         assert s.info()["variant"] == variant
         if len(pr["loaded"][r]):

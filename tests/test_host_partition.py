@@ -350,7 +350,7 @@ def test_mesh_etree_reader_and_mesh_from_leaves(tmp_path):
     ob.close()
 
 
-@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level"])
+@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level", "c5_basin"])
 def test_mesh_from_leaves_on_the_references_other_meshes(name):
     """hqh_mesh_from_leaves on the element dumps of the reference's uniform, two-level and
     three-level meshes."""
@@ -373,7 +373,8 @@ def test_mesh_from_leaves_on_the_references_other_meshes(name):
     ob.close()
 
 
-@pytest.mark.parametrize("name,nranks", [("c5_layered", 8), ("c5_three_level", 5), ("c5_two_level", 8)])
+@pytest.mark.parametrize("name,nranks", [("c5_layered", 8), ("c5_three_level", 5), ("c5_two_level", 8),
+                                         ("c5_basin", 8), ("c5_basin", 5), ("c5_basin", 3)])
 def test_mesh_from_leaves_partitions_are_octors(name, nranks):
     """hqh_mesh_from_leaves with nranks > 1 (general octrees: the leaf containing a node is found
     by Z-order search) against ho.octree_partition, for the reference's own meshes; the two-level
@@ -408,6 +409,35 @@ def test_mesh_from_leaves_partitions_are_octors(name, nranks):
                 for (_, a), (_, b) in zip(got, exp):
                     assert np.array_equal(a, b)
         ob.close()
+
+
+@pytest.mark.parametrize("name", ["c5_basin", "c5_two_level", "c5_three_level", "c5_layered"])
+def test_octree_generate_makes_the_references_meshes(name):
+    """hqh_octree_generate -- octor_newtree / refinetree (Vs rule on setrec's 27-sample record) / balancetree (2:1 across
+    faces and edges) restated on per-level bitmaps -- from the material model alone: leaf for leaf (corner, edge,
+    pre-order) and record for record (Vp, Vs, rho incl. the vscut adjustment) the mesh the REAL reference made;
+    c5_basin is the laterally refined one (x-, y-, z-normal interfaces, staircase corners after balancing)."""
+    g = H.load(name)
+    vp, vs, rho, cell = H.cvm_grid(name)
+    spec = H.CVM_MODELS[name]
+    ticks, edge, edata, far, ticksize = host.octree_generate(vp, vs, rho, cell, (1000.0, 1000.0, 500.0),
+                                                             spec["freq"] * 8, spec["vscut"])    # simulation_node_per_wavelength = 8 (numerical.in:24)
+    et = g["elem_ticks"]
+    assert far == H.C1_FAR_TICKS and ticksize == 1000.0 / 2 ** 30
+    assert len(ticks) == len(et) == int(g["total_elements"])
+    assert np.array_equal(ticks.astype(np.int64), et[:, 0, :]) and np.array_equal(edge.astype(np.int64), et[:, 7, 0] - et[:, 0, 0])
+    assert np.array_equal(edata[:, 1:], g["mat_vs_vp_rho"][:, [1, 0, 2]])
+    assert np.array_equal(edata[:, 0], (edge * (1000.0 / 2 ** 30)).astype(np.float32))
+
+
+def test_octree_generate_refuses_what_it_cannot_mesh():
+    vp, vs, rho, cell = H.cvm_grid("c5_basin")
+    with pytest.raises(Exception):                       # the Vs rule asks for leaves below max_level
+        host.octree_generate(vp, vs, rho, cell, (1000.0, 1000.0, 500.0), 40.0, 100.0, max_level=4)
+    with pytest.raises(Exception):                       # the model does not cover the domain
+        host.octree_generate(vp[:4], vs[:4], rho[:4], cell, (1000.0, 1000.0, 500.0), 40.0, 100.0)
+    with pytest.raises(Exception):                       # 3 : 2 : 1 does not fit octor's root cube (octor.c:4130-4146)
+        host.octree_generate(vp, vs, rho, cell, (1500.0, 1000.0, 500.0), 50.0, 100.0)
 
 
 def test_million_element_box_has_octors_node_order():

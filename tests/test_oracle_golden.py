@@ -233,6 +233,74 @@ def test_layered_model_mesh_checkpoints_bitwise():
     assert np.abs(tm2).max() > 1.0
 
 
+def test_basin_mesh_lateral_refinement_bitwise():
+    """BASELINE config 5's mesh class: the reference on a LATERALLY varying model (a dipping sediment
+    wedge + a soft box against a domain face; tests/golden/make_golden.py case_basin) -- its Vs rule
+    and 2:1 balancing leave refinement interfaces with x-, y- and z-normal faces and staircase
+    corners.  Hanging nodes of EVERY orientation (mid-edge on x / y / z edges, mid-face on xy / xz / yz
+    faces, also on domain faces) are classified as node_setproperty does (octor.c:3294) and the
+    checkpoints are bit-identical."""
+    p = H.c5_problem("c5_basin")
+    g = p["golden"]
+    assert p["E"] == int(g["total_elements"]) == 5429 and p["N"] == int(g["total_nodes"]) == 7046
+    ids, ptr, anchors = p["dangling"]
+    assert len(ids) == int(g["total_dangling"]) == 1196
+    assert sorted(set(p["elem_size"].tolist())) == [1, 2, 4]
+    # the orientation of every hanging node from its anchors: edge nodes along x / y / z, face nodes normal to x / y / z
+    q = p["node_q"].astype(np.int64)
+    kinds = set()
+    for k in range(len(ids)):
+        a = q[anchors[ptr[k]:ptr[k + 1]]]
+        varies = tuple(int(a[:, d].min() != a[:, d].max()) for d in range(3))
+        kinds.add((len(a), varies))
+    assert kinds == {(2, (1, 0, 0)), (2, (0, 1, 0)), (2, (0, 0, 1)), (4, (1, 1, 0)), (4, (1, 0, 1)), (4, (0, 1, 1))}
+    far = q.max(axis=0)
+    on_face = ((q[ids] == 0) | (q[ids] == far)).any(axis=1)
+    assert on_face.sum() > 20                               # hanging nodes ON the domain's faces
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"], dangling=p["dangling"])
+        done = int(step)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k]) and np.array_equal(tm2, g["ckpt_tm1"][k])
+    assert np.abs(tm2).max() > 100.0
+
+
+@pytest.mark.parametrize("name", ["c5_basin_np8", "c5_basin_np5"])
+def test_basin_mesh_on_several_ranks_tables_and_fields(name):
+    """The basin mesh on 8 and on 5 MPI ranks of the reference: block partition of a mixed-level leaf
+    list, ownership, direct and indirect sharing across x / y / z-normal level interfaces, hanging nodes
+    whose anchors live on other ranks -- octor's per-rank statistics and psolve's schedule summary
+    EXACTLY, per-rank checkpoint stripes to 1e-12."""
+    import re
+    pr = H.c5_np8_problem(name)
+    g, parts, nr = pr["golden"], pr["parts"], pr["nranks"]
+    rows = [[int(v) for v in l.split()] for l in str(g["stat_mesh"]).splitlines() if re.match(r"^\d{6}\s", l)]
+    sch = [[int(v) for v in l.split()] for l in str(g["stat_sched"]).splitlines() if re.match(r"^\s+\d+\s+\d+\s+\d+", l)]
+    assert len(rows) == nr and len(sch) == nr
+    for p, row, sc in zip(parts, rows, sch):
+        r = p["rank"]
+        assert row == [r, len(p["elems"]), int((p["owner"] == r).sum()), len(p["dangling"][0]), len(p["nodes"])]
+        cnt = lambda lst: (len(lst), sum(len(v) for _, v in lst))
+        assert sc[:9] == [r, *cnt(p["dn_sched"]["c"]), *cnt(p["dn_sched"]["s"]), *cnt(p["an_sched"]["c"]), *cnt(p["an_sched"]["s"])]
+        assert np.array_equal(g["elem_ticks_%d" % r], pr["base"]["elem_ticks"][p["elems"]])
+    assert sum(r_[3] for r_ in rows) == 1196 and any(r_[2] for r_ in sch)     # hanging nodes shared between ranks
+    tm1s = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    tm2s = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    done = 0
+    for step in g["ckpt_steps"]:
+        ho.multi_rank_run(parts, pr["ets"], pr["nts"], tm1s, tm2s, done, int(step) - done, pr["dt"],
+                          pr["loaded"], pr["forces"])
+        done = int(step)
+        for p in parts:
+            ref2, ref1 = H.np8_stripe(g, step, p["rank"], len(p["nodes"]))
+            scale = max(np.abs(ref1).max(), 1.0)
+            assert np.abs(tm1s[p["rank"]] - ref2).max() <= 1e-12 * scale
+            assert np.abs(tm2s[p["rank"]] - ref1).max() <= 1e-12 * scale
+    assert max(np.abs(t).max() for t in tm2s) > 100.0
+
+
 def test_octree_mesh_on_eight_ranks_tables_and_fields():
     """The reference ran its two-level mesh on 8 MPI ranks.  octor's multi-rank tables
     restated from the global view (block partition, ownership by containing leaf, direct +
