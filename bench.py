@@ -80,6 +80,22 @@ OCT_LAYERED = {
 }
 for _k, _v in OCT_LAYERED.items():
     WORKLOADS[_k] = (_v[0], _v[1], 0, _v[2], _v[3], _v[4])
+# LATERALLY varying basin models meshed by hqh_octree_generate (the reference's Vs rule on setrec's 27-sample record +
+# 2:1 balancing across faces and edges, pinned on tests/golden/c5_basin): a layered background and a sediment bowl whose
+# depth varies with x and y, so the level interfaces have x-, y- and z-normal faces and staircase corners.
+# name: domain (m), material grid cells along x, finest h (m), dt, freq, points per wavelength,
+#       background [(ztop, vp, vs, rho)], bowl (xc, yc, a, b as fractions of Lx; depth in m; vp, vs, rho)
+OCT_BASIN = {
+    # BASELINE config 5 with lateral refinement: 102.4 km x 102.4 km x 51.2 km, 0.5 Hz, 100 m elements in the sediments
+    "o4": dict(domain=(102400.0, 102400.0, 51200.0), grid=128, h=100.0, dt=0.02, freq=0.5, ppw=8,
+               background=[(0.0, 2000.0, 1100.0, 2300.0), (4000.0, 3600.0, 2000.0, 2500.0), (12800.0, 6000.0, 3464.0, 2700.0)],
+               bowl=(0.42, 0.55, 0.46, 0.40, 32000.0, 1100.0, 600.0, 2000.0)),
+    "o4s": dict(domain=(25600.0, 25600.0, 12800.0), grid=64, h=100.0, dt=0.02, freq=0.5, ppw=8,
+                background=[(0.0, 2000.0, 1100.0, 2300.0), (1600.0, 3600.0, 2000.0, 2500.0), (4800.0, 6000.0, 3464.0, 2700.0)],
+                bowl=(0.42, 0.55, 0.40, 0.30, 6400.0, 1100.0, 600.0, 2000.0)),
+}
+for _k, _v in OCT_BASIN.items():
+    WORKLOADS[_k] = (int(_v["domain"][0] / _v["h"]), int(_v["domain"][1] / _v["h"]), 0, _v["h"], _v["dt"], _v["freq"])
 WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-couple source",
                   "c2": "8M-element uniform box 256x256x128, homogeneous half-space",
                   "c1": "examples/simple-sized box 16x16x8", "m1": "1M-element box 128x128x64",
@@ -89,7 +105,10 @@ WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-coupl
                   "o1": "23M-element two-level octree box (soft 64-layer top refined 2:1, 262k hanging nodes)",
                   "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
                   "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",
-                  "o3s": "3M-element layered basin on four octree levels (small version of o3)"}
+                  "o3s": "3M-element layered basin on four octree levels (small version of o3)",
+                  "o4": "laterally refined basin (102.4 km x 102.4 km x 51.2 km, 0.5 Hz): sediment bowl in a layered half-space, "
+                        "octree levels of 100-800 m with x-, y- and z-normal interfaces (Vs rule + 2:1 balance as the reference's mesher)",
+                  "o4s": "small laterally refined basin (25.6 km x 25.6 km x 12.8 km), four octree levels"}
 
 
 def usable_cores():
@@ -194,6 +213,8 @@ def seeded_field(node_ijk, nx, ny, interfaces=()):
     starts equal).  Octree boxes: interfaces = [(z of the plane, finer edge hf), ...] in finest
     units; a node of such a plane that is not on the coarser grid hangs, and starts at the mean of
     its anchors (its 2 edge or 4 face neighbours at +-hf, compute_adjust ASSIGNMENT)."""
+    if isinstance(interfaces, dict):
+        return interfaces["field"].copy()                   # OCT_BASIN: computed on the whole mesh by make_octbox
     ijk = np.asarray(node_ijk).astype(np.int64)
 
     def raw(i, j, k):
@@ -216,10 +237,59 @@ def seeded_field(node_ijk, nx, ny, interfaces=()):
     return u
 
 
+def basin_grid(spec):
+    """The material model of an OCT_BASIN workload on its grid: vp, vs, rho [nz][ny][nx] float32 (mesh axes), cell edge."""
+    Lx, Ly, Lz = spec["domain"]
+    n = spec["grid"]
+    cell = Lx / n
+    ny, nz = int(round(Ly / cell)), int(round(Lz / cell))
+    z, y, x = np.meshgrid((np.arange(nz) + 0.5) * cell, (np.arange(ny) + 0.5) * cell, (np.arange(n) + 0.5) * cell, indexing="ij")
+    vp, vs, rho = [np.zeros(z.shape, np.float32) for _ in range(3)]
+    for ztop, a, b, c in spec["background"]:
+        sel = z >= ztop
+        vp[sel], vs[sel], rho[sel] = a, b, c
+    xc, yc, a, b, depth, bvp, bvs, brho = spec["bowl"]
+    sed = z < depth * np.maximum(0.0, 1.0 - ((x - xc * Lx) / (a * Lx)) ** 2 - ((y - yc * Lx) / (b * Lx)) ** 2)
+    vp[sed], vs[sed], rho[sed] = bvp, bvs, brho
+    return vp, vs, rho, cell
+
+
+def basin_leaves(workload):
+    """-> (elem_ticks, elem_edge, edata, far_ticks, ticksize) of an OCT_BASIN workload (hqh_octree_generate)."""
+    from hercules_amd import host as hhost
+    spec = OCT_BASIN[workload]
+    vp, vs, rho, cell = basin_grid(spec)
+    return hhost.octree_generate(vp, vs, rho, cell, spec["domain"], spec["freq"] * spec["ppw"], 0.0)
+
+
+def basin_field(box, nx, ny):
+    """Seeded start field of a WHOLE octree mesh: a function of the node coordinates, hanging nodes at the mean of their
+    anchors (compute_adjust ASSIGNMENT, psolve.c:5992-6035; anchors never hang in a mesh balanced across faces and edges)."""
+    u = seeded_field(box.node_xyz, nx, ny)
+    ids, ptr, anchors = box.dangling
+    if len(ids):
+        deps = np.diff(ptr).astype(np.int64)
+        u[ids] = np.add.reduceat(u[anchors], ptr[:-1].astype(np.int64), axis=0) / deps[:, None]
+    return u
+
+
 def make_octbox(workload, rank, nranks):
     """-> (OctBox, total elements, total nodes, interfaces for seeded_field)"""
     from hercules_amd import host as hhost
     nx, ny, nz, h, dt, freq = WORKLOADS[workload]
+    if workload in OCT_BASIN:
+        ticks, edge, edata, far, ticksize = basin_leaves(workload)
+        assert abs(int(edge.min()) * ticksize - h) < 1e-9 * h, "the finest leaf is not the workload's h"
+        whole = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq)
+        field = basin_field(whole, nx, ny)
+        E, N = whole.E, whole.N
+        if nranks > 1:
+            whole.close()
+            box = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq, rank=rank, nranks=nranks)
+            field = field[box.gid]
+        else:
+            box = whole
+        return box, E, N, {"field": field}
     if workload in OCT_LAYERED:
         _, _, _, _, _, ppw, h0, ncoarse, model = OCT_LAYERED[workload]
         col = hhost.layered_column(model, h0, ncoarse, freq * ppw)
@@ -238,6 +308,7 @@ def make_octbox_interfaces(workload):
     """The level interfaces of an octree workload for seeded_field (what make_octbox returns as its fourth value)."""
     from hercules_amd import host as hhost
     nx, ny, nz, h, dt, freq = WORKLOADS[workload]
+    assert workload not in OCT_BASIN, "basins keep their start field (make_octbox's fourth value)"
     if workload in OCT_LAYERED:
         _, _, _, _, _, ppw, h0, ncoarse, model = OCT_LAYERED[workload]
         _, levels = hhost.levels_from_column(hhost.layered_column(model, h0, ncoarse, freq * ppw))
@@ -275,7 +346,7 @@ def inproc_diagnostic(args):
     P = args.inproc_parts
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
     boxes, solvers = [], []
-    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED
+    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED or args.workload in OCT_BASIN
     for r in range(P):
         if octree:
             b, total_e, _, interfaces = make_octbox(args.workload, r, P)
@@ -442,13 +513,14 @@ def build_problem(args, rank, world, device):
     import hercules_amd as ha
     from hercules_amd import host as hhost
     nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
-    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED
+    octree = args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED or args.workload in OCT_BASIN
     variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
     interfaces = ()
     if octree:
         box, total_e, total_n, interfaces = make_octbox(args.workload, rank, world)
         box.info = {"nharbored": box.N, "total_elements": total_e, "lenum": box.E, "total_nodes": total_n}
         box.node_ijk = box.node_xyz
+        box.start_interfaces = interfaces
     else:
         ncls, amp = LATERAL.get(args.workload, (0, 0.0))
         box = hhost.Box(nx, ny, nz, h, dt, freq, rank=rank, nranks=world, lateral_classes=ncls, lateral_amp=amp)
@@ -649,7 +721,8 @@ def main():
     def new_solver():
         variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
         nx_, ny_ = WORKLOADS[args.workload][:2]
-        interfaces = make_octbox_interfaces(args.workload) if octree else ()
+        interfaces = () if not octree else (box.start_interfaces if args.workload in OCT_BASIN
+                                            else make_octbox_interfaces(args.workload))
         u1 = seeded_field(box.node_ijk, nx_, ny_, interfaces)
         return box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3))
 

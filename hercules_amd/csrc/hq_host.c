@@ -2109,11 +2109,11 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     uint32_t nq[3];
     for (int d = 0; d < 3; d++) { if (far_ticks[d] % emin) return HQ_ERR_ARG; nq[d] = far_ticks[d] / emin; if (nq[d] >= (1u << 20)) return HQ_ERR_ARG; }
     hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
-    hqh_keyidx* ki = (hqh_keyidx*)malloc(sizeof(hqh_keyidx) * 8 * (size_t)E);
+    uint64_t* ck = (uint64_t*)malloc(sizeof(uint64_t) * 8 * (size_t)E);
     uint64_t* nkey = NULL;
     int32_t *touch = NULL, *small = NULL;
     int rc = HQ_ERR_NOMEM;
-    if (!b || !ki) goto fail;
+    if (!b || !ck) goto fail;
     const int P = ip->nranks > 1 ? ip->nranks : 1;
     if (P > 64 || ip->rank < 0 || ip->rank >= P) { rc = HQ_ERR_ARG; goto fail; }
     b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.rank = ip->rank; b->p.nranks = P;
@@ -2123,50 +2123,64 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     b->etable = (double*)malloc(sizeof(double) * 4 * (size_t)E);
     if (!b->lnid || !b->etable) goto fail;
     /* every element corner, keyed by the Z-value of its doubled, far-adjusted coordinates */
-    for (int64_t e = 0; e < E; e++) {
-        if (et[3 * e] % emin || et[3 * e + 1] % emin || et[3 * e + 2] % emin || eedge[e] % emin) { rc = HQ_ERR_ARG; goto fail; }
-        const uint32_t s = eedge[e] / emin;
-        for (int c = 0; c < 8; c++) {
-            uint32_t q[3], k2[3];
-            for (int d = 0; d < 3; d++) {
-                q[d] = et[3 * e + d] / emin + (((c >> d) & 1) ? s : 0);
-                if (q[d] > nq[d]) { rc = HQ_ERR_ARG; goto fail; }
-                k2[d] = (q[d] == nq[d]) ? 2 * q[d] - 1 : 2 * q[d];
+    {
+        int badarg = 0;
+#pragma omp parallel for schedule(static) reduction(| : badarg)
+        for (int64_t e = 0; e < E; e++) {
+            if (et[3 * e] % emin || et[3 * e + 1] % emin || et[3 * e + 2] % emin || eedge[e] % emin) { badarg |= 1; continue; }
+            const uint32_t s = eedge[e] / emin;
+            for (int c = 0; c < 8; c++) {
+                uint32_t q[3], k2[3];
+                for (int d = 0; d < 3; d++) {
+                    q[d] = et[3 * e + d] / emin + (((c >> d) & 1) ? s : 0);
+                    if (q[d] > nq[d]) { badarg |= 1; q[d] = nq[d]; }
+                    k2[d] = (q[d] == nq[d]) ? 2 * q[d] - 1 : 2 * q[d];
+                }
+                ck[8 * e + c] = zvalue(k2[0], k2[1], k2[2]);
             }
-            ki[8 * e + c].key = zvalue(k2[0], k2[1], k2[2]);
-            ki[8 * e + c].idx = 8 * e + c;
         }
+        if (badarg) { rc = HQ_ERR_ARG; goto fail; }
     }
-    qsort(ki, 8 * (size_t)E, sizeof(hqh_keyidx), cmp_keyidx);
+    /* the distinct keys in order = the nodes (octor.c:6166); every corner then finds its node by bisection */
     int64_t N = 0;
-    for (int64_t i = 0; i < 8 * E; i++) {
-        if (i == 0 || ki[i].key != ki[i - 1].key) N++;
-        b->lnid[ki[i].idx] = (int32_t)(N - 1);
+    {
+        uint64_t* sk = (uint64_t*)malloc(sizeof(uint64_t) * 8 * (size_t)E);
+        if (!sk) goto fail;
+        memcpy(sk, ck, sizeof(uint64_t) * 8 * (size_t)E);
+        int kb = 0;
+        for (int d = 0; d < 3; d++) { int w = 1; while (((uint64_t)2 * nq[d]) >> w) w++; if (w > kb) kb = w; }
+        if (radix_sort_u64(sk, 8 * E, 3 * kb) != 0) { free(sk); goto fail; }
+        for (int64_t i = 0; i < 8 * E; i++) if (i == 0 || sk[i] != sk[i - 1]) sk[N++] = sk[i];
+        if (N > 0x7fffffff / 8) { free(sk); rc = HQ_ERR_ARG; goto fail; }
+        nkey = (uint64_t*)realloc(sk, sizeof(uint64_t) * (size_t)N);
+        if (!nkey) { free(sk); goto fail; }
     }
-    if (N > 0x7fffffff / 8) { rc = HQ_ERR_ARG; goto fail; }
     b->N = N;
-    nkey = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
     b->node_xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)N);
     b->ntable = (double*)calloc((size_t)N * 7, sizeof(double));
     touch = (int32_t*)calloc((size_t)N, sizeof(int32_t));
     small = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
-    if (!nkey || !b->node_xyz || !b->ntable || !touch || !small) goto fail;
-    {
-        int64_t n = -1;
-        for (int64_t i = 0; i < 8 * E; i++) {
-            if (i == 0 || ki[i].key != ki[i - 1].key) {
-                n++;
-                nkey[n] = ki[i].key;
-                uint32_t d2[3] = { compact3(ki[i].key), compact3(ki[i].key >> 1), compact3(ki[i].key >> 2) };
-                for (int d = 0; d < 3; d++) b->node_xyz[3 * n + d] = (int32_t)((d2[d] & 1) ? nq[d] : (d2[d] >> 1));
-                small[n] = 0x7fffffff;
-            }
-            const int32_t s = (int32_t)(eedge[ki[i].idx / 8] / emin);
-            touch[n]++;
-            if (s < small[n]) small[n] = s;
+    if (!b->node_xyz || !b->ntable || !touch || !small) goto fail;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        uint32_t d2[3] = { compact3(nkey[n]), compact3(nkey[n] >> 1), compact3(nkey[n] >> 2) };
+        for (int d = 0; d < 3; d++) b->node_xyz[3 * n + d] = (int32_t)((d2[d] & 1) ? nq[d] : (d2[d] >> 1));
+        small[n] = 0x7fffffff;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < E; e++) {
+        const int32_t s = (int32_t)(eedge[e] / emin);
+        for (int c = 0; c < 8; c++) {
+            const uint64_t key = ck[8 * e + c];
+            int64_t lo = 0, hi = N - 1;
+            while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (nkey[m] < key) lo = m + 1; else hi = m; }
+            b->lnid[8 * e + c] = (int32_t)lo;
+            __atomic_fetch_add(&touch[lo], 1, __ATOMIC_RELAXED);
+            int32_t cur = __atomic_load_n(&small[lo], __ATOMIC_RELAXED);
+            while (s < cur && !__atomic_compare_exchange_n(&small[lo], &cur, s, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
         }
     }
-    free(ki); ki = NULL;
+    free(ck); ck = NULL;
     /* node_setproperty: anchored unless it misses touches for where it sits; a hanging node sits
      * on the grid of its smallest toucher but off the next coarser one in 1 (edge) or 2 (face) axes */
     {
@@ -2286,7 +2300,7 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     *out = b;
     return HQ_OK;
 fail:
-    free(ki); free(nkey); free(touch); free(small);
+    free(ck); free(nkey); free(touch); free(small);
     hqh_octbox_destroy(b);
     return rc;
 }

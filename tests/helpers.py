@@ -217,3 +217,50 @@ def octree_window_oracle(win, etable, ntable, u1, u2, k, dt):
     dn = win["dangling"] if len(win["dangling"][0]) else None
     ho.solver_run(win["lnid"], etable[win["elems"]].copy(), ntable[win["nodes"]].copy(), o1, o2, 0, k, dt, dangling=dn)
     return o2, o1
+
+
+def hanging_kinds(node_xyz, dangling):
+    """Per hanging node: (number of anchors, axes along which its anchors differ as a 3-bit mask, distance to an anchor)
+    -- 2 anchors: mid-edge node of an edge along x (1) / y (2) / z (4); 4 anchors: mid-face node of a face normal to
+    z (3) / y (5) / x (6)."""
+    ids, ptr, anchors = dangling
+    q = node_xyz.astype(np.int64)
+    first = q[anchors[ptr[:-1]]]
+    last = q[anchors[ptr[1:] - 1]]
+    diff = (first != last)
+    mask = diff[:, 0] * 1 + diff[:, 1] * 2 + diff[:, 2] * 4
+    dist = np.abs(first - q[ids]).max(axis=1)
+    return np.diff(ptr), mask, dist
+
+
+def lateral_windows(node_xyz, dangling, elem_lo, elem_edge, k, per_kind=1, seed=5, kinds=None, max_elems=700000):
+    """Dependency-cone windows of an octree mesh centred on hanging nodes of every kind present (orientation x level),
+    `per_kind` of each picked by a seeded generator: -> [(lo, hi, margin, centre node)].  Window faces are aligned to
+    the coarsest edge of the mesh (no element straddles them); margin = 2 k c with c the coarsest edge INSIDE the
+    window (octree_window's rule)."""
+    ids, ptr, anchors = dangling
+    deps, mask, dist = hanging_kinds(node_xyz, dangling)
+    rng = np.random.default_rng(seed)
+    A = int(elem_edge.max())
+    far = node_xyz.max(axis=0).astype(np.int64)
+    e_hi = elem_lo.astype(np.int64) + elem_edge.astype(np.int64)[:, None]
+    out = []
+    for key in sorted(set(zip(mask.tolist(), dist.tolist()))):
+        if kinds is not None and key not in kinds:
+            continue
+        cand = np.nonzero((mask == key[0]) & (dist == key[1]))[0]
+        for pick in rng.choice(cand, min(per_kind, len(cand)), replace=False):
+            q = node_xyz[ids[pick]].astype(np.int64)
+            c = 2 * int(key[1])
+            for _ in range(3):
+                half = 2 * k * c + c
+                lo = np.maximum(0, (q - half) // A * A)
+                hi = np.minimum(far, -((-(q + half)) // A) * A)
+                inside = np.all(elem_lo >= lo, axis=1) & np.all(e_hi <= hi, axis=1)
+                c2 = int(elem_edge[inside].max())
+                if c2 == c:
+                    break
+                c = c2
+            if inside.sum() <= max_elems:
+                out.append((lo.tolist(), hi.tolist(), 2 * k * c, int(ids[pick])))
+    return out

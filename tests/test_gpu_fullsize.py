@@ -608,3 +608,117 @@ def test_small_basin_against_the_oracle():
     s.close()
     assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
     box.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5 with LATERAL refinement (bench.py workloads o4s / o4): a sediment bowl in a layered half-space,
+# meshed by hqh_octree_generate as the reference's mesher would (pinned on tests/golden/c5_basin) -- level interfaces
+# with x-, y- and z-normal faces and staircase corners, hanging nodes of every orientation
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["bricks", "patches-only", "scatter"])
+def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
+    """o4s (0.93 M elements on four levels, 62 k hanging nodes of all six kinds): the oracle's reference loops with
+    compute_adjust on the WHOLE mesh for three steps against the default path (bricks where a level's interior is
+    uniform -- here beside x- and y-normal level interfaces --, patches around them), the patch kernels alone and the
+    scatter kernels."""
+    import bench
+    if mode == "patches-only":
+        monkeypatch.setenv("HQ_NO_BRICKS", "1")
+    box, E, N, it = bench.make_octbox("o4s", 0, 1)
+    u = it["field"]
+    deps, mask, dist = H.hanging_kinds(box.node_xyz, box.dangling)
+    assert set(mask.tolist()) == {1, 2, 3, 4, 5, 6}
+    nsteps = 3
+    o1, o2 = (0.999 * u).copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling)
+    s = box.create_solver(variant=ha.HQ_VARIANT_SCATTER if mode == "scatter" else ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
+    if mode == "bricks":
+        assert s.info()["brick_nodes"] > 0.3 * N
+    elif mode == "patches-only":
+        assert s.info()["brick_nodes"] == 0
+    s.run(nsteps)
+    tm1, tm2 = s.download()
+    s.close()
+    assert H.rel_linf(tm1, o1) < 1e-9 and H.rel_linf(tm2, o2) < 1e-9
+    box.close()
+
+
+@pytest.mark.parametrize("nranks", [8, 5])
+def test_small_lateral_basin_in_partitions_matches_one_partition(nranks):
+    """o4s cut into octor's block partitions (hqh_mesh_from_leaves with rank / nranks: ownership by Z-order point
+    location, anchors of shared hanging nodes across x- / y- / z-normal interfaces), patch variant with bricks, in-process
+    transport, against the whole basin on one partition."""
+    import bench
+    from hercules_amd import capi
+    nsteps = 4
+    one, E, N, it = bench.make_octbox("o4s", 0, 1)
+    u = it["field"]
+    ref1, ref2 = _run_oct(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    one.close()
+    solvers, gids = [], []
+    for r in range(nranks):
+        b, _, _, itr = bench.make_octbox("o4s", r, nranks)
+        assert np.array_equal(itr["field"], u[b.gid])
+        solvers.append(b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=itr["field"], tm2=0.999 * itr["field"]))
+        gids.append(b.gid.copy())
+        b.close()
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    scale = np.abs(ref1).max()
+    for sv, gid in zip(solvers, gids):
+        tm1, tm2 = sv.download()
+        assert np.abs(tm1 - ref1[gid]).max() <= 1e-11 * scale and np.abs(tm2 - ref2[gid]).max() <= 1e-11 * scale
+        sv.close()
+
+
+def test_full_lateral_basin_against_the_oracle():
+    """o4 = BASELINE config 5's mesh class at scale on ONE GPU: 101 M elements on four octree levels whose interfaces
+    follow a sediment bowl (x-, y- and z-normal faces, staircase corners).  ORACLE parity through dependency-cone
+    windows centred on hanging nodes of every orientation and level pair (tests/helpers.lateral_windows, pinned on a
+    whole-mesh oracle run in tests/test_octree_windows_cpu.py), stepped by the oracle's reference loops with the true
+    table rows: <= 1e-9 of the field's scale.  Also: finite, hanging nodes = mean of their anchors."""
+    import gc
+    import bench
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 70 * 2 ** 30:
+        pytest.skip("needs ~60 GiB of host memory for the 101M-element mesh tables")
+    box, E, N, it = bench.make_octbox("o4", 0, 1)
+    u = it["field"]
+    assert E > 100e6 and box.ldnnum > 3e5
+    nsteps = 2
+    scale0 = np.abs(u).max()
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
+    assert s.info()["brick_nodes"] > 0.8 * N
+    s.run(nsteps)
+    xyz = box.node_xyz
+    elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
+    elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
+    deps, mask, dist = H.hanging_kinds(xyz, box.dangling)
+    assert set(mask.tolist()) == {1, 2, 3, 4, 5, 6}
+    wins = H.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, nsteps, per_kind=1)
+    worst, nchecked, nhang, kinds = 0.0, 0, 0, set()
+    for lo, hi, margin, centre in wins:
+        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+        g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
+        ok, nodes = win["ok"], win["nodes"]
+        assert centre in nodes[ok]
+        tm1, tm2 = s.gather(nodes[ok])
+        worst = max(worst, np.abs(tm1 - g1[ok]).max() / scale0, np.abs(tm2 - g2[ok]).max() / scale0)
+        nchecked += int(ok.sum())
+        hang = np.isin(box.dangling[0], nodes[ok])
+        nhang += int(hang.sum())
+        kinds |= set(zip(mask[hang].tolist(), dist[hang].tolist()))
+    del elem_lo, elem_edge
+    assert len(wins) >= 12 and nchecked > 5000 and nhang > 200
+    assert {m for m, _ in kinds} == {1, 2, 3, 4, 5, 6}
+    assert worst < 1e-9, worst
+    tm1, _ = s.download(want_tm2=False)
+    s.close()
+    scale = np.abs(tm1).max()
+    assert np.isfinite(tm1).all() and scale > 0
+    chk = tm1.copy()
+    ho.compute_adjust(chk, 1, box.dangling)
+    assert np.abs(chk - tm1).max() <= 1e-13 * scale
+    box.close()
+    gc.collect()

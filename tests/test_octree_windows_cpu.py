@@ -49,3 +49,35 @@ def test_windows_across_level_interfaces_reproduce_the_whole_mesh():
         checked += int(ok.sum())
     assert checked > 500
     box.close()
+
+
+def test_windows_across_lateral_interfaces_reproduce_the_whole_mesh():
+    """The same for a LATERALLY refined mesh (bench.py's o4s: a sediment bowl in a layered half-space meshed by
+    hqh_octree_generate, 0.93 M elements on four levels): windows centred on hanging nodes of every orientation --
+    mid-edge nodes on x / y / z edges, mid-face nodes on faces normal to x / y / z -- cut out by tests/helpers.lateral_windows
+    and stepped by the oracle give the whole-mesh oracle's values at their inner nodes."""
+    import bench
+    box, E, N, it = bench.make_octbox("o4s", 0, 1)
+    u1 = it["field"]
+    u2 = 0.999 * u1
+    deps, mask, dist = H.hanging_kinds(box.node_xyz, box.dangling)
+    assert set(mask.tolist()) == {1, 2, 3, 4, 5, 6} and set(dist.tolist()) >= {1, 2, 4}
+    k = 2
+    w1, w2 = u2.copy(), u1.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), w1, w2, 0, k, box.dt, dangling=box.dangling)
+    whole1, whole2 = w2, w1
+    xyz = box.node_xyz
+    elem_lo = xyz[box.lnid[:, 0]].astype(np.int64)
+    elem_edge = (xyz[box.lnid[:, 1], 0].astype(np.int64) - elem_lo[:, 0])
+    scale = np.abs(u1).max()
+    wins = H.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, k, kinds={(1, 1), (2, 2), (4, 1), (3, 1), (5, 2), (6, 1), (6, 4)})
+    assert len(wins) == 7
+    for lo, hi, margin, centre in wins:
+        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+        g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u1, u2, k, box.dt)
+        ok, nodes = win["ok"], win["nodes"]
+        assert centre in nodes[ok]
+        assert np.abs(g1[ok] - whole1[nodes[ok]]).max() <= 1e-12 * scale
+        assert np.abs(g2[ok] - whole2[nodes[ok]]).max() <= 1e-12 * scale
+        assert np.abs(g1[~ok] - whole1[nodes[~ok]]).max() > 1e-9 * scale
+    box.close()
