@@ -14,7 +14,7 @@ _LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 IPC_BLOB_BYTES = 4096                   # HQ_IPC_BLOB_BYTES
 
-EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info", "hq_get_info_sized", "hq_abi_version",
+EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info", "hq_get_info_sized", "hq_abi_version", "hq_comm_init_ipc_n",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
@@ -62,7 +62,8 @@ class _Info(ctypes.Structure):
                 ("ragged_patches", ctypes.c_int32), ("brick_units", ctypes.c_int32),
                 ("brick_nodes", ctypes.c_int64), ("brick_units_pernode", ctypes.c_int32),
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
-                ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32)]
+                ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
+                ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32)]
 
 
 _lib = None
@@ -211,8 +212,10 @@ class Solver:
     def comm_init_ipc(self, blobs):
         """hq_comm_init_ipc: `blobs` = every rank's export, in rank order (list of bytes or one bytes object)."""
         raw = blobs if isinstance(blobs, (bytes, bytearray)) else b"".join(blobs)
+        if len(raw) % IPC_BLOB_BYTES:
+            raise HqError("comm_init_ipc: %d bytes is not a whole number of %d-byte blobs" % (len(raw), IPC_BLOB_BYTES))
         buf = (ctypes.c_char * len(raw)).from_buffer_copy(bytes(raw))
-        _check(self._lib.hq_comm_init_ipc(self._h, buf))
+        _check(self._lib.hq_comm_init_ipc_n(self._h, buf, ctypes.c_int32(len(raw) // IPC_BLOB_BYTES)))
 
     def comm_init_loopback(self):
         _check(self._lib.hq_comm_init_loopback(self._h))

@@ -146,6 +146,11 @@ struct hq_dev_schedule {
     double*  h_c_in = nullptr;
     double*  h_s_out = nullptr;
     double*  h_s_in = nullptr;
+    /* ... and, under HQ_DEBUG_HALO, of the four check-word buffers */
+    int64_t* h_c_out_id = nullptr;
+    int64_t* h_c_in_id = nullptr;
+    int64_t* h_s_out_id = nullptr;
+    int64_t* h_s_in_id = nullptr;
 };
 
 struct hq_ctx {
@@ -233,6 +238,8 @@ struct hq_ctx {
     std::vector<int32_t> perm;        /* caller's node id -> device id */
     /* HQ_DEBUG_HALO (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) */
     bool debug_halo = false;
+    /* HQ_DEBUG_HALO over the IPC and the host-staged transport: exchanges counted on both sides (part of the check word) */
+    unsigned long long dbg_send_epoch[4] = { 0, 0, 0, 0 }, dbg_recv_epoch[4] = { 0, 0, 0, 0 };
     int64_t* d_gkey = nullptr;        /* [N] global identity of every harbored node          */
     int32_t* d_halo_err = nullptr;    /* [4] records whose identity did not match; non-finite values seen by hq_check_finite;
                                        * [2] IPC waits that timed out */
@@ -270,6 +277,7 @@ struct hq_ipc_blob {
     hipIpcMemHandle_t mem;
     uint64_t buf_off[4];                             /* receive buffer of exchange x in the arena (bytes)            */
     uint64_t flag_off;                               /* flags [4][HQ_IPC_MAXNB] uint64 in the arena (bytes)          */
+    uint64_t id_off[4];                              /* HQ_DEBUG_HALO: check words [records] int64 of exchange x (bytes); 0: none */
     int32_t nrecv[4];
     struct { int32_t procid, offset, count; } recv[4][HQ_IPC_MAXNB];
 };
@@ -279,11 +287,14 @@ struct hq_ipc_state {
     void* arena = nullptr;
     size_t arena_bytes = 0;
     bool coarse = false, ready = false, loopback = false;
+    int arena_kind = 0;                              /* 0 fine-grained, 1 uncached, 2 coarse-grained */
     hq_ipc_blob mine;
     std::vector<void*> opened;                       /* hipIpcOpenMemHandle results to close */
     unsigned long long* d_flags = nullptr;           /* in the arena */
     double** d_dst[4] = { nullptr, nullptr, nullptr, nullptr };             /* where every send record of exchange x lands */
     unsigned long long** d_sig[4] = { nullptr, nullptr, nullptr, nullptr }; /* the flags exchange x raises at its peers     */
+    int64_t** d_dst_id[4] = { nullptr, nullptr, nullptr, nullptr };         /* HQ_DEBUG_HALO: where every record's check word lands */
+    int64_t* d_in_id[4] = { nullptr, nullptr, nullptr, nullptr };           /* ... and where this rank's arrive (in the arena)      */
     int32_t nsig[4] = { 0, 0, 0, 0 };
     unsigned long long wait_mask[4] = { 0, 0, 0, 0 };
     unsigned long long send_epoch[4] = { 0, 0, 0, 0 }, recv_epoch[4] = { 0, 0, 0, 0 };
@@ -522,6 +533,44 @@ __global__ void hq_k_check_id(int32_t count, const int32_t* __restrict__ map, co
     if (t < count && in[t] != gkey[map[t]]) atomicAdd(err, 1);
 }
 
+/* HQ_DEBUG_HALO on the transports that STORE records where the peer reads them (IPC) or stage them through the host: the
+ * reference's -DDEBUG sends the node id with every record (psolve.c:5002-5007, 5058-5069); here the check word also binds
+ * the record's payload and the number of the exchange, so that a record that is stale (an earlier exchange's), torn or
+ * misrouted fails the receiver's check: word = id ^ mix(exchange) ^ bits(x) ^ rotl(bits(y), 21) ^ rotl(bits(z), 42) */
+static __device__ __forceinline__ int64_t hq_check_word(int64_t id, unsigned long long epoch, double x, double y, double z)
+{
+    const unsigned long long a = (unsigned long long)__double_as_longlong(x), b = (unsigned long long)__double_as_longlong(y),
+                             cc = (unsigned long long)__double_as_longlong(z);
+    return (int64_t)((unsigned long long)id ^ (epoch * 0x9E3779B97F4A7C15ull) ^ a ^ ((b << 21) | (b >> 43)) ^ ((cc << 42) | (cc >> 22)));
+}
+
+/* vmap: the rows of `table` the records are packed from (node ids or interface slots); nmap: the nodes they belong to.
+ * dst != NULL: every word goes where the peer reads it (system-scope store; the flags are raised by the record kernel
+ * enqueued BEHIND this one); else out[i] */
+__global__ void hq_k_pack_check(int32_t count, const int32_t* __restrict__ vmap, const int32_t* __restrict__ nmap,
+                                const double* __restrict__ table, const int64_t* __restrict__ gkey, unsigned long long epoch,
+                                int64_t* const* __restrict__ dst, int64_t* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double* r = table + 3 * (int64_t)vmap[i];
+    const int64_t w = hq_check_word(gkey[nmap[i]], epoch, r[0], r[1], r[2]);
+    if (dst) __hip_atomic_store(dst[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else out[i] = w;
+}
+
+__global__ void hq_k_verify_check(int32_t count, const int32_t* __restrict__ nmap, const int64_t* __restrict__ gkey,
+                                  unsigned long long epoch, const double* rec, const int64_t* words, int32_t* __restrict__ err)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double x = __hip_atomic_load(rec + 3 * (int64_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                 y = __hip_atomic_load(rec + 3 * (int64_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                 z = __hip_atomic_load(rec + 3 * (int64_t)i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int64_t w = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (w != hq_check_word(gkey[nmap[i]], epoch, x, y, z)) atomicAdd(err, 1);
+}
+
 /* solver_check_nan (psolve.c:3769-3782): count the values that are not finite */
 __global__ void hq_k_count_nonfinite(int64_t n, const double* __restrict__ a, int32_t* __restrict__ cnt)
 {
@@ -630,9 +679,11 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
         /* between processes: the records are written where the peers read them, the last block raises the peers' flags */
         hq_ipc_state* I = c->ipc;
         if (prepacked) return HQ_OK;
-        if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the IPC transport%s", "");
         const int x = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
         if (total) {
+            if (c->debug_halo)      /* the check words first: they are in place when the record kernel raises the flags */
+                hq_k_pack_check<<<hq_blocks(total, 256), 256, 0, xs>>>(total, d_map, contribution ? s->d_cmap : s->d_smap, table, c->d_gkey,
+                                                                      ++c->dbg_send_epoch[x], I->d_dst_id[x], nullptr);
             I->send_epoch[x]++;
             hq_k_pack_to_peers_sig<<<hq_blocks((int64_t)total * 3, 256), 256, 0, xs>>>(total, d_map, table, I->d_dst[x], I->d_done + x,
                                                                                      I->nsig[x], I->d_sig[x], I->send_epoch[x], I->delay_ticks);
@@ -652,7 +703,7 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
     /* HQ_DEBUG_HALO: the global identity of every record's node travels with it (psolve.c:5002-5007) */
     int64_t* d_out_id = contribution ? s->d_c_out_id : s->d_s_out_id;
     int64_t* d_in_id = contribution ? s->d_s_in_id : s->d_c_in_id;
-    if (c->debug_halo && total)
+    if (c->debug_halo && total && !c->host_xchg)
         hq_k_pack_id<<<hq_blocks(total, 256), 256, 0, xs>>>(total, contribution ? s->d_cmap : s->d_smap, c->d_gkey, d_out_id);
     if (c->group) {
         for (auto& m : snd) {
@@ -679,10 +730,22 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
         /* records through pinned host memory and the caller's transport (the MPI_Irecv / MPI_Isend / MPI_Waitall of
          * schedule_senddata, psolve.c:5013-5033, stay the caller's): pack -> D2H -> callback -> H2D, on the exchange
          * stream; only that stream is waited for, the interior kernels keep running on the compute stream */
-        if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the host-staged transport%s", "");
         double** ph_out = contribution ? &s->h_c_out : &s->h_s_out;
         double** ph_in = contribution ? &s->h_s_in : &s->h_c_in;
         const int32_t total_in = contribution ? s->stotal : s->ctotal;
+        int64_t** ph_out_id = contribution ? &s->h_c_out_id : &s->h_s_out_id;
+        int64_t** ph_in_id = contribution ? &s->h_s_in_id : &s->h_c_in_id;
+        if (c->debug_halo) {
+            /* the check words travel as a second message per neighbour (tag + 4), 8 bytes per record */
+            const int xd = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
+            if (total && !*ph_out_id) HQ_HIP(hipHostMalloc((void**)ph_out_id, sizeof(int64_t) * (size_t)total, hipHostMallocDefault));
+            if (total_in && !*ph_in_id) HQ_HIP(hipHostMalloc((void**)ph_in_id, sizeof(int64_t) * (size_t)total_in, hipHostMallocDefault));
+            if (total) {
+                hq_k_pack_check<<<hq_blocks(total, 256), 256, 0, xs>>>(total, d_map, contribution ? s->d_cmap : s->d_smap, table, c->d_gkey,
+                                                                      ++c->dbg_send_epoch[xd], nullptr, d_out_id);
+                HQ_HIP(hipMemcpyAsync(*ph_out_id, d_out_id, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, xs));
+            }
+        }
         if (total && !*ph_out) HQ_HIP(hipHostMalloc((void**)ph_out, sizeof(double) * 3 * (size_t)total, hipHostMallocDefault));
         if (total_in && !*ph_in) HQ_HIP(hipHostMalloc((void**)ph_in, sizeof(double) * 3 * (size_t)total_in, hipHostMallocDefault));
         if (total) HQ_HIP(hipMemcpyAsync(*ph_out, d_out, sizeof(double) * 3 * (size_t)total, hipMemcpyDeviceToHost, xs));
@@ -700,6 +763,19 @@ static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool
                          sb.data(), tag) != 0)
             return hq_fail(HQ_ERR_COMM, "the host transport's exchange callback failed%s", "");
         if (total_in) HQ_HIP(hipMemcpyAsync(d_in, *ph_in, sizeof(double) * 3 * (size_t)total_in, hipMemcpyHostToDevice, xs));
+        if (c->debug_halo) {
+            std::vector<double*> rbi;
+            std::vector<const double*> sbi;
+            std::vector<int64_t> rni, sni;
+            for (auto& m : rcv) if (m.nodecount) { rni.push_back((int64_t)m.nodecount); rbi.push_back((double*)(*ph_in_id + m.offset)); }
+            for (auto& m : snd) if (m.nodecount) { sni.push_back((int64_t)m.nodecount); sbi.push_back((const double*)(*ph_out_id + m.offset)); }
+            if (c->host_xchg(c->host_user, (int32_t)rp.size(), rp.data(), rni.data(), rbi.data(), (int32_t)sp.size(), sp.data(), sni.data(),
+                             sbi.data(), tag + 4) != 0)
+                return hq_fail(HQ_ERR_COMM, "the host transport's exchange callback failed%s", "");
+            if (total_in) HQ_HIP(hipMemcpyAsync(d_in_id, *ph_in_id, sizeof(int64_t) * (size_t)total_in, hipMemcpyHostToDevice, xs));
+            c->d2h_bytes += 8 * (int64_t)total;
+            c->h2d_bytes += 8 * (int64_t)total_in;
+        }
     } else {
         HQ_NCCL(g_rccl.GroupStart());
         for (auto& m : rcv)
@@ -729,6 +805,14 @@ static void hq_xchg_check(hq_ctx* c, hq_dev_schedule* s, bool contribution, hipS
 {
     if (!c->debug_halo) return;
     const int32_t total = contribution ? s->stotal : s->ctotal;
+    if (total && (c->host_xchg || hq_ipc_ready(c))) {
+        /* check words (see hq_k_pack_check); the IPC transport's callers have waited for the flags already */
+        const int x = (s == &c->an ? 0 : 2) + (contribution ? 0 : 1);
+        const int64_t* words = hq_ipc_ready(c) ? c->ipc->d_in_id[x] : (contribution ? s->d_s_in_id : s->d_c_in_id);
+        hq_k_verify_check<<<hq_blocks(total, 256), 256, 0, xs>>>(total, contribution ? s->d_smap : s->d_cmap, c->d_gkey, ++c->dbg_recv_epoch[x],
+                                                                contribution ? s->d_s_in : s->d_c_in, words, c->d_halo_err);
+        return;
+    }
     if (total)
         hq_k_check_id<<<hq_blocks(total, 256), 256, 0, xs>>>(total, contribution ? s->d_smap : s->d_cmap, c->d_gkey,
                                                               contribution ? s->d_s_in_id : s->d_c_in_id, c->d_halo_err);
@@ -756,7 +840,7 @@ static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contr
     if (c->group)
         for (auto& m : rcv)
             if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
-    if (hq_ipc_ready(c) && !contribution && s->ctotal) {
+    if (hq_ipc_ready(c) && !contribution && s->ctotal && !c->debug_halo) {
         /* IPC sharing: wait and unpack in one kernel */
         hq_ipc_state* I = c->ipc;
         const int x = (s == &c->an ? 0 : 2) + 1;
@@ -1057,12 +1141,15 @@ static int hq_phase(hq_ctx* c, int ph)
             if (c->group)
                 for (auto& m : c->an.s)
                     if (m.nodecount) HQ_HIP(hipStreamWaitEvent(xs, (*c->group)[m.procid]->ev_sent, 0));
+            /* HQ_DEBUG_HALO over the IPC transport: wait for the flags here, check, and leave the update unfused */
+            const bool ipc_dbg = hq_ipc_ready(c) && c->debug_halo;
+            if (ipc_dbg) hq_ipc_wait(c, &c->an, true, xs);
             hq_xchg_check(c, &c->an, true, xs);
             c->share_packed = false;
             if (c->nOI) {
                 /* the update also packs the displacement sharing (phase 5 then only hands the records on) */
                 hq_ipc_args ia = {};
-                const bool fuse = c->opt_fused_share;
+                const bool fuse = c->opt_fused_share && !(c->debug_halo && (hq_ipc_ready(c) || c->host_xchg));
                 double* s_out = fuse ? c->an.d_s_out : nullptr;
                 double* const* s_dst = nullptr;
                 if (fuse && c->group && c->an.d_s_dst && !c->debug_halo) s_dst = c->an.d_s_dst;
@@ -1086,13 +1173,13 @@ static int hq_phase(hq_ctx* c, int ph)
                         c->share_packed = true;
                         return HQ_OK;
                     }
-                    hq_ipc_wait(c, &c->an, true, xs);
+                    if (!ipc_dbg) hq_ipc_wait(c, &c->an, true, xs);
                 }
                 hq_k_interface_update<0><<<hq_blocks(c->nOI * 3, 256), 256, 0, xs>>>(
                     c->nOI, c->d_oi_node, c->d_oi_slot, c->d_oi_ptr, c->d_oi_pos, c->d_oi_fc, c->d_iforce, c->an.d_s_in,
                     c->d_nt, c->d_u[c->now], c->d_u[c->prev], unew, s_dst ? nullptr : s_out, s_dst, ia);
                 c->share_packed = fuse;
-            } else if (hq_ipc_ready(c)) {
+            } else if (hq_ipc_ready(c) && !ipc_dbg) {
                 hq_ipc_wait(c, &c->an, true, xs);
             }
         } else {
@@ -2093,6 +2180,7 @@ extern "C" int hq_destroy(hq_ctx* c)
             if (x & 1) sc->d_c_in = nullptr; else sc->d_s_in = nullptr;
             if (I->d_dst[x]) hipFree(I->d_dst[x]);
             if (I->d_sig[x]) hipFree(I->d_sig[x]);
+            if (I->d_dst_id[x]) hipFree(I->d_dst_id[x]);
         }
         for (void* p : I->opened) hipIpcCloseMemHandle(p);
         if (I->d_done) hipFree(I->d_done);
@@ -2114,6 +2202,8 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->dn.d_smap_f && c->dn.d_smap_f != c->dn.d_smap) hipFree(c->dn.d_smap_f);
     for (hq_dev_schedule* sc : { &c->an, &c->dn }) {
         for (double* hp : { sc->h_c_out, sc->h_c_in, sc->h_s_out, sc->h_s_in })
+            if (hp) hipHostFree(hp);
+        for (int64_t* hp : { sc->h_c_out_id, sc->h_c_in_id, sc->h_s_out_id, sc->h_s_in_id })
             if (hp) hipHostFree(hp);
         if (sc->d_c_dst) hipFree(sc->d_c_dst);
         if (sc->d_s_dst) hipFree(sc->d_s_dst);
@@ -2167,13 +2257,16 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.pcie_d2h_bytes = c->d2h_bytes;
     v.transport = c->comm ? 1 : (hq_ipc_ready(c) ? (c->ipc->loopback ? 5 : 2) : (c->host_xchg ? 3 : (c->group ? 4 : 0)));
     v.ipc_arena_coarse = (c->ipc && c->ipc->coarse) ? 1 : 0;
+    v.ipc_arena_kind = c->ipc ? c->ipc->arena_kind : 0;
+    v.debug_halo = c->debug_halo ? 1 : 0;
     memset(info, 0, (size_t)size);
     memcpy(info, &v, (size_t)std::min<uint64_t>(size, sizeof(v)));
     return HQ_OK;
 }
 
-/* the symbol of the rounds before the struct grew: 48 bytes, never more (include/hq_solver.h) */
-extern "C" int hq_get_info(hq_ctx* c, hq_info* info) { return hq_get_info_sized(c, info, 48); }
+/* the symbol of the rounds before hq_get_info_sized: the struct of the last header that bound it ended with brick_nodes
+ * (56 bytes); never more than that is written (include/hq_solver.h) */
+extern "C" int hq_get_info(hq_ctx* c, hq_info* info) { return hq_get_info_sized(c, info, 56); }
 
 /*
  * With the exchange chain on its own stream BETWEEN GPUs the compute stream must leave it somewhere to run: stream
@@ -2308,7 +2401,6 @@ static int hq_ipc_prepare(hq_ctx* c)
 {
     if (c->ipc) return HQ_OK;
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
-    if (c->debug_halo) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO is not carried by the IPC transport%s", "");
     for (int x = 0; x < 4; x++)
         if (hq_ipc_list(c, x, false).size() > HQ_IPC_MAXNB || hq_ipc_list(c, x, true).size() > HQ_IPC_MAXNB)
             return hq_fail(HQ_ERR_ARG, "IPC transport: more than %s neighbours in one schedule", "64");
@@ -2328,19 +2420,42 @@ static int hq_ipc_prepare(hq_ctx* c)
     }
     const size_t dump_off = off;
     off += 256;
+    if (c->debug_halo)                               /* the check words of every received record (hq_k_pack_check) */
+        for (int x = 0; x < 4; x++) {
+            B.id_off[x] = off;
+            off += ((size_t)hq_ipc_total(c, x, false) * 8 + 255) / 256 * 256 + 256;
+        }
     I->arena_bytes = off;
+    /* everything that can fail comes before the schedules' receive buffers are touched (round-4 advisor) */
+    if (hipMalloc((void**)&I->d_done, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(I->d_done, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
+        if (I->d_done) hipFree(I->d_done);
+        delete I;
+        return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", "");
+    }
     /* fine-grained device memory: remote stores over xGMI become visible to the local consumer kernels without an L2
      * flush (what RCCL uses for its buffers); where the runtime cannot export it, coarse-grained memory -- coherent only
      * between ranks that share the device, which hq_comm_init_ipc checks */
+    /* three kinds of memory, in this order: fine-grained (what RCCL uses for its buffers), uncached (MTYPE_UC: no L2
+     * holds it either, so remote stores are seen as well -- for runtimes that will not export a fine-grained
+     * allocation), and coarse-grained as the last resort (ranks of ONE device only).  HQ_IPC_COARSE=1 / HQ_IPC_ARENA=
+     * fine | uncached | coarse pins the kind (tests). */
     bool coarse = getenv("HQ_IPC_COARSE") && atoi(getenv("HQ_IPC_COARSE")) != 0;
-    for (int attempt = coarse ? 1 : 0; attempt < 2; attempt++) {
+    int first_kind = coarse ? 2 : 0, last_kind = 2;
+    if (const char* k = getenv("HQ_IPC_ARENA")) {
+        if (!strcmp(k, "fine")) first_kind = last_kind = 0;
+        else if (!strcmp(k, "uncached")) first_kind = last_kind = 1;
+        else if (!strcmp(k, "coarse")) first_kind = last_kind = 2;
+    }
+    for (int attempt = first_kind; attempt <= last_kind; attempt++) {
         hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&I->arena, I->arena_bytes, hipDeviceMallocFinegrained)
+                     : attempt == 1 ? hipExtMallocWithFlags(&I->arena, I->arena_bytes, hipDeviceMallocUncached)
                                     : hipMalloc(&I->arena, I->arena_bytes);
         if (e == hipSuccess) e = hipIpcGetMemHandle(&B.mem, I->arena);
-        if (e == hipSuccess) { coarse = attempt == 1; break; }
+        if (e == hipSuccess) { coarse = attempt == 2; I->arena_kind = attempt; break; }
         (void)hipGetLastError();
         if (I->arena) { hipFree(I->arena); I->arena = nullptr; }
-        if (attempt == 1) {
+        if (attempt == last_kind) {
+            hipFree(I->d_done);
             delete I;
             return hq_fail(HQ_ERR_DEVICE, "IPC transport: cannot allocate / export the receive arena: %s", hipGetErrorString(e));
         }
@@ -2350,7 +2465,7 @@ static int hq_ipc_prepare(hq_ctx* c)
     B.arena_bytes = I->arena_bytes;
     B.arena_addr = (uint64_t)(uintptr_t)I->arena;
     if (hipDeviceGetPCIBusId(B.busid, (int)sizeof(B.busid), c->device) != hipSuccess) B.busid[0] = 0;
-    if (hipMemset(I->arena, 0, I->arena_bytes) != hipSuccess) { hipFree(I->arena); delete I; return hq_fail(HQ_ERR_DEVICE, "memset%s", ""); }
+    if (hipMemset(I->arena, 0, I->arena_bytes) != hipSuccess) { hipFree(I->arena); hipFree(I->d_done); delete I; return hq_fail(HQ_ERR_DEVICE, "memset%s", ""); }
     c->bytes += (int64_t)I->arena_bytes;
     I->d_flags = (unsigned long long*)I->arena;
     for (int x = 0; x < 4; x++) {
@@ -2365,10 +2480,8 @@ static int hq_ipc_prepare(hq_ctx* c)
         }
     }
     B.reserved = (int32_t)(dump_off / 8);
-    if (hipMalloc((void**)&I->d_done, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(I->d_done, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
-        hipFree(I->arena); delete I;
-        return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", "");
-    }
+    if (c->debug_halo)
+        for (int x = 0; x < 4; x++) I->d_in_id[x] = (int64_t*)((char*)I->arena + B.id_off[x]);
     if (getenv("HQ_IPC_TIMEOUT_MS") && atof(getenv("HQ_IPC_TIMEOUT_MS")) > 0)
         I->timeout_ticks = (unsigned long long)(atof(getenv("HQ_IPC_TIMEOUT_MS")) * 1.0e5);
     c->ipc = I;
@@ -2421,12 +2534,15 @@ static int hq_ipc_connect(hq_ctx* c, const char* blobs)
         std::vector<hq_dev_messenger>& snd = hq_ipc_list(c, x, true);
         const int32_t total = hq_ipc_total(c, x, true);
         std::vector<double*> dst((size_t)total, nullptr);
+        std::vector<int64_t*> dst_id((size_t)(c->debug_halo ? total : 0), nullptr);
         std::vector<unsigned long long*> sig;
         if (loop) {
             const int32_t in_total = hq_ipc_total(c, x, false);
             double* in = *hq_ipc_inbuf(c, x);
             double* dump = (double*)I->arena + I->mine.reserved;
             for (int32_t i = 0; i < total; i++) dst[(size_t)i] = in_total ? in + 3 * (int64_t)(i % in_total) : dump;
+            if (c->debug_halo)
+                for (int32_t i = 0; i < total; i++) dst_id[(size_t)i] = I->d_in_id[x] + (in_total ? i % in_total : 0);
             if (!total) I->wait_mask[x] = 0;
             for (int j = 0; j < HQ_IPC_MAXNB; j++)
                 if ((I->wait_mask[x] >> j) & 1ull) sig.push_back(I->d_flags + (size_t)x * HQ_IPC_MAXNB + j);
@@ -2442,6 +2558,13 @@ static int hq_ipc_connect(hq_ctx* c, const char* blobs)
                 char* pbase = (char*)base[(size_t)m.procid];
                 double* p_in = (double*)(pbase + pb->buf_off[x]);
                 for (int32_t k = 0; k < m.nodecount; k++) dst[(size_t)m.offset + k] = p_in + 3 * ((int64_t)pb->recv[x][j].offset + k);
+                if (c->debug_halo) {
+                    if (!pb->id_off[x]) return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO must be set on every rank of an IPC run%s", "");
+                    int64_t* p_id = (int64_t*)(pbase + pb->id_off[x]);
+                    for (int32_t k = 0; k < m.nodecount; k++) dst_id[(size_t)m.offset + k] = p_id + ((int64_t)pb->recv[x][j].offset + k);
+                } else if (pb->id_off[x]) {
+                    return hq_fail(HQ_ERR_STATE, "HQ_DEBUG_HALO must be set on every rank of an IPC run%s", "");
+                }
                 sig.push_back((unsigned long long*)(pbase + pb->flag_off) + (size_t)x * HQ_IPC_MAXNB + j);
             }
         }
@@ -2451,6 +2574,10 @@ static int hq_ipc_connect(hq_ctx* c, const char* blobs)
             HQ_HIP(hipMemcpy(I->d_dst[x], dst.data(), sizeof(double*) * (size_t)total, hipMemcpyHostToDevice));
             HQ_TRY(hq_dev_alloc(c, &I->d_sig[x], sig.size()));
             if (!sig.empty()) HQ_HIP(hipMemcpy(I->d_sig[x], sig.data(), sizeof(void*) * sig.size(), hipMemcpyHostToDevice));
+            if (c->debug_halo) {
+                HQ_TRY(hq_dev_alloc(c, &I->d_dst_id[x], (size_t)total));
+                HQ_HIP(hipMemcpy(I->d_dst_id[x], dst_id.data(), sizeof(int64_t*) * (size_t)total, hipMemcpyHostToDevice));
+            }
         }
     }
     I->ready = true;
@@ -2468,6 +2595,13 @@ extern "C" int hq_comm_init_ipc(hq_ctx* c, const void* blobs)
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     HQ_HIP(hipSetDevice(c->device));
     return hq_ipc_connect(c, (const char*)blobs);
+}
+
+/* the same with the number of blobs the caller holds: a short all-gather is refused instead of read out of bounds */
+extern "C" int hq_comm_init_ipc_n(hq_ctx* c, const void* blobs, int32_t nblobs)
+{
+    if (c && nblobs != c->nranks) return hq_fail(HQ_ERR_ARG, "hq_comm_init_ipc_n: one blob per rank, in rank order%s", "");
+    return hq_comm_init_ipc(c, blobs);
 }
 
 extern "C" int hq_comm_init_loopback(hq_ctx* c)

@@ -122,6 +122,8 @@ typedef struct {
                                  /* downloads, host-staged halos): what a run costs on PCIe between outputs         */
     int32_t transport;           /* 0 none, 1 RCCL, 2 IPC, 3 host-staged, 4 in-process group, 5 loopback (diagnostic)  */
     int32_t ipc_arena_coarse;    /* IPC: 1 if the receive arena had to be coarse-grained memory (ranks of one device only) */
+    int32_t ipc_arena_kind;      /* IPC: 0 fine-grained, 1 uncached, 2 coarse-grained device memory                        */
+    int32_t debug_halo;          /* 1: every halo record is checked on receipt (HQ_DEBUG_HALO / hq_options.debug_halo)     */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -146,9 +148,9 @@ HQ_API int hq_destroy(hq_ctx* ctx);
  * hq_info carries no size field of its own, so the call does: hq_get_info_sized writes min(size, sizeof(hq_info))
  * bytes, and the hq_get_info() of this header passes the caller's own sizeof -- a client compiled against an older
  * (shorter) hq_info is never written past its struct, a newer one gets what this library knows and zeros behind.
- * The exported SYMBOL hq_get_info is kept for binaries built before round 3 and writes the 48-byte struct of then
- * (up to and including the field that was `reserved`).  hq_abi_version() == HQ_ABI_VERSION is the check a separately
- * compiled client makes at start-up.
+ * The exported SYMBOL hq_get_info is kept for binaries built against the headers that had no hq_get_info_sized; the
+ * last of those ended its struct with brick_nodes, so the symbol writes those 56 bytes and never more.
+ * hq_abi_version() == HQ_ABI_VERSION is the check a separately compiled client makes at start-up.
  */
 #define HQ_ABI_VERSION 4
 HQ_API int hq_abi_version(void);
@@ -196,11 +198,19 @@ HQ_API int hq_comm_init_host(hq_ctx* ctx, hq_host_exchange_fn fn, void* user);
  *   2. the host all-gathers the blobs in rank order          (MPI_Allgather on comm_solver in the reference's world)
  *   3. every rank: hq_comm_init_ipc(ctx, all_blobs)          all_blobs: nranks x HQ_IPC_BLOB_BYTES
  * A rank whose neighbour stops sending does not spin for ever: a wait longer than HQ_IPC_TIMEOUT_MS (default 20 000)
- * gives up, and the next hq_sync returns HQ_ERR_COMM.  HQ_DEBUG_HALO is not carried.
+ * gives up, and the next hq_sync returns HQ_ERR_COMM.
+ * HQ_DEBUG_HALO (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) is carried: every record travels with
+ * a check word -- its node's global id, mixed with the number of the exchange and the record's own three values -- in
+ * an id arena beside the record arena; a record that is misrouted, stale (an earlier exchange's) or torn fails the
+ * receiver's check and the next hq_sync returns HQ_ERR_COMM.  Every rank of the run must set it.  The receive arena is
+ * fine-grained device memory, uncached device memory where the runtime will not export that, coarse-grained as the last
+ * resort (ranks of one device only): hq_info.ipc_arena_kind says which.
  */
 #define HQ_IPC_BLOB_BYTES 4096
 HQ_API int hq_comm_ipc_export(hq_ctx* ctx, void* blob);
 HQ_API int hq_comm_init_ipc(hq_ctx* ctx, const void* all_blobs);
+/* the same with the number of blobs the caller holds (must be nranks): a short gather is refused, not read past its end */
+HQ_API int hq_comm_init_ipc_n(hq_ctx* ctx, const void* all_blobs, int32_t nblobs);
 /* Diagnostic (profiles/tools/rank_alone_trace.py): the IPC transport with this rank as its own only peer -- every record
  * it sends lands in its own receive buffers and raises its own flags.  The displacements of interface nodes are then
  * WRONG by construction; the step's kernels, streams and waits are exactly those of a rank whose neighbours answer

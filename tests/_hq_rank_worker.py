@@ -72,7 +72,16 @@ def main():
         from oracle import herc_oracle as ho                # (checker-side helper: hanging rows = means of their anchors)
         ho.compute_adjust(g1, 1, ref["dangling"])
         ho.compute_adjust(g2, 1, ref["dangling"])
-    s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid])
+    if os.environ.get("HQ_TEST_SWAP_RANK") == str(rank):
+        # a deliberately WRONG schedule on this rank: two records of one c-list messenger swapped, so that the owner adds
+        # them to the wrong nodes -- what HQ_DEBUG_HALO exists to catch (the parent expects the run to fail)
+        sch = b.schedules()
+        k = next(i for i, (_, m) in enumerate(sch["an"]["c"]) if len(m) > 1)
+        sch["an"]["c"][k][1][[0, 1]] = sch["an"]["c"][k][1][[1, 0]]
+        s = ha.Solver(b.lnid, b.etable, b.ntable, b.dt, tm1=g1[gid], tm2=g2[gid], node_xyz=b.node_xyz, dangling=b.dangling,
+                      an_sched=sch["an"], dn_sched=sch["dn"], rank=rank, nranks=world, variant=ha.HQ_VARIANT_PATCH)
+    else:
+        s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid])
     if os.environ.get("HQ_TEST_TRANSPORT", "host") == "ipc":
         # device-to-device between the processes: blobs all-gathered over gloo (MPI_Allgather in the reference's world)
         mine = torch.frombuffer(bytearray(s.comm_ipc_export()), dtype=torch.uint8)
@@ -84,16 +93,24 @@ def main():
     if F is not None:
         s.set_source(loaded, F)
     dist.barrier()
-    s.run(nsteps)
-    s.sync()
+    failed = None
+    try:
+        s.run(nsteps)
+        s.sync()
+    except ha.HqError as e:                                 # e.g. HQ_DEBUG_HALO's report: every rank still leaves in step
+        failed = str(e)
+        open(os.path.join(outdir, "rank%d.err" % rank), "w").write(failed)
     tm1, tm2 = s.download()
     info = s.info()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), gid=gid, tm1=tm1, tm2=tm2, brick_nodes=info["brick_nodes"],
-             kernel=s.dominant_kernel(), transport=info["transport"], ipc_arena_coarse=info["ipc_arena_coarse"])
+             kernel=s.dominant_kernel(), transport=info["transport"], ipc_arena_coarse=info["ipc_arena_coarse"],
+             ipc_arena_kind=info["ipc_arena_kind"], debug_halo=info["debug_halo"])
     s.close()
     b.close()
     dist.barrier()
     dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _launch(tmp_path, world, kind, nsteps, env_extra=None):
+def _launch(tmp_path, world, kind, nsteps, env_extra=None, expect_failure=False):
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
@@ -38,6 +38,9 @@ def _launch(tmp_path, world, kind, nsteps, env_extra=None):
            os.path.join(ROOT, "tests", "_hq_rank_worker.py"), str(tmp_path), kind, str(nsteps)]
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          universal_newlines=True, timeout=900)
+    if expect_failure:
+        assert out.returncode != 0, "the run was expected to fail"
+        return out.stdout
     assert out.returncode == 0, out.stdout[-3000:]
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
@@ -72,7 +75,8 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
         assert int(z["brick_nodes"]) > 0 and str(z["kernel"]) == "hq_k_brick"
         assert int(z["transport"]) == (2 if transport == "ipc" else 3)       # hq_info.transport: IPC / host-staged
     if transport == "ipc":
-        print("IPC receive arena:", "coarse-grained" if int(parts[0]["ipc_arena_coarse"]) else "fine-grained")
+        # first contact of the fine-grained arena: exported here and opened by ANOTHER process (HQ_IPC_COARSE unset)
+        assert all(int(z["ipc_arena_coarse"]) == 0 and int(z["ipc_arena_kind"]) == 0 for z in parts)
 
 
 @pytest.mark.parametrize("transport,env", [("ipc", {"HQ_NO_FUSED_SHARE": "1", "HQ_PATCH_MERGE_ROUNDS": "0"}),
@@ -145,3 +149,58 @@ def test_the_references_basin_on_five_processes_against_its_own_stripes(tmp_path
         assert int(z["transport"]) == (2 if transport == "ipc" else 3)
     assert worst < 1e-9
     assert max(np.abs(z["tm1"]).max() for z in parts) > 100.0
+
+
+@pytest.mark.parametrize("transport", ["ipc", "host"])
+def test_halo_debug_mode_between_processes(tmp_path, transport):
+    """HQ_DEBUG_HALO=1 (the reference's -DDEBUG exchange, psolve.c:5002-5007, 5058-5069) on the transports that run
+    between processes: every record of all four exchanges travels with a check word -- its node's global identity mixed
+    with the number of the exchange and the record's own values (an id arena beside the IPC record arena; a second
+    message per neighbour on the host-staged transport).  Three ranks of the two-level octree box: a correct run passes
+    and equals the oracle; with two records of one rank's c-list swapped the owner's check fails and hq_sync says so."""
+    nsteps = 8
+    env = {"HQ_TEST_TRANSPORT": transport, "HQ_DEBUG_HALO": "1"}
+    parts = _launch(tmp_path, 3, "octree", nsteps, env)
+    ref = H.two_level_mesh(16, 8, 6, 3)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (ref["N"], 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (ref["N"], 3)) * 1e-6
+    ho.compute_adjust(g1, 1, ref["dangling"])
+    ho.compute_adjust(g2, 1, ref["dangling"])
+    o1, o2 = g2.copy(), g1.copy()
+    ho.solver_run(ref["lnid"], ref["etable"], ref["ntable"], o1, o2, 0, nsteps, ref["dt"], dangling=ref["dangling"])
+    for z in parts:
+        assert int(z["debug_halo"]) == 1
+        assert H.rel_linf(z["tm1"], o2[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], o1[z["gid"]]) < 1e-9
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    log = _launch(bad, 3, "octree", 2, dict(env, HQ_TEST_SWAP_RANK="1"), expect_failure=True)
+    errs = [f.read_text() for f in bad.glob("rank*.err")]
+    assert errs and all("HQ_DEBUG_HALO" in e for e in errs), log[-2000:]
+
+
+@pytest.mark.parametrize("kind", ["uncached", "coarse"])
+def test_ipc_arena_kinds_between_processes(tmp_path, kind):
+    """The IPC receive arena as uncached device memory (the fallback where a runtime will not export a fine-grained
+    allocation) and as coarse-grained memory (ranks of one device only): two ranks as processes against the oracle."""
+    nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 12
+    parts = _launch(tmp_path, 2, "box", nsteps, {"HQ_OVERLAP": "1", "HQ_CU_MASK": "0", "HQ_TEST_TRANSPORT": "ipc", "HQ_IPC_ARENA": kind})
+    from hercules_amd import host
+    b = host.Box(nx, ny, nz, h, dt, freq)
+    ijk = b.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    Ng = (nx + 1) * (ny + 1) * (nz + 1)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
+    loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
+    rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
+    F = b.source_table(rp, 0, nsteps)
+    o1, o2 = g2[gid].copy(), g1[gid].copy()
+    ho.solver_run(b.lnid, b.etable.copy(), b.ntable.copy(), o1, o2, 0, nsteps, dt, loaded_lnid=loaded, forces=F)
+    ref1, ref2 = np.zeros((Ng, 3)), np.zeros((Ng, 3))
+    ref1[gid], ref2[gid] = o2, o1
+    b.close()
+    for z in parts:
+        assert H.rel_linf(z["tm1"], ref1[z["gid"]]) < 1e-9 and H.rel_linf(z["tm2"], ref2[z["gid"]]) < 1e-9
+        assert int(z["ipc_arena_kind"]) == {"uncached": 1, "coarse": 2}[kind]

@@ -63,11 +63,11 @@ def _run(binary, params, timeout=900, nranks=1, env_extra=None):
     return run, out.stdout
 
 
-def _stations(run, n=5):
+def _stations(run, n=5, ncol=4):
     def one(i):
         rows = [l.split() for l in open(os.path.join(run, "out", "stations", "station.%d" % i)).read().splitlines()
                 if l.strip() and not l.lstrip().startswith("#")]
-        return np.array([[float(v) for v in r[:4]] for r in rows])
+        return np.array([[float(v) for v in r[:ncol]] for r in rows])
     return np.stack([one(i) for i in range(n)])
 
 
@@ -196,5 +196,29 @@ def test_the_reference_program_reads_the_device_at_its_output_cadence_only():
         ref = g["stations"][:, ::10, :]
         scale = np.abs(g["stations"][:, :, 1:]).max()
         assert np.abs(st - ref).max() <= 2e-6 * scale
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)
+
+
+@needs_binaries
+def test_station_accelerations_at_steps_that_also_write_a_checkpoint():
+    """print_station_accelerations = yes with stations every 10 steps and a checkpoint every 100: at steps 100, 200, ...
+    the whole field comes back for the checkpoint (hq_download: tm1 / tm2) AND the stations' tm3 rows must still come
+    from the device (hq_gather3) -- interpolate_station_displacements reads them (psolve.c:6775-6777).  All ten columns
+    against the unmodified reference's run with the same switches (tests/golden/c1_stations_va.npz)."""
+    g = H.load("c1_stations_va")
+    t = _params(float(g["end_time"]), 100, 10)
+    t = _setkey(t, "print_station_velocities", "yes")
+    t = _setkey(t, "print_station_accelerations", "yes")
+    run_hq, _ = _run(PSOLVE_HQ, t)
+    try:
+        st = _stations(run_hq, ncol=10)
+        ref = g["stations"][:, ::10, :]
+        assert st.shape == ref.shape == (5, 60, 10)
+        for q in range(3):                                  # displacement, velocity, acceleration: each in its own scale
+            cols = slice(1 + 3 * q, 4 + 3 * q)
+            scale = np.abs(g["stations"][:, :, cols]).max()
+            assert scale > 0 and np.abs(st[:, :, cols] - ref[:, :, cols]).max() <= 2e-6 * scale
+        assert np.abs(ref[:, 10::10, 7:]).max() > 1.0        # the lines written at checkpoint steps carry real accelerations
     finally:
         shutil.rmtree(run_hq, ignore_errors=True)
