@@ -27,7 +27,7 @@ def _newer(target, sources):
 
 
 def build_solver(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("hq_engine.hip", "hq_kernels.h", "hq_patch.h", "hq_brick.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("hq_engine.hip", "hq_kernels.h", "hq_opts.h", "hq_patch.h", "hq_brick.h")]
     srcs.append(os.path.join(ROOT, "include", "hq_solver.h"))
     if force or _newer(SOLVER_LIB, srcs):
         cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",

@@ -15,6 +15,7 @@ HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 IPC_BLOB_BYTES = 4096                   # HQ_IPC_BLOB_BYTES
 
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info", "hq_get_info_sized", "hq_abi_version", "hq_comm_init_ipc_n",
+           "hq_options_init", "hq_create_opts", "hq_get_options",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
@@ -64,6 +65,32 @@ class _Info(ctypes.Structure):
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
                 ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
                 ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32)]
+
+
+# hq_options (include/hq_solver.h): int32 fields in the header's order, two doubles, two more int32
+OPTION_FIELDS = ["no_bricks", "brick_cz", "brick_minz", "brick_minnodes", "brick_no_het", "brick_no_ntsame", "brick_by_component",
+                 "brick_stream", "patch_pipe", "patch_threads", "patch_pmax", "patch_pmerge", "patch_psplit", "patch_nlmax",
+                 "patch_vmax", "patch_ragged", "patch_no_lattice", "patch_no_stencil", "patch_no_uniform", "patch_no_iso",
+                 "patch_no_ntsame", "patch_no_dedup", "patch_wform", "patch_merge_rounds", "overlap", "no_overlap", "reserve_cus",
+                 "cu_mask", "no_fused_share", "group_copies", "debug_halo", "ipc_arena"]
+
+
+class Options(ctypes.Structure):
+    """hq_options.  Options(brick_cz=16, debug_halo=1): every other field stays -1 = library default."""
+    _fields_ = ([("size", ctypes.c_uint64)] + [(n, ctypes.c_int32) for n in OPTION_FIELDS] +
+                [("ipc_timeout_ms", ctypes.c_double), ("loopback_delay_us", ctypes.c_double),
+                 ("verbose", ctypes.c_int32), ("quiet", ctypes.c_int32)])
+
+    def __init__(self, **kw):
+        super().__init__()
+        load_library().hq_options_init(ctypes.byref(self), ctypes.c_uint64(ctypes.sizeof(self)))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("hq_options has no field %r" % k)
+            setattr(self, k, v)
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
 
 
 _lib = None
@@ -127,8 +154,11 @@ class Solver:
 
     def __init__(self, lnid, etable, ntable, dt, tm1=None, tm2=None, node_xyz=None,
                  dangling=None, an_sched=None, dn_sched=None, rank=0, nranks=1,
-                 variant=HQ_VARIANT_AUTO, device=0):
+                 variant=HQ_VARIANT_AUTO, device=0, options=None):
+        """options: an Options (hq_options) or a dict of its fields; None = hq_create's defaults."""
         lib = load_library()
+        if isinstance(options, dict):
+            options = Options(**options)
         keep = []
         lnid = np.ascontiguousarray(lnid, np.int32)
         etable = np.ascontiguousarray(etable, np.float64)
@@ -156,7 +186,10 @@ class Solver:
         d.deltaT, d.rank, d.nranks, d.variant = dt, rank, nranks, variant
         self._h = ctypes.c_void_p()
         self.N, self.E = d.nharbored, d.lenum
-        _check(lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(self._h)))
+        if options is None:
+            _check(lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(self._h)))
+        else:
+            _check(lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(self._h)))
         self._lib = lib
 
     def close(self):
@@ -170,6 +203,12 @@ class Solver:
         i = _Info()
         _check(self._lib.hq_get_info_sized(self._h, ctypes.byref(i), ctypes.c_uint64(ctypes.sizeof(i))))
         return {k: getattr(i, k) for k, _ in _Info._fields_}
+
+    def options(self):
+        """hq_get_options: what the context runs with (its options with the environment's overrides applied)."""
+        o = Options()
+        _check(self._lib.hq_get_options(self._h, ctypes.byref(o), ctypes.c_uint64(ctypes.sizeof(o))))
+        return o.as_dict()
 
     def set_source(self, loaded_lnid, forces, step0=0):
         ids = np.ascontiguousarray(loaded_lnid, np.int32)

@@ -85,7 +85,7 @@ struct hq_brick_cfg {
 static hq_brick_cfg hq_brick_cfg_from_env(void)
 {
     hq_brick_cfg c;
-    auto geti = [](const char* n, int def) { const char* v = getenv(n); return (v && *v) ? atoi(v) : def; };
+    auto geti = [](const char* n, int def) { return hq_opt_int(n, def); };
     c.cz = std::max(2, geti("HQ_BRICK_CZ", c.cz));
     c.minz = std::max(1, geti("HQ_BRICK_MINZ", c.minz));
     c.minnodes = std::max(1, geti("HQ_BRICK_MINNODES", c.minnodes));
@@ -129,7 +129,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     *B = hq_brick_host();
     if (!xyz || E <= 0 || N <= 0) return 0;
     const hq_brick_cfg cfg = hq_brick_cfg_from_env();
-    const bool verbose = getenv("HQ_PATCH_VERBOSE") && atoi(getenv("HQ_PATCH_VERBOSE")) > 1;
+    const bool verbose = (hq_opt_int("HQ_PATCH_VERBOSE", 0) > 1);
     auto t_lap = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!verbose) return;
@@ -138,7 +138,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         t_lap = now;
     };
     const int TX = HQ_BK_TX, TY = HQ_BK_TY;
-    const bool want_het = !(getenv("HQ_BRICK_NO_HET") && atoi(getenv("HQ_BRICK_NO_HET")) != 0);
+    const bool want_het = !(hq_opt_on("HQ_BRICK_NO_HET"));
     /* the uniform units use the assembled stencil's coefficients: without a verified table (hq_stencil().ok, the gate
      * hq_k_patch_stencil has too) their nodes go to the element-by-element HET units or stay with the patches */
     const bool stencil_ok = hq_stencil().ok;
@@ -397,7 +397,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
      * chunks -- each costs two more planes of loads, but 64 workgroups do not fill 256 CUs (1 M-element box: 0.068 ms
      * per step with 32 planes per unit, 0.039 with 8; 8 M box: 0.164 / 0.172).  HQ_BRICK_CZ fixes it. */
     int cz = cfg.cz;
-    if (!getenv("HQ_BRICK_CZ")) {
+    if (!hq_opt_has("HQ_BRICK_CZ")) {
         for (cz = 32; cz > 8; cz /= 2) {
             int64_t n = 0;
             for (auto& c : cols) n += (c.nz + cz - 1) / cz;
@@ -481,7 +481,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     const double* q = ntab + 7 * (int64_t)n;
                     if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) { sm = false; break; }
                 }
-        if (sm && !c.het && !getenv("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
+        if (sm && !c.het && !hq_opt_flag("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
         U.m0 = q0[0]; U.m2 = q0[1]; U.m1 = q0[4];
         U.coef = 0;
         if (c.het) {

@@ -40,6 +40,7 @@
 #define HQ_SOLVER_IMPLEMENTATION 1
 #include "../../include/hq_solver.h"
 #include "hq_kernels.h"
+#include "hq_opts.h"
 #include "hq_patch.h"
 #include "hq_brick.h"
 
@@ -154,6 +155,7 @@ struct hq_dev_schedule {
 };
 
 struct hq_ctx {
+    hq_options opts;                  /* the caller's options, completed with defaults (hq_create_opts) */
     int device = 0;
     hipStream_t stream = nullptr;
     int32_t E = 0, N = 0, ldnnum = 0;
@@ -1347,7 +1349,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
     }
     if (hq_patch_set_interface(&c->plan, slot.data(), (int64_t)c->N, &c->bytes) != 0)
         return hq_fail(HQ_ERR_NOMEM, "interface tables: %s", hq_patch_error());
-    if (!getenv("HQ_NO_OVERLAP")) {
+    if (!hq_opt_flag("HQ_NO_OVERLAP")) {
         /* the exchange chain is short and latency-bound: let its kernels (and RCCL's) get CUs ahead
          * of the thousands of interior patch workgroups queued on the compute stream */
         int prio_lo = 0, prio_hi = 0;
@@ -1361,7 +1363,7 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
         /* whether the chain really runs beside the interior patches is decided with the transport:
          * hq_comm_init (RCCL between GPUs: yes) / hq_group_link (copies inside one GPU: no, see there) */
         c->can_overlap = true;
-        if (getenv("HQ_RESERVE_CUS")) c->reserve_cus = std::max(0, atoi(getenv("HQ_RESERVE_CUS")));
+        if (hq_opt_has("HQ_RESERVE_CUS")) c->reserve_cus = std::max(0, hq_opt_int("HQ_RESERVE_CUS", 8));
     }
     return HQ_OK;
 }
@@ -1421,7 +1423,42 @@ static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
     return HQ_OK;
 }
 
-extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
+static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out);
+
+extern "C" void hq_options_init(hq_options* o, uint64_t size)
+{
+    if (!o) return;
+    hq_options full;
+    hq_options_defaults(&full);
+    memcpy(o, &full, (size_t)std::min<uint64_t>(size, sizeof(full)));
+    o->size = std::min<uint64_t>(size, sizeof(full));
+}
+
+extern "C" int hq_create_opts(const hq_desc* d, int device, const hq_options* opts, hq_ctx** out)
+{
+    if (opts && opts->size < sizeof(uint64_t)) return hq_fail(HQ_ERR_ARG, "hq_options.size is not set (hq_options_init)%s", "");
+    hq_options full;
+    hq_options_adopt(&full, opts);
+    hq_opt_scope scope(&full);
+    int rc = hq_create_impl(d, device, out);
+    if (rc == HQ_OK && out && *out) (*out)->opts = full;
+    return rc;
+}
+
+extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out) { return hq_create_opts(d, device, nullptr, out); }
+
+extern "C" int hq_get_options(hq_ctx* c, hq_options* out, uint64_t size)
+{
+    if (!c || !out || size < sizeof(uint64_t)) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
+    hq_opt_scope scope(&c->opts);
+    hq_options eff;
+    hq_options_effective(&eff);
+    memcpy(out, &eff, (size_t)std::min<uint64_t>(size, sizeof(eff)));
+    out->size = std::min<uint64_t>(size, sizeof(eff));
+    return HQ_OK;
+}
+
+static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
 {
     if (!d || !out) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     *out = nullptr;
@@ -1498,14 +1535,14 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
      */
     if (variant == HQ_VARIANT_PATCH && !d->node_xyz) {
         static bool warned = false;
-        if (!warned && !getenv("HQ_QUIET")) {
+        if (!warned && !hq_opt_flag("HQ_QUIET")) {
             warned = true;
             fprintf(stderr, "hq_create: hq_desc.node_xyz is NULL -- no bricks, no lattice / stencil patches (fixed runs of the node "
                             "order, element-form kernels only): expect about a third of the throughput; pass node_t.x/y/z\n");
         }
     }
     /* HQ_PATCH_VERBOSE: where hq_create's time goes */
-    const bool verbose = getenv("HQ_PATCH_VERBOSE") != nullptr;
+    const bool verbose = hq_opt_flag("HQ_PATCH_VERBOSE");
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!verbose) return;
@@ -1521,7 +1558,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
     std::vector<hq_messenger> p_msg[4];
     hq_brick_host BH;
     const double *h_tm1 = d->tm1, *h_tm2 = d->tm2;
-    if (variant == HQ_VARIANT_PATCH && d->node_xyz && !(getenv("HQ_NO_BRICKS") && atoi(getenv("HQ_NO_BRICKS")) != 0)) {
+    if (variant == HQ_VARIANT_PATCH && d->node_xyz && !(hq_opt_on("HQ_NO_BRICKS"))) {
         std::vector<char> excl;
         if ((rc = hq_brick_excluded(d, excl)) != HQ_OK) return bail(rc);
         if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH) != 0)
@@ -1614,7 +1651,7 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
 
     if ((rc = hq_dev_alloc(c, &c->d_halo_err, 4)) != HQ_OK) return bail(rc);
     if (hipMemset(c->d_halo_err, 0, 4 * sizeof(int32_t)) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
-    if (getenv("HQ_DEBUG_HALO") && atoi(getenv("HQ_DEBUG_HALO")) != 0 && c->nranks > 1) {
+    if (hq_opt_on("HQ_DEBUG_HALO") && c->nranks > 1) {
         /* the reference's -DDEBUG exchange: every halo record carries the global id of its node and the
          * receiver checks it (psolve.c:5002-5007, 5058-5069).  Identity = node_t.gnid where the caller
          * passes it, else a 64-bit mix of the node's coordinates (equal on every rank that harbors it). */
@@ -1718,10 +1755,10 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
-    c->opt_brick_stream = getenv("HQ_BRICK_STREAM") && atoi(getenv("HQ_BRICK_STREAM")) != 0;
-    c->opt_fused_share = !(getenv("HQ_NO_FUSED_SHARE") && atoi(getenv("HQ_NO_FUSED_SHARE")) != 0);
-    if (getenv("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, atoi(getenv("HQ_PATCH_MERGE_ROUNDS")));
-    if (getenv("HQ_BRICK_BY_COMPONENT")) c->opt_brick_light = atoi(getenv("HQ_BRICK_BY_COMPONENT")) != 0;
+    c->opt_brick_stream = hq_opt_on("HQ_BRICK_STREAM");
+    c->opt_fused_share = !(hq_opt_on("HQ_NO_FUSED_SHARE"));
+    if (hq_opt_has("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, hq_opt_int("HQ_PATCH_MERGE_ROUNDS", 1));
+    if (hq_opt_has("HQ_BRICK_BY_COMPONENT")) c->opt_brick_light = hq_opt_int("HQ_BRICK_BY_COMPONENT", 0) != 0;
     c->h2d_bytes = c->d2h_bytes = 0;          /* the counters of hq_info start with the first call behind hq_create */
     *out = c;
     return HQ_OK;
@@ -1759,7 +1796,7 @@ extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
     hq_patch_cfg cfg = hq_patch_cfg_from_env();
     if (dn.n > 0 && cfg.vmax == 0) cfg.vmax = 384;
     hq_patch_host H;
-    const bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && d->node_xyz && cfg.pmax >= HQ_LAT_ACC;
+    const bool want_lattice = !hq_opt_flag("HQ_PATCH_NO_LATTICE") && d->node_xyz && cfg.pmax >= HQ_LAT_ACC;
     if (hq_patch_plan_host(cfg, E, N, d->lnid, d->node_xyz, dn, want_lattice, &H) != 0)
         return hq_fail(HQ_ERR_ARG, "patch plan: %s", hq_patch_error());
     const hq_lattice_tab& T = hq_lattice();
@@ -1811,7 +1848,7 @@ extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
             }
     }
     for (int64_t n = 0; n < N; n++) if (covered[(size_t)n] != 1) bad++;
-    if (getenv("HQ_PATCH_VERBOSE")) {                      /* owned-node histogram of the patches */
+    if (hq_opt_flag("HQ_PATCH_VERBOSE")) {                      /* owned-node histogram of the patches */
         int64_t hist[8] = { 0 }, hp[8] = { 0 };
         for (auto& D : H.desc) {
             int b = D.nown <= 8 ? 0 : D.nown <= 64 ? 1 : D.nown <= 128 ? 2 : D.nown <= 256 ? 3 : D.nown < 512 ? 4 : D.nown == 512 ? 5 : D.nown <= 640 ? 6 : 7;
@@ -1873,7 +1910,7 @@ extern "C" int hq_stencil_plan_check(const hq_desc* d, int64_t report[6])
     hq_patch_cfg cfg = hq_patch_cfg_from_env();
     if (dn.n > 0 && cfg.vmax == 0) cfg.vmax = 384;
     hq_patch_host H;
-    const bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && cfg.pmax >= HQ_LAT_ACC;
+    const bool want_lattice = !hq_opt_flag("HQ_PATCH_NO_LATTICE") && cfg.pmax >= HQ_LAT_ACC;
     if (hq_patch_plan_host(cfg, E, N, d->lnid, d->node_xyz, dn, want_lattice, &H) != 0)
         return hq_fail(HQ_ERR_ARG, "patch plan: %s", hq_patch_error());
     int64_t ntab = 0, nfull = 0, nbnd_tot = 0, ncorner = 0, bad = 0;
@@ -2281,7 +2318,7 @@ static int hq_mask_compute_stream(hq_ctx* c)
     /* opt-in (HQ_CU_MASK=1): measured on one rank of an 8-way split of the 64M box alone on the GPU
      * (profiles/r03/rank_alone_trace.txt), the chain's kernels then do run beside the brick launch, but that launch
      * -- 512 workgroups for 496 slots -- takes 164 us instead of 122: a second, nearly empty round */
-    if (!(getenv("HQ_CU_MASK") && atoi(getenv("HQ_CU_MASK")) != 0)) return HQ_OK;
+    if (!(hq_opt_on("HQ_CU_MASK"))) return HQ_OK;
     hipDeviceProp_t prop;
     HQ_HIP(hipGetDeviceProperties(&prop, c->device));
     const int ncu = prop.multiProcessorCount;
@@ -2319,6 +2356,7 @@ extern "C" int hq_comm_unique_id(void* id128)
 
 extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
 {
+    hq_opt_scope opt_scope(c ? &c->opts : nullptr);
     if (!c || !id128) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     HQ_TRY(hq_rccl_load());
@@ -2327,7 +2365,7 @@ extern "C" int hq_comm_init(hq_ctx* c, const void* id128)
     memcpy(&id, id128, sizeof id);
     HQ_NCCL(g_rccl.CommInitRank(&c->comm, c->nranks, id, c->rank));
     /* between GPUs the exchange is latency the interior patches can hide: run the chain on its own stream */
-    c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
+    c->overlap = c->can_overlap && !(hq_opt_off("HQ_OVERLAP"));
     return hq_mask_compute_stream(c);
 }
 
@@ -2359,12 +2397,13 @@ extern "C" int hq_comm_selftest(hq_ctx* c, int32_t count)
 
 extern "C" int hq_comm_init_host(hq_ctx* c, hq_host_exchange_fn fn, void* user)
 {
+    hq_opt_scope opt_scope(c ? &c->opts : nullptr);
     if (!c || !fn) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     c->host_xchg = fn;
     c->host_user = user;
     /* as between GPUs: the chain on its own stream, so that the host waits for the exchange stream only */
-    c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
+    c->overlap = c->can_overlap && !(hq_opt_off("HQ_OVERLAP"));
     return hq_mask_compute_stream(c);
 }
 
@@ -2439,13 +2478,9 @@ static int hq_ipc_prepare(hq_ctx* c)
      * holds it either, so remote stores are seen as well -- for runtimes that will not export a fine-grained
      * allocation), and coarse-grained as the last resort (ranks of ONE device only).  HQ_IPC_COARSE=1 / HQ_IPC_ARENA=
      * fine | uncached | coarse pins the kind (tests). */
-    bool coarse = getenv("HQ_IPC_COARSE") && atoi(getenv("HQ_IPC_COARSE")) != 0;
+    bool coarse = hq_opt_on("HQ_IPC_COARSE");
     int first_kind = coarse ? 2 : 0, last_kind = 2;
-    if (const char* k = getenv("HQ_IPC_ARENA")) {
-        if (!strcmp(k, "fine")) first_kind = last_kind = 0;
-        else if (!strcmp(k, "uncached")) first_kind = last_kind = 1;
-        else if (!strcmp(k, "coarse")) first_kind = last_kind = 2;
-    }
+    if (hq_opt_has("HQ_IPC_ARENA")) first_kind = last_kind = std::min(2, std::max(0, hq_opt_int("HQ_IPC_ARENA", 0)));
     for (int attempt = first_kind; attempt <= last_kind; attempt++) {
         hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&I->arena, I->arena_bytes, hipDeviceMallocFinegrained)
                      : attempt == 1 ? hipExtMallocWithFlags(&I->arena, I->arena_bytes, hipDeviceMallocUncached)
@@ -2482,14 +2517,15 @@ static int hq_ipc_prepare(hq_ctx* c)
     B.reserved = (int32_t)(dump_off / 8);
     if (c->debug_halo)
         for (int x = 0; x < 4; x++) I->d_in_id[x] = (int64_t*)((char*)I->arena + B.id_off[x]);
-    if (getenv("HQ_IPC_TIMEOUT_MS") && atof(getenv("HQ_IPC_TIMEOUT_MS")) > 0)
-        I->timeout_ticks = (unsigned long long)(atof(getenv("HQ_IPC_TIMEOUT_MS")) * 1.0e5);
+    if (hq_opt_double("HQ_IPC_TIMEOUT_MS", 0.0) > 0)
+        I->timeout_ticks = (unsigned long long)(hq_opt_double("HQ_IPC_TIMEOUT_MS", 0.0) * 1.0e5);
     c->ipc = I;
     return HQ_OK;
 }
 
 extern "C" int hq_comm_ipc_export(hq_ctx* c, void* blob)
 {
+    hq_opt_scope opt_scope(c ? &c->opts : nullptr);
     if (!c || !blob) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_TRY(hq_ipc_prepare(c));
     memset(blob, 0, HQ_IPC_BLOB_BYTES);
@@ -2582,14 +2618,15 @@ static int hq_ipc_connect(hq_ctx* c, const char* blobs)
     }
     I->ready = true;
     I->loopback = loop;
-    if (loop && getenv("HQ_LOOPBACK_DELAY_US")) I->delay_ticks = (unsigned long long)(atof(getenv("HQ_LOOPBACK_DELAY_US")) * 100.0);
+    if (loop && hq_opt_has("HQ_LOOPBACK_DELAY_US")) I->delay_ticks = (unsigned long long)(hq_opt_double("HQ_LOOPBACK_DELAY_US", 0.0) * 100.0);
     /* as between GPUs: the chain on its own stream beside the interior work */
-    c->overlap = c->can_overlap && !(getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) == 0);
+    c->overlap = c->can_overlap && !(hq_opt_off("HQ_OVERLAP"));
     return hq_mask_compute_stream(c);
 }
 
 extern "C" int hq_comm_init_ipc(hq_ctx* c, const void* blobs)
 {
+    hq_opt_scope opt_scope(c ? &c->opts : nullptr);
     if (!c || !blobs) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     if (!c->ipc) return hq_fail(HQ_ERR_STATE, "hq_comm_init_ipc needs the blobs of hq_comm_ipc_export (this rank's among them)%s", "");
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
@@ -2606,6 +2643,7 @@ extern "C" int hq_comm_init_ipc_n(hq_ctx* c, const void* blobs, int32_t nblobs)
 
 extern "C" int hq_comm_init_loopback(hq_ctx* c)
 {
+    hq_opt_scope opt_scope(c ? &c->opts : nullptr);
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_TRY(hq_ipc_prepare(c));
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
@@ -2614,6 +2652,7 @@ extern "C" int hq_comm_init_loopback(hq_ctx* c)
 
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
 {
+    hq_opt_scope opt_scope((ctxs && n > 0 && ctxs[0]) ? &ctxs[0]->opts : nullptr);      /* the group follows its first member's options */
     if (!ctxs || n < 1) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     for (int32_t i = 0; i < n; i++) {
         if (!ctxs[i] || ctxs[i]->rank != i || ctxs[i]->nranks != n)
@@ -2650,7 +2689,7 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
      * COPIES (hipMemcpyAsync), whose coherence with the destination device's L2 the runtime answers for -- plain peer
      * stores into coarse-grained memory do not have it; the IPC transport with its fine-grained arena is the
      * peer-store path between devices */
-    const bool direct = one_device && !getenv("HQ_GROUP_COPIES");
+    const bool direct = one_device && !hq_opt_flag("HQ_GROUP_COPIES");
     if (direct) {
         for (int32_t i = 0; i < n; i++) {
             hq_ctx* c = ctxs[i];
@@ -2696,7 +2735,7 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
      * the device anyway -- and pay for its events: the 64M box in 8 in-process partitions steps in 2.54 ms on one
      * stream per partition against 3.28 ms with the chain on a second one (round 2; HQ_OVERLAP=1 forces it, which is
      * how the GPU tests cover that path without a second GPU). */
-    const bool ov = getenv("HQ_OVERLAP") && atoi(getenv("HQ_OVERLAP")) != 0;
+    const bool ov = hq_opt_on("HQ_OVERLAP");
     for (int32_t i = 0; i < n; i++) { ctxs[i]->group = g; ctxs[i]->overlap = ov && ctxs[i]->can_overlap; }
     for (size_t k = 0; k < tables.size(); k++) {
         hq_dev_schedule* s = tables[k].which ? &tables[k].c->dn : &tables[k].c->an;

@@ -40,6 +40,7 @@ static inline int omp_get_thread_num(void) { return 0; }
 #include <cstring>
 
 #include "hq_kernels.h"
+#include "hq_opts.h"
 
 #define HQ_PATCH_MAX_THREADS 512
 
@@ -51,8 +52,7 @@ static inline int omp_get_thread_num(void) { return 0; }
  * patches with partition-interface nodes.  -> -1 (not set) or the value. */
 static inline int hq_patch_ragged_env(void)
 {
-    const char* e = getenv("HQ_PATCH_RAGGED");
-    return e ? atoi(e) : -1;         /* 2: as 1, but patches with partition-interface nodes keep the element form */
+    return hq_opt_int("HQ_PATCH_RAGGED", -1);         /* 2: as 1, but patches with partition-interface nodes keep the element form */
 }
 
 struct hq_patch_cfg {
@@ -69,7 +69,7 @@ struct hq_patch_cfg {
 static hq_patch_cfg hq_patch_cfg_from_env(void)
 {
     hq_patch_cfg c;
-    auto geti = [](const char* n, int def) { const char* v = getenv(n); return (v && *v) ? atoi(v) : def; };
+    auto geti = [](const char* n, int def) { return hq_opt_int(n, def); };
     c.threads = geti("HQ_PATCH_THREADS", c.threads);
     c.pmax = geti("HQ_PATCH_PMAX", c.pmax);
     c.pmerge = geti("HQ_PATCH_PMERGE", c.pmerge);
@@ -198,7 +198,7 @@ struct hq_patch_plan {
  * 4 = hq_k_patch_pers where it fits, 0 = hq_k_patch_step always */
 static int hq_patch_kernel_choice(void)              /* read when a plan is built and kept in it (hq_patch_plan.pipe) */
 {
-    return getenv("HQ_PATCH_PIPE") ? atoi(getenv("HQ_PATCH_PIPE")) : 6;
+    return hq_opt_int("HQ_PATCH_PIPE", 6);
 }
 
 static thread_local std::string g_patch_err;
@@ -837,7 +837,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         {
             std::unordered_map<uint64_t, std::vector<int32_t>> seen;
             int32_t ndistinct = 0;
-            const bool dedup = !getenv("HQ_PATCH_NO_DEDUP");
+            const bool dedup = !hq_opt_flag("HQ_PATCH_NO_DEDUP");
             for (int32_t p = 0; p < P; p++) {
                 hq_patch_desc& D = H->desc[p];
                 D.pidx_off = D.pair_off;
@@ -2158,7 +2158,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                max_npairs <= HQ_PERS_THREADS &&
                (12 * (size_t)nrows + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax) + 36) * sizeof(double) <= 160 * 1024;
     };
-    bool want_lattice = !getenv("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
+    bool want_lattice = !hq_opt_flag("HQ_PATCH_NO_LATTICE") && xyz && P->cfg.pmax >= HQ_LAT_ACC &&
                         pers_fits(std::max(P->cfg.nlmax, HQ_LAT_ROWS), 0);
     std::vector<int32_t> cand;                       /* the shell's elements: found once, used by every plan below */
     for (;;) {
@@ -2167,7 +2167,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
          * persistent kernels' prologue and work queue cost more than they save there, and one workgroup per patch
          * (hq_k_patch_step, two per CU) fills the device at once: 64M box 1.104 -> 1.060 ms per step, 8M box
          * 0.159 -> 0.148 on the same box.  HQ_PATCH_PIPE overrides. */
-        if (n0 > 0 && !getenv("HQ_PATCH_PIPE") && P->pipe != 0 && H.desc.size() <= 16384) {
+        if (n0 > 0 && !hq_opt_has("HQ_PATCH_PIPE") && P->pipe != 0 && H.desc.size() <= 16384) {
             P->pipe = 0;
             if (want_lattice) { want_lattice = false; H = hq_patch_host(); continue; }
         }
@@ -2203,7 +2203,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         nt3[3 * n] = (P->seeded && seed0[n]) ? -ntab[7 * n] : ntab[7 * n];
         nt3[3 * n + 1] = ntab[7 * n + 1]; nt3[3 * n + 2] = ntab[7 * n + 4];
     }
-    const bool use_iso = !getenv("HQ_PATCH_NO_ISO");
+    const bool use_iso = !hq_opt_flag("HQ_PATCH_NO_ISO");
     int32_t nntsame = 0;
     for (auto& D : H.desc) {
         bool iso = use_iso;
@@ -2213,14 +2213,14 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
         }
         D.flags = (D.flags & HQ_PATCH_LATTICE) | (iso ? HQ_PATCH_ISO : 0);
         /* interior of a homogeneous region: one n_t row serves the whole patch (bitwise equal rows) */
-        bool same = iso && D.nown > 0 && !getenv("HQ_PATCH_NO_NTSAME");
+        bool same = iso && D.nown > 0 && !hq_opt_flag("HQ_PATCH_NO_NTSAME");
         for (int32_t n = D.base + 1; n < D.base + D.nown && same; n++)
             same = memcmp(&nt3[3 * (size_t)n], &nt3[3 * (size_t)D.base], 24) == 0;
         if (same) { D.flags |= HQ_PATCH_NTSAME; nntsame++; }
     }
     int32_t nuniform = 0;
-    const bool wform = !(getenv("HQ_PATCH_WFORM") && atoi(getenv("HQ_PATCH_WFORM")) == 0);
-    if (!getenv("HQ_PATCH_NO_UNIFORM")) {
+    const bool wform = !(hq_opt_off("HQ_PATCH_WFORM"));
+    if (!hq_opt_flag("HQ_PATCH_NO_UNIFORM")) {
         for (auto& D : H.desc) {
             bool uni = D.npairs > 0;
             const int32_t e0 = D.npairs > 0 ? H.pelem[(size_t)D.pair_off] : 0;
@@ -2239,7 +2239,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
      * distribute (full_only: only the full lattice without dashpot) */
     std::vector<uint32_t> rg_tab;
     std::vector<int64_t> rg_off(H.desc.size(), 0);       /* table offset + 2^40 x boundary nodes */
-    if (hq_stencil().ok && xyz && !getenv("HQ_PATCH_NO_STENCIL")) {
+    if (hq_stencil().ok && xyz && !hq_opt_flag("HQ_PATCH_NO_STENCIL")) {
         const bool full_only = !(hq_patch_ragged_env() >= 0 ? hq_patch_ragged_env() != 0 : P->ragged_default);
         std::vector<std::vector<uint32_t>> tabs(H.desc.size());
         std::vector<int32_t> nbnds(H.desc.size(), 0);
@@ -2277,7 +2277,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     {
         int nst = 0;
         for (auto& D : H.desc) nst += (D.flags & HQ_PATCH_STENCIL) != 0;
-        if (getenv("HQ_PATCH_VERBOSE"))
+        if (hq_opt_flag("HQ_PATCH_VERBOSE"))
         fprintf(stderr, "hq patch plan: %zu patches (%d lattice, %d stencil), %d distinct local connectivities, %d with uniform coefficients, %d with one n_t row\n",
                 H.desc.size(), P->nlattice, nst, H.ndistinct, nuniform, nntsame);
     }
@@ -2499,7 +2499,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (count <= 0) return;
     int per_xcd = (count + 7) / 8;
     size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double);
-    static const bool nt_hint = getenv("HQ_PATCH_NT") && atoi(getenv("HQ_PATCH_NT")) != 0;
+    static const bool nt_hint = hq_opt_on("HQ_PATCH_NT");
 #ifdef HQ_PATCH_PROFILING
     if (getenv("HQ_PATCH_DIAG") && atoi(getenv("HQ_PATCH_DIAG")) == 6) {
         static unsigned long long* d_st = nullptr;
@@ -2544,7 +2544,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     }
     auto kern = nt_hint ? hq_k_patch_step<true, 0> : hq_k_patch_step<false, 0>;
 #ifdef HQ_PATCH_PROFILING   /* ablation builds for profiles/: results are WRONG by construction */
-    static const int diag = getenv("HQ_PATCH_DIAG") ? atoi(getenv("HQ_PATCH_DIAG")) : 0;
+    static const int diag = hq_opt_int("HQ_PATCH_DIAG", 0);
     if (diag == 1) kern = hq_k_patch_step<false, 1>;
     if (diag == 2) kern = hq_k_patch_step<false, 2>;
     if (diag == 3) kern = hq_k_patch_step<false, 3>;

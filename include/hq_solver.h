@@ -141,6 +141,67 @@ HQ_API const char* hq_last_error(void);
  */
 HQ_API int hq_create(const hq_desc* desc, int device, hq_ctx** out);
 
+/*
+ * Typed options (ABI 5).  The reference steers its solver through one explicit parameter struct (Param, psolve.c:193-284);
+ * this is the library's: everything that selects kernels, plans or transports, per CONTEXT -- two contexts of one process
+ * may differ, and nothing depends on the environment unless the caller wants it to.  hq_options_init fills every field
+ * with "library default" (-1); hq_create_opts(desc, device, NULL, &ctx) == hq_create(desc, device, &ctx).
+ * Precedence: an HQ_* environment variable of the same name, where set, still overrides the field (experiments,
+ * profiles/tools); hq_get_options returns what the context really runs with, the environment applied.
+ * `size` = sizeof(hq_options) of the caller: a newer library treats the fields an older client does not know as -1.
+ */
+typedef struct {
+    uint64_t size;
+    /* which kernels */
+    int32_t no_bricks;           /* HQ_NO_BRICKS          1: no z-marching brick kernels, patches everywhere             */
+    int32_t brick_cz;            /* HQ_BRICK_CZ           planes per brick unit (default: 32, shorter on small meshes)   */
+    int32_t brick_minz;          /* HQ_BRICK_MINZ         shortest run of planes worth a tile column (4)                 */
+    int32_t brick_minnodes;      /* HQ_BRICK_MINNODES     fewest nodes worth a tile column (512)                         */
+    int32_t brick_no_het;        /* HQ_BRICK_NO_HET       1: no per-element-coefficient brick units (hq_k_brick_het)     */
+    int32_t brick_no_ntsame;     /* HQ_BRICK_NO_NTSAME    1: n_t rows per node even where a unit shares one              */
+    int32_t brick_by_component;  /* HQ_BRICK_BY_COMPONENT 1 / 0: the 100-register / 118-register form of hq_k_brick
+                                                          (default: 100 on contexts with a transport)                   */
+    int32_t brick_stream;        /* HQ_BRICK_STREAM       1: bricks on a stream of their own beside the patches          */
+    int32_t patch_pipe;          /* HQ_PATCH_PIPE         6 hq_k_patch_seed (default), 4 hq_k_patch_pers, 0 hq_k_patch_step */
+    int32_t patch_threads;       /* HQ_PATCH_THREADS      workgroup size of the patch kernels (512)                      */
+    int32_t patch_pmax;          /* HQ_PATCH_PMAX         owned nodes per patch (768)                                    */
+    int32_t patch_pmerge;        /* HQ_PATCH_PMERGE       neighbouring cubes are merged up to this (512)                 */
+    int32_t patch_psplit;        /* HQ_PATCH_PSPLIT       a cube with more owned nodes is halved (pmax)                  */
+    int32_t patch_nlmax;         /* HQ_PATCH_NLMAX        owned + halo nodes staged in LDS (1024)                        */
+    int32_t patch_vmax;          /* HQ_PATCH_VMAX         extra accumulators for hanging nodes (set by the planner)      */
+    int32_t patch_ragged;        /* HQ_PATCH_RAGGED       lattice-subset patches: 0 element form, 1 stencil form, 2 stencil
+                                                          form except on the partition interface                        */
+    int32_t patch_no_lattice;    /* HQ_PATCH_NO_LATTICE   1: no lattice patches                                          */
+    int32_t patch_no_stencil;    /* HQ_PATCH_NO_STENCIL   1: lattice patches through the element kernels                 */
+    int32_t patch_no_uniform;    /* HQ_PATCH_NO_UNIFORM   1: per-element coefficients even in uniform patches            */
+    int32_t patch_no_iso;        /* HQ_PATCH_NO_ISO       1: 7-double n_t rows everywhere                                */
+    int32_t patch_no_ntsame;     /* HQ_PATCH_NO_NTSAME    1: n_t rows per node even where a patch shares one             */
+    int32_t patch_no_dedup;      /* HQ_PATCH_NO_DEDUP     1: every patch keeps its own connectivity rows                 */
+    int32_t patch_wform;         /* HQ_PATCH_WFORM        0: hq_k_patch_pers keeps u1, u2 instead of w in LDS            */
+    int32_t patch_merge_rounds;  /* HQ_PATCH_MERGE_ROUNDS one patch launch where the shell is at most this many rounds (1) */
+    /* the exchange chain */
+    int32_t overlap;             /* HQ_OVERLAP            1 / 0: the chain on its own stream beside the interior kernels
+                                                          (default: yes between processes / GPUs, no inside one process) */
+    int32_t no_overlap;          /* HQ_NO_OVERLAP         1: never create the exchange stream                            */
+    int32_t reserve_cus;         /* HQ_RESERVE_CUS        CUs the interior launch leaves to the chain (8)                */
+    int32_t cu_mask;             /* HQ_CU_MASK            1: compute stream with a CU mask that leaves reserve_cus free  */
+    int32_t no_fused_share;      /* HQ_NO_FUSED_SHARE     1: the displacement sharing packed by its own kernel           */
+    int32_t group_copies;        /* HQ_GROUP_COPIES       1: in-process groups exchange through peer copies              */
+    int32_t debug_halo;          /* HQ_DEBUG_HALO         1: every halo record checked on receipt (-DDEBUG, psolve.c:5002-5007) */
+    /* the IPC transport */
+    int32_t ipc_arena;           /* HQ_IPC_ARENA          0 fine-grained, 1 uncached, 2 coarse-grained; default: first that exports */
+    double  ipc_timeout_ms;      /* HQ_IPC_TIMEOUT_MS     a wait for a neighbour's records gives up after this (20 000)  */
+    double  loopback_delay_us;   /* HQ_LOOPBACK_DELAY_US  diagnostic: loopback flags raised this late                    */
+    /* messages */
+    int32_t verbose;             /* HQ_PATCH_VERBOSE      1: where hq_create's time goes; 2: the brick planner's too     */
+    int32_t quiet;               /* HQ_QUIET              1: no advice on stderr                                         */
+} hq_options;
+
+HQ_API void hq_options_init(hq_options* opts, uint64_t size);
+HQ_API int  hq_create_opts(const hq_desc* desc, int device, const hq_options* opts, hq_ctx** out);
+/* what the context runs with (its options, the environment's overrides applied); writes min(size, sizeof) bytes */
+HQ_API int  hq_get_options(hq_ctx* ctx, hq_options* out, uint64_t size);
+
 /* solver_delete (psolve.c:3627-3649). */
 HQ_API int hq_destroy(hq_ctx* ctx);
 
@@ -152,7 +213,7 @@ HQ_API int hq_destroy(hq_ctx* ctx);
  * last of those ended its struct with brick_nodes, so the symbol writes those 56 bytes and never more.
  * hq_abi_version() == HQ_ABI_VERSION is the check a separately compiled client makes at start-up.
  */
-#define HQ_ABI_VERSION 4
+#define HQ_ABI_VERSION 5
 HQ_API int hq_abi_version(void);
 HQ_API int hq_get_info_sized(hq_ctx* ctx, hq_info* info, uint64_t size);
 HQ_API int hq_get_info(hq_ctx* ctx, hq_info* info);

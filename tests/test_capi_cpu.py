@@ -56,3 +56,31 @@ def test_no_cpu_fallback(lib):
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(ha.HqError):
         ha.load_library(str(tmp_path / "libhq_solver.so"))
+
+
+def test_options_struct_matches_the_header_and_initialises_to_defaults(lib):
+    """hq_options (ABI 5): the ctypes mirror has the header's fields in the header's order, hq_options_init writes -1
+    ("library default") into every one of them and never past the size it is given."""
+    txt = open(os.path.join(ROOT, "include", "hq_solver.h")).read()
+    body = txt[txt.index("typedef struct {\n    uint64_t size;"):txt.index("} hq_options;")]
+    fields = re.findall(r"^\s+(?:int32_t|double|uint64_t)\s+(\w+);", body, re.M)
+    assert fields == [n for n, _ in capi.Options._fields_]
+    assert re.search(r"#define HQ_ABI_VERSION 5", txt) and lib.hq_abi_version() == 5
+    o = capi.Options()
+    assert o.size == ctypes.sizeof(o) and all(v == -1 for v in o.as_dict().values())
+    o = capi.Options(brick_cz=16, ipc_timeout_ms=250.0)
+    assert o.brick_cz == 16 and o.ipc_timeout_ms == 250.0 and o.no_bricks == -1
+    with pytest.raises(TypeError):
+        capi.Options(no_such_field=1)
+    # an older client with a shorter struct: nothing is written past its size
+    raw = (ctypes.c_char * ctypes.sizeof(capi.Options))(*([b"\x55"] * ctypes.sizeof(capi.Options)))
+    lib.hq_options_init(raw, ctypes.c_uint64(24))
+    assert bytes(raw)[24:] == b"\x55" * (ctypes.sizeof(capi.Options) - 24)
+    assert int.from_bytes(bytes(raw)[:8], "little") == 24 and bytes(raw)[8:24] == b"\xff" * 16
+
+
+def test_create_opts_without_a_device_fails_like_create(lib):
+    if ha.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(ha.HqError):
+        ha.Solver(np.zeros((1, 8), np.int32), np.ones((1, 4)), np.ones((8, 7)), 1e-3, options={"no_bricks": 1})

@@ -152,3 +152,34 @@ def test_brick_kernel_in_the_form_partitions_launch(monkeypatch, pernode):
     info, tm1, tm2, r1, r2 = _run_both(lnid, node_ijk, et, nt, dt, 12, seed=3)
     assert info["brick_units"] > 0 and (info["brick_units_pernode"] == info["brick_units"]) == pernode
     assert H.rel_linf(tm1, r1) < TOL and H.rel_linf(tm2, r2) < TOL
+
+
+def test_typed_options_select_kernels_per_context(monkeypatch):
+    """hq_options (ABI 5) instead of the environment: two contexts of ONE process differ -- one with bricks, one with
+    hq_options.no_bricks = 1 and hq_k_patch_pers (patch_pipe = 4) -- both against the oracle; hq_get_options returns what
+    each runs with; an HQ_* variable in the environment still overrides the field (experiments)."""
+    lnid, node_ijk, et, nt, dt = _box(96, 40, 24)
+    rng = np.random.default_rng(11)
+    u1 = rng.uniform(-1, 1, (len(nt), 3)) * 1e-3
+    u2 = u1 * 0.999
+    nsteps = 5
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(lnid, et, nt, o1, o2, 0, nsteps, dt)
+    a = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH)
+    b = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH,
+                  options={"no_bricks": 1, "patch_pipe": 4})
+    c = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH,
+                  options=ha.capi.Options(brick_cz=6, brick_by_component=1))
+    assert a.info()["brick_nodes"] > 0 and b.info()["brick_nodes"] == 0
+    assert c.info()["brick_units"] > a.info()["brick_units"]
+    oa, ob, oc = a.options(), b.options(), c.options()
+    assert oa["no_bricks"] == -1 and ob["no_bricks"] == 1 and ob["patch_pipe"] == 4 and oc["brick_cz"] == 6
+    for s in (a, b, c):
+        s.run(nsteps)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+        s.close()
+    monkeypatch.setenv("HQ_NO_BRICKS", "1")                  # the environment still wins
+    d = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH, options={"no_bricks": 0})
+    assert d.info()["brick_nodes"] == 0 and d.options()["no_bricks"] == 1
+    d.close()
