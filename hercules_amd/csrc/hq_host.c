@@ -40,6 +40,8 @@ struct hqh_box {
     hqh_box_params p;
     int ax, ay, az;                 /* log2 of nx, ny, nz */
     uint64_t zmask;                 /* Z-value bits that in-domain elements can set */
+    int64_t *zx, *zy, *zz;          /* the element index's bits from i, j, k: index = zx[i] | zy[j] | zz[k] (the compaction
+                                       of the Z-value over zmask maps the three axes' bits to disjoint positions) */
     int64_t Eg, Ng;                 /* whole box */
     int64_t elo, ehi;               /* my element interval */
     int32_t lenum, nharbored, nowned;
@@ -123,6 +125,7 @@ static int ilog2_exact(int32_t n)
 /* index of element (i,j,k) in the Z-ordered list of in-domain elements */
 static int64_t elem_index(const hqh_box* b, int32_t i, int32_t j, int32_t k)
 {
+    if (b->zx) return b->zx[i] | b->zy[j] | b->zz[k];
     return (int64_t)bits_extract(zvalue((uint32_t)i, (uint32_t)j, (uint32_t)k), b->zmask);
 }
 
@@ -366,6 +369,16 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, do
     }
 }
 
+/* HQH_VERBOSE=1: where the host side's time goes */
+static double hqh_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void hqh_lap(double* t, const char* what)
+{
+    if (!getenv("HQH_VERBOSE")) return;
+    const double n = hqh_now();
+    fprintf(stderr, "  hq_host: %-32s %6.2f s\n", what, n - *t);
+    *t = n;
+}
+
 /* ------------------------------------------------------------------------ */
 /* box                                                                      */
 /* ------------------------------------------------------------------------ */
@@ -379,6 +392,7 @@ void hqh_box_destroy(hqh_box* b)
     free(b->k_c1); free(b->k_c2); free(b->k_c3); free(b->k_c4); free(b->k_a); free(b->k_M);
     free(b->mc); free(b->ms); free(b->cmap); free(b->smap);
     free(b->layer_store);
+    free(b->zx); free(b->zy); free(b->zz);
     free(b);
 }
 
@@ -410,6 +424,13 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     }
     b->ax = ax; b->ay = ay; b->az = az;
     b->zmask = zvalue((uint32_t)p->nx - 1, (uint32_t)p->ny - 1, (uint32_t)p->nz - 1);
+    b->zx = (int64_t*)malloc(sizeof(int64_t) * (size_t)p->nx);
+    b->zy = (int64_t*)malloc(sizeof(int64_t) * (size_t)p->ny);
+    b->zz = (int64_t*)malloc(sizeof(int64_t) * (size_t)p->nz);
+    if (!b->zx || !b->zy || !b->zz) { free(b->zx); free(b->zy); free(b->zz); b->zx = b->zy = b->zz = NULL; hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    for (int32_t i = 0; i < p->nx; i++) b->zx[i] = (int64_t)bits_extract(zvalue((uint32_t)i, 0, 0), b->zmask);
+    for (int32_t j = 0; j < p->ny; j++) b->zy[j] = (int64_t)bits_extract(zvalue(0, (uint32_t)j, 0), b->zmask);
+    for (int32_t k = 0; k < p->nz; k++) b->zz[k] = (int64_t)bits_extract(zvalue(0, 0, (uint32_t)k), b->zmask);
     b->Eg = (int64_t)p->nx * p->ny * p->nz;
     b->Ng = (int64_t)(p->nx + 1) * (p->ny + 1) * (p->nz + 1);
     if (b->Eg < p->nranks) { hqh_box_destroy(b); return HQ_ERR_ARG; }
@@ -430,6 +451,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     }
     if (depth_constants(b) != 0) { hqh_box_destroy(b); return HQ_ERR_ARG; }
 
+    double t_lap = hqh_now();
     /* harbored nodes: corners of my elements, marked on the global node grid */
     b->loc = (int32_t*)malloc(sizeof(int32_t) * (size_t)b->Ng);
     if (!b->loc) { hqh_box_destroy(b); return HQ_ERR_NOMEM; }
@@ -448,6 +470,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
             z = ((z | ~b->zmask) + 1) & b->zmask;          /* next in-domain Z-value */
         }
     }
+    hqh_lap(&t_lap, "box: mark harbored nodes");
     if (nh > 0x7fffffff / 8) { hqh_box_destroy(b); return HQ_ERR_ARG; }
     b->nharbored = (int32_t)nh;
     uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)nh);
@@ -459,8 +482,10 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
                 for (int32_t i = 0; i <= p->nx; i++)
                     if (p->nranks == 1 || b->loc[grid_index(b, i, j, k)] == 0) keys[t++] = node_key(b, i, j, k);
     }
+    hqh_lap(&t_lap, "box: node keys");
     int kbits = 3 * ((ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az)) + 2);
     if (radix_sort_u64(keys, nh, kbits) != 0) { free(keys); hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    hqh_lap(&t_lap, "box: sort");
 
     b->node_ijk = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)nh);
     b->node_xyz = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)nh);
@@ -493,6 +518,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     }
     b->nowned = nown;
     free(keys);
+    hqh_lap(&t_lap, "box: node tables");
 
     /* elements */
 #pragma omp parallel
@@ -515,7 +541,9 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
             z = ((z | ~b->zmask) + 1) & b->zmask;
         }
     }
+    hqh_lap(&t_lap, "box: element tables");
     int rc = build_schedule(b);
+    hqh_lap(&t_lap, "box: schedule");
     if (rc != HQ_OK) { hqh_box_destroy(b); return rc; }
     *out = b;
     return HQ_OK;
