@@ -375,12 +375,14 @@ def inproc_diagnostic(args):
                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "overlap": os.environ.get("HQ_OVERLAP", "0")}))
 
 
-def select_transport(want, solver, new_solver, bring_up, trial, trials):
+def select_transport(want, solver, new_solver, bring_up, trial, trials, agree=None):
     """Which transport carries the halo records of an N > 1 run.  Pure control flow (tests/test_bench_roofline_cpu.py
     drives it with stand-ins): `solver` is the context built so far, `new_solver()` builds another one on the same mesh,
     `bring_up(kind, solver)` -> True if transport `kind` is in place on EVERY rank, `trial(solver)` -> ms per step or None.
     want = auto: RCCL and IPC are both brought up (a context each), both timed, the faster kept; one of them alone if the
-    other does not come up; host-staged if neither does.  want = rccl / ipc: that one, else the other device-side one
+    other does not come up; host-staged if neither does.  `agree(a, b)` (optional) -> do the two timed contexts hold the
+    same field after their identical trial runs?  If not, the IPC transport -- peer stores ordered by flags, the newer
+    and less proven of the two -- is rejected whatever it measured (round-4 advisor).  want = rccl / ipc: that one, else the other device-side one
     (rccl -> ipc), else host-staged.  A context whose bring-up failed is closed, never reused.
     -> (solver that carries the chosen transport, its name); `trials` is filled with what was measured."""
     chosen = None
@@ -397,6 +399,9 @@ def select_transport(want, solver, new_solver, bring_up, trial, trials):
                 trials[kind] = trial(sv)
             alive = {k: v for k, v in trials.items() if v is not None}
             chosen = min(alive, key=alive.get) if alive else None
+            if agree is not None and len(alive) == 2 and not agree(up["rccl"], up["ipc"]):
+                trials["ipc_rejected"] = "its field differs from the RCCL context's after the same trial run"
+                chosen = "rccl"
         elif up:
             chosen = next(iter(up))
         for kind, sv in up.items():
@@ -622,6 +627,81 @@ def traffic_of(pmc, kernel, steps=PMC_STEPS):
     return rd + wr, rd, wr, steps
 
 
+PARITY_STEPS = 3                # steps of the parity run behind the timed region
+PARITY_EDGE = 16                # elements per axis of a window (a power of two: hqh_box_create)
+PARITY_TOL = 1e-9               # the GPU parity bar: relative L-inf on nodal displacement
+PARITY_WORKLOADS = ("c1", "c2", "c3", "m1")     # homogeneous boxes: a window of them is a small box of the same material
+
+
+def parity_windows(args, box, solver, rank, world):
+    """Parity that travels with the bench line (round-4 review, item 5): BEHIND the timed region the context -- same
+    partition, same transport -- is reset to the seeded start field and stepped PARITY_STEPS times; after k steps a node
+    depends on its k-ring only, so a window of 16^3 elements cut from the box (here: built as a box of its own with the
+    same h, dt and material, domain faces where the window touches the domain's) and stepped by the oracle's reference
+    loops gives the exact values of the nodes at least k layers inside every cut face.  The windows are centred on nodes
+    this rank SHARES with others (its partition interfaces: pack, transport, interface update and unpack are inside the
+    checked cones), plus brick-tile borders and domain faces.
+    -> (windows, nodes checked, worst relative error) of this rank; None for workloads without a window oracle."""
+    if args.workload not in PARITY_WORKLOADS:
+        return None
+    from hercules_amd import host as hhost
+    from oracle import herc_oracle as ho             # the checker, behind the timed region only
+    nx, ny, nz, h, dt, freq = WORKLOADS[args.workload]
+    k, W = PARITY_STEPS, PARITY_EDGE
+    dims = (nx, ny, nz)
+    if min(dims) < W:
+        return None
+    u1 = seeded_field(box.node_ijk, nx, ny)
+    solver.set_source(np.zeros(0, np.int32), np.zeros((0, 0, 3)))
+    solver.upload(u1, u1 * (1.0 - 1e-3), 0)
+    solver.run(k)
+    solver.sync()
+    ijk = box.node_ijk.astype(np.int64)
+    key = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    order = np.argsort(key)
+    skey = key[order]
+    centres = []
+    if world > 1:
+        sch = box.schedule()
+        shared = np.unique(np.concatenate([m for _, m in sch["c"] + sch["s"]] or [np.zeros(0, np.int32)]))
+        if len(shared):
+            centres += [tuple(ijk[n]) for n in shared[np.linspace(0, len(shared) - 1, 12).astype(np.int64)]]
+    lo_n, hi_n = ijk.min(axis=0), ijk.max(axis=0)
+    mid = (lo_n + hi_n) // 2
+    centres += [tuple(mid), (int(lo_n[0]) + 64, int(lo_n[1]) + 8, int(mid[2])), (int(lo_n[0]), int(mid[1]), int(mid[2])),
+                (int(mid[0]), int(mid[1]), int(lo_n[2])), (int(hi_n[0]), int(hi_n[1]), int(hi_n[2]))]
+    scale = np.abs(u1).max()
+    nwin, nchecked, worst, seen = 0, 0, 0.0, set()
+    for c in centres:
+        lo = tuple(int(min(max(c[d] - W // 2, 0), dims[d] - W)) for d in range(3))
+        if lo in seen:
+            continue
+        seen.add(lo)
+        sub = hhost.Box(W, W, W, h, dt, freq)
+        g = sub.node_ijk.astype(np.int64) + np.array(lo)
+        w1 = seeded_field(g, nx, ny)
+        o1, o2 = w1 * (1.0 - 1e-3), w1.copy()
+        ho.solver_run(sub.lnid, sub.etable.copy(), sub.ntable.copy(), o1, o2, 0, k, dt)
+        ok = np.ones(len(g), bool)
+        for d in range(3):
+            if lo[d] > 0:                                   # a cut face unless it is the domain's own near face
+                ok &= g[:, d] >= lo[d] + k
+            if lo[d] + W < dims[d]:
+                ok &= g[:, d] <= lo[d] + W - k
+        sub.close()
+        gk = (g[:, 2] * (ny + 1) + g[:, 1]) * (nx + 1) + g[:, 0]
+        pos = np.searchsorted(skey, gk)
+        pos[pos >= len(skey)] = 0
+        mine = ok & (skey[pos] == gk)                       # the checked nodes this rank harbors
+        if not mine.any():
+            continue
+        tm1, tm2 = solver.gather(order[pos[mine]].astype(np.int32))
+        worst = max(worst, float(np.abs(tm1 - o2[mine]).max() / scale), float(np.abs(tm2 - o1[mine]).max() / scale))
+        nwin += 1
+        nchecked += int(mine.sum())
+    return nwin, nchecked, worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -635,6 +715,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--pmc-dir", default=None, help="keep the rocprofv3 counter CSVs of the traffic passes here")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the oracle cone windows behind the timed region (config.parity_*)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N: start the N ranks, let them rendezvous over gloo on the CPU and exit "
@@ -718,13 +800,27 @@ def main():
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         return float(t_ok[0]) >= 1.0
 
-    def new_solver():
-        variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+    def start_field():
         nx_, ny_ = WORKLOADS[args.workload][:2]
         interfaces = () if not octree else (box.start_interfaces if args.workload in OCT_BASIN
                                             else make_octbox_interfaces(args.workload))
-        u1 = seeded_field(box.node_ijk, nx_, ny_, interfaces)
-        return box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3))
+        return seeded_field(box.node_ijk, nx_, ny_, interfaces)
+
+    def new_solver():
+        """A second context on the same partition -- on EVERY rank or on none: a rank that cannot build one (device
+        memory) must not leave the others waiting in the next collective (round-4 advisor)."""
+        variant = {"auto": ha.HQ_VARIANT_AUTO, "scatter": ha.HQ_VARIANT_SCATTER, "patch": ha.HQ_VARIANT_PATCH}[args.variant]
+        sv, why = None, ""
+        try:
+            u1 = start_field()
+            sv = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3))
+        except Exception as exc:
+            why = str(exc)
+        if not everywhere(sv is not None):
+            if sv is not None:
+                sv.close()
+            raise SystemExit("bench.py: rank %d: a rank could not build a second solver context %s" % (rank, why))
+        return sv
 
     def bring_up(kind, sv):
         """-> True if `kind` is in place on every rank's `sv`."""
@@ -787,7 +883,21 @@ def main():
     if world > 1:
         names = {"rccl": "RCCL grouped send/recv", "ipc": "IPC peer stores + epoch flags (hq_comm_init_ipc)",
                  "host": "host-staged (pinned buffers + gloo)"}
-        solver, chosen = select_transport(want, solver, new_solver, bring_up, trial, trials)
+        def agree(a, b):
+            """Same start, same trial steps, two transports: the fields must agree to the parity bar on every rank."""
+            n_here = box.info["nharbored"]
+            sample = np.unique(np.linspace(0, n_here - 1, min(n_here, 65536)).astype(np.int32))
+            ga, gb = a.gather(sample)[0], b.gather(sample)[0]
+            err = float(np.abs(ga - gb).max() / max(np.abs(ga).max(), 1e-300))
+            return everywhere(err <= PARITY_TOL)
+
+        solver, chosen = select_transport(want, solver, new_solver, bring_up, trial, trials, agree)
+        if trials:
+            # the chosen context has run the trial's steps: back to the start field and step 0, so that the measured run
+            # (its source window included) is the N = 1 run's (round-4 advisor)
+            u1 = start_field()
+            solver.upload(u1, u1 * (1.0 - 1e-3), 0)
+            del u1
         rccl_ranks = int(solver.info()["nranks"]) if chosen == "rccl" else 0
         if chosen == "ipc":
             names["ipc"] += ", %s-grained receive arena" % ("coarse" if solver.info()["ipc_arena_coarse"] else "fine")
@@ -824,6 +934,24 @@ def main():
         t = torch.tensor([elapsed, kernel_ms, float(nonfinite)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, nonfinite = float(t[0]), float(t[1]), int(t[2])
+
+    # parity that travels with the line: oracle cone windows on THIS context (partition + transport), behind the timed region
+    parity = None
+    if not args.no_parity:
+        try:
+            parity = parity_windows(args, box, solver, rank, world)
+        except Exception as exc:                            # reported, never silently dropped
+            parity = (0, 0, 1e300)
+            print("bench.py: rank %d: parity windows failed: %s" % (rank, exc), file=sys.stderr)
+        if world > 1:
+            have = parity is not None
+            t = torch.tensor([float(parity[0]) if have else 0.0, float(parity[1]) if have else 0.0], dtype=torch.float64)
+            w = torch.tensor([parity[2] if have else 0.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            if have:
+                parity = (int(t[0]), int(t[1]), float(w[0]))
+    parity_failed = parity is not None and not (parity[0] > 0 and parity[2] <= PARITY_TOL)
 
     if rank == 0:
         E_total = box.info["total_elements"]
@@ -881,7 +1009,12 @@ def main():
                        "setup_s": round(setup_s, 1), "finite": nonfinite == 0, "rccl_ranks": rccl_ranks,
                        "transport": transport, "transport_trials_ms_per_step": trials or None,
                        "brick_nodes": int(info["brick_nodes"]),
-                       "preheat_s": args.preheat},
+                       "preheat_s": args.preheat,
+                       # oracle cone windows stepped on this very context behind the timed region (parity_windows)
+                       "parity_windows": parity[0] if parity else None,
+                       "parity_nodes": parity[1] if parity else None,
+                       "parity_worst": parity[2] if parity else None,
+                       "parity_steps": PARITY_STEPS if parity else None, "parity_tol": PARITY_TOL},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch
             # time (HIP events on its stream); where the counters are unavailable, the compulsory bytes
             # (a lower bound).  The reference formulation's 336 B per element-update is kept only as
@@ -907,9 +1040,12 @@ def main():
     barrier()                # every rank's library chatter is out before the one JSON line
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            print("bench.py: PARITY FAILED: %s windows, worst relative error %s (bar %g)" % (parity[0], parity[2], PARITY_TOL),
+                  file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
-    return 0
+    return 1 if parity_failed else 0
 
 
 if __name__ == "__main__":

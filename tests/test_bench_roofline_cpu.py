@@ -109,8 +109,9 @@ class _FakeSolver:
         self.closed = True
 
 
-def _select(want, comes_up, ms):
-    """comes_up: {kind: bool}; ms: {kind: ms per step or None (the trial failed)}."""
+def _select(want, comes_up, ms, agree=None):
+    """comes_up: {kind: bool}; ms: {kind: ms per step or None (the trial failed)}; agree: do the two trial contexts hold
+    the same field (None: not asked)."""
     _FakeSolver.made = 0
     first = _FakeSolver()
     made = [first]
@@ -128,7 +129,8 @@ def _select(want, comes_up, ms):
         return False
 
     trials = {}
-    solver, chosen = bench.select_transport(want, first, new_solver, bring_up, lambda sv: ms[sv.transport], trials)
+    solver, chosen = bench.select_transport(want, first, new_solver, bring_up, lambda sv: ms[sv.transport], trials,
+                                            None if agree is None else (lambda a, b: agree))
     alive = [s for s in made if not s.closed]
     assert alive == [solver] and solver.transport == chosen    # exactly the chosen context survives, and it carries it
     return chosen, trials
@@ -138,6 +140,10 @@ def test_transport_selection_of_a_multi_gpu_bench_run():
     # both device-side transports come up: both are timed, the faster one is kept
     assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.30, "ipc": 0.21}) == ("ipc", {"rccl": 0.30, "ipc": 0.21})
     assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.18, "ipc": 0.21})[0] == "rccl"
+    # the faster IPC transport is REJECTED when its field differs from the RCCL context's after the same trial run
+    chosen, tr = _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.30, "ipc": 0.21}, agree=False)
+    assert chosen == "rccl" and "ipc_rejected" in tr
+    assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": 0.30, "ipc": 0.21}, agree=True)[0] == "ipc"
     # a trial that fails (timeouts, a device error) takes its transport out
     assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": None, "ipc": 0.4})[0] == "ipc"
     assert _select("auto", {"rccl": True, "ipc": True}, {"rccl": None, "ipc": None})[0] == "host"
@@ -152,3 +158,49 @@ def test_transport_selection_of_a_multi_gpu_bench_run():
     assert _select("ipc", {"ipc": True}, {})[0] == "ipc"
     assert _select("ipc", {"ipc": False}, {})[0] == "host"
     assert _select("host", {}, {})[0] == "host"
+
+
+def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch):
+    """bench.parity_windows (the oracle cone windows every bench line carries, config.parity_*) with a stand-in for the
+    device context that steps the WHOLE box with the oracle: a window built as a 16^3 box of its own must then agree to
+    rounding at every checked node -- in the interior, at brick-tile borders and where windows touch the domain's faces,
+    edges and corners (dashpots, free surface) -- and must notice a context that computes something else."""
+    import argparse
+    import bench
+    from hercules_amd import host
+    from oracle import herc_oracle as ho
+    monkeypatch.setitem(bench.WORKLOADS, "c1", (128, 32, 32, 62.5, 1e-3, 5.0))
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS["c1"]
+    box = host.Box(nx, ny, nz, h, dt, freq)
+
+    class WholeBoxOracle:
+        wrong = 0.0
+
+        def set_source(self, ids, F):
+            assert len(ids) == 0
+
+        def upload(self, tm1, tm2, step):
+            self.u1, self.u2 = tm1.copy(), tm2.copy()
+
+        def run(self, k):
+            o1, o2 = self.u2.copy(), self.u1.copy()
+            ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, k, dt)
+            self.u1, self.u2 = o2, o1
+            self.u1[1000] += self.wrong
+
+        def sync(self):
+            pass
+
+        def gather(self, ids):
+            return self.u1[ids], self.u2[ids]
+
+    args = argparse.Namespace(workload="c1")
+    s = WholeBoxOracle()
+    nwin, nchecked, worst = bench.parity_windows(args, box, s, 0, 1)
+    assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-13
+    s.wrong = 1e-6
+    checked_1000 = bench.parity_windows(args, box, s, 0, 1)[2]
+    args2 = argparse.Namespace(workload="o3")
+    assert bench.parity_windows(args2, box, s, 0, 1) is None          # no window oracle for this workload: reported as null
+    assert checked_1000 < 1e-13 or checked_1000 > 1e-9                  # node 1000 is either outside every window or caught
+    box.close()

@@ -1,0 +1,44 @@
+"""bench.py itself on the GPU: the line it prints carries its own parity (config.parity_*: oracle cone windows stepped on
+the timed context behind the timed region), on one rank and on ranks that share this box's one GPU -- the N > 1 path
+the driver's scaling run takes (launcher, rendezvous, transport selection with both device-side transports brought up
+and timed, partitioned stepping), minus a second GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env_extra=None, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_one_rank_line_carries_its_parity():
+    d = _bench("--workload", "m1", "--steps", "20", "--warmup", "5", "--no-pmc", "--no-cpu-baseline")
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["finite"] and c["brick_nodes"] > 0
+    assert c["parity_windows"] >= 4 and c["parity_nodes"] > 4 * 11 ** 3 and c["parity_worst"] <= c["parity_tol"] == 1e-9
+
+
+@pytest.mark.parametrize("world,transport", [(2, "auto"), (8, "ipc"), (2, "host")])
+def test_ranks_sharing_the_gpu_carry_their_parity(world, transport):
+    """HQ_BENCH_SHARE_GPU=1: the ranks of `bench.py --gpus N` on one device (RCCL refuses that, so `auto` times the IPC
+    transport alone and keeps it).  Every rank's windows sit on ITS partition interfaces: pack, transport, interface
+    update and unpack of the run that was timed are inside the checked cones."""
+    d = _bench("--gpus", str(world), "--workload", "c2" if world == 8 else "m1", "--steps", "10", "--warmup", "3",
+               env_extra={"HQ_BENCH_SHARE_GPU": "1", "HQ_BENCH_TRANSPORT": transport})
+    c = d["config"]
+    assert d["n_gpus"] == world and c["finite"]
+    assert ("IPC" in c["transport"] or "ipc" in c["transport"].lower()) if transport != "host" else "host" in c["transport"].lower()
+    assert c["parity_windows"] >= 4 * world and c["parity_worst"] <= 1e-9
