@@ -52,7 +52,9 @@ class _Desc(ctypes.Structure):
                 ("tm1", ctypes.c_void_p), ("tm2", ctypes.c_void_p),
                 ("an_sched", _Schedule), ("dn_sched", _Schedule),
                 ("deltaT", ctypes.c_double), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32), ("node_gnid", ctypes.c_void_p)]
+                ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32), ("node_gnid", ctypes.c_void_p),
+                ("edata", ctypes.c_void_p), ("mat_bbase", ctypes.c_double), ("mat_threshold_damping", ctypes.c_double),
+                ("mat_threshold_vpvs", ctypes.c_double)]
 
 
 class _Info(ctypes.Structure):
@@ -64,12 +66,13 @@ class _Info(ctypes.Structure):
                 ("brick_nodes", ctypes.c_int64), ("brick_units_pernode", ctypes.c_int32),
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
                 ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
-                ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32)]
+                ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32),
+                ("brick_units_packed", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 # hq_options (include/hq_solver.h): int32 fields in the header's order, two doubles, two more int32
 OPTION_FIELDS = ["no_bricks", "brick_cz", "brick_minz", "brick_minnodes", "brick_no_het", "brick_no_ntsame", "brick_by_component",
-                 "brick_stream", "patch_pipe", "patch_threads", "patch_pmax", "patch_pmerge", "patch_psplit", "patch_nlmax",
+                 "brick_stream", "brick_no_pack", "patch_pipe", "patch_threads", "patch_pmax", "patch_pmerge", "patch_psplit", "patch_nlmax",
                  "patch_vmax", "patch_ragged", "patch_no_lattice", "patch_no_stencil", "patch_no_uniform", "patch_no_iso",
                  "patch_no_ntsame", "patch_no_dedup", "patch_wform", "patch_merge_rounds", "overlap", "no_overlap", "reserve_cus",
                  "cu_mask", "no_fused_share", "group_copies", "debug_halo", "ipc_arena"]
@@ -154,8 +157,10 @@ class Solver:
 
     def __init__(self, lnid, etable, ntable, dt, tm1=None, tm2=None, node_xyz=None,
                  dangling=None, an_sched=None, dn_sched=None, rank=0, nranks=1,
-                 variant=HQ_VARIANT_AUTO, device=0, options=None):
-        """options: an Options (hq_options) or a dict of its fields; None = hq_create's defaults."""
+                 variant=HQ_VARIANT_AUTO, device=0, options=None, edata=None, material=None):
+        """options: an Options (hq_options) or a dict of its fields; None = hq_create's defaults.
+        edata [E,4] float32 (edgesize, Vp, Vs, rho as solver_init left them) + material = (bBase, threshold_damping,
+        threshold_vpvs): hq_desc.edata / mat_* -- lets hq_k_brick_het keep 12 bytes per element."""
         lib = load_library()
         if isinstance(options, dict):
             options = Options(**options)
@@ -181,6 +186,12 @@ class Solver:
             keep += [ids, ptr, anchors]
             d.ldnnum = len(ids)
             d.dn_ldnid, d.dn_ptr, d.dn_lanid = _ptr(ids), _ptr(ptr), _ptr(anchors)
+        if edata is not None:
+            edata = np.ascontiguousarray(edata, np.float32)
+            assert edata.shape == (lnid.shape[0], 4) and material is not None
+            keep.append(edata)
+            d.edata = _ptr(edata)
+            d.mat_bbase, d.mat_threshold_damping, d.mat_threshold_vpvs = [float(v) for v in material]
         d.an_sched = _schedule(an_sched, keep)
         d.dn_sched = _schedule(dn_sched, keep)
         d.deltaT, d.rank, d.nranks, d.variant = dt, rank, nranks, variant

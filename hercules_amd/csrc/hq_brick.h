@@ -48,6 +48,9 @@
 #endif
 #define HQ_BK_NTSAME 1           /* every node of the unit has the same n_t row: it is in the unit's record */
 #define HQ_BK_HET 2              /* the elements around the unit's nodes have coefficients of their own: hq_k_brick_het */
+#define HQ_BK_PACKED 4           /* HET, and every element's (c1, c2, beta) comes out of three floats bit for bit
+                                  * (hq_material_coef) and every node's n_t row out of two doubles: 12 + 16 bytes per element /
+                                  * node and step instead of 24 + 24; the unit's record carries dt^2 h and h in c1, c2 */
 /* tile of a HET unit: 62 x 7 owned nodes -- the 64 x 8 threads of the workgroup each evaluate ONE element of the layer,
  * the elements around the owned nodes (element (i, j) has its low corner at node (i - 1, j - 1)); the 78 threads that own
  * no node (row 7, columns 62 and 63) load the <= 142 ring nodes, two each, in the registers the owners use for their node */
@@ -73,7 +76,8 @@ struct hq_brick_unit {
     double  m0, m2, m1;          /* HQ_BK_NTSAME: mass_simple, mass2_minusaM, mass_minusaM of every node        */
     int64_t coef;                /* HQ_BK_HET: the unit's element coefficients in d_coef, [np + 1 layers]
                                   * [c1 | c2 | beta][8][64]: layer l lies between the planes za - 1 + l and za + l, element
-                                  * (i, j) has its low corner at node (i - 1, j - 1) of the tile; 0 where there is none */
+                                  * (i, j) has its low corner at node (i - 1, j - 1) of the tile; 0 where there is none.
+                                  * HQ_BK_PACKED: in d_coef32 (floats), [np + 1 layers][rho | Vs | Vp][8][64]            */
 };
 
 struct hq_brick_cfg {
@@ -99,16 +103,22 @@ struct hq_brick_host {
     int32_t nsame = 0;                       /* units with HQ_BK_NTSAME                                           */
     std::vector<int32_t> tab;                /* id tables (device ids)                                            */
     std::vector<double> coef;                /* element coefficients of the HQ_BK_HET units                       */
+    std::vector<float> coef32;               /* ... of the HQ_BK_PACKED ones: rho (sign: see hq_material_coef), Vs, Vp */
+    std::vector<double> nt2;                 /* [nb][2] {mass_simple, mass_simple - mass_minusaM} of the nodes of packed units */
     int32_t nhet = 0;                        /* HQ_BK_HET units: the last of the launch order                     */
+    int32_t npacked = 0;                     /* of those, HQ_BK_PACKED: the last of the HET units                 */
     int32_t ncolumns = 0, nlevels = 0;
 };
 
 struct hq_brick_plan {
     int64_t nb = 0;
-    int32_t nunits = 0, nsame = 0, nhet = 0;
+    int32_t nunits = 0, nsame = 0, nhet = 0, npacked = 0;
     hq_brick_unit* d_units = nullptr;
     int32_t* d_tab = nullptr;
     double* d_coef = nullptr;
+    float* d_coef32 = nullptr;
+    double* d_nt2 = nullptr;
+    hq_mat_const mat = { 0, 0, 0, 0, 0, 0 };  /* dt, bBase and the thresholds of the packed units (A and h ride in their records) */
     int32_t* d_src_ptr = nullptr;            /* [nunits + 1] source entries per unit (hq_brick_set_source)        */
     int32_t* d_src_ent = nullptr;            /* [n][2] = {node of the unit (plane * ny + y) * nx + x, loaded idx} */
     std::vector<int64_t> h_base;             /* units' first ids, ascending, and their launch slots: owner lookup */
@@ -122,9 +132,15 @@ struct hq_brick_plan {
  * -> 0, or -1 with g_patch_err set (only on inconsistent input: a level whose geometry cannot be understood is
  * skipped, not refused).
  */
+/* what solver_init built the eTable from, where the caller hands it over (hq_desc.edata, mat_*): lets HET units pack */
+struct hq_mat_src {
+    const float* edata = nullptr;            /* [E][4] edgesize, Vp, Vs, rho (edata_t, psolve.h:95-97)            */
+    double dt = 0, bbase = 0, thr_damp = 0, thr_vpvs = 0;
+};
+
 static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const int32_t* xyz, const double* c1,
                               const double* c2, const double* beta, const double* ntab, const char* excl,
-                              hq_brick_host* B)
+                              hq_brick_host* B, const hq_mat_src* MS = nullptr)
 {
     *B = hq_brick_host();
     if (!xyz || E <= 0 || N <= 0) return 0;
@@ -429,6 +445,8 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     for (size_t u = 0; u < us.size(); u++)
         coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BH_THREADS * 3 : 0);
     B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
+    const bool try_pack = MS && MS->edata && MS->dt > 0 && !hq_opt_flag("HQ_BRICK_NO_PACK");
+    if (try_pack) { B->coef32.assign((size_t)coff[us.size()] + 8, 0.0f); B->nt2.assign(2 * (size_t)nb, 0.0); }
     int fault = 0;                                       /* written by many threads: atomic writes only */
     auto set_fault = [&]() {
 #pragma omp atomic write
@@ -500,6 +518,46 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         if (e >= 0) { o[0] = c1[e]; o[HQ_BH_CS] = c2[e]; o[2 * HQ_BH_CS] = beta[e]; }
                         else if (i <= nx && j <= ny) set_fault();       /* an element around an owned node is missing */
                     }
+            /* the packed form: every element of the block out of (rho, Vs, Vp) bit for bit, every owned node's n_t row out
+             * of {m0, m0 - m1} (m1 exactly; m2 = 2 m0 - (m0 - m1) to 1e-15: it is summed in another order, psolve.c:3436-3471) */
+            if (try_pack) {
+                bool ok = true;
+                const int32_t e0 = L.Eg[(size_t)(((int64_t)za * L.D[1] + c.y0) * L.D[0] + c.x0)];
+                const float hf = e0 >= 0 ? MS->edata[4 * (int64_t)e0] : 0.0f;
+                hq_mat_const K = { (MS->dt * MS->dt) * (double)hf, (double)hf, MS->dt, MS->bbase, MS->thr_damp, MS->thr_vpvs };
+                float* cq = B->coef32.data() + coff[(size_t)u];
+                for (int32_t l = 0; l <= np && ok; l++)
+                    for (int32_t j = 0; j < HQ_BH_WAVES && ok; j++)
+                        for (int32_t i = 0; i < 64; i++) {
+                            const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
+                            int32_t e = -1;
+                            if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
+                                e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
+                            float* o = cq + (int64_t)l * (3 * HQ_BH_THREADS) + (j * 64 + i);
+                            o[0] = o[HQ_BH_CS] = o[2 * HQ_BH_CS] = 0.0f;
+                            if (e < 0) continue;
+                            const float* ed = MS->edata + 4 * (int64_t)e;
+                            if (ed[0] != hf || !(ed[3] > 0.0f)) { ok = false; break; }
+                            bool hit = false;
+                            for (int fixed = 0; fixed < 2 && !hit; fixed++) {
+                                double k1, k2, kb;
+                                hq_material_coef(fixed ? -ed[3] : ed[3], ed[2], ed[1], K, &k1, &k2, &kb);
+                                if (k1 == c1[e] && k2 == c2[e] && kb == beta[e]) { o[0] = fixed ? -ed[3] : ed[3]; o[HQ_BH_CS] = ed[2]; o[2 * HQ_BH_CS] = ed[1]; hit = true; }
+                            }
+                            if (!hit) { ok = false; break; }
+                        }
+                for (int32_t z = 0; z < np && ok; z++)
+                    for (int32_t y = 0; y < ny && ok; y++)
+                        for (int32_t x = 0; x < nx; x++) {
+                            const int32_t n = L.Ng[(size_t)((((int64_t)za + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
+                            const double* q = ntab + 7 * (int64_t)n;
+                            const double sdiff = q[0] - q[4];
+                            if (q[0] - sdiff != q[4] || fabs((2.0 * q[0] - sdiff) - q[1]) > 1e-15 * fabs(q[1])) { ok = false; break; }
+                            double* o2 = B->nt2.data() + 2 * (U.base + ((int64_t)z * ny + y) * nx + x);
+                            o2[0] = q[0]; o2[1] = sdiff;
+                        }
+                if (ok) { U.flags |= HQ_BK_PACKED; same[(size_t)u] = 3; U.c1 = K.A; U.c2 = K.h; }
+            }
         }
     }
     lap("unit tables");
@@ -507,13 +565,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     /* launch order: the units whose nodes share one n_t row (the row rides in the record), then those with per-node
      * rows, then the HET units -- a launch each */
     {
-        std::vector<hq_brick_unit> a, b, h;
-        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 2 ? h : b)).push_back(B->units[u]);
+        std::vector<hq_brick_unit> a, b, h, hp;
+        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 2 ? h : (same[u] == 3 ? hp : b))).push_back(B->units[u]);
         B->nsame = (int32_t)a.size();
-        B->nhet = (int32_t)h.size();
+        B->nhet = (int32_t)(h.size() + hp.size());
+        B->npacked = (int32_t)hp.size();
         a.insert(a.end(), b.begin(), b.end());
         a.insert(a.end(), h.begin(), h.end());
+        a.insert(a.end(), hp.begin(), hp.end());
         B->units.swap(a);
+        if (B->npacked == 0) { std::vector<float>().swap(B->coef32); std::vector<double>().swap(B->nt2); }
+        if (verbose) fprintf(stderr, "  brick plan: %d units: %d with one n_t row, %d per-element coefficients of which %d packed\n",
+                             (int)B->units.size(), B->nsame, B->nhet, B->npacked);
     }
     return 0;
 }
@@ -749,11 +812,15 @@ static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
     return __hiloint2double(hi, lo);
 }
 
+/* PACKED (HQ_BK_PACKED units): `coef` holds three FLOATS per element (rho, Vs, Vp: hq_material_coef expands them to the
+ * caller's very doubles, ~50 VALU operations per element and layer), `nt3` two doubles per node {m0, m0 - m1}: 28 bytes
+ * per node and step instead of 52 */
+template <bool PACKED>
 __global__ void __launch_bounds__(HQ_BH_THREADS, HQ_BH_WAVES == 12 ? 3 : 4)   /* 8 waves: 4 per SIMD = two workgroups per CU, <= 128 VGPRs */
 hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
-               const double* __restrict__ coef, const double* __restrict__ u1g, const double* __restrict__ u2g,
+               const void* __restrict__ coef_any, const double* __restrict__ u1g, const double* __restrict__ u2g,
                double* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
-               const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2)
+               const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2, hq_mat_const mat)
 {
     extern __shared__ __align__(16) double s_het[];
     hq_lds_double* const img = (hq_lds_double*)s_het;                  /* [slot][u1 | v][3 x rows] */
@@ -783,7 +850,11 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     const int32_t* __restrict__ rtabB = tab + U.tab + (ringB ? rq + HQ_BH_NRT : 0);
     const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
     const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
-    const double* __restrict__ cf = coef + U.coef + t;                 /* [layer][c1 | c2 | beta][thread] */
+    const double* __restrict__ cf = (const double*)coef_any + (PACKED ? 0 : U.coef + t);   /* [layer][c1 | c2 | beta][thread] */
+    const float* __restrict__ cf32 = (const float*)coef_any + (PACKED ? U.coef + t : 0);      /* [layer][rho | Vs | Vp][thread] */
+    hq_mat_const K = mat;
+    if (PACKED) { K.A = hq_uniform(U.c1); K.h = hq_uniform(U.c2); }
+    const int third = (PACKED && owner) ? 1 : 2;                       /* PACKED: an owner's third n_t load repeats the second */
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
     /* an owner's registers: x1, x2 = u1, u2 of its node of the plane in flight, mn = its n_t row, accA / accB = the
@@ -802,9 +873,9 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 #define HQ_BH_LOAD(node_)                                                                             \
     {                                                                                                 \
         const int64_t a_ = owner ? (int64_t)(node_) : (int64_t)ridA;                                  \
-        const double* __restrict__ pb_ = owner ? nt3 + 3 * a_ : u1g + 3 * (int64_t)ridB;              \
+        const double* __restrict__ pb_ = owner ? nt3 + (PACKED ? 2 : 3) * a_ : u1g + 3 * (int64_t)ridB; \
         _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
-        if (HQ_BH_ABL != 4) { _Pragma("unroll") for (int d = 0; d < 3; d++) mn[d] = pb_[d]; }          \
+        if (HQ_BH_ABL != 4) { mn[0] = pb_[0]; mn[1] = pb_[1]; mn[2] = pb_[third]; }                    \
     }
 #define HQ_BH_LOAD_B()                                                                                \
     {                                                                                                 \
@@ -820,9 +891,10 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
         hq_lds_double* iu_ = img + (size_t)(s_) * (2 * 3 * HQ_BH_ROWS);                                \
         hq_lds_double* iv_ = iu_ + 3 * HQ_BH_ROWS;                                                    \
         if (owner) {                                                                                  \
+            const double m2_ = PACKED ? 2.0 * mn[0] - mn[1] : mn[1], m1_ = PACKED ? mn[0] - mn[1] : mn[2]; \
             _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
                 iu_[3 * myrow + d] = x1[d]; iv_[3 * myrow + d] = x1[d] - x2[d];                       \
-                acc_[d] = mn[1] * x1[d] - mn[2] * x2[d];                                              \
+                acc_[d] = m2_ * x1[d] - m1_ * x2[d];                                                  \
             }                                                                                         \
             m0_ = 1.0 / mn[0];                                                                        \
         }                                                                                             \
@@ -832,10 +904,12 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 
     /* request plane p_ (1 .. np + 1) of the march, the ring ids of the plane after it and the coefficients of layer p_ - 1 */
     double nc1 = 0.0, nc2 = 0.0, nbeta = 0.0, c1 = 0.0, c2 = 0.0, beta = 0.0;
+    float nrho = 0.0f, nvs = 0.0f, nvp = 0.0f;
 #define HQ_BH_REQUEST(p_)                                                                             \
     {                                                                                                 \
         const int pp_ = (p_);                                                                         \
-        if (HQ_BH_ABL != 2) { const double* q_ = cf + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nc1 = q_[0]; nc2 = q_[HQ_BH_CS]; nbeta = q_[2 * HQ_BH_CS]; } \
+        if (HQ_BH_ABL != 2 && !PACKED) { const double* q_ = cf + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nc1 = q_[0]; nc2 = q_[HQ_BH_CS]; nbeta = q_[2 * HQ_BH_CS]; } \
+        if (HQ_BH_ABL != 2 && PACKED) { const float* q_ = cf32 + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nrho = q_[0]; nvs = q_[HQ_BH_CS]; nvp = q_[2 * HQ_BH_CS]; } \
         HQ_BH_LOAD(pp_ == np + 1 ? id_hi : U.base + (int64_t)(pp_ - 1) * nxy + sidx)                  \
         HQ_BH_LOAD_B()                                                                                \
         { const int64_t r_ = (int64_t)(pp_ < np + 1 ? pp_ + 1 : np + 1) * nr; ridA = rtabA[r_]; ridB = rtabB[r_]; } \
@@ -906,7 +980,8 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
             }
         }
         if (l < np) HQ_BH_PUT(l & 1, accB, m0B)
-        c1 = nc1; c2 = nc2; beta = nbeta;
+        if (PACKED) hq_material_coef(nrho, nvs, nvp, K, &c1, &c2, &beta);
+        else { c1 = nc1; c2 = nc2; beta = nbeta; }
         /* the coefficients and the ring ids are taken HERE, behind the PUT that has waited for the loads of their batch: a
          * wait for them further down would have to drain the loads requested next (the compiler cannot count loads
          * behind branches) */
@@ -926,7 +1001,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 
 static void hq_brick_free(hq_brick_plan* P)
 {
-    void* ptrs[] = { P->d_units, P->d_tab, P->d_coef, P->d_src_ptr, P->d_src_ent };
+    void* ptrs[] = { P->d_units, P->d_tab, P->d_coef, P->d_coef32, P->d_nt2, P->d_src_ptr, P->d_src_ent };
     for (void* p : ptrs) if (p) hipFree(p);
     *P = hq_brick_plan();
 }
@@ -937,14 +1012,25 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
     P->nunits = (int32_t)B.units.size();
     P->nsame = B.nsame;
     P->nhet = B.nhet;
+    P->npacked = B.npacked;
     if (P->nunits == 0) return 0;
     if (P->nhet > 0) {
-        if (hipMalloc((void**)&P->d_coef, 8 * B.coef.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
-        *bytes += (int64_t)(8 * B.coef.size());
-        if (hipMemcpy(P->d_coef, B.coef.data(), 8 * B.coef.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick coefficient upload failed"; return -3; }
+        /* (the double block of a packed unit is never read: only the blocks of the unpacked ones travel) */
+        if (P->nhet > P->npacked) {
+            if (hipMalloc((void**)&P->d_coef, 8 * B.coef.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+            *bytes += (int64_t)(8 * B.coef.size());
+            if (hipMemcpy(P->d_coef, B.coef.data(), 8 * B.coef.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick coefficient upload failed"; return -3; }
+        }
+        if (P->npacked > 0) {
+            if (hipMalloc((void**)&P->d_coef32, 4 * B.coef32.size()) != hipSuccess || hipMalloc((void**)&P->d_nt2, 8 * B.nt2.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
+            *bytes += (int64_t)(4 * B.coef32.size() + 8 * B.nt2.size());
+            if (hipMemcpy(P->d_coef32, B.coef32.data(), 4 * B.coef32.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(P->d_nt2, B.nt2.data(), 8 * B.nt2.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick coefficient upload failed"; return -3; }
+        }
         static bool attr_set = false;            /* 80.7 KB of dynamic LDS per workgroup */
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)hq_k_brick_het, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess) { g_patch_err = "hq_k_brick_het: LDS attribute"; return -3; }
+            if (hipFuncSetAttribute((const void*)hq_k_brick_het<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)hq_k_brick_het<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess) { g_patch_err = "hq_k_brick_het: LDS attribute"; return -3; }
             attr_set = true;
         }
     }
@@ -1000,9 +1086,9 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
 static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
                             const double* F, double dt2, hipStream_t stream, bool light = false)
 {
-    const int32_t cnt[3] = { P->nsame, P->nunits - P->nsame - P->nhet, P->nhet };
+    const int32_t cnt[4] = { P->nsame, P->nunits - P->nsame - P->nhet, P->nhet - P->npacked, P->npacked };
     int32_t first = 0;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         const int32_t count = cnt[k];
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
@@ -1012,8 +1098,10 @@ static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const doub
         else if (k == 0) hq_k_brick<false, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1 && light) hq_k_brick<true, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1) hq_k_brick<true, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
-        else hq_k_brick_het<<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
-                                                                             P->d_src_ent, (sp ? F : nullptr), dt2);
+        else if (k == 2) hq_k_brick_het<false><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
+                                                                                               P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
+        else hq_k_brick_het<true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef32, u1, u2, un, P->d_nt2, sp,
+                                                                                   P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
 #undef HQ_BK_ARGS
         first += count;
     }

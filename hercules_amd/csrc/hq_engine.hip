@@ -1561,7 +1561,9 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
     if (variant == HQ_VARIANT_PATCH && d->node_xyz && !(hq_opt_on("HQ_NO_BRICKS"))) {
         std::vector<char> excl;
         if ((rc = hq_brick_excluded(d, excl)) != HQ_OK) return bail(rc);
-        if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH) != 0)
+        hq_mat_src ms;
+        ms.edata = d->edata; ms.dt = d->deltaT; ms.bbase = d->mat_bbase; ms.thr_damp = d->mat_threshold_damping; ms.thr_vpvs = d->mat_threshold_vpvs;
+        if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH, &ms) != 0)
             return bail(hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error()));
         lap("brick plan");
     }
@@ -1743,6 +1745,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
                             dn, seed0.data(), &pb, BH.nb);
         lap("state upload + patch plan");
         if (rc == 0 && BH.nb > 0) rc = hq_brick_upload(&c->bricks, BH, &pb);
+        c->bricks.mat = { 0.0, 0.0, d->deltaT, d->mat_bbase, d->mat_threshold_damping, d->mat_threshold_vpvs };
         lap("brick upload");
         if (rc != 0)
             return bail(hq_fail(rc == -1 ? HQ_ERR_ARG : (rc == -2 ? HQ_ERR_NOMEM : HQ_ERR_DEVICE), "patch plan: %s",
@@ -2051,7 +2054,9 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     std::vector<char> excl;
     HQ_TRY(hq_brick_excluded(d, excl));
     hq_brick_host B;
-    if (hq_brick_plan_host(E, N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &B) != 0)
+    hq_mat_src ms;
+    ms.edata = d->edata; ms.dt = d->deltaT; ms.bbase = d->mat_bbase; ms.thr_damp = d->mat_threshold_damping; ms.thr_vpvs = d->mat_threshold_vpvs;
+    if (hq_brick_plan_host(E, N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &B, &ms) != 0)
         return hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error());
     int64_t bad = 0, nchecked = 0;
     for (int k = 0; k < 8; k++) report[k] = 0;
@@ -2290,6 +2295,7 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.brick_nodes = c->bricks.nb;
     v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet;
     v.brick_units_het = c->bricks.nhet;
+    v.brick_units_packed = c->bricks.npacked;
     v.pcie_h2d_bytes = c->h2d_bytes;
     v.pcie_d2h_bytes = c->d2h_bytes;
     v.transport = c->comm ? 1 : (hq_ipc_ready(c) ? (c->ipc->loopback ? 5 : 2) : (c->host_xchg ? 3 : (c->group ? 4 : 0)));

@@ -62,6 +62,9 @@ struct hqh_box {
     int32_t *cmap, *smap;
     int64_t shared_nodes;
     float* layer_store;
+    float* edata;                   /* [lenum][4] edgesize, Vp, Vs, rho as solver_init leaves edata_t (material that differs
+                                       between elements only: hq_desc.edata lets hq_k_brick_het keep 12 bytes per element) */
+    double bbase;                   /* Global.theBBase */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -393,6 +396,7 @@ void hqh_box_destroy(hqh_box* b)
     free(b->mc); free(b->ms); free(b->cmap); free(b->smap);
     free(b->layer_store);
     free(b->zx); free(b->zy); free(b->zz);
+    free(b->edata);
     free(b);
 }
 
@@ -541,6 +545,13 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
             z = ((z | ~b->zmask) + 1) & b->zmask;
         }
     }
+    if (b->ncls > 1 || p->nlayers > 1) {
+        double aBase;
+        rayleigh_base(p->freq, p->damping, &aBase, &b->bbase);
+        b->edata = (float*)malloc(sizeof(float) * 4 * (size_t)(b->lenum ? b->lenum : 1));
+        if (!b->edata) { hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+        hqh_box_material(b, NULL);                       /* fills b->edata */
+    }
     hqh_lap(&t_lap, "box: element tables");
     int rc = build_schedule(b);
     hqh_lap(&t_lap, "box: schedule");
@@ -552,13 +563,18 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
 /* edata_t of this partition's elements as solver_init reads them (psolve.c:3372-3385): out[lenum][3] = Vp, Vs, rho */
 int hqh_box_material(const hqh_box* b, float* out)
 {
-    if (!b || !out) return HQ_ERR_ARG;
+    if (!b || (!out && !b->edata)) return HQ_ERR_ARG;
     uint64_t z = bits_deposit((uint64_t)b->elo, b->zmask);
     for (int64_t e = b->elo; e < b->ehi; e++) {
         int32_t i = (int32_t)compact3(z), j = (int32_t)compact3(z >> 1), k = (int32_t)compact3(z >> 2);
         const int64_t mi = mat_index(b, i, j, k);
-        float* o = out + 3 * (e - b->elo);
-        o[0] = b->k_vp[mi]; o[1] = b->k_vs[mi]; o[2] = b->k_rho[mi];
+        if (out) {
+            float* o = out + 3 * (e - b->elo);
+            o[0] = b->k_vp[mi]; o[1] = b->k_vs[mi]; o[2] = b->k_rho[mi];
+        } else {                                         /* the box's own edata_t rows */
+            float* o = b->edata + 4 * (e - b->elo);
+            o[0] = (float)b->p.h; o[1] = b->k_vp[mi]; o[2] = b->k_vs[mi]; o[3] = b->k_rho[mi];
+        }
         z = ((z | ~b->zmask) + 1) & b->zmask;
     }
     return HQ_OK;
@@ -651,6 +667,10 @@ int hqh_box_desc(const hqh_box* b, hq_desc* d)
     d->an_sched.s_count = b->ns; d->an_sched.first_s = b->ms;
     d->deltaT = b->p.deltaT; d->rank = b->p.rank; d->nranks = b->p.nranks;
     d->variant = HQ_VARIANT_AUTO;
+    if (b->edata) {
+        d->edata = b->edata; d->mat_bbase = b->bbase;
+        d->mat_threshold_damping = b->p.threshold_damping; d->mat_threshold_vpvs = b->p.threshold_vpvs;
+    }
     return HQ_OK;
 }
 
@@ -1196,6 +1216,8 @@ struct hqh_octbox {
     hq_messenger *mc[2], *ms[2];    /* [0] anchored-node schedule, [1] dangling-node schedule */
     int32_t nc[2], ns[2];
     int32_t *cmap[2], *smap[2];
+    float* edata;                   /* [E][4] as solver_init leaves edata_t (hqh_mesh_from_leaves); NULL: not kept */
+    double bbase, thr_damp, thr_vpvs;
 };
 
 void hqh_octbox_destroy(hqh_octbox* b)
@@ -1205,6 +1227,7 @@ void hqh_octbox_destroy(hqh_octbox* b)
     free(b->etable); free(b->ntable); free(b->owner); free(b->gid);
     free(b->vp); free(b->vs); free(b->rho);
     for (int s = 0; s < 2; s++) { free(b->mc[s]); free(b->ms[s]); free(b->cmap[s]); free(b->smap[s]); }
+    free(b->edata);
     free(b);
 }
 
@@ -1350,6 +1373,11 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
         b->dn_id = dn_id; b->dn_ptr = dn_ptr; b->dn_anchor = dn_anchor;
         b->owner = own; b->gid = gid;
         lnid = xyz = own = gid = dn_id = dn_ptr = dn_anchor = NULL; et = nt = NULL;
+        if (b->edata) {                                      /* this rank's rows: its block of the element list */
+            int64_t e_first = 0;
+            while (e_first < E && HQH_ERANK(e_first) != me) e_first++;
+            memmove(b->edata, b->edata + 4 * e_first, sizeof(float) * 4 * (size_t)ne);
+        }
         b->E = ne; b->N = nh; b->ldnnum = ndn;
         rc = HQ_OK;
     }
@@ -2271,6 +2299,10 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
         double aBase, bBase;
         const double dt = ip->deltaT, dt2 = dt * dt;
         rayleigh_base(ip->freq, ip->damping, &aBase, &bBase);
+        b->edata = (float*)malloc(sizeof(float) * 4 * (size_t)E);
+        if (!b->edata) goto fail;
+        memcpy(b->edata, edata, sizeof(float) * 4 * (size_t)E);
+        b->bbase = bBase; b->thr_damp = ip->threshold_damping; b->thr_vpvs = ip->threshold_vpvs;
         for (int64_t e = 0; e < E; e++) {
             float h = edata[4 * e], Vp = edata[4 * e + 1], Vs = edata[4 * e + 2], rho = edata[4 * e + 3];
             double mu = rho * Vs * Vs, lambda;
@@ -2281,6 +2313,7 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
                 lambda = rho * Vp * Vp;
             }
             if (lambda < 0) { rc = HQ_ERR_ARG; goto fail; }
+            b->edata[4 * e + 1] = Vp;                        /* mu_and_lambda rewrites edata->Vp (psolve.c:3253-3263) */
             double zeta = 10 / Vs;
             if (zeta > ip->threshold_damping) zeta = ip->threshold_damping;
             const double a = zeta * aBase, bb = zeta * bBase;
@@ -2453,6 +2486,7 @@ int hqh_octbox_desc(const hqh_octbox* b, hq_desc* d)
     d->rank = b->p.nranks > 1 ? b->p.rank : 0;
     d->nranks = b->p.nranks > 1 ? b->p.nranks : 1;
     d->variant = HQ_VARIANT_AUTO;
+    if (b->edata) { d->edata = b->edata; d->mat_bbase = b->bbase; d->mat_threshold_damping = b->thr_damp; d->mat_threshold_vpvs = b->thr_vpvs; }
     return HQ_OK;
 }
 

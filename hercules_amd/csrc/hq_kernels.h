@@ -20,6 +20,7 @@
 #define HQ_KERNELS_H
 
 #ifdef HQ_KERNEL_MATH_HOST_CHECK   /* tests/test_kernel_math_cpu.py: g++ compiles the arithmetic alone */
+#include <cmath>
 #define __device__
 #define __host__
 #define __forceinline__ inline
@@ -123,6 +124,70 @@ __host__ __device__ __forceinline__ void hq_element_force(double X[8], double Y[
 
     if (ZMODES) { hq_wht_inv_xy(X); hq_wht_inv_xy(Y); hq_wht_inv_xy(Z); }
     else { hq_wht_inv(X); hq_wht_inv(Y); hq_wht_inv(Z); }
+}
+
+/*
+ * (c1, c2, beta) of an element from the three floats solver_init derived them from -- 12 bytes instead of 24, exactly:
+ * mu_and_lambda (psolve.c:3236-3272) evaluates mu = rho Vs Vs in SINGLE precision (float operands), lambda as a
+ * double difference, and solver_init (psolve.c:3387-3409) builds
+ *     c1 = dt^2 h mu / 9,   c2 = dt^2 h lambda / 9,   c3 = b dt h mu / 9,   b = zeta bBase,   zeta = min(10 / Vs, threshold)
+ * (10 / Vs again a float division), beta = c3 / c1 (hq_create).  Every operation below is the reference's, in its order
+ * and its precision, as ONE IEEE operation each (no contraction: intrinsics on the device, an x86-64 host has no fused
+ * form without -mfma); the divisions by 9 are Markstein's q = t r, q += fma(-9, q, t) r with r = RN(1/9).  hq_create
+ * runs this very function on the host for every element of a unit and packs the unit only if the caller's eTable comes
+ * out bit for bit; anything else keeps its 24 bytes.
+ *   rho < 0: |rho| is the density and lambda = rho Vp Vp (the Poisson-ratio fix, psolve.c:3253-3263, whose Vp the caller's
+ *   edata already holds); rho == 0: no element (all three come out 0).
+ */
+struct hq_mat_const {
+    double A;                    /* dt^2 * h (psolve.c:3387: theDeltaTSquared * edgesize) */
+    double h, dt;                /* edgesize (the float's value), theDeltaT                */
+    double bbase, thr_damp, thr_vpvs;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HQ_FMUL(a, b) __fmul_rn((a), (b))
+#define HQ_DMUL(a, b) __dmul_rn((a), (b))
+#define HQ_DSUB(a, b) __dsub_rn((a), (b))
+#define HQ_FDIV(a, b) __fdiv_rn((a), (b))
+#define HQ_DDIV(a, b) __ddiv_rn((a), (b))
+#else
+#define HQ_FMUL(a, b) ((float)((float)(a) * (float)(b)))
+#define HQ_DMUL(a, b) ((double)(a) * (double)(b))
+#define HQ_DSUB(a, b) ((double)(a) - (double)(b))
+#define HQ_FDIV(a, b) ((float)((float)(a) / (float)(b)))
+#define HQ_DDIV(a, b) ((double)(a) / (double)(b))
+#endif
+
+__host__ __device__ __forceinline__ double hq_div9(double t)
+{
+    const double r9 = 0.1111111111111111;            /* RN(1/9) */
+    const double q = HQ_DMUL(t, r9);
+    const double rem = fma(-9.0, q, t);              /* exact */
+    return fma(rem, r9, q);
+}
+
+__host__ __device__ __forceinline__ void hq_material_coef(float rho_s, float Vs, float Vp, const hq_mat_const& K,
+                                                          double* c1, double* c2, double* beta)
+{
+    const bool fixed = rho_s < 0.0f;
+    const float rho = fixed ? -rho_s : rho_s;
+    const double mu = (double)HQ_FMUL(HQ_FMUL(rho, Vs), Vs);
+    const double P = (double)HQ_FMUL(HQ_FMUL(rho, Vp), Vp);
+    const double two_mu = HQ_DMUL(2.0, mu);
+    const double capped = HQ_DSUB(HQ_DMUL(HQ_DMUL(mu, K.thr_vpvs), K.thr_vpvs), two_mu);
+    const double plain = HQ_DSUB(P, two_mu);
+    const double lambda = fixed ? P : (((double)Vp > HQ_DMUL((double)Vs, K.thr_vpvs)) ? capped : plain);
+    const double k1 = hq_div9(HQ_DMUL(K.A, mu));
+    const double k2 = hq_div9(HQ_DMUL(K.A, lambda));
+    double zeta = (double)HQ_FDIV(10.0f, Vs);
+    if (zeta > K.thr_damp) zeta = K.thr_damp;
+    const double b = HQ_DMUL(zeta, K.bbase);
+    const double k3 = hq_div9(HQ_DMUL(HQ_DMUL(HQ_DMUL(b, K.dt), K.h), mu));
+    const bool none = rho == 0.0f;
+    *c1 = none ? 0.0 : k1;
+    *c2 = none ? 0.0 : k2;
+    *beta = (none || k1 == 0.0) ? 0.0 : HQ_DDIV(k3, k1);
 }
 
 #endif /* HQ_KERNELS_H */

@@ -283,8 +283,8 @@ class Box:
             raise capi.HqError("hqh_box_desc failed: %d" % rc)
         return capi.brick_plan_check(d)
 
-    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
-        """hq_create on the arrays the C host side built (no copies through Python)."""
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None):
+        """hq_create[_opts] on the arrays the C host side built (no copies through Python)."""
         d = capi._Desc()
         rc = self._lib.hqh_box_desc(self._h, ctypes.byref(d))
         if rc != 0:
@@ -300,7 +300,12 @@ class Box:
         s._lib = capi.load_library()
         s._h = ctypes.c_void_p()
         s.N, s.E = d.nharbored, d.lenum
-        capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        if isinstance(options, dict):
+            options = capi.Options(**options)
+        if options is None:
+            capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        else:
+            capi._check(s._lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(s._h)))
         return s
 
     def point_source(self, x, y, z, strike=0.0, dip=90.0, rake=0.0):
@@ -541,7 +546,7 @@ class OctBox:
             raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
         return capi.brick_plan_check(d)
 
-    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None):
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None):
         d = capi._Desc()
         rc = self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
         if rc != 0:
@@ -557,7 +562,12 @@ class OctBox:
         s._lib = capi.load_library()
         s._h = ctypes.c_void_p()
         s.N, s.E = d.nharbored, d.lenum
-        capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        if isinstance(options, dict):
+            options = capi.Options(**options)
+        if options is None:
+            capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
+        else:
+            capi._check(s._lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(s._h)))
         return s
 
 

@@ -101,6 +101,15 @@ typedef struct {
     int32_t        reserved;
     const int64_t* node_gnid;    /* [nharbored] node_t.gnid (octor.h:133-147); optional (NULL): only used by
                                     HQ_DEBUG_HALO, which falls back to a mix of node_xyz */
+    /* ABI 5.  What solver_init built eTable FROM, optional (NULL / 0): edata_t of every element as solver_init left it
+     * (psolve.h:95-97; mu_and_lambda may have rewritten Vp, psolve.c:3253-3263) and the constants it combined them with.
+     * Where given, the kernel for meshes whose material differs from element to element (hq_k_brick_het) keeps 12 bytes per
+     * element -- rho, Vs, Vp -- instead of the 24 of (c1, c2, beta), and rebuilds the caller's very doubles on the fly:
+     * hq_create checks every element bit for bit against eTable first and keeps the 24 bytes wherever one differs. */
+    const float*  edata;         /* [lenum][4] edgesize (m), Vp, Vs, rho                                             */
+    double mat_bbase;            /* Global.theBBase (compute_setab, psolve.c:5813-5876)                              */
+    double mat_threshold_damping;/* Param.theThresholdDamping                                                        */
+    double mat_threshold_vpvs;   /* Param.theThresholdVpVs                                                           */
 } hq_desc;
 
 typedef struct {
@@ -124,6 +133,8 @@ typedef struct {
     int32_t ipc_arena_coarse;    /* IPC: 1 if the receive arena had to be coarse-grained memory (ranks of one device only) */
     int32_t ipc_arena_kind;      /* IPC: 0 fine-grained, 1 uncached, 2 coarse-grained device memory                        */
     int32_t debug_halo;          /* 1: every halo record is checked on receipt (HQ_DEBUG_HALO / hq_options.debug_halo)     */
+    int32_t brick_units_packed;  /* of brick_units_het: coefficients as three floats, n_t rows as two doubles (hq_desc.edata) */
+    int32_t reserved0;
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -162,6 +173,8 @@ typedef struct {
     int32_t brick_by_component;  /* HQ_BRICK_BY_COMPONENT 1 / 0: the 100-register / 118-register form of hq_k_brick
                                                           (default: 100 on contexts with a transport)                   */
     int32_t brick_stream;        /* HQ_BRICK_STREAM       1: bricks on a stream of their own beside the patches          */
+    int32_t brick_no_pack;       /* HQ_BRICK_NO_PACK      1: per-element coefficients as 24-byte (c1, c2, beta) even where
+                                                          hq_desc.edata would let them travel as 12 bytes                */
     int32_t patch_pipe;          /* HQ_PATCH_PIPE         6 hq_k_patch_seed (default), 4 hq_k_patch_pers, 0 hq_k_patch_step */
     int32_t patch_threads;       /* HQ_PATCH_THREADS      workgroup size of the patch kernels (512)                      */
     int32_t patch_pmax;          /* HQ_PATCH_PMAX         owned nodes per patch (768)                                    */

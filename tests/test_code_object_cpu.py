@@ -32,7 +32,8 @@ def _kernel_notes(tmp_path):
 def test_brick_kernels_do_not_spill(tmp_path):
     k = _kernel_notes(tmp_path)
     found = {}
-    tags = ("hq_k_brickILb0ELb0E", "hq_k_brickILb0ELb1E", "hq_k_brickILb1ELb0E", "hq_k_brickILb1ELb1E", "hq_k_brick_het")
+    tags = ("hq_k_brickILb0ELb0E", "hq_k_brickILb0ELb1E", "hq_k_brickILb1ELb0E", "hq_k_brickILb1ELb1E", "hq_k_brick_hetILb0E",
+            "hq_k_brick_hetILb1E")
     for name, v in k.items():
         for tag in tags:
             if tag in name:

@@ -27,8 +27,11 @@ def _field(box, seed, amp=1e-3):
     return u
 
 
-def _run(box, variant, u1, u2, nsteps, src=None):
-    s = box.create_solver(variant=variant, tm1=u1, tm2=u2)
+def _run(box, variant, u1, u2, nsteps, src=None, options=None, want=None):
+    s = box.create_solver(variant=variant, tm1=u1, tm2=u2, options=options)
+    if want:
+        info = s.info()
+        assert all(want[k](info) for k in want), info
     if src is not None:
         s.set_source(src[0], src[1])
     s.run(nsteps)
@@ -104,6 +107,15 @@ def test_one_million_elements_with_lateral_material_against_oracle():
     for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
         tm1, tm2 = _run(box, variant, u, 0.999 * u, nsteps)
         assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    # the box hands over hq_desc.edata: every HET unit travels packed (12 B per element: rho, Vs, Vp; 16 B per node) ...
+    packed = _run(box, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps,
+                  want={"packed": lambda i: i["brick_units_packed"] == i["brick_units_het"] > 0})
+    # ... and with hq_options.brick_no_pack = 1 as the 24-byte (c1, c2, beta) + 24-byte n_t rows of the rounds before
+    plain = _run(box, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps, options={"brick_no_pack": 1},
+                 want={"plain": lambda i: i["brick_units_packed"] == 0 and i["brick_units_het"] > 0})
+    assert H.rel_linf(plain[0], o2) < 1e-9 and H.rel_linf(packed[0], o2) < 1e-9
+    # the coefficients are the caller's doubles bit for bit either way; the n_t rows differ by <= 1e-15 (m2 = 2 m0 - (m0 - m1))
+    assert H.rel_linf(packed[0], plain[0]) < 1e-12
     gid = (box.node_ijk[:, 2].astype(np.int64) * (ny + 1) + box.node_ijk[:, 1]) * (nx + 1) + box.node_ijk[:, 0]
     lut = np.empty(gid.max() + 1, np.int64)
     lut[gid] = np.arange(len(gid))

@@ -18,6 +18,12 @@ HARNESS = r"""
 #define HQ_KERNEL_MATH_HOST_CHECK
 #include "hq_kernels.h"
 extern "C" void element_force(double* X, double* Y, double* Z, double c1, double c2) { hq_element_force(X, Y, Z, c1, c2); }
+extern "C" void material_coef(float rho, float Vs, float Vp, double A, double h, double dt, double bbase, double thr_damp,
+                              double thr_vpvs, double* out)
+{
+    hq_mat_const K = { A, h, dt, bbase, thr_damp, thr_vpvs };
+    hq_material_coef(rho, Vs, Vp, K, out, out + 1, out + 2);
+}
 extern "C" void element_force_zmodes(double* X, double* Y, double* Z, double c1, double c2) { hq_element_force<true>(X, Y, Z, c1, c2); }
 """
 
@@ -111,3 +117,43 @@ def test_assembled_stencil_coefficients_equal_the_assembled_element_matrices():
                         c = 3 - a - b
                         want = q[int(dd[c] != 0)] * np.sign(dd[a]) * np.sign(dd[b])
                     assert abs(S[d][a, b] - want) <= 1e-13 * scale, (which, dd, a, b)
+
+
+def test_coefficients_from_three_floats_are_solver_inits_bit_for_bit(lib):
+    """hq_material_coef (the 12-byte form of an element's (c1, c2, beta) that hq_k_brick_het<PACKED> expands on the
+    device) against the eTable the oracle's solver_init builds (pinned bitwise on the reference's own checkpoints):
+    thousands of random materials through every branch of mu_and_lambda (psolve.c:3236-3272: the Vp/Vs cap, the
+    negative-lambda fix that rewrites Vp) and both sides of the damping threshold (psolve.c:3397-3401), several
+    element sizes, time steps and damping types -- c1, c2 and beta = c3 / c1 equal to the last bit."""
+    rng = np.random.default_rng(77)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.material_coef.argtypes = [ctypes.c_float] * 3 + [ctypes.c_double] * 6 + [dp]
+    n = 4000
+    checked = {"plain": 0, "capped": 0, "fixed": 0, "zeta_thr": 0}
+    for h, dt, freq, damping in ((62.5, 1e-3, 5.0, ho.DAMP_RAYLEIGH), (1.953125, 9e-5, 200.0, ho.DAMP_RAYLEIGH),
+                                 (100.0, 0.02, 0.5, ho.DAMP_RAYLEIGH), (31.25, 5e-4, 10.0, ho.DAMP_NONE)):
+        vs = rng.uniform(80.0, 4000.0, n).astype(np.float32)
+        ratio = np.where(rng.random(n) < 0.25, rng.uniform(3.0, 12.0, n), rng.uniform(1.0, 3.0, n))
+        vp = (vs * ratio).astype(np.float32)
+        vp[: n // 8] = (vs[: n // 8] * rng.uniform(0.9, 1.45, n // 8)).astype(np.float32)     # Vp^2 < 2 Vs^2: negative lambda
+        rho = rng.uniform(1500.0, 3000.0, n).astype(np.float32)
+        edata = np.stack([np.full(n, h, np.float32), vp, vs, rho], 1).copy()
+        before = edata.copy()
+        lnid = np.arange(8 * n, dtype=np.int32).reshape(n, 8)          # disjoint elements: only the eTable matters here
+        et, _ = ho.solver_init(lnid, edata, np.zeros(n, np.uint8), 8 * n, dt, freq, damping=damping)
+        _, bbase = ho.setab(freq, damping)
+        hf = float(np.float32(h))
+        A = (dt * dt) * hf
+        out = np.zeros(3)
+        for e in range(n):
+            fixed = edata[e, 1] != before[e, 1]                         # solver_init rewrote Vp
+            r = -float(edata[e, 3]) if fixed else float(edata[e, 3])
+            lib.material_coef(r, float(edata[e, 2]), float(edata[e, 1]), A, hf, dt, bbase, 0.05, 3.0, out.ctypes.data_as(dp))
+            assert out[0] == et[e, 0] and out[1] == et[e, 1], (e, out, et[e])
+            assert out[2] == (et[e, 2] / et[e, 0])
+            checked["fixed" if fixed else ("capped" if before[e, 1] > before[e, 2] * 3.0 else "plain")] += 1
+            checked["zeta_thr"] += int(10.0 / float(edata[e, 2]) > 0.05)
+    assert min(checked.values()) > 200, checked
+    out = np.ones(3)
+    lib.material_coef(0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0, 0.05, 3.0, out.ctypes.data_as(dp))      # no element
+    assert not out.any()
