@@ -48,6 +48,12 @@
 #endif
 #define HQ_BK_NTSAME 1           /* every node of the unit has the same n_t row: it is in the unit's record */
 #define HQ_BK_HET 2              /* the elements around the unit's nodes have coefficients of their own: hq_k_brick_het */
+#define HQ_BK_TOPFACE 8          /* the plane above the unit's first one (cap plane za - 1) is a DOMAIN FACE normal to z whose nodes
+                                  * the unit steps too: their four elements are the ones between the two planes, so everything
+                                  * their update needs is in the workgroup already -- the plane's own sums (halved: the stencil's
+                                  * even part; plus rho (Uo_x, Uo_y, -Uo_z): its odd part, hq_stencil()), the next plane's g + Uo,
+                                  * and their n_t row (7 doubles: dashpots differ per axis), one for the whole face of the unit */
+#define HQ_BK_BOTFACE 16         /* the same for the plane below the unit's last one (za + np)                          */
 #define HQ_BK_PACKED 4           /* HET, and every element's (c1, c2, beta) comes out of three floats bit for bit
                                   * (hq_material_coef) and every node's n_t row out of two doubles: 12 + 16 bytes per element /
                                   * node and step instead of 24 + 24; the unit's record carries dt^2 h and h in c1, c2 */
@@ -74,6 +80,7 @@ struct hq_brick_unit {
     int32_t nx, ny, np, flags;
     double  c1, c2, beta;        /* of the elements around the unit's nodes                                     */
     double  m0, m2, m1;          /* HQ_BK_NTSAME: mass_simple, mass2_minusaM, mass_minusaM of every node        */
+    double  ft[7], fb[7];        /* HQ_BK_TOPFACE / BOTFACE: the n_t row (psolve.h:210-214) of every node of that face plane     */
     int64_t coef;                /* HQ_BK_HET: the unit's element coefficients in d_coef, [np + 1 layers]
                                   * [c1 | c2 | beta][8][64]: layer l lies between the planes za - 1 + l and za + l, element
                                   * (i, j) has its low corner at node (i - 1, j - 1) of the tile; 0 where there is none.
@@ -104,7 +111,7 @@ struct hq_brick_host {
     std::vector<int32_t> tab;                /* id tables (device ids)                                            */
     std::vector<double> coef;                /* element coefficients of the HQ_BK_HET units                       */
     std::vector<float> coef32;               /* ... of the HQ_BK_PACKED ones: rho (sign: see hq_material_coef), Vs, Vp */
-    std::vector<double> nt2;                 /* [nb][2] {mass_simple, mass_simple - mass_minusaM} of the nodes of packed units */
+    std::vector<double> nt2;                 /* [N][2] {mass_simple, mass_simple - mass_minusaM} of the nodes of packed units (0 elsewhere) */
     int32_t nhet = 0;                        /* HQ_BK_HET units: the last of the launch order                     */
     int32_t npacked = 0;                     /* of those, HQ_BK_PACKED: the last of the HET units                 */
     int32_t ncolumns = 0, nlevels = 0;
@@ -124,6 +131,8 @@ struct hq_brick_plan {
     std::vector<int64_t> h_base;             /* units' first ids, ascending, and their launch slots: owner lookup */
     std::vector<int32_t> h_slot;
     std::vector<int64_t> h_size;
+    std::vector<int64_t> h_first;            /* the unit's first PLANE node (U.base): a node's index in the unit is id - h_first,
+                                              * negative in its top face plane, >= nx ny np in its bottom face plane */
 };
 
 /*
@@ -182,6 +191,19 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     }
     lap("edge lengths");
 
+    /* elements around every node (any level): a node with four of them can be the interior of a domain face */
+    const bool want_faces = stencil_ok && hq_stencil().face_ok && !hq_opt_flag("HQ_BRICK_NO_FACES") && !hq_opt_flag("HQ_BRICK_NO_NTSAME");
+    std::vector<uint8_t> touch;
+    if (want_faces) {
+        touch.assign((size_t)N, 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < E * 8; i++) {
+            uint8_t& t8 = touch[(size_t)lnid[i]];
+#pragma omp atomic
+            t8++;
+        }
+    }
+
     struct level_t {
         int32_t h;
         int64_t O[3];
@@ -189,7 +211,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         std::vector<int32_t> Ng;             /* node at a lattice position, or -1 */
         std::vector<int32_t> Eg;             /* element in a lattice cell, or -1 */
     };
-    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; int het; };
+    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; int het; int top, bot; };
     std::vector<level_t> levels;
     std::vector<column_t> cols;
     std::vector<int32_t> ntx_of_level;
@@ -283,6 +305,28 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y);
                 }
         if (nsimple < cfg.minnodes) continue;
+        /* face nodes: on the first / last plane of the level's grid, touched by exactly the four elements of this level on
+         * the inner side (so no element of ANY level lies beyond: a domain face, not a level interface), those with one
+         * (c1, c2, beta), inside the grid in x and y, not excluded.  3: top (elements towards +z), 4: bottom */
+        if (want_faces && L.D[2] >= 2) {
+#pragma omp parallel for schedule(static) collapse(2)
+            for (int side = 0; side < 2; side++)
+                for (int64_t Y = 1; Y < L.D[1]; Y++)
+                    for (int64_t X = 1; X < L.D[0]; X++) {
+                        const int64_t Z = side ? L.D[2] : 0, cz = side ? L.D[2] - 1 : 0;
+                        const int32_t n = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                        if (n < 0 || (excl && excl[n]) || touch[(size_t)n] != 4) continue;
+                        int32_t e0 = -1;
+                        bool s4 = true;
+                        for (int o = 0; o < 4 && s4; o++) {
+                            const int32_t e = Eg[(size_t)((cz * L.D[1] + (Y - ((o >> 1) & 1))) * L.D[0] + (X - (o & 1)))];
+                            if (e < 0) { s4 = false; break; }
+                            if (e0 < 0) e0 = e;
+                            else s4 = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
+                        }
+                        if (s4) S[(size_t)((Z * NY + Y) * NX + X)] = side ? 4 : 3;
+                    }
+        }
         lap("simple nodes");
         /* tile columns: footprints on a TX x TY grid from the first simple node; runs of planes all of whose nodes
          * in the footprint are simple.  Two passes: 64 x 8 tiles of nodes whose eight elements share their coefficients
@@ -292,13 +336,15 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         int32_t ntx_lvl = 1;
         for (int pass = 0; pass < 2; pass++) {
             const int PTX = pass == 0 ? TX : HQ_BH_TX, PTY = pass == 0 ? TY : HQ_BH_TY;
-            const char want = pass == 0 ? 2 : 1;             /* pass 1: any flag still set (taken nodes are cleared) */
+            /* pass 0: uniform simple nodes (2); pass 1: what is left of them and the per-element ones (1).  3 / 4 are face
+             * nodes: never part of a run, but a run of pass 0 that starts / ends beside a full face plane takes it along */
+            auto in_run = [pass](char v) { return pass == 0 ? v == 2 : (v == 1 || v == 2); };
             if (pass == 1) {
                 sx0 = INT64_MAX; sx1 = -1; sy0 = INT64_MAX; sy1 = -1;
                 for (int64_t Z = 0; Z < NZ; Z++)
                     for (int64_t Y = 0; Y < NY; Y++)
                         for (int64_t X = 0; X < NX; X++)
-                            if (S[(size_t)((Z * NY + Y) * NX + X)]) { sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y); }
+                            if (in_run(S[(size_t)((Z * NY + Y) * NX + X)])) { sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y); }
                 if (sx1 < 0) break;
             }
             const int32_t ntx = (int32_t)((sx1 - sx0) / PTX + 1), nty = (int32_t)((sy1 - sy0) / PTY + 1);
@@ -317,13 +363,41 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         bool full = Z < NZ;
                         for (int64_t y = y0; y < y0 + ny && full; y++) {
                             const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
-                            for (int32_t x = 0; x < nx; x++) if (row[x] < want) { full = false; break; }
+                            for (int32_t x = 0; x < nx; x++) if (!in_run(row[x])) { full = false; break; }
                         }
                         if (full) { if (run0 < 0) run0 = Z; continue; }
                         if (run0 >= 0) {
                             const int64_t nz = Z - run0;
-                            if (nz >= cfg.minz && nz * nx * ny >= cfg.minnodes)
-                                found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)run0, (int32_t)nz, ti, tj, 0, pass });
+                            if (nz >= cfg.minz && nz * nx * ny >= cfg.minnodes) {
+                                /* a face plane beside the run: every node of the footprint a face node with ONE n_t row */
+                                auto face = [&](int64_t Zf, char cls) -> int {
+                                    if (pass != 0 || Zf < 0 || Zf > L.D[2]) return 0;
+                                    const double* q0 = nullptr;
+                                    for (int64_t y = y0; y < y0 + ny; y++)
+                                        for (int32_t x = 0; x < nx; x++) {
+                                            if (S[(size_t)((Zf * NY + y) * NX + x0 + x)] != cls) return 0;
+                                            const double* q = ntab + 7 * (int64_t)L.Ng[(size_t)((Zf * NY + y) * NX + x0 + x)];
+                                            if (!q0) q0 = q;
+                                            else if (memcmp(q, q0, 7 * sizeof(double)) != 0) return 0;
+                                        }
+                                    return 1;
+                                };
+                                /* ... and only beside a column whose own nodes share one n_t row (its units are then all
+                                 * HQ_BK_NTSAME: the kernel form that carries the face code) */
+                                auto one_row = [&]() -> bool {
+                                    const double* q0 = ntab + 7 * (int64_t)L.Ng[(size_t)((run0 * NY + y0) * NX + x0)];
+                                    for (int64_t z = run0; z < Z; z++)
+                                        for (int64_t y = y0; y < y0 + ny; y++)
+                                            for (int32_t x = 0; x < nx; x++) {
+                                                const double* q = ntab + 7 * (int64_t)L.Ng[(size_t)((z * NY + y) * NX + x0 + x)];
+                                                if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) return false;
+                                            }
+                                    return true;
+                                };
+                                int top = run0 == 1 ? face(0, 3) : 0, bot = Z == L.D[2] ? face(L.D[2], 4) : 0;
+                                if ((top || bot) && !one_row()) top = bot = 0;
+                                found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)run0, (int32_t)nz, ti, tj, 0, pass, top, bot });
+                            }
                             run0 = -1;
                         }
                     }
@@ -332,7 +406,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             /* the nodes the pass took are gone for the next one */
             for (size_t f = f0; f < found.size(); f++)
                 for (auto& c : found[f])
-                    for (int32_t z = 0; z < c.nz; z++)
+                    for (int32_t z = -c.top; z < c.nz + c.bot; z++)
                         for (int32_t y = 0; y < c.ny; y++)
                             memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
             if (!want_het) break;
@@ -349,7 +423,8 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
 
     /* device numbering: tile columns first (plane-major inside a column), everything else behind in its old order */
     int64_t nb = 0;
-    for (auto& c : cols) { c.base = nb; nb += (int64_t)c.nx * c.ny * c.nz; }
+    /* a column's nodes: [its top face plane][its planes][its bottom face plane] */
+    for (auto& c : cols) { c.base = nb; nb += (int64_t)c.nx * c.ny * (c.nz + c.top + c.bot); }
     if (nb > 0x7fffffff) return 0;
     B->perm.assign((size_t)N, -1);
     {
@@ -360,14 +435,14 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             const column_t& c = cols[(size_t)ci];
             const level_t& L = levels[(size_t)c.lvl];
             const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
-            for (int32_t z = 0; z < c.nz; z++)
+            for (int32_t z = -c.top; z < c.nz + c.bot; z++)
                 for (int32_t y = 0; y < c.ny; y++)
                     for (int32_t x = 0; x < c.nx; x++) {
                         const int32_t n = L.Ng[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
                         int32_t& slot = B->perm[(size_t)n];
                         int32_t was;
 #pragma omp atomic capture
-                        { was = slot; slot = (int32_t)(c.base + ((int64_t)z * c.ny + y) * c.nx + x); }
+                        { was = slot; slot = (int32_t)(c.base + ((int64_t)(z + c.top) * c.ny + y) * c.nx + x); }
                         twice += was != -1;
                     }
         }
@@ -446,7 +521,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BH_THREADS * 3 : 0);
     B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
     const bool try_pack = MS && MS->edata && MS->dt > 0 && !hq_opt_flag("HQ_BRICK_NO_PACK");
-    if (try_pack) { B->coef32.assign((size_t)coff[us.size()] + 8, 0.0f); B->nt2.assign(2 * (size_t)nb, 0.0); }
+    if (try_pack) { B->coef32.assign((size_t)coff[us.size()] + 8, 0.0f); B->nt2.assign(2 * (size_t)N, 0.0); }        /* [N]: a unit also LOADS the rows of its two cap planes, which may be anybody's nodes */
     int fault = 0;                                       /* written by many threads: atomic writes only */
     auto set_fault = [&]() {
 #pragma omp atomic write
@@ -479,9 +554,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 cap[nx * ny + j * nx + i] = dev(c.x0 + i, c.y0 + j, (int64_t)za + np);
             }
         hq_brick_unit& U = B->units[(size_t)u];
-        U.base = c.base + (int64_t)(za - c.z0) * nx * ny;
+        U.base = c.base + (int64_t)(za - c.z0 + c.top) * nx * ny;
         U.tab = toff[(size_t)u];
         U.nx = nx; U.ny = ny; U.np = np; U.flags = 0;
+        memset(U.ft, 0, sizeof U.ft); memset(U.fb, 0, sizeof U.fb);
+        if (c.top && za == c.z0) {
+            U.flags |= HQ_BK_TOPFACE;
+            memcpy(U.ft, ntab + 7 * (int64_t)L.Ng[(size_t)((((int64_t)za - 1) * NY + c.y0) * NX + c.x0)], sizeof U.ft);
+        }
+        if (c.bot && za + np == c.z0 + c.nz) {
+            U.flags |= HQ_BK_BOTFACE;
+            memcpy(U.fb, ntab + 7 * (int64_t)L.Ng[(size_t)((((int64_t)za + np) * NY + c.y0) * NX + c.x0)], sizeof U.fb);
+        }
         /* coefficients: those of any element around the first node (all eight are equal: the node is simple) */
         const int32_t n0 = L.Ng[(size_t)(((int64_t)za * NY + c.y0) * NX + c.x0)];
         {
@@ -664,21 +748,30 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         }                                                                                             \
     }
     /* the loaded plane -> LDS slot s_; its nodes' own term m2 u1 - m1 u2 joins the accumulator acc_ */
-#define HQ_BK_PUT(s_, acc_)                                                                           \
+    /* (M2_, M1_: mass2_minusaM and mass_minusaM of the plane's nodes, expressions in the axis d -- the unit's row, or a
+     *  face plane's 7-double row whose dashpot terms differ per axis) */
+#define HQ_BK_PUT(s_, acc_, M2_, M1_)                                                                 \
     {                                                                                                 \
         hq_lds_double* img_ = (hq_lds_double*)s_w + 3 * HQ_BK_PLANE * (s_);                            \
         if (active) {                                                                                 \
             _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
                 img_[3 * myrow + d] = x1[d] + beta * (x1[d] - x2[d]);                                 \
-                acc_[d] += mn[1] * x1[d] - mn[2] * x2[d];                                             \
+                acc_[d] += (M2_) * x1[d] - (M1_) * x2[d];                                             \
             }                                                                                         \
         }                                                                                             \
         if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) img_[3 * rrow + d] = y1[d] + beta * (y1[d] - y2[d]); } \
     }
 
+    /* face planes (HQ_BK_TOPFACE / BOTFACE): uniform per unit */
+    /* (only columns whose nodes all share one n_t row take their faces along -- the planner sees to it --, so the PERNODE
+     *  form, which no mesh of solver_init reaches, does not carry the face code: it would spill) */
+    const bool topf = !PERNODE && (U.flags & HQ_BK_TOPFACE) != 0, botf = !PERNODE && (U.flags & HQ_BK_BOTFACE) != 0;
+    const double rho = hq_uniform((U.c1 - U.c2) / (U.c1 + U.c2));
+
     HQ_BK_LOAD((int64_t)id_lo)
     rid = utab[nr + rofs];
-    { double dummy[3] = { 0.0, 0.0, 0.0 }; HQ_BK_PUT(0, dummy) }
+    if (topf) HQ_BK_PUT(0, fB, U.ft[1 + d], U.ft[4 + d])        /* the face plane's own term m2 u1 - m1 u2, per axis */
+    else { double dummy[3] = { 0.0, 0.0, 0.0 }; HQ_BK_PUT(0, dummy, mn[1], mn[2]) }
     for (int k = 0; k <= np + 1; k++) {
         if (k <= np) {                       /* request plane k + 1 */
             HQ_BK_LOAD(k == np ? (int64_t)cap[nxy + sidx] : U.base + (int64_t)k * nxy + sidx)
@@ -757,11 +850,31 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             Uo[1] = fma(Q[0], By0_z, Q[1] * By1_z);
             Uo[2] = fma(Q[0], Bx0_x, fma(Q[1], Bx1_x, fma(Q[0], By0_y, Q[1] * By1_y)));
         }
-        if (k >= 2 && active) {              /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
+        if (k == 0 && topf) {                /* the face plane seen from its own nodes: half the even part, rho x the odd part */
+            m[0] = fma(rho, Uo[0], 0.5 * m[0]); m[1] = fma(rho, Uo[1], 0.5 * m[1]); m[2] = fma(-rho, Uo[2], 0.5 * m[2]);
+        }
+        if (k == np + 1 && botf && active) { /* the bottom face plane: elements on its -z side only (the mirror image) */
+            double f[3];
+            f[0] = fB[0] + fma(-rho, Uo[0], 0.5 * m[0]); f[1] = fB[1] + fma(-rho, Uo[1], 0.5 * m[1]); f[2] = fB[2] + fma(rho, Uo[2], 0.5 * m[2]);
+            const int local = np * nxy + sidx;
+            if (has_src) {
+                for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
+                    if (src_ent[2 * i] == local) {
+                        const int li = src_ent[2 * i + 1];
+                        for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
+                    }
+            }
+            double* out = ung + 3 * (int64_t)cap[nxy + sidx];
+            const double rm = 1.0 / U.fb[0];
+#pragma unroll
+            for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
+        }
+        const bool outface = k == 1 && topf; /* plane 1 completes the TOP face plane (cap plane za - 1) */
+        if ((k >= 2 || outface) && active) { /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
             double f[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) f[d] = fA[d] + (g[d] + Uo[d]);
-            const int local = (k - 2) * nxy + sidx;
+            const int local = (k - 2) * nxy + sidx;          /* (the top face plane: -nxy + sidx) */
             if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
                 for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
                     if (src_ent[2 * i] == local) {
@@ -769,14 +882,16 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
                         for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
                     }
             }
-            double* out = ung + 3 * (U.base + (int64_t)local);
+            double* out = ung + 3 * (outface ? (int64_t)cap[sidx] : U.base + (int64_t)local);
+            const double rm = outface ? 1.0 / U.ft[0] : m0A;
 #pragma unroll
-            for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
+            for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
         }
 #pragma unroll
         for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - Uo[d]; }
         if (PERNODE) { m0A = m0B; m0B = 1.0 / mn[0]; }
-        if (k <= np) HQ_BK_PUT((k + 1) & 1, fB)
+        if (k < np || (k == np && !botf)) HQ_BK_PUT((k + 1) & 1, fB, mn[1], mn[2])
+        else if (k == np) HQ_BK_PUT((k + 1) & 1, fB, U.fb[1 + d], U.fb[4 + d])
     }
 #undef HQ_BK_LOAD
 #undef HQ_BK_PUT
@@ -1045,7 +1160,10 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
     std::sort(by_base.begin(), by_base.end());
     for (auto& pr : by_base) {
         const hq_brick_unit& U = B.units[(size_t)pr.second];
-        P->h_base.push_back(pr.first); P->h_slot.push_back(pr.second); P->h_size.push_back((int64_t)U.nx * U.ny * U.np);
+        const int64_t nxy = (int64_t)U.nx * U.ny;
+        const int top = (U.flags & HQ_BK_TOPFACE) != 0, bot = (U.flags & HQ_BK_BOTFACE) != 0;
+        P->h_base.push_back(pr.first - top * nxy); P->h_slot.push_back(pr.second); P->h_size.push_back(nxy * (U.np + top + bot));
+        P->h_first.push_back(pr.first);
     }
     return 0;
 }
@@ -1060,7 +1178,7 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
     for (int32_t i = 0; i < nloaded; i++) {
         if (loaded[i] >= P->nb) continue;
         const size_t k = (size_t)(std::upper_bound(P->h_base.begin(), P->h_base.end(), (int64_t)loaded[i]) - P->h_base.begin()) - 1;
-        rec.push_back({ P->h_slot[k], (int32_t)(loaded[i] - P->h_base[k]), i });
+        rec.push_back({ P->h_slot[k], (int32_t)(loaded[i] - P->h_first[k]), i });
     }
     if (rec.empty()) return 0;
     std::sort(rec.begin(), rec.end());

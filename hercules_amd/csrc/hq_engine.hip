@@ -2148,6 +2148,69 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                             }
                 }
     }
+    /* face planes (HQ_BK_TOPFACE / BOTFACE): every node of the plane is the corner of exactly FOUR elements, all on the
+     * unit's side, with the unit's coefficients; its n_t row is the one in the unit's record; the kernel finds it in the
+     * cap table and its 17 neighbours where it reads them */
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : bad, nchecked)
+    for (int64_t u = 0; u < (int64_t)B.units.size(); u++) {
+        const hq_brick_unit& U = B.units[(size_t)u];
+        const int nx = U.nx, ny = U.ny, np = U.np, nr = 2 * (nx + 2) + 2 * ny;
+        if (!(U.flags & (HQ_BK_TOPFACE | HQ_BK_BOTFACE))) continue;
+        if ((U.flags & HQ_BK_HET) || !(U.flags & HQ_BK_NTSAME)) { bad++; continue; }
+        const int32_t* ring = B.tab.data() + U.tab;
+        const int32_t* cap = ring + (int64_t)(np + 2) * nr;
+        auto at = [&](int x, int y, int k) -> int64_t {
+            const bool in = x >= 0 && x < nx && y >= 0 && y < ny;
+            if (in) {
+                if (k >= 0 && k < np) return U.base + ((int64_t)k * ny + y) * nx + x;
+                return cap[(k < 0 ? 0 : nx * ny) + y * nx + x];
+            }
+            const int32_t* r = ring + (int64_t)(k + 1) * nr;
+            if (y == -1) return r[x + 1];
+            if (y == ny) return r[nx + 2 + x + 1];
+            if (x == -1) return r[2 * (nx + 2) + y];
+            return r[2 * (nx + 2) + ny + y];
+        };
+        for (int side = 0; side < 2; side++) {
+            if (!(U.flags & (side ? HQ_BK_BOTFACE : HQ_BK_TOPFACE))) continue;
+            const double* row = side ? U.fb : U.ft;
+            const int kf = side ? np : -1;
+            for (int y = 0; y < ny; y++)
+                for (int x = 0; x < nx; x++) {
+                    const int64_t q = U.base + ((int64_t)(side ? np : -1) * ny + y) * nx + x;
+                    if (q < 0 || q >= B.nb) { bad++; continue; }
+#pragma omp atomic
+                    covered[(size_t)q]++;
+                    if (at(x, y, kf) != q) bad++;
+                    const int32_t n = inv[(size_t)q];
+                    if (n < 0) { bad++; continue; }
+                    if (excl[(size_t)n]) bad++;
+                    if (memcmp(d->nTable + 7 * (int64_t)n, row, 7 * sizeof(double)) != 0) bad++;
+                    int64_t el[8];
+                    for (int o = 0; o < 8; o++) el[o] = -1;
+                    if (aptr[(size_t)n + 1] - aptr[(size_t)n] != 4) { bad++; continue; }
+                    bool ok = true;
+                    for (int64_t a = aptr[(size_t)n]; a < aptr[(size_t)n + 1]; a++) {
+                        const int64_t e = adj[(size_t)a] >> 3;
+                        const int o = (int)(adj[(size_t)a] & 7);
+                        if (((o >> 2) & 1) != side || el[o] != -1) ok = false;     /* top: the node is the elements' low-z corner */
+                        el[o] = e;
+                        if (c1[(size_t)e] != U.c1 || c2[(size_t)e] != U.c2 || beta[(size_t)e] != U.beta) ok = false;
+                    }
+                    if (!ok) { bad++; continue; }
+                    for (int dz = (side ? -1 : 0); dz <= (side ? 0 : 1); dz++)
+                        for (int dy = -1; dy <= 1; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (!dx && !dy && !dz) continue;
+                                const int o = (dx < 0 ? 1 : 0) | (dy < 0 ? 2 : 0) | (side ? 4 : 0);
+                                const int m = (dx > 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | ((side ? dz == 0 : dz > 0) ? 4 : 0);
+                                const int32_t nb_abi = d->lnid[8 * el[o] + m];
+                                if (at(x + dx, y + dy, kf + dz) != (int64_t)B.perm[(size_t)nb_abi]) bad++;
+                                nchecked++;
+                            }
+                }
+        }
+    }
     for (int64_t q = 0; q < B.nb; q++) if (covered[(size_t)q] != 1) bad++;
     /* the patches behind the bricks: planned on the renumbered mesh as hq_create does it -- walking only the elements
      * of the shell (hq_patch_candidates) -- and once more walking every element: the two plans must be the same, and

@@ -398,6 +398,7 @@ struct hq_stencil_coef {
 };
 struct hq_stencil_tab {
     bool ok;
+    bool face_ok;                    /* the half-space form of the stencil is what hq_k_brick's face planes assume (below) */
     hq_stencil_coef c;
     double E1[576], E2[576];         /* element matrix for (c1, c2) = (1, 0) / (0, 1): E[((o * 8 + m) * 3 + a) * 3 + b] = force on
                                       * corner o, component a, per unit displacement of corner m, component b */
@@ -456,7 +457,38 @@ static const hq_stencil_tab& hq_stencil(void)
                                 if (fabs(v - want) > 1e-13 * scale) t.ok = false;
                             }
                     }
+            /* A node on a domain face normal to z, its four elements on the +z side (the node is their low-z corner, o_z = 0):
+             * its coupling to its own plane is  H(dx, dy) = S(dx, dy, 0) / 2 + T(dx, dy)  -- the part of S even under the
+             * mirror z -> -z halves, the odd part T does not cancel any more -- and T couples z with x and y only,
+             * antisymmetrically:  T[x][z] = -T[z][x] = r(|dy|) dx,  T[y][z] = -T[z][y] = r(|dx|) dy,  with r = +q for S1 and
+             * r = -q for S2.  Hence, with q1 == q2 (checked), the face term is  rho (Uo_x, Uo_y, -Uo_z)  of the node's OWN
+             * plane, rho = (c1 - c2) / (c1 + c2), Uo the odd-in-dz sums hq_k_brick forms for every plane anyway. */
+            if (which == 0) t.face_ok = true;
+            {
+                double H[3][3][3][3] = {};
+                for (int o = 0; o < 4; o++)                      /* o_z = 0 */
+                    for (int m = 0; m < 4; m++) {                /* m_z = 0: dz = 0 */
+                        const int dx = -(o & 1) + (m & 1), dy = -((o >> 1) & 1) + ((m >> 1) & 1);
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) H[dx + 1][dy + 1][a][b] += E[3 * o + a][3 * m + b];
+                    }
+                const double sign = which == 0 ? 1.0 : -1.0;
+                for (int dx = -1; dx <= 1; dx++)
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int a = 0; a < 3; a++)
+                            for (int b = 0; b < 3; b++) {
+                                double want = 0.5 * S[dx + 1][dy + 1][1][a][b];
+                                if (a == 0 && b == 2) want += sign * q[dy ? 1 : 0] * dx;
+                                if (a == 2 && b == 0) want -= sign * q[dy ? 1 : 0] * dx;
+                                if (a == 1 && b == 2) want += sign * q[dx ? 1 : 0] * dy;
+                                if (a == 2 && b == 1) want -= sign * q[dx ? 1 : 0] * dy;
+                                if (fabs(H[dx + 1][dy + 1][a][b] - want) > 1e-13 * scale) t.face_ok = false;
+                            }
+            }
         }
+        for (int i = 0; i < 2; i++)
+            if (fabs(t.c.q1[i] - t.c.q2[i]) > 1e-14 * fabs(t.c.q1[i])) t.face_ok = false;
+        if (!t.ok) t.face_ok = false;
         return t;
     }();
     return tab;

@@ -102,14 +102,24 @@ def test_stencil_tables_on_the_partitions_of_a_uniform_box():
 def test_brick_plan_of_a_uniform_box_matches_the_connectivity():
     """hq_brick_plan_check: the simple nodes of a uniform box -- everything but the six faces -- become tile columns of
     64 x 8 nodes; every neighbour hq_k_brick will read (unit-internal, ring table, first / last plane lists) is the node
-    the connectivity says, the numbering is a permutation, the patches keep the rest."""
+    the connectivity says, the numbering is a permutation, the patches keep the rest.  Since round 5 the interior of the
+    two faces normal to z rides with the columns under / above it (the free surface and the bottom dashpot face: first /
+    last plane of the first / last unit, 17 neighbours each); HQ_BRICK_NO_FACES=1 leaves them to the patches."""
     b = host.Box(64, 64, 32, 10.0, 2e-4, 50.0)
     r = b.brick_plan_check()
+    os.environ["HQ_BRICK_NO_FACES"] = "1"
+    try:
+        r0 = b.brick_plan_check()
+    finally:
+        del os.environ["HQ_BRICK_NO_FACES"]
     b.close()
-    assert r["faults"] == 0
-    assert r["brick_nodes"] == 63 * 63 * 31 and r["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
-    assert r["columns"] == 8 and r["units"] == 8 * 4 and r["units_one_nt_row"] == r["units"] and r["het_units"] == 0   # 31 planes in chunks of 8: a small mesh
-    assert r["neighbours_checked"] == 26 * r["brick_nodes"]
+    assert r["faults"] == 0 and r0["faults"] == 0
+    assert r0["brick_nodes"] == 63 * 63 * 31 and r0["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 31
+    assert r0["neighbours_checked"] == 26 * r0["brick_nodes"]
+    assert r["brick_nodes"] == 63 * 63 * 33 and r["patch_nodes"] == 65 * 65 * 33 - 63 * 63 * 33
+    assert r["neighbours_checked"] == 26 * 63 * 63 * 31 + 17 * 63 * 63 * 2
+    for q in (r, r0):
+        assert q["columns"] == 8 and q["units"] == 8 * 4 and q["units_one_nt_row"] == q["units"] and q["het_units"] == 0   # 31 planes in chunks of 8: a small mesh
 
 
 def test_brick_plan_on_partitions_layers_and_lateral_material():
@@ -124,12 +134,13 @@ def test_brick_plan_on_partitions_layers_and_lateral_material():
         b.close()
         assert r["faults"] == 0 and r["brick_nodes"] > 0
         tot += r["brick_nodes"]
-    assert tot == 63 * 63 * (31 + 31)                        # the interface plane z = 32 and the faces are left out
+    assert tot == 63 * 63 * (31 + 31 + 2)                    # the interface plane z = 32 and the x / y faces are left out;
+                                                             # the free surface rides with rank 0's columns, the bottom face with rank 1's
     layers = [(0.0, 3000.0, 1400.0, 2200.0), (200.0, 6000.0, 3464.0, 2700.0)]
     b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, layers=layers)
     r = b.brick_plan_check()
     b.close()
-    assert r["faults"] == 0 and r["brick_nodes"] == 31 * 31 * (15 + 15) and r["units_one_nt_row"] == r["units"]
+    assert r["faults"] == 0 and r["brick_nodes"] == 31 * 31 * (15 + 15 + 2) and r["units_one_nt_row"] == r["units"]
     b = host.Box(32, 32, 32, 12.5, 2e-4, 50.0, lateral_classes=61, lateral_amp=0.1)
     r = b.brick_plan_check()
     assert r["faults"] == 0 and r["brick_nodes"] == 31 ** 3 and r["columns"] == 5 and r["het_units"] == r["units"] == 5 * 4 and r["units_one_nt_row"] == 0
