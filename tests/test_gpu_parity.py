@@ -832,8 +832,10 @@ def test_every_patch_kernel_on_a_partitioned_octree_box(pipe, monkeypatch, brick
     p1, p2 = v2.copy(), v1.copy()
     ho.solver_run(lnid, et, nt, p1, p2, 0, 6, 2e-4, loaded_lnid=loaded, forces=F)
     s = ha.Solver(lnid, et, nt, 2e-4, tm1=v1, tm2=v2, node_xyz=_ticks(node_ijk, 1 << 20), variant=ha.HQ_VARIANT_PATCH)
-    if brick_mode == "bricks":                      # the 31^3 simple nodes are brick nodes; the patch kernels keep the shell
-        assert s.dominant_kernel() == "hq_k_brick" and s.info()["brick_nodes"] == 31 ** 3
+    if brick_mode == "bricks":                      # the 31^3 simple nodes and the interior of the two z faces (31^2 each: the
+                                                    # free surface and the bottom dashpot face ride with their columns) are
+                                                    # brick nodes; the patch kernels keep the rest of the shell
+        assert s.dominant_kernel() == "hq_k_brick" and s.info()["brick_nodes"] == 31 * 31 * 33
     elif ragged:                                    # all 64 patches are lattice subsets (dashpot faces included)
         assert s.dominant_kernel() == "hq_k_patch_stencil" and s.info()["ragged_patches"] > 0
         assert s.info()["stencil_patches"] == s.info()["npatches"]
