@@ -273,23 +273,29 @@ def basin_field(box, nx, ny):
     return u
 
 
+_BASIN_CACHE = {}         # workload -> (leaves, whole-mesh start field, E, N): what every partition of one process shares
+
+
 def make_octbox(workload, rank, nranks):
     """-> (OctBox, total elements, total nodes, interfaces for seeded_field)"""
     from hercules_amd import host as hhost
     nx, ny, nz, h, dt, freq = WORKLOADS[workload]
     if workload in OCT_BASIN:
-        ticks, edge, edata, far, ticksize = basin_leaves(workload)
-        assert abs(int(edge.min()) * ticksize - h) < 1e-9 * h, "the finest leaf is not the workload's h"
-        whole = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq)
-        field = basin_field(whole, nx, ny)
-        E, N = whole.E, whole.N
-        if nranks > 1:
-            whole.close()
-            box = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq, rank=rank, nranks=nranks)
-            field = field[box.gid]
+        if nranks > 1 and workload in _BASIN_CACHE:
+            (ticks, edge, edata, far), field, E, N = _BASIN_CACHE[workload]
         else:
-            box = whole
-        return box, E, N, {"field": field}
+            ticks, edge, edata, far, ticksize = basin_leaves(workload)
+            assert abs(int(edge.min()) * ticksize - h) < 1e-9 * h, "the finest leaf is not the workload's h"
+            whole = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq)
+            field = basin_field(whole, nx, ny)
+            E, N = whole.E, whole.N
+            if nranks == 1:
+                return whole, E, N, {"field": field}
+            whole.close()
+            if E < 8000000:               # the small basin: the leaves and the whole-mesh field serve every rank of this process
+                _BASIN_CACHE[workload] = ((ticks, edge, edata, far), field, E, N)
+        box = hhost.OctBox.from_leaves(ticks, edge, edata, far, dt, freq, rank=rank, nranks=nranks)
+        return box, E, N, {"field": field[box.gid]}
     if workload in OCT_LAYERED:
         _, _, _, _, _, ppw, h0, ncoarse, model = OCT_LAYERED[workload]
         col = hhost.layered_column(model, h0, ncoarse, freq * ppw)

@@ -334,21 +334,26 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         const int lvl = (int)levels.size();
         std::vector<std::vector<column_t>> found;
         int32_t ntx_lvl = 1;
-        for (int pass = 0; pass < 2; pass++) {
-            const int PTX = pass == 0 ? TX : HQ_BH_TX, PTY = pass == 0 ? TY : HQ_BH_TY;
+        /* rounds: the 64-wide tiles, then (round 5) 32-wide ones over what is left of the uniform simple nodes -- beside a
+         * level interface or a material boundary that runs along y or z a strip of up to 63 nodes per row is left over,
+         * and half a workgroup's lanes in the marching kernel still beat the patches by a wide margin -- then the het tiles */
+        const int half = hq_opt_int("HQ_BRICK_HALF_TILES", 1) != 0 ? 1 : 0;
+        for (int round = 0; round < 2 + half; round++) {
+            const int pass = round == 1 + half ? 1 : 0;
+            const int PTX = pass == 1 ? HQ_BH_TX : (round == 0 ? TX : TX / 2), PTY = pass == 0 ? TY : HQ_BH_TY;
             /* pass 0: uniform simple nodes (2); pass 1: what is left of them and the per-element ones (1).  3 / 4 are face
              * nodes: never part of a run, but a run of pass 0 that starts / ends beside a full face plane takes it along */
             auto in_run = [pass](char v) { return pass == 0 ? v == 2 : (v == 1 || v == 2); };
-            if (pass == 1) {
+            if (round >= 1) {
                 sx0 = INT64_MAX; sx1 = -1; sy0 = INT64_MAX; sy1 = -1;
                 for (int64_t Z = 0; Z < NZ; Z++)
                     for (int64_t Y = 0; Y < NY; Y++)
                         for (int64_t X = 0; X < NX; X++)
                             if (in_run(S[(size_t)((Z * NY + Y) * NX + X)])) { sx0 = std::min(sx0, X); sx1 = std::max(sx1, X); sy0 = std::min(sy0, Y); sy1 = std::max(sy1, Y); }
-                if (sx1 < 0) break;
+                if (sx1 < 0) { if (pass == 1) break; else continue; }
             }
             const int32_t ntx = (int32_t)((sx1 - sx0) / PTX + 1), nty = (int32_t)((sy1 - sy0) / PTY + 1);
-            if (pass == 0) ntx_lvl = ntx;
+            if (round == 0) ntx_lvl = ntx;
             const size_t f0 = found.size();
             found.resize(f0 + (size_t)nty);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -409,7 +414,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     for (int32_t z = -c.top; z < c.nz + c.bot; z++)
                         for (int32_t y = 0; y < c.ny; y++)
                             memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
-            if (!want_het) break;
+            if (!want_het && round + 1 >= 1 + half) break;
         }
         lap("tile columns");
         const int32_t ntx = ntx_lvl;

@@ -200,7 +200,9 @@ struct hq_ctx {
     bool group_owner = false;
     bool share_packed = false;               /* this step's hq_k_interface_update wrote the sharing records as well */
     /* switches read at hq_create (per context, so that a host -- or a test process -- can differ between contexts) */
-    bool opt_brick_stream = false;           /* HQ_BRICK_STREAM=1 */
+    int opt_brick_stream = -1;               /* HQ_BRICK_STREAM: 1 / 0; -1: on a context that steps alone (no transport), where
+                                              * the shell's patch launch then runs BESIDE the first round of brick workgroups
+                                              * instead of ahead of it */
     bool opt_fused_share = true;             /* HQ_NO_FUSED_SHARE=1 clears it */
     int opt_merge_rounds = 2;                /* HQ_PATCH_MERGE_ROUNDS */
     int opt_brick_light = -1;                /* HQ_BRICK_BY_COMPONENT: 0 / 1; default (-1): where the chain has its own stream */
@@ -1031,7 +1033,11 @@ enum { HQ_NPHASE = 9 };
  * them.  Kept for boxes where the shell is larger than one round of workgroups; parity-tested (HQ_OVERLAP=1 tests). */
 static bool hq_use_brick_stream(hq_ctx* c)
 {
-    if (!c->opt_brick_stream || !c->overlap || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
+    /* (a context alone: the patches of the thin shell left behind the bricks are latency-bound gathers, 1 TB/s; beside the
+     *  bandwidth-bound brick launch they cost next to nothing, ahead of it their 30 us count in full) */
+    const bool solo = !hq_has_transport(c) && c->nranks == 1;
+    const bool want = c->opt_brick_stream < 0 ? solo : c->opt_brick_stream != 0;
+    if (!want || !(c->overlap || solo) || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
     if (!c->bstream) {
         int prio_lo = 0, prio_hi = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return false;
@@ -1070,7 +1076,7 @@ static int hq_phase(hq_ctx* c, int ph)
                 /* the bricks' own stream: behind the last step's chain (they read shared nodes in their rings and overwrite
                  * the buffer its interface update read) and the last step's patches (ring rows; the buffer those read as
                  * u(t - dt)) -- ev_patches still names THAT record here, this step's comes below */
-                HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_shared, 0));
+                if (c->ev_shared) HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_shared, 0));
                 HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_patches, 0));
             }
             hq_mark(c);
@@ -1758,7 +1764,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
-    c->opt_brick_stream = hq_opt_on("HQ_BRICK_STREAM");
+    c->opt_brick_stream = hq_opt_has("HQ_BRICK_STREAM") ? (hq_opt_on("HQ_BRICK_STREAM") ? 1 : 0) : -1;
     c->opt_fused_share = !(hq_opt_on("HQ_NO_FUSED_SHARE"));
     if (hq_opt_has("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, hq_opt_int("HQ_PATCH_MERGE_ROUNDS", 1));
     if (hq_opt_has("HQ_BRICK_BY_COMPONENT")) c->opt_brick_light = hq_opt_int("HQ_BRICK_BY_COMPONENT", 0) != 0;

@@ -167,7 +167,7 @@ def np8_stripe(g, step, rank, n):
 # dependency-cone windows of an octree mesh (oracle parity at sizes the oracle cannot run whole)
 # ---------------------------------------------------------------------------------------------
 
-def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin):
+def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin, cand=None):
     """The elements of an octree mesh that lie inside the box [lo, hi] (node coordinates, finest-element units; lo / hi
     must be multiples of the coarsest edge inside, so that no element straddles a face and every hanging node of the
     window finds its anchors in it), renumbered as a mesh of their own.
@@ -177,10 +177,13 @@ def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin):
     the hop from a hanging node to its anchors, compute_adjust psolve.c:5936-6039), so with margin >= 2 k c the oracle
     on the window gives the exact values of those nodes."""
     lo, hi = np.asarray(lo, np.int64), np.asarray(hi, np.int64)
-    inside = np.ones(len(elem_edge), bool)
+    if cand is None:                                            # (cand: elements known to hold every element of the window)
+        cand = np.arange(len(elem_edge))
+    c_lo, c_edge = elem_lo[cand], elem_edge[cand]
+    inside = np.ones(len(cand), bool)
     for d in range(3):
-        inside &= (elem_lo[:, d] >= lo[d]) & (elem_lo[:, d] + elem_edge <= hi[d])
-    elems = np.nonzero(inside)[0]
+        inside &= (c_lo[:, d] >= lo[d]) & (c_lo[:, d] + c_edge <= hi[d])
+    elems = cand[np.nonzero(inside)[0]]
     assert len(elems) > 0
     assert int(elem_edge[elems].astype(np.int64).__pow__(3).sum()) == int(np.prod(hi - lo)), "the window is not filled by whole elements"
     nodes, inv = np.unique(lnid[elems], return_inverse=True)
@@ -235,7 +238,7 @@ def hanging_kinds(node_xyz, dangling):
 
 def lateral_windows(node_xyz, dangling, elem_lo, elem_edge, k, per_kind=1, seed=5, kinds=None, max_elems=700000):
     """Dependency-cone windows of an octree mesh centred on hanging nodes of every kind present (orientation x level),
-    `per_kind` of each picked by a seeded generator: -> [(lo, hi, margin, centre node)].  Window faces are aligned to
+    `per_kind` of each picked by a seeded generator: -> [(lo, hi, margin, centre node, candidate elements)].  Window faces are aligned to
     the coarsest edge of the mesh (no element straddles them); margin = 2 k c with c the coarsest edge INSIDE the
     window (octree_window's rule)."""
     ids, ptr, anchors = dangling
@@ -243,7 +246,6 @@ def lateral_windows(node_xyz, dangling, elem_lo, elem_edge, k, per_kind=1, seed=
     rng = np.random.default_rng(seed)
     A = int(elem_edge.max())
     far = node_xyz.max(axis=0).astype(np.int64)
-    e_hi = elem_lo.astype(np.int64) + elem_edge.astype(np.int64)[:, None]
     out = []
     for key in sorted(set(zip(mask.tolist(), dist.tolist()))):
         if kinds is not None and key not in kinds:
@@ -252,15 +254,23 @@ def lateral_windows(node_xyz, dangling, elem_lo, elem_edge, k, per_kind=1, seed=
         for pick in rng.choice(cand, min(per_kind, len(cand)), replace=False):
             q = node_xyz[ids[pick]].astype(np.int64)
             c = 2 * int(key[1])
+            # ONE pass over the mesh per window: the elements that can lie in the largest window this node may get
+            reach = 2 * k * A + 2 * A
+            near = np.ones(len(elem_edge), bool)
+            for d in range(3):
+                near &= (elem_lo[:, d] >= q[d] - reach - A) & (elem_lo[:, d] <= q[d] + reach)
+            cand = np.nonzero(near)[0]
+            c_lo = elem_lo[cand].astype(np.int64)
+            c_hi = c_lo + elem_edge[cand].astype(np.int64)[:, None]
             for _ in range(3):
                 half = 2 * k * c + c
                 lo = np.maximum(0, (q - half) // A * A)
                 hi = np.minimum(far, -((-(q + half)) // A) * A)
-                inside = np.all(elem_lo >= lo, axis=1) & np.all(e_hi <= hi, axis=1)
-                c2 = int(elem_edge[inside].max())
+                inside = np.all(c_lo >= lo, axis=1) & np.all(c_hi <= hi, axis=1)
+                c2 = int(elem_edge[cand][inside].max())
                 if c2 == c:
                     break
                 c = c2
             if inside.sum() <= max_elems:
-                out.append((lo.tolist(), hi.tolist(), 2 * k * c, int(ids[pick])))
+                out.append((lo.tolist(), hi.tolist(), 2 * k * c, int(ids[pick]), cand))
     return out

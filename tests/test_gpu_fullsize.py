@@ -413,7 +413,10 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
     nx, ny = bench.WORKLOADS["o3"][:2]
     worst, nchecked, nhang = 0.0, 0, 0
-    for lo, hi, margin in _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps):
+    wins = _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps)
+    # (every interface in the interior; the first one also at a domain face and in a corner -- the windows of the
+    #  laterally refined basin o4 below carry the rest of the load since round 5)
+    for lo, hi, margin in [wins[0], wins[1], wins[2], wins[3], wins[6]]:
         win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
         g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
         ok, nodes = win["ok"], win["nodes"]
@@ -422,7 +425,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
         nchecked += int(ok.sum())
         nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
     del elem_lo, elem_edge
-    assert nchecked > 2000 and nhang > 50
+    assert nchecked > 1000 and nhang > 25
     assert worst < 1e-9, worst
     tm1, _ = s.download(want_tm2=False)
     s.close()
@@ -437,25 +440,30 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     gc.collect()
     # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
     # of every rank through their coordinates
-    key = lambda xyz: (xyz[:, 2].astype(np.int64) << 42) | (xyz[:, 1].astype(np.int64) << 21) | xyz[:, 0].astype(np.int64)
-    k1 = key(box.node_xyz)
-    order = np.argsort(k1)
-    k1s = k1[order]
-    del k1, u
+    # (a dense table over the node lattice instead of a sort of 190 M keys: 3.4 GB for half a minute less)
+    far = box.node_xyz.max(axis=0).astype(np.int64)
+    key = lambda xyz: (xyz[:, 2].astype(np.int64) * (far[1] + 1) + xyz[:, 1]) * (far[0] + 1) + xyz[:, 0]
+    lut = np.full(int((far[0] + 1) * (far[1] + 1) * (far[2] + 1)), -1, np.int32)
+    lut[key(box.node_xyz)] = np.arange(box.N, dtype=np.int32)
+    del u
     box.close()
     gc.collect()
     solvers, maps = [], []
-    for r in range(8):
-        b, _, _, ur = _basin("o3", r, 8)
-        kr = key(b.node_xyz)
-        m = order[np.searchsorted(k1s, kr)]
-        assert np.array_equal(k1s[np.searchsorted(k1s, kr)], kr)
-        maps.append(m)
-        solvers.append(b.create_solver(tm1=ur, tm2=0.999 * ur))
-        assert solvers[-1].info()["brick_nodes"] > 0
-        del ur, kr
-        b.close()
-        gc.collect()
+    # the ranks' tables are built four at a time (the C host side releases the GIL; a rank alone takes ~10 s)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as pool:
+        built = pool.map(lambda r: _basin("o3", r, 8), range(8))
+        for r in range(8):
+            b, _, _, ur = next(built)
+            m = lut[key(b.node_xyz)]
+            assert (m >= 0).all()
+            maps.append(m)
+            solvers.append(b.create_solver(tm1=ur, tm2=0.999 * ur))
+            assert solvers[-1].info()["brick_nodes"] > 0
+            del ur
+            b.close()
+            gc.collect()
+    del lut
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     for sv, m in zip(solvers, maps):
@@ -656,7 +664,7 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     box.close()
 
 
-@pytest.mark.parametrize("nranks", [8, 5])
+@pytest.mark.parametrize("nranks", [8])       # (5 ranks: the reference's own 5-rank run of its basin, tests/test_gpu_parity.py and test_gpu_multiprocess.py)
 def test_small_lateral_basin_in_partitions_matches_one_partition(nranks):
     """o4s cut into octor's block partitions (hqh_mesh_from_leaves with rank / nranks: ownership by Z-order point
     location, anchors of shared hanging nodes across x- / y- / z-normal interfaces), patch variant with bricks, in-process
@@ -710,8 +718,8 @@ def test_full_lateral_basin_against_the_oracle():
     assert set(mask.tolist()) == {1, 2, 3, 4, 5, 6}
     wins = H.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, nsteps, per_kind=1)
     worst, nchecked, nhang, kinds = 0.0, 0, 0, set()
-    for lo, hi, margin, centre in wins:
-        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+    for lo, hi, margin, centre, cand in wins:
+        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin, cand)
         g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
         ok, nodes = win["ok"], win["nodes"]
         assert centre in nodes[ok]

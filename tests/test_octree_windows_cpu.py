@@ -72,8 +72,8 @@ def test_windows_across_lateral_interfaces_reproduce_the_whole_mesh():
     scale = np.abs(u1).max()
     wins = H.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, k, kinds={(1, 1), (2, 2), (4, 1), (3, 1), (5, 2), (6, 1), (6, 4)})
     assert len(wins) == 7
-    for lo, hi, margin, centre in wins:
-        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
+    for lo, hi, margin, centre, cand in wins:
+        win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin, cand)
         g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u1, u2, k, box.dt)
         ok, nodes = win["ok"], win["nodes"]
         assert centre in nodes[ok]
