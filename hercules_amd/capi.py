@@ -72,7 +72,7 @@ class _Info(ctypes.Structure):
 
 # hq_options (include/hq_solver.h): int32 fields in the header's order, two doubles, two more int32
 OPTION_FIELDS = ["no_bricks", "brick_cz", "brick_minz", "brick_minnodes", "brick_no_het", "brick_no_ntsame", "brick_by_component",
-                 "brick_stream", "brick_no_faces", "brick_no_pack", "patch_pipe", "patch_threads", "patch_pmax", "patch_pmerge", "patch_psplit", "patch_nlmax",
+                 "brick_stream", "brick_no_faces", "brick_half_tiles", "brick_no_pack", "patch_pipe", "patch_threads", "patch_pmax", "patch_pmerge", "patch_psplit", "patch_nlmax",
                  "patch_vmax", "patch_ragged", "patch_no_lattice", "patch_no_stencil", "patch_no_uniform", "patch_no_iso",
                  "patch_no_ntsame", "patch_no_dedup", "patch_wform", "patch_merge_rounds", "overlap", "no_overlap", "reserve_cus",
                  "cu_mask", "no_fused_share", "group_copies", "debug_halo", "ipc_arena"]

