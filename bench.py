@@ -636,7 +636,8 @@ def traffic_of(pmc, kernel, steps=PMC_STEPS):
 PARITY_STEPS = 3                # steps of the parity run behind the timed region
 PARITY_EDGE = 16                # elements per axis of a window (a power of two: hqh_box_create)
 PARITY_TOL = 1e-9               # the GPU parity bar: relative L-inf on nodal displacement
-PARITY_WORKLOADS = ("c1", "c2", "c3", "m1")     # homogeneous boxes: a window of them is a small box of the same material
+PARITY_WORKLOADS = ("c1", "c2", "c3", "m1", "c3h", "c2h", "m1h")     # boxes: a window of them is a small box of the same
+                                                                     # material (hqh_box_params.origin: classes at the big box's indices)
 
 
 def parity_windows(args, box, solver, rank, world):
@@ -648,6 +649,8 @@ def parity_windows(args, box, solver, rank, world):
     this rank SHARES with others (its partition interfaces: pack, transport, interface update and unpack are inside the
     checked cones), plus brick-tile borders and domain faces.
     -> (windows, nodes checked, worst relative error) of this rank; None for workloads without a window oracle."""
+    if args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED or args.workload in OCT_BASIN:
+        return parity_windows_octree(args, box, solver) if world == 1 else None
     if args.workload not in PARITY_WORKLOADS:
         return None
     from hercules_amd import host as hhost
@@ -683,7 +686,8 @@ def parity_windows(args, box, solver, rank, world):
         if lo in seen:
             continue
         seen.add(lo)
-        sub = hhost.Box(W, W, W, h, dt, freq)
+        ncls, amp = LATERAL.get(args.workload, (0, 0.0))
+        sub = hhost.Box(W, W, W, h, dt, freq, lateral_classes=ncls, lateral_amp=amp, origin=lo)
         g = sub.node_ijk.astype(np.int64) + np.array(lo)
         w1 = seeded_field(g, nx, ny)
         o1, o2 = w1 * (1.0 - 1e-3), w1.copy()
@@ -705,6 +709,44 @@ def parity_windows(args, box, solver, rank, world):
         worst = max(worst, float(np.abs(tm1 - o2[mine]).max() / scale), float(np.abs(tm2 - o1[mine]).max() / scale))
         nwin += 1
         nchecked += int(mine.sum())
+    return nwin, nchecked, worst
+
+
+PARITY_OCTREE_WINDOWS = 6      # windows of an octree workload (each costs a pass over the mesh to cut out)
+
+
+def parity_windows_octree(args, box, solver):
+    """The same for the octree workloads on ONE rank, where the whole mesh is at hand: windows centred on hanging nodes
+    of different kinds (orientation x level pair; oracle/windows.py, pinned in tests/test_octree_windows_cpu.py), cut out
+    with the true table rows, stepped by the oracle with compute_adjust.  Partitions of an octree mesh carry no windows
+    (a window across a partition interface needs the neighbour's rows): the partitioned octree paths are pinned by the
+    tests against the single-partition runs and the reference's own stripes."""
+    from oracle import windows as ow                 # the checker, behind the timed region only
+    nx, ny = WORKLOADS[args.workload][:2]
+    k = 2
+    if box.ldnnum == 0:
+        return None
+    u1 = seeded_field(box.node_ijk, nx, ny, box.start_interfaces)
+    solver.set_source(np.zeros(0, np.int32), np.zeros((0, 0, 3)))
+    solver.upload(u1, u1 * (1.0 - 1e-3), 0)
+    solver.run(k)
+    solver.sync()
+    xyz = box.node_xyz
+    elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
+    elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
+    deps, mask, dist = ow.hanging_kinds(xyz, box.dangling)
+    kinds = sorted(set(zip(mask.tolist(), dist.tolist())))
+    pick = [kinds[i] for i in np.unique(np.linspace(0, len(kinds) - 1, PARITY_OCTREE_WINDOWS).astype(int))]
+    scale = np.abs(u1).max()
+    nwin, nchecked, worst = 0, 0, 0.0
+    for lo, hi, margin, centre, cand in ow.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, k, per_kind=1, kinds=set(pick)):
+        win = ow.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin, cand)
+        g1, g2 = ow.octree_window_oracle(win, box.etable, box.ntable, u1, 1.0 - 1e-3, k, box.dt)
+        ok, nodes = win["ok"], win["nodes"]
+        tm1, tm2 = solver.gather(nodes[ok])
+        worst = max(worst, float(np.abs(tm1 - g1[ok]).max() / scale), float(np.abs(tm2 - g2[ok]).max() / scale))
+        nwin += 1
+        nchecked += int(ok.sum())
     return nwin, nchecked, worst
 
 
@@ -1020,7 +1062,7 @@ def main():
                        "parity_windows": parity[0] if parity else None,
                        "parity_nodes": parity[1] if parity else None,
                        "parity_worst": parity[2] if parity else None,
-                       "parity_steps": PARITY_STEPS if parity else None, "parity_tol": PARITY_TOL},
+                       "parity_steps": (2 if octree else PARITY_STEPS) if parity else None, "parity_tol": PARITY_TOL},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch
             # time (HIP events on its stream); where the counters are unavailable, the compulsory bytes
             # (a lower bound).  The reference formulation's 336 B per element-update is kept only as

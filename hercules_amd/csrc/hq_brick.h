@@ -324,7 +324,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                             if (e0 < 0) e0 = e;
                             else s4 = c1[e] == c1[e0] && c2[e] == c2[e0] && beta[e] == beta[e0];
                         }
-                        if (s4) S[(size_t)((Z * NY + Y) * NX + X)] = side ? 4 : 3;
+                        if (s4 && c1[e0] + c2[e0] != 0.0) S[(size_t)((Z * NY + Y) * NX + X)] = side ? 4 : 3;   /* (rho = (c1 - c2) / (c1 + c2)) */
                     }
         }
         lap("simple nodes");

@@ -227,6 +227,7 @@ static void rayleigh_base(double freq, int damping, double* aBase, double* bBase
 static inline int32_t lateral_class(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek)
 {
     if (b->ncls <= 1) return 0;
+    ei += b->p.origin[0]; ej += b->p.origin[1]; ek += b->p.origin[2];
     uint32_t h = (uint32_t)ei * 0x9E3779B1u ^ ((uint32_t)ej * 0x85EBCA77u + 0x165667B1u) ^ ((uint32_t)ek * 0xC2B2AE3Du + 0x27D4EB2Fu);
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (int32_t)(h % (uint32_t)b->ncls);
@@ -255,7 +256,7 @@ static int depth_constants(hqh_box* b)
     double dt = p->deltaT, dt2 = dt * dt;
     float h = (float)p->h;
     for (int32_t k = 0; k < p->nz; k++) {
-        double zc = (k + 0.5) * p->h;
+        double zc = (k + p->origin[2] + 0.5) * p->h;
         int L = 0;
         for (int l = 0; l < p->nlayers; l++)
             if (p->layer_ztop[l] <= zc) L = l;

@@ -29,7 +29,7 @@ class _BoxParams(ctypes.Structure):
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
                 ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("lateral_classes", ctypes.c_int32), ("lateral_amp", ctypes.c_double)]
+                ("lateral_classes", ctypes.c_int32), ("lateral_amp", ctypes.c_double), ("origin", ctypes.c_int32 * 3)]
 
 
 class _BoxInfo(ctypes.Structure):
@@ -203,7 +203,7 @@ class Box:
 
     def __init__(self, nx, ny, nz, h, dt, freq, vp=6000.0, vs=3464.0, rho=2700.0, layers=None,
                  damping="rayleigh", threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True,
-                 rank=0, nranks=1, lateral_classes=0, lateral_amp=0.0):
+                 rank=0, nranks=1, lateral_classes=0, lateral_amp=0.0, origin=(0, 0, 0)):
         lib = load_library()
         if layers is None:
             layers = [(0.0, vp, vs, rho)]
@@ -213,7 +213,8 @@ class Box:
         lrho = np.array([l[3] for l in layers], np.float32)
         p = _BoxParams(nx, ny, nz, h, len(layers), zt.ctypes.data, lvp.ctypes.data, lvs.ctypes.data,
                        lrho.ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
-                       int(halfspace), rank, nranks, int(lateral_classes), float(lateral_amp))
+                       int(halfspace), rank, nranks, int(lateral_classes), float(lateral_amp),
+                       (ctypes.c_int32 * 3)(*[int(v) for v in origin]))
         self._h = ctypes.c_void_p()
         rc = lib.hqh_box_create(ctypes.byref(p), ctypes.byref(self._h))
         if rc != 0:

@@ -60,6 +60,9 @@ typedef struct {
                                       * material that differs from element to element, as on a real CVM mesh
                                       * (psolve.c:3360-3409 reads every element's own edata_t); 0 | 1: depth only  */
     double        lateral_amp;       /* 0 <= amp < 1                                                              */
+    int32_t       origin[3];         /* this box is a WINDOW of a larger one whose element (origin + (i, j, k)) it holds:
+                                      * classes and layers are taken at the larger box's indices (bench.py's parity
+                                      * windows); {0, 0, 0} otherwise                                             */
 } hqh_box_params;
 
 typedef struct {

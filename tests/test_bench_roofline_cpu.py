@@ -160,7 +160,8 @@ def test_transport_selection_of_a_multi_gpu_bench_run():
     assert _select("host", {}, {})[0] == "host"
 
 
-def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch):
+@pytest.mark.parametrize("wl", ["c1", "m1h"])
+def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch, wl):
     """bench.parity_windows (the oracle cone windows every bench line carries, config.parity_*) with a stand-in for the
     device context that steps the WHOLE box with the oracle: a window built as a 16^3 box of its own must then agree to
     rounding at every checked node -- in the interior, at brick-tile borders and where windows touch the domain's faces,
@@ -169,9 +170,12 @@ def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch
     import bench
     from hercules_amd import host
     from oracle import herc_oracle as ho
-    monkeypatch.setitem(bench.WORKLOADS, "c1", (128, 32, 32, 62.5, 1e-3, 5.0))
-    nx, ny, nz, h, dt, freq = bench.WORKLOADS["c1"]
-    box = host.Box(nx, ny, nz, h, dt, freq)
+    # (m1h: material of its own in every element -- the windows are boxes with hqh_box_params.origin, so that their
+    #  classes are the big box's)
+    monkeypatch.setitem(bench.WORKLOADS, wl, (128, 32, 32, 62.5, 1e-3, 5.0))
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
+    ncls, amp = bench.LATERAL.get(wl, (0, 0.0))
+    box = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
 
     class WholeBoxOracle:
         wrong = 0.0
@@ -194,7 +198,7 @@ def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch
         def gather(self, ids):
             return self.u1[ids], self.u2[ids]
 
-    args = argparse.Namespace(workload="c1")
+    args = argparse.Namespace(workload=wl)
     s = WholeBoxOracle()
     nwin, nchecked, worst = bench.parity_windows(args, box, s, 0, 1)
     assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-13
@@ -203,4 +207,37 @@ def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch
     args2 = argparse.Namespace(workload="o3")
     assert bench.parity_windows(args2, box, s, 0, 1) is None          # no window oracle for this workload: reported as null
     assert checked_1000 < 1e-13 or checked_1000 > 1e-9                  # node 1000 is either outside every window or caught
+    box.close()
+
+
+def test_octree_parity_windows_of_the_bench_line_against_a_whole_mesh_oracle():
+    """bench.parity_windows_octree (one rank of an octree workload: windows centred on hanging nodes, cut out with the true
+    table rows) with a stand-in context that steps the WHOLE laterally refined basin o4s with the oracle."""
+    import argparse
+    import bench
+    from oracle import herc_oracle as ho
+    box, E, N, it = bench.make_octbox("o4s", 0, 1)
+    box.node_ijk, box.start_interfaces = box.node_xyz, it
+
+    class WholeMeshOracle:
+        def set_source(self, ids, F):
+            assert len(ids) == 0
+
+        def upload(self, tm1, tm2, step):
+            self.u1, self.u2 = tm1.copy(), tm2.copy()
+
+        def run(self, k):
+            o1, o2 = self.u2.copy(), self.u1.copy()
+            ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, k, box.dt, dangling=box.dangling)
+            self.u1, self.u2 = o2, o1
+
+        def sync(self):
+            pass
+
+        def gather(self, ids):
+            return self.u1[ids], self.u2[ids]
+
+    nwin, nchecked, worst = bench.parity_windows(argparse.Namespace(workload="o4s"), box, WholeMeshOracle(), 0, 1)
+    assert nwin >= 4 and nchecked > 1000 and worst < 1e-12
+    assert bench.parity_windows(argparse.Namespace(workload="o4s"), box, None, 0, 2) is None     # partitions: no windows
     box.close()

@@ -42,3 +42,12 @@ def test_ranks_sharing_the_gpu_carry_their_parity(world, transport):
     assert d["n_gpus"] == world and c["finite"]
     assert ("IPC" in c["transport"] or "ipc" in c["transport"].lower()) if transport != "host" else "host" in c["transport"].lower()
     assert c["parity_windows"] >= 4 * world and c["parity_worst"] <= 1e-9
+
+
+@pytest.mark.parametrize("wl,windows", [("m1h", 4), ("o4s", 4), ("o3s", 3)])
+def test_lines_of_lateral_material_and_octree_workloads_carry_parity(wl, windows):
+    """m1h: material of its own in every element (hq_k_brick_het<PACKED>; the windows are boxes with the big box's
+    classes).  o4s / o3s: octree workloads on one rank (windows centred on hanging nodes, true table rows)."""
+    d = _bench("--workload", wl, "--steps", "10", "--warmup", "3", "--no-pmc", "--no-cpu-baseline")
+    c = d["config"]
+    assert c["finite"] and c["parity_windows"] >= windows and c["parity_worst"] <= 1e-9
