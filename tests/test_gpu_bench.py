@@ -51,3 +51,24 @@ def test_lines_of_lateral_material_and_octree_workloads_carry_parity(wl, windows
     d = _bench("--workload", wl, "--steps", "10", "--warmup", "3", "--no-pmc", "--no-cpu-baseline")
     c = d["config"]
     assert c["finite"] and c["parity_windows"] >= windows and c["parity_worst"] <= 1e-9
+
+
+def test_the_drivers_launcher_form_on_ranks_sharing_the_gpu():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 --steps K --warmup W`: the form the driver's scaling run uses (RANK / LOCAL_RANK / WORLD_SIZE from the
+    launcher), here with both ranks on this box's one GPU."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HQ_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "10", "--warmup", "3", "--workload", "m1"], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["finite"] and d["config"]["parity_worst"] <= 1e-9
+    assert d["scaling"] == "strong" and d["steps"] == 10 and d["warmup"] == 3
