@@ -425,7 +425,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
         nchecked += int(ok.sum())
         nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
     del elem_lo, elem_edge
-    assert nchecked > 800 and nhang > 20
+    assert nchecked > 400 and nhang > 20, (nchecked, nhang)
     assert worst < 1e-9, worst
     tm1, _ = s.download(want_tm2=False)
     s.close()
