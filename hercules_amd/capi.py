@@ -19,7 +19,7 @@ EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_ge
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
-           "hq_stencil_coefficients", "hq_brick_plan_check", "hq_comm_init_host",
+           "hq_stencil_coefficients", "hq_brick_plan_check", "hq_brick_plan_check_n", "hq_comm_init_host",
            "hq_comm_ipc_export", "hq_comm_init_ipc", "hq_comm_init_loopback"]
 
 
@@ -67,7 +67,7 @@ class _Info(ctypes.Structure):
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
                 ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
                 ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32),
-                ("brick_units_packed", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("brick_units_packed", ctypes.c_int32), ("brick_units_ragged", ctypes.c_int32)]
 
 
 # hq_options (include/hq_solver.h): int32 fields in the header's order, two doubles, two more int32
@@ -82,7 +82,8 @@ class Options(ctypes.Structure):
     """hq_options.  Options(brick_cz=16, debug_halo=1): every other field stays -1 = library default."""
     _fields_ = ([("size", ctypes.c_uint64)] + [(n, ctypes.c_int32) for n in OPTION_FIELDS] +
                 [("ipc_timeout_ms", ctypes.c_double), ("loopback_delay_us", ctypes.c_double),
-                 ("verbose", ctypes.c_int32), ("quiet", ctypes.c_int32)])
+                 ("verbose", ctypes.c_int32), ("quiet", ctypes.c_int32),
+                 ("brick_ragged", ctypes.c_int32), ("brick_ragged_minfill", ctypes.c_int32)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -353,13 +354,13 @@ def stencil_plan_check(desc):
 
 
 BRICK_PLAN_REPORT = ("brick_nodes", "columns", "units", "units_one_nt_row", "het_units", "neighbours_checked",
-                     "patch_nodes", "faults")
+                     "patch_nodes", "faults", "ragged_units", "ragged_nodes")
 
 
 def brick_plan_check(desc):
     """hq_brick_plan_check on a filled _Desc: the brick planner against the mesh's connectivity (no device needed)."""
-    rep = (ctypes.c_int64 * 8)()
-    _check(load_library().hq_brick_plan_check(ctypes.byref(desc), rep))
+    rep = (ctypes.c_int64 * len(BRICK_PLAN_REPORT))()
+    _check(load_library().hq_brick_plan_check_n(ctypes.byref(desc), rep, ctypes.c_int32(len(BRICK_PLAN_REPORT))))
     return dict(zip(BRICK_PLAN_REPORT, [int(v) for v in rep]))
 
 

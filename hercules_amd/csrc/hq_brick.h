@@ -54,6 +54,13 @@
                                   * even part; plus rho (Uo_x, Uo_y, -Uo_z): its odd part, hq_stencil()), the next plane's g + Uo,
                                   * and their n_t row (7 doubles: dashpots differ per axis), one for the whole face of the unit */
 #define HQ_BK_BOTFACE 16         /* the same for the plane below the unit's last one (za + np)                          */
+#define HQ_BK_RAGGED 32          /* (round 5) the unit owns a SUBSET of its tile's lattice positions: beside a level interface or a
+                                  * material boundary that cuts through the footprint the planes are not full, and what used to be left
+                                  * to the patches (a laterally refined basin: 11 % of the nodes at a fifth of the bricks' rate) marches
+                                  * too -- every plane's 512 positions come out of an id table [np + 2][ny][nx] behind the ring table
+                                  * (v >= 0: a node the unit owns; v <= -2: node -v - 2 of somebody else, loaded for the stencils of the
+                                  * owned ones and never written; -1: no node there), the owned nodes are numbered plane by plane
+                                  * without gaps from U.base on, and all of them share (c1, c2, beta) and one n_t row (HQ_BK_NTSAME) */
 #define HQ_BK_PACKED 4           /* HET, and every element's (c1, c2, beta) comes out of three floats bit for bit
                                   * (hq_material_coef) and every node's n_t row out of two doubles: 12 + 16 bytes per element /
                                   * node and step instead of 24 + 24; the unit's record carries dt^2 h and h in c1, c2 */
@@ -91,6 +98,9 @@ struct hq_brick_cfg {
     int cz = 32;                 /* planes per unit (HQ_BRICK_CZ)                                                */
     int minz = 4;                /* shortest run of planes worth a tile column (HQ_BRICK_MINZ)                   */
     int minnodes = 512;          /* fewest nodes worth a tile column (HQ_BRICK_MINNODES)                         */
+    int ragged = 1;              /* HQ_BRICK_RAGGED: the second planner round takes partly filled tiles (HQ_BK_RAGGED); 0: round 5's
+                                  * first arrangement, 32-wide full tiles (HQ_BRICK_HALF_TILES)                                   */
+    int minfill = 128;           /* HQ_BRICK_RAGGED_MINFILL: fewest owned nodes of a plane of a ragged tile column (of 512)      */
 };
 
 static hq_brick_cfg hq_brick_cfg_from_env(void)
@@ -100,6 +110,8 @@ static hq_brick_cfg hq_brick_cfg_from_env(void)
     c.cz = std::max(2, geti("HQ_BRICK_CZ", c.cz));
     c.minz = std::max(1, geti("HQ_BRICK_MINZ", c.minz));
     c.minnodes = std::max(1, geti("HQ_BRICK_MINNODES", c.minnodes));
+    c.ragged = geti("HQ_BRICK_RAGGED", c.ragged) != 0;
+    c.minfill = std::min(HQ_BK_THREADS, std::max(1, geti("HQ_BRICK_RAGGED_MINFILL", c.minfill)));
     return c;
 }
 
@@ -108,6 +120,7 @@ struct hq_brick_host {
     std::vector<int32_t> perm;               /* caller's node id -> device id (all N nodes); empty: identity      */
     std::vector<hq_brick_unit> units;        /* launch order: the HQ_BK_NTSAME units first                        */
     int32_t nsame = 0;                       /* units with HQ_BK_NTSAME                                           */
+    int32_t nrag = 0;                        /* of those, HQ_BK_RAGGED: the last of the NTSAME units                */
     std::vector<int32_t> tab;                /* id tables (device ids)                                            */
     std::vector<double> coef;                /* element coefficients of the HQ_BK_HET units                       */
     std::vector<float> coef32;               /* ... of the HQ_BK_PACKED ones: rho (sign: see hq_material_coef), Vs, Vp */
@@ -119,7 +132,7 @@ struct hq_brick_host {
 
 struct hq_brick_plan {
     int64_t nb = 0;
-    int32_t nunits = 0, nsame = 0, nhet = 0, npacked = 0;
+    int32_t nunits = 0, nsame = 0, nrag = 0, nhet = 0, npacked = 0;
     hq_brick_unit* d_units = nullptr;
     int32_t* d_tab = nullptr;
     double* d_coef = nullptr;
@@ -211,9 +224,13 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         std::vector<int32_t> Ng;             /* node at a lattice position, or -1 */
         std::vector<int32_t> Eg;             /* element in a lattice cell, or -1 */
     };
-    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; int het; int top, bot; };
+    struct column_t { int lvl; int32_t x0, y0, nx, ny, z0, nz, ti, tj; int64_t base; int het; int top, bot; int rag; };
+    /* a ragged column (column_t.rag = 1 + its index here): which positions it owns, how many before each plane, and the
+     * coefficients and n_t row all of them share */
+    struct ragged_t { std::vector<uint8_t> own; std::vector<int32_t> pfx; double c[3], m[3]; };
     std::vector<level_t> levels;
     std::vector<column_t> cols;
+    std::vector<ragged_t> rags;
     std::vector<int32_t> ntx_of_level;
 
     for (auto& kv : cnt) {
@@ -337,10 +354,13 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         /* rounds: the 64-wide tiles, then (round 5) 32-wide ones over what is left of the uniform simple nodes -- beside a
          * level interface or a material boundary that runs along y or z a strip of up to 63 nodes per row is left over,
          * and half a workgroup's lanes in the marching kernel still beat the patches by a wide margin -- then the het tiles */
-        const int half = hq_opt_int("HQ_BRICK_HALF_TILES", 1) != 0 ? 1 : 0;
+        /* ... or (the default since the ragged units exist) 64-wide tiles again that need not be full: HQ_BK_RAGGED */
+        const int rag = cfg.ragged && stencil_ok && !hq_opt_flag("HQ_BRICK_NO_NTSAME") ? 1 : 0;
+        const int half = rag || hq_opt_int("HQ_BRICK_HALF_TILES", 1) != 0 ? 1 : 0;
         for (int round = 0; round < 2 + half; round++) {
             const int pass = round == 1 + half ? 1 : 0;
-            const int PTX = pass == 1 ? HQ_BH_TX : (round == 0 ? TX : TX / 2), PTY = pass == 0 ? TY : HQ_BH_TY;
+            const bool rag_round = rag && round == 1;
+            const int PTX = pass == 1 ? HQ_BH_TX : (round == 0 || rag_round ? TX : TX / 2), PTY = pass == 0 ? TY : HQ_BH_TY;
             /* pass 0: uniform simple nodes (2); pass 1: what is left of them and the per-element ones (1).  3 / 4 are face
              * nodes: never part of a run, but a run of pass 0 that starts / ends beside a full face plane takes it along */
             auto in_run = [pass](char v) { return pass == 0 ? v == 2 : (v == 1 || v == 2); };
@@ -356,13 +376,84 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             if (round == 0) ntx_lvl = ntx;
             const size_t f0 = found.size();
             found.resize(f0 + (size_t)nty);
+            std::vector<std::vector<ragged_t>> found_r(rag_round ? (size_t)nty : 0);
 #pragma omp parallel for schedule(dynamic, 1)
             for (int32_t tj = 0; tj < nty; tj++) {
                 const int64_t y0 = sy0 + (int64_t)tj * PTY;
                 const int32_t ny = (int32_t)std::min<int64_t>(PTY, sy1 - y0 + 1);
+                std::vector<int32_t> cntz;
                 for (int32_t ti = 0; ti < ntx; ti++) {
                     const int64_t x0 = sx0 + (int64_t)ti * PTX;
                     const int32_t nx = (int32_t)std::min<int64_t>(PTX, sx1 - x0 + 1);
+                    if (rag_round) {
+                        /* ragged tile columns: runs of planes each of which holds >= minfill uniform simple nodes of ONE
+                         * material and n_t row (the first candidate's; up to four materials per footprint, one after the other) */
+                        cntz.assign((size_t)NZ, 0);
+                        for (int iter = 0; iter < 4; iter++) {
+                            int32_t n0 = -1;
+                            int64_t Z0 = 0, X0 = 0, Y0 = 0;
+                            for (int64_t Z = 1; Z < L.D[2] && n0 < 0; Z++)
+                                for (int64_t y = y0; y < y0 + ny && n0 < 0; y++) {
+                                    const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
+                                    for (int32_t x = 0; x < nx; x++)
+                                        if (row[x] == 2) { n0 = L.Ng[(size_t)((Z * NY + y) * NX + x0 + x)]; Z0 = Z; Y0 = y; X0 = x0 + x; break; }
+                                }
+                            if (n0 < 0) break;
+                            const int32_t e0 = L.Eg[(size_t)(((Z0 - 1) * L.D[1] + (Y0 - 1)) * L.D[0] + (X0 - 1))];
+                            const double rc[3] = { c1[e0], c2[e0], beta[e0] };
+                            const double* q0 = ntab + 7 * (int64_t)n0;
+                            auto match = [&](int64_t X, int64_t Y, int64_t Z) -> bool {
+                                const double* q = ntab + 7 * (int64_t)L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                                if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) return false;
+                                const int32_t e = L.Eg[(size_t)(((Z - 1) * L.D[1] + (Y - 1)) * L.D[0] + (X - 1))];
+                                return c1[e] == rc[0] && c2[e] == rc[1] && beta[e] == rc[2];
+                            };
+                            for (int64_t Z = Z0; Z < L.D[2]; Z++) {
+                                int32_t cnt = 0;
+                                for (int64_t y = y0; y < y0 + ny; y++) {
+                                    const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
+                                    for (int32_t x = 0; x < nx; x++) cnt += row[x] == 2 && match(x0 + x, y, Z);
+                                }
+                                cntz[(size_t)Z] = cnt;
+                            }
+                            int64_t ra = -1;
+                            for (int64_t Z = Z0; Z <= L.D[2]; Z++) {
+                                const bool in = Z < L.D[2] && cntz[(size_t)Z] >= cfg.minfill;
+                                if (in) { if (ra < 0) ra = Z; continue; }
+                                if (ra < 0) continue;
+                                const int64_t nz = Z - ra;
+                                int64_t total = 0;
+                                for (int64_t z = ra; z < Z; z++) total += cntz[(size_t)z];
+                                if (nz >= cfg.minz && total >= cfg.minnodes) {
+                                    ragged_t R;
+                                    R.own.assign((size_t)(nz * nx * ny), 0);
+                                    R.pfx.assign((size_t)nz + 1, 0);
+                                    for (int d = 0; d < 3; d++) R.c[d] = rc[d];
+                                    R.m[0] = q0[0]; R.m[1] = q0[1]; R.m[2] = q0[4];
+                                    for (int64_t z = ra; z < Z; z++) {
+                                        int32_t k = 0;
+                                        for (int64_t y = y0; y < y0 + ny; y++) {
+                                            char* row = &S[(size_t)((z * NY + y) * NX + x0)];
+                                            for (int32_t x = 0; x < nx; x++)
+                                                if (row[x] == 2 && match(x0 + x, y, z)) { R.own[(size_t)(((z - ra) * ny + (y - y0)) * nx + x)] = 1; row[x] = 0; k++; }
+                                        }
+                                        R.pfx[(size_t)(z - ra) + 1] = R.pfx[(size_t)(z - ra)] + k;
+                                    }
+                                    found_r[(size_t)tj].push_back(std::move(R));
+                                    found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)ra, (int32_t)nz, ti, tj, 0, 0, 0, 0,
+                                                                       (int)found_r[(size_t)tj].size() });
+                                }
+                                ra = -1;
+                            }
+                            /* what the runs left of this material waits (5) until the round is over */
+                            for (int64_t Z = Z0; Z < L.D[2]; Z++)
+                                for (int64_t y = y0; y < y0 + ny; y++) {
+                                    char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
+                                    for (int32_t x = 0; x < nx; x++) if (row[x] == 2 && match(x0 + x, y, Z)) row[x] = 5;
+                                }
+                        }
+                        continue;
+                    }
                     int64_t run0 = -1;
                     for (int64_t Z = 0; Z <= NZ; Z++) {
                         bool full = Z < NZ;
@@ -410,10 +501,22 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             }
             /* the nodes the pass took are gone for the next one */
             for (size_t f = f0; f < found.size(); f++)
-                for (auto& c : found[f])
+                for (auto& c : found[f]) {
+                    if (c.rag) continue;                 /* (a ragged column has cleared what it owns) */
                     for (int32_t z = -c.top; z < c.nz + c.bot; z++)
                         for (int32_t y = 0; y < c.ny; y++)
                             memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
+                }
+            if (rag_round) {
+                for (int32_t tj = 0; tj < nty; tj++) {
+                    const size_t r0 = rags.size();
+                    for (auto& c : found[f0 + (size_t)tj]) c.rag += (int)r0;
+                    for (auto& R : found_r[(size_t)tj]) rags.push_back(std::move(R));
+                }
+                const int64_t nS = NX * NY * NZ;
+#pragma omp parallel for schedule(static)
+                for (int64_t i = 0; i < nS; i++) if (S[(size_t)i] == 5) S[(size_t)i] = 2;
+            }
             if (!want_het && round + 1 >= 1 + half) break;
         }
         lap("tile columns");
@@ -429,7 +532,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     /* device numbering: tile columns first (plane-major inside a column), everything else behind in its old order */
     int64_t nb = 0;
     /* a column's nodes: [its top face plane][its planes][its bottom face plane] */
-    for (auto& c : cols) { c.base = nb; nb += (int64_t)c.nx * c.ny * (c.nz + c.top + c.bot); }
+    for (auto& c : cols) { c.base = nb; nb += c.rag ? (int64_t)rags[(size_t)c.rag - 1].pfx[(size_t)c.nz] : (int64_t)c.nx * c.ny * (c.nz + c.top + c.bot); }
     if (nb > 0x7fffffff) return 0;
     B->perm.assign((size_t)N, -1);
     {
@@ -440,14 +543,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             const column_t& c = cols[(size_t)ci];
             const level_t& L = levels[(size_t)c.lvl];
             const int64_t NX = L.D[0] + 1, NY = L.D[1] + 1;
+            const ragged_t* R = c.rag ? &rags[(size_t)c.rag - 1] : nullptr;
+            int64_t next = c.base;                   /* a ragged column numbers what it owns, plane by plane */
             for (int32_t z = -c.top; z < c.nz + c.bot; z++)
                 for (int32_t y = 0; y < c.ny; y++)
                     for (int32_t x = 0; x < c.nx; x++) {
+                        if (R && !R->own[(size_t)(((int64_t)z * c.ny + y) * c.nx + x)]) continue;
                         const int32_t n = L.Ng[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
                         int32_t& slot = B->perm[(size_t)n];
                         int32_t was;
+                        const int32_t id = (int32_t)(R ? next++ : c.base + ((int64_t)(z + c.top) * c.ny + y) * c.nx + x);
 #pragma omp atomic capture
-                        { was = slot; slot = (int32_t)(c.base + ((int64_t)(z + c.top) * c.ny + y) * c.nx + x); }
+                        { was = slot; slot = id; }
                         twice += was != -1;
                     }
         }
@@ -518,7 +625,8 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     for (size_t u = 0; u < us.size(); u++) {
         const column_t& c = cols[(size_t)us[u].col];
         const int64_t nr = 2 * (c.nx + 2) + 2 * c.ny;
-        toff[u + 1] = toff[u] + ((int64_t)(us[u].np + 2) * nr + 2 * (int64_t)c.nx * c.ny + 3) / 4 * 4;
+        /* (a ragged unit: a table row of nx ny ids for EVERY plane, the two cap planes included) */
+        toff[u + 1] = toff[u] + ((int64_t)(us[u].np + 2) * nr + (c.rag ? us[u].np + 2 : 2) * (int64_t)c.nx * c.ny + 3) / 4 * 4;
     }
     B->tab.assign((size_t)toff[us.size()] + 64, 0);
     std::vector<int64_t> coff(us.size() + 1, 0);         /* coefficient blocks of the HET units */
@@ -546,6 +654,59 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             return B->perm[(size_t)n];
         };
         int32_t* t = B->tab.data() + toff[(size_t)u];
+        hq_brick_unit& U = B->units[(size_t)u];
+        if (c.rag) {
+            /* HQ_BK_RAGGED: a position of the ring or of a plane may hold no node of this level at all (-1: beyond the
+             * level's region; no owned node has it for a neighbour -- a simple node's 26 neighbours exist) */
+            const ragged_t& R = rags[(size_t)c.rag - 1];
+            auto any = [&](int64_t X, int64_t Y, int64_t Z) -> int32_t {
+                if (X < 0 || Y < 0 || Z < 0 || X > L.D[0] || Y > L.D[1] || Z > L.D[2]) return -1;
+                const int32_t n = L.Ng[(size_t)((Z * NY + Y) * NX + X)];
+                return n < 0 ? -1 : B->perm[(size_t)n];
+            };
+            /* does the UNIT own the node at (i, j) of plane k (k = 1 .. np)? */
+            auto owns = [&](int32_t i, int32_t j, int32_t k) -> bool {
+                return i >= 0 && i < nx && j >= 0 && j < ny && k >= 1 && k <= np && R.own[(size_t)((((int64_t)za - 1 + k - c.z0) * ny + j) * nx + i)];
+            };
+            /* ... and is a position the neighbour of a node the unit owns?  Only those are loaded: the others (the far
+             * side of a level interface, another material's nodes) are -1 like the positions without a node */
+            auto wanted = [&](int32_t i, int32_t j, int32_t k) -> bool {
+                for (int32_t dk = -1; dk <= 1; dk++)
+                    for (int32_t dj = -1; dj <= 1; dj++)
+                        for (int32_t di = -1; di <= 1; di++)
+                            if (owns(i + di, j + dj, k + dk)) return true;
+                return false;
+            };
+            for (int32_t k = 0; k < np + 2; k++) {
+                const int64_t Z = (int64_t)za - 1 + k;
+                int32_t* r = t + (int64_t)k * nr;
+                for (int32_t i = 0; i < nx + 2; i++) {
+                    r[i] = wanted(i - 1, -1, k) ? any(c.x0 - 1 + i, c.y0 - 1, Z) : -1;
+                    r[nx + 2 + i] = wanted(i - 1, ny, k) ? any(c.x0 - 1 + i, c.y0 + ny, Z) : -1;
+                }
+                for (int32_t j = 0; j < ny; j++) {
+                    r[2 * (nx + 2) + j] = wanted(-1, j, k) ? any(c.x0 - 1, c.y0 + j, Z) : -1;
+                    r[2 * (nx + 2) + ny + j] = wanted(nx, j, k) ? any(c.x0 + nx, c.y0 + j, Z) : -1;
+                }
+                int32_t* pl = t + (int64_t)(np + 2) * nr + (int64_t)k * nx * ny;
+                for (int32_t j = 0; j < ny; j++)
+                    for (int32_t i = 0; i < nx; i++) {
+                        const bool own = owns(i, j, k);
+                        const int32_t q = own || wanted(i, j, k) ? any(c.x0 + i, c.y0 + j, Z) : -1;
+                        if (own && q < 0) set_fault();
+                        pl[j * nx + i] = own ? q : (q < 0 ? -1 : -q - 2);
+                    }
+            }
+            U.base = c.base + R.pfx[(size_t)(za - c.z0)];
+            U.tab = toff[(size_t)u];
+            U.nx = nx; U.ny = ny; U.np = np; U.flags = HQ_BK_NTSAME | HQ_BK_RAGGED;
+            memset(U.ft, 0, sizeof U.ft); memset(U.fb, 0, sizeof U.fb);
+            U.c1 = R.c[0]; U.c2 = R.c[1]; U.beta = R.c[2];
+            U.m0 = R.m[0]; U.m2 = R.m[1]; U.m1 = R.m[2];
+            U.coef = 0;
+            same[(size_t)u] = 4;
+            continue;
+        }
         for (int32_t k = 0; k < np + 2; k++) {
             const int64_t Z = (int64_t)za - 1 + k;
             int32_t* r = t + (int64_t)k * nr;
@@ -558,7 +719,6 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 cap[j * nx + i] = dev(c.x0 + i, c.y0 + j, (int64_t)za - 1);
                 cap[nx * ny + j * nx + i] = dev(c.x0 + i, c.y0 + j, (int64_t)za + np);
             }
-        hq_brick_unit& U = B->units[(size_t)u];
         U.base = c.base + (int64_t)(za - c.z0 + c.top) * nx * ny;
         U.tab = toff[(size_t)u];
         U.nx = nx; U.ny = ny; U.np = np; U.flags = 0;
@@ -654,18 +814,29 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     /* launch order: the units whose nodes share one n_t row (the row rides in the record), then those with per-node
      * rows, then the HET units -- a launch each */
     {
-        std::vector<hq_brick_unit> a, b, h, hp;
-        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 2 ? h : (same[u] == 3 ? hp : b))).push_back(B->units[u]);
-        B->nsame = (int32_t)a.size();
+        std::vector<hq_brick_unit> a, r, b, h, hp;
+        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 4 ? r : (same[u] == 2 ? h : (same[u] == 3 ? hp : b)))).push_back(B->units[u]);
+        B->nsame = (int32_t)(a.size() + r.size());
+        B->nrag = (int32_t)r.size();
         B->nhet = (int32_t)(h.size() + hp.size());
         B->npacked = (int32_t)hp.size();
+        a.insert(a.end(), r.begin(), r.end());
         a.insert(a.end(), b.begin(), b.end());
         a.insert(a.end(), h.begin(), h.end());
         a.insert(a.end(), hp.begin(), hp.end());
         B->units.swap(a);
         if (B->npacked == 0) { std::vector<float>().swap(B->coef32); std::vector<double>().swap(B->nt2); }
-        if (verbose) fprintf(stderr, "  brick plan: %d units: %d with one n_t row, %d per-element coefficients of which %d packed\n",
-                             (int)B->units.size(), B->nsame, B->nhet, B->npacked);
+        if (verbose) fprintf(stderr, "  brick plan: %d units: %d with one n_t row of which %d ragged, %d per-element coefficients of which %d packed\n",
+                             (int)B->units.size(), B->nsame, B->nrag, B->nhet, B->npacked);
+        if (verbose && B->nrag) {
+            int64_t pos = 0, own = 0, other = 0;
+            for (const hq_brick_unit& U : B->units) {
+                if (!(U.flags & HQ_BK_RAGGED)) continue;
+                const int32_t* pl = B->tab.data() + U.tab + (int64_t)(U.np + 2) * (2 * (U.nx + 2) + 2 * U.ny);
+                for (int64_t i = 0; i < (int64_t)U.nx * U.ny * (U.np + 2); i++) { pos++; own += pl[i] >= 0; other += pl[i] <= -2; }
+            }
+            fprintf(stderr, "  brick plan: ragged units: %lld positions, %lld owned, %lld loaded for their neighbours' sake\n", (long long)pos, (long long)own, (long long)other);
+        }
     }
     return 0;
 }
@@ -688,8 +859,9 @@ static __device__ __forceinline__ double hq_uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
-template <bool PERNODE, bool BYCOMP>
-/* PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds ten
+template <bool PERNODE, bool BYCOMP, bool RAGGED = false>
+/* RAGGED (HQ_BK_RAGGED): every plane's nodes through the unit's id table, output only where the unit owns the node.
+ * PERNODE (a caller's nTable whose rows differ inside a homogeneous region: no mesh solver_init builds has one) holds ten
  * more values per lane -- the plane's n_t row and the reciprocal masses of the two unfinished planes; with the stencil
  * numbers in scalar registers it fits 128 VGPRs too (round 3: 33 spilled) */
 __global__ void HQ_BK_ATTR __launch_bounds__(HQ_BK_THREADS, 4)   /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
@@ -719,8 +891,11 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     }
     const int32_t* __restrict__ utab = tab + U.tab;                  /* uniform: scalar registers */
     const int rofs = ring ? t : 0;
-    const int32_t* __restrict__ cap = utab + (int64_t)(np + 2) * nr;
-    const int32_t id_lo = cap[sidx];
+    const int32_t* __restrict__ cap = utab + (int64_t)(np + 2) * nr;    /* RAGGED: the plane table [np + 2][ny][nx] */
+    /* RAGGED: the table values of the planes k - 1 (the one being completed), k, k + 1 (being loaded) and k + 2 (fetched a
+     * plane ahead, as the ring ids are: the node loads must not wait for their ids) */
+    int32_t vOut = -1, vMid = RAGGED ? cap[sidx] : 0, vCur = RAGGED ? cap[nxy + sidx] : 0, vNext = 0;
+    const int32_t id_lo = RAGGED ? (vMid >= 0 ? vMid : -vMid - 2) : cap[sidx];
     const double beta = U.beta;
     /* the eight stencil numbers are the same for every lane, but fp64 products are vector instructions: without the
      * readfirstlane their results would sit in 16 VGPRs for the whole march.  In SGPRs (a VALU instruction takes one
@@ -734,7 +909,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     for (int i = 0; i < 2; i++) Q[i] = hq_uniform(U.c1 * sc.q1[i] + U.c2 * sc.q2[i]);
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
-    double x1[3], x2[3], y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
+    double x1[3] = { 0.0, 0.0, 0.0 }, x2[3] = { 0.0, 0.0, 0.0 }, y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
     double m0A = hq_uniform(1.0 / U.m0), m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
     double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
@@ -743,11 +918,11 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
 #define HQ_BK_LOAD(node_)                                                                             \
     {                                                                                                 \
         const int64_t a_ = (node_);                                                                   \
-        if (active) {                                                                                 \
+        if (active && (!RAGGED || a_ >= 0)) {                                                         \
             _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
             if (PERNODE) { _Pragma("unroll") for (int d = 0; d < 3; d++) mn[d] = nt3[3 * a_ + d]; }    \
         }                                                                                             \
-        if (ring) {                                                                                   \
+        if (ring && (!RAGGED || rid >= 0)) {                                                          \
             const int64_t b_ = (int64_t)rid;                                                          \
             _Pragma("unroll") for (int d = 0; d < 3; d++) { y1[d] = u1g[3 * b_ + d]; y2[d] = u2g[3 * b_ + d]; } \
         }                                                                                             \
@@ -770,7 +945,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     /* face planes (HQ_BK_TOPFACE / BOTFACE): uniform per unit */
     /* (only columns whose nodes all share one n_t row take their faces along -- the planner sees to it --, so the PERNODE
      *  form, which no mesh of solver_init reaches, does not carry the face code: it would spill) */
-    const bool topf = !PERNODE && (U.flags & HQ_BK_TOPFACE) != 0, botf = !PERNODE && (U.flags & HQ_BK_BOTFACE) != 0;
+    const bool topf = !PERNODE && !RAGGED && (U.flags & HQ_BK_TOPFACE) != 0, botf = !PERNODE && !RAGGED && (U.flags & HQ_BK_BOTFACE) != 0;
     const double rho = hq_uniform((U.c1 - U.c2) / (U.c1 + U.c2));
 
     HQ_BK_LOAD((int64_t)id_lo)
@@ -779,7 +954,10 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     else { double dummy[3] = { 0.0, 0.0, 0.0 }; HQ_BK_PUT(0, dummy, mn[1], mn[2]) }
     for (int k = 0; k <= np + 1; k++) {
         if (k <= np) {                       /* request plane k + 1 */
-            HQ_BK_LOAD(k == np ? (int64_t)cap[nxy + sidx] : U.base + (int64_t)k * nxy + sidx)
+            if (RAGGED) {
+                HQ_BK_LOAD((int64_t)(vCur >= 0 ? vCur : -vCur - 2))
+                if (k < np) vNext = cap[(k + 2) * nxy + sidx];
+            } else HQ_BK_LOAD(k == np ? (int64_t)cap[nxy + sidx] : U.base + (int64_t)k * nxy + sidx)
             if (k < np) rid = utab[(k + 2) * nr + rofs];
         }
         __syncthreads();
@@ -875,11 +1053,11 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
             for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
         }
         const bool outface = k == 1 && topf; /* plane 1 completes the TOP face plane (cap plane za - 1) */
-        if ((k >= 2 || outface) && active) { /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
+        if ((k >= 2 || outface) && active && (!RAGGED || vOut >= 0)) { /* plane k is at dz = +1 of output plane k - 1 = node plane k - 2 of the unit */
             double f[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) f[d] = fA[d] + (g[d] + Uo[d]);
-            const int local = (k - 2) * nxy + sidx;          /* (the top face plane: -nxy + sidx) */
+            const int local = RAGGED ? (int)(vOut - U.base) : (k - 2) * nxy + sidx;          /* (the top face plane: -nxy + sidx) */
             if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
                 for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
                     if (src_ent[2 * i] == local) {
@@ -887,13 +1065,14 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
                         for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
                     }
             }
-            double* out = ung + 3 * (outface ? (int64_t)cap[sidx] : U.base + (int64_t)local);
+            double* out = ung + 3 * (RAGGED ? (int64_t)vOut : (outface ? (int64_t)cap[sidx] : U.base + (int64_t)local));
             const double rm = outface ? 1.0 / U.ft[0] : m0A;
 #pragma unroll
             for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
         }
 #pragma unroll
         for (int d = 0; d < 3; d++) { fA[d] = fB[d] + m[d]; fB[d] = g[d] - Uo[d]; }
+        if (RAGGED) { vOut = vMid; vMid = vCur; vCur = vNext; }
         if (PERNODE) { m0A = m0B; m0B = 1.0 / mn[0]; }
         if (k < np || (k == np && !botf)) HQ_BK_PUT((k + 1) & 1, fB, mn[1], mn[2])
         else if (k == np) HQ_BK_PUT((k + 1) & 1, fB, U.fb[1 + d], U.fb[4 + d])
@@ -1131,6 +1310,7 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
     P->nb = B.nb;
     P->nunits = (int32_t)B.units.size();
     P->nsame = B.nsame;
+    P->nrag = B.nrag;
     P->nhet = B.nhet;
     P->npacked = B.npacked;
     if (P->nunits == 0) return 0;
@@ -1167,7 +1347,13 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
         const hq_brick_unit& U = B.units[(size_t)pr.second];
         const int64_t nxy = (int64_t)U.nx * U.ny;
         const int top = (U.flags & HQ_BK_TOPFACE) != 0, bot = (U.flags & HQ_BK_BOTFACE) != 0;
-        P->h_base.push_back(pr.first - top * nxy); P->h_slot.push_back(pr.second); P->h_size.push_back(nxy * (U.np + top + bot));
+        int64_t size = nxy * (U.np + top + bot);
+        if (U.flags & HQ_BK_RAGGED) {            /* what it owns: ids [base, base + count), a node's index in the unit = id - base */
+            const int32_t* pl = B.tab.data() + U.tab + (int64_t)(U.np + 2) * (2 * (U.nx + 2) + 2 * U.ny);
+            size = 0;
+            for (int64_t i = nxy; i < nxy * (U.np + 1); i++) size += pl[i] >= 0;
+        }
+        P->h_base.push_back(pr.first - top * nxy); P->h_slot.push_back(pr.second); P->h_size.push_back(size);
         P->h_first.push_back(pr.first);
     }
     return 0;
@@ -1209,9 +1395,10 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
 static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
                             const double* F, double dt2, hipStream_t stream, bool light = false)
 {
-    const int32_t cnt[4] = { P->nsame, P->nunits - P->nsame - P->nhet, P->nhet - P->npacked, P->npacked };
+    const int32_t cnt[5] = { P->nsame - P->nrag, P->nunits - P->nsame - P->nhet, P->nhet - P->npacked, P->npacked, P->nrag };
     int32_t first = 0;
-    for (int k = 0; k < 4; k++) {
+    for (int k4 = 0; k4 < 5; k4++) {
+        const int k = k4 == 0 ? 0 : (k4 == 1 ? 4 : k4 - 1);       /* launch order = unit order: one row, ragged, per-node rows, HET, packed */
         const int32_t count = cnt[k];
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
@@ -1221,6 +1408,8 @@ static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const doub
         else if (k == 0) hq_k_brick<false, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1 && light) hq_k_brick<true, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1) hq_k_brick<true, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 4 && light) hq_k_brick<false, true, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
+        else if (k == 4) hq_k_brick<false, false, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 2) hq_k_brick_het<false><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
                                                                                                P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
         else hq_k_brick_het<true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef32, u1, u2, un, P->d_nt2, sp,

@@ -2048,6 +2048,8 @@ static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl)
  * the unit, an entry of the unit's ring table or of its first / last plane's id list.
  * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}
  */
+static int64_t g_brick_check_extra[2];    /* the last check's ragged units and the nodes they own (hq_brick_plan_check_n) */
+
 extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
 {
     if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid) || !d->node_xyz || !d->eTable || !d->nTable)
@@ -2094,11 +2096,12 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     for (int64_t u = 0; u < (int64_t)B.units.size(); u++) {
         const hq_brick_unit& U = B.units[(size_t)u];
         const int nx = U.nx, ny = U.ny, np = U.np, nr = 2 * (nx + 2) + 2 * ny;
-        const bool het = (U.flags & HQ_BK_HET) != 0;
+        const bool het = (U.flags & HQ_BK_HET) != 0, rag = (U.flags & HQ_BK_RAGGED) != 0;
         if (nx < 1 || nx > (het ? HQ_BH_TX : HQ_BK_TX) || ny < 1 || ny > (het ? HQ_BH_TY : HQ_BK_TY) || np < 1 || U.base < 0 ||
-            U.base + (int64_t)nx * ny * np > B.nb) { bad++; continue; }
+            (!rag && U.base + (int64_t)nx * ny * np > B.nb)) { bad++; continue; }
         nsame += (U.flags & HQ_BK_NTSAME) != 0;
         if (((U.flags & HQ_BK_NTSAME) != 0) != (u < B.nsame)) bad++;
+        if (rag != (u >= B.nsame - B.nrag && u < B.nsame) || (rag && (het || (U.flags & (HQ_BK_TOPFACE | HQ_BK_BOTFACE))))) { bad++; continue; }
         if (het != (u >= (int64_t)B.units.size() - B.nhet)) bad++;
         if (het && (U.coef < 0 || U.coef + (int64_t)(np + 1) * HQ_BH_THREADS * 3 > (int64_t)B.coef.size())) { bad++; continue; }
         const int32_t* ring = B.tab.data() + U.tab;
@@ -2106,6 +2109,10 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
         /* the device id the kernel reads at (x, y) of plane k, k = -1 .. np */
         auto at = [&](int x, int y, int k) -> int64_t {
             const bool in = x >= 0 && x < nx && y >= 0 && y < ny;
+            if (in && rag) {                 /* the plane table: owned ids as they are, the others as -id - 2 */
+                const int32_t v = cap[(int64_t)(k + 1) * nx * ny + y * nx + x];
+                return v >= 0 ? v : (v == -1 ? -1 : -(int64_t)v - 2);
+            }
             if (in) {
                 if (k >= 0 && k < np) return U.base + ((int64_t)k * ny + y) * nx + x;
                 return cap[(k < 0 ? 0 : nx * ny) + y * nx + x];
@@ -2116,10 +2123,17 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
             if (x == -1) return r[2 * (nx + 2) + y];
             return r[2 * (nx + 2) + ny + y];
         };
+        int64_t next = U.base;               /* a ragged unit numbers what it owns plane by plane without gaps */
         for (int k = 0; k < np; k++)
             for (int y = 0; y < ny; y++)
                 for (int x = 0; x < nx; x++) {
-                    const int64_t q = U.base + ((int64_t)k * ny + y) * nx + x;
+                    int64_t q = U.base + ((int64_t)k * ny + y) * nx + x;
+                    if (rag) {
+                        const int32_t v = cap[(int64_t)(k + 1) * nx * ny + y * nx + x];
+                        if (v < 0) continue;
+                        if (v != next++ || v >= B.nb) { bad++; continue; }
+                        q = v;
+                    }
 #pragma omp atomic
                     covered[(size_t)q]++;
                     const int32_t n = inv[(size_t)q];
@@ -2278,8 +2292,27 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     }
     report[0] = B.nb; report[1] = B.ncolumns; report[2] = (int64_t)B.units.size(); report[3] = nsame;
     report[4] = B.nhet; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
+    g_brick_check_extra[0] = B.nrag;
+    g_brick_check_extra[1] = 0;
+    for (const hq_brick_unit& U : B.units) {
+        if (!(U.flags & HQ_BK_RAGGED)) continue;
+        const int32_t* pl = B.tab.data() + U.tab + (int64_t)(U.np + 2) * (2 * (U.nx + 2) + 2 * U.ny);
+        for (int64_t i = (int64_t)U.nx * U.ny; i < (int64_t)U.nx * U.ny * (U.np + 1); i++) g_brick_check_extra[1] += pl[i] >= 0;
+    }
     if (bad) return hq_fail(HQ_ERR_STATE, "brick plan self-check failed%s", "");
     return HQ_OK;
+}
+
+/* the same with a longer report: [8] = ragged units (HQ_BK_RAGGED), [9] = the nodes they own; n = entries the caller has */
+extern "C" int hq_brick_plan_check_n(const hq_desc* d, int64_t* report, int32_t n)
+{
+    int64_t r8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (!report || n < 8) return hq_fail(HQ_ERR_ARG, "hq_brick_plan_check_n: a report of at least 8 entries%s", "");
+    g_brick_check_extra[0] = g_brick_check_extra[1] = 0;
+    const int rc = hq_brick_plan_check(d, r8);
+    for (int k = 0; k < 8; k++) report[k] = r8[k];
+    for (int k = 8; k < n; k++) report[k] = k < 10 ? g_brick_check_extra[k - 8] : 0;
+    return rc;
 }
 
 extern "C" int hq_destroy(hq_ctx* c)
@@ -2369,6 +2402,7 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet;
     v.brick_units_het = c->bricks.nhet;
     v.brick_units_packed = c->bricks.npacked;
+    v.brick_units_ragged = c->bricks.nrag;
     v.pcie_h2d_bytes = c->h2d_bytes;
     v.pcie_d2h_bytes = c->d2h_bytes;
     v.transport = c->comm ? 1 : (hq_ipc_ready(c) ? (c->ipc->loopback ? 5 : 2) : (c->host_xchg ? 3 : (c->group ? 4 : 0)));

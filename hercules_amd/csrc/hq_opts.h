@@ -33,6 +33,7 @@ static const hq_opt_entry g_opt_table[] = {
     HQ_OPT_I("HQ_CU_MASK", cu_mask), HQ_OPT_I("HQ_NO_FUSED_SHARE", no_fused_share), HQ_OPT_I("HQ_GROUP_COPIES", group_copies),
     HQ_OPT_I("HQ_DEBUG_HALO", debug_halo), HQ_OPT_I("HQ_IPC_ARENA", ipc_arena), HQ_OPT_D("HQ_IPC_TIMEOUT_MS", ipc_timeout_ms),
     HQ_OPT_D("HQ_LOOPBACK_DELAY_US", loopback_delay_us), HQ_OPT_I("HQ_PATCH_VERBOSE", verbose), HQ_OPT_I("HQ_QUIET", quiet),
+    HQ_OPT_I("HQ_BRICK_RAGGED", brick_ragged), HQ_OPT_I("HQ_BRICK_RAGGED_MINFILL", brick_ragged_minfill),
 };
 #undef HQ_OPT_I
 #undef HQ_OPT_D

@@ -134,7 +134,7 @@ typedef struct {
     int32_t ipc_arena_kind;      /* IPC: 0 fine-grained, 1 uncached, 2 coarse-grained device memory                        */
     int32_t debug_halo;          /* 1: every halo record is checked on receipt (HQ_DEBUG_HALO / hq_options.debug_halo)     */
     int32_t brick_units_packed;  /* of brick_units_het: coefficients as three floats, n_t rows as two doubles (hq_desc.edata) */
-    int32_t reserved0;
+    int32_t brick_units_ragged;  /* of the units with one n_t row: partly filled tiles (HQ_BK_RAGGED, hq_options.brick_ragged) */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -211,6 +211,10 @@ typedef struct {
     /* messages */
     int32_t verbose;             /* HQ_PATCH_VERBOSE      1: where hq_create's time goes; 2: the brick planner's too     */
     int32_t quiet;               /* HQ_QUIET              1: no advice on stderr                                         */
+    /* (added behind the others) */
+    int32_t brick_ragged;        /* HQ_BRICK_RAGGED       0: no partly filled tile columns beside level interfaces and material
+                                                          boundaries (the second planner round is then brick_half_tiles')    */
+    int32_t brick_ragged_minfill;/* HQ_BRICK_RAGGED_MINFILL fewest nodes a plane of such a column owns, of 512 (128)        */
 } hq_options;
 
 HQ_API void hq_options_init(hq_options* opts, uint64_t size);
@@ -405,6 +409,8 @@ HQ_API int hq_stencil_plan_check(const hq_desc* desc, int64_t report[6]);
  *           (hq_k_brick_het), neighbours checked, patch nodes, faults}.
  */
 HQ_API int hq_brick_plan_check(const hq_desc* desc, int64_t report[8]);
+/* ... with report[8] = units that own only part of their tile (ragged), report[9] = the nodes those own; n >= 8 entries */
+HQ_API int hq_brick_plan_check_n(const hq_desc* desc, int64_t* report, int32_t n);
 
 /*
  * Host-only: the sixteen coefficients {p1[6], p2[6], q1[2], q2[2]} of the assembled 27-point stencil

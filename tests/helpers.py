@@ -167,3 +167,18 @@ def np8_stripe(g, step, rank, n):
 # dependency-cone windows of an octree mesh (oracle parity at sizes the oracle cannot run whole): oracle/windows.py
 # ---------------------------------------------------------------------------------------------
 from oracle.windows import hanging_kinds, lateral_windows, octree_window, octree_window_oracle    # noqa: E402,F401
+
+
+def lap_timer(name):
+    """-> lap(what): with HQ_TEST_LAPS=1 prints where a long test's time goes (stderr; run pytest with -s)."""
+    import os
+    import sys
+    import time
+    t = [time.time()]
+
+    def lap(what):
+        if os.environ.get("HQ_TEST_LAPS"):
+            now = time.time()
+            sys.stderr.write("  [%s] %-40s %7.1f s\n" % (name, what, now - t[0]))
+            t[0] = now
+    return lap

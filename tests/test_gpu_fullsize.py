@@ -222,14 +222,21 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
     ncls, amp = bench.LATERAL.get(wl, (0, 0.0))        # c2h: material of its own in every element (hq_k_brick_het in every partition)
     nsteps = 3
+    lap = H.lap_timer(wl + " x 8")
     one = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
     u = _field(one, 31337)
+    lap("whole box + field")
     ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    lap("whole box: hq_create, run, download")
     gid_one = (one.node_ijk[:, 2].astype(np.int64) * (ny + 1) + one.node_ijk[:, 1]) * (nx + 1) + one.node_ijk[:, 0]
     lut = np.empty(gid_one.max() + 1, np.int64)
     lut[gid_one] = np.arange(len(gid_one))
     one.close()
-    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, lateral_classes=ncls, lateral_amp=amp) for r in range(8)]
+    # (the ranks' meshes side by side: the C host side releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as pool:
+        boxes = list(pool.map(lambda r: host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, lateral_classes=ncls, lateral_amp=amp), range(8)))
+    lap("8 rank boxes")
     solvers, maps = [], []
     for b in boxes:
         g = (b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]
@@ -243,6 +250,7 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
                 assert solvers[-1].info()["brick_units_het"] == solvers[-1].info()["brick_units"] > 0
         else:
             assert (solvers[-1].info()["ragged_patches"] > 0) == bool(ragged)
+    lap("8 x hq_create")
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     scale = np.abs(ref1).max()
@@ -253,6 +261,7 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
         s.close()
     for b in boxes:
         b.close()
+    lap("run, download, compare")
 
 
 def test_large_two_level_box_variants_agree():
@@ -399,7 +408,9 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 90 * 2 ** 30:
         pytest.skip("needs ~80 GiB of host memory for the 189M-element mesh tables")
+    lap = H.lap_timer("o3")
     box, E, N, u, interfaces = _basin("o3", want_interfaces=True)
+    lap("mesh + field")
     assert E > 180e6 and box.ldnnum > 1e6 and len(interfaces) == 3
     nsteps = 2
     scale0 = np.abs(u).max()
@@ -407,6 +418,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
     assert s.info()["variant"] == ha.HQ_VARIANT_PATCH and s.info()["brick_nodes"] > 0.9 * N
     s.run(nsteps)
+    lap("hq_create + run")
     # oracle windows across the level interfaces
     xyz = box.node_xyz
     elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
@@ -425,6 +437,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
         nchecked += int(ok.sum())
         nhang += int(np.isin(nodes[ok], box.dangling[0]).sum())
     del elem_lo, elem_edge
+    lap("oracle windows")
     assert nchecked > 400 and nhang > 20, (nchecked, nhang)
     assert worst < 1e-9, worst
     tm1, _ = s.download(want_tm2=False)
@@ -449,10 +462,11 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     del u
     box.close()
     gc.collect()
+    lap("download, anchors, node table")
     solvers, maps = [], []
-    # the ranks' tables are built four at a time (the C host side releases the GIL; a rank alone takes ~10 s)
+    # the ranks' tables are built side by side (the C host side releases the GIL; a rank alone takes ~10 s)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(4) as pool:
+    with ThreadPoolExecutor(8) as pool:
         built = pool.map(lambda r: _basin("o3", r, 8), range(8))
         for r in range(8):
             b, _, _, ur = next(built)
@@ -465,6 +479,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
             b.close()
             gc.collect()
     del lut
+    lap("8 ranks: meshes, maps, hq_create")
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     for sv, m in zip(solvers, maps):
@@ -637,12 +652,14 @@ def test_small_basin_against_the_oracle():
 # with x-, y- and z-normal faces and staircase corners, hanging nodes of every orientation
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["bricks", "patches-only", "scatter"])
+@pytest.mark.parametrize("mode", ["bricks", "full-tiles-only", "patches-only", "scatter"])
 def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     """o4s (0.93 M elements on four levels, 62 k hanging nodes of all six kinds): the oracle's reference loops with
     compute_adjust on the WHOLE mesh for three steps against the default path (bricks where a level's interior is
-    uniform -- here beside x- and y-normal level interfaces --, patches around them), the patch kernels alone and the
-    scatter kernels."""
+    uniform -- full tile columns, and beside the x- and y-normal level interfaces and the bowl's staircase the RAGGED ones,
+    HQ_BK_RAGGED --, patches around them), the same with full tile columns only (hq_options.brick_ragged = 0), the patch
+    kernels alone and the scatter kernels.  Forces on 3 000 nodes all over the mesh at every step: the ragged units' nodes
+    among them (compute_addforce_s, psolve.c:5912-5928)."""
     import bench
     if mode == "patches-only":
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
@@ -651,13 +668,23 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     deps, mask, dist = H.hanging_kinds(box.node_xyz, box.dangling)
     assert set(mask.tolist()) == {1, 2, 3, 4, 5, 6}
     nsteps = 3
+    free = np.setdiff1d(np.arange(N, dtype=np.int64), box.dangling[0])
+    loaded = free[np.linspace(0, len(free) - 1, 3000).astype(np.int64)].astype(np.int32)
+    rng = np.random.default_rng(99)
+    F = rng.uniform(-1.0, 1.0, (nsteps, len(loaded), 3)) * (1e-4 * np.abs(u).max() / box.dt ** 2) * box.ntable[loaded, 0][None, :, None]
     o1, o2 = (0.999 * u).copy(), u.copy()
-    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling)
-    s = box.create_solver(variant=ha.HQ_VARIANT_SCATTER if mode == "scatter" else ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling,
+                  loaded_lnid=loaded, forces=F)
+    s = box.create_solver(variant=ha.HQ_VARIANT_SCATTER if mode == "scatter" else ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u,
+                          options={"brick_ragged": 0} if mode == "full-tiles-only" else None)
+    info = s.info()
     if mode == "bricks":
-        assert s.info()["brick_nodes"] > 0.3 * N
+        assert info["brick_nodes"] > 0.6 * N and info["brick_units_ragged"] > 0
+    elif mode == "full-tiles-only":
+        assert 0.3 * N < info["brick_nodes"] < 0.6 * N and info["brick_units_ragged"] == 0
     elif mode == "patches-only":
-        assert s.info()["brick_nodes"] == 0
+        assert info["brick_nodes"] == 0
+    s.set_source(loaded, F)
     s.run(nsteps)
     tm1, tm2 = s.download()
     s.close()
@@ -665,13 +692,15 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     box.close()
 
 
-@pytest.mark.parametrize("nranks", [8])       # (5 ranks: the reference's own 5-rank run of its basin, tests/test_gpu_parity.py and test_gpu_multiprocess.py)
-def test_small_lateral_basin_in_partitions_matches_one_partition(nranks):
+@pytest.mark.parametrize("nranks,overlap", [(8, 0), (8, 1)])       # (5 ranks: the reference's own 5-rank run of its basin, tests/test_gpu_parity.py and test_gpu_multiprocess.py)
+def test_small_lateral_basin_in_partitions_matches_one_partition(nranks, overlap, monkeypatch):
     """o4s cut into octor's block partitions (hqh_mesh_from_leaves with rank / nranks: ownership by Z-order point
     location, anchors of shared hanging nodes across x- / y- / z-normal interfaces), patch variant with bricks, in-process
-    transport, against the whole basin on one partition."""
+    transport, against the whole basin on one partition.  overlap: the exchange chain on its own stream beside the
+    interior launches -- the 100-register forms of hq_k_brick, the ragged one among them."""
     import bench
     from hercules_amd import capi
+    monkeypatch.setenv("HQ_OVERLAP", str(overlap))
     nsteps = 4
     one, E, N, it = bench.make_octbox("o4s", 0, 1)
     u = it["field"]
@@ -684,6 +713,7 @@ def test_small_lateral_basin_in_partitions_matches_one_partition(nranks):
         solvers.append(b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=itr["field"], tm2=0.999 * itr["field"]))
         gids.append(b.gid.copy())
         b.close()
+    assert sum(sv.info()["brick_units_ragged"] for sv in solvers) > 0
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     scale = np.abs(ref1).max()
@@ -704,14 +734,17 @@ def test_full_lateral_basin_against_the_oracle():
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 70 * 2 ** 30:
         pytest.skip("needs ~60 GiB of host memory for the 101M-element mesh tables")
+    lap = H.lap_timer("o4")
     box, E, N, it = bench.make_octbox("o4", 0, 1)
     u = it["field"]
+    lap("mesh + field")
     assert E > 100e6 and box.ldnnum > 3e5
     nsteps = 2
     scale0 = np.abs(u).max()
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
     assert s.info()["brick_nodes"] > 0.8 * N
     s.run(nsteps)
+    lap("hq_create + run")
     xyz = box.node_xyz
     elem_lo = xyz[box.lnid[:, 0]].astype(np.int32)
     elem_edge = xyz[box.lnid[:, 1], 0] - elem_lo[:, 0]
@@ -731,6 +764,7 @@ def test_full_lateral_basin_against_the_oracle():
         nhang += int(hang.sum())
         kinds |= set(zip(mask[hang].tolist(), dist[hang].tolist()))
     del elem_lo, elem_edge
+    lap("oracle windows")
     assert len(wins) >= 12 and nchecked > 5000 and nhang > 200
     assert {m for m, _ in kinds} == {1, 2, 3, 4, 5, 6}
     assert worst < 1e-9, worst

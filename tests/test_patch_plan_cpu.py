@@ -167,3 +167,28 @@ def test_brick_plan_on_an_octree_box(nranks):
         bricks += rep["brick_nodes"]
         nodes += rep["brick_nodes"] + rep["patch_nodes"]
     assert bricks > 0.3 * nodes
+
+
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_ragged_brick_units_beside_lateral_level_interfaces(nranks, monkeypatch):
+    """The laterally refined basin o4s (level interfaces with x-, y- and z-normal faces along a sediment bowl): few 64 x 8
+    tiles are FULL of uniform simple nodes over a run of planes; the second planner round takes partly filled ones
+    (HQ_BK_RAGGED: every plane through an id table, owned nodes numbered without gaps, all of one material and n_t row).
+    hq_brick_plan_check follows every owned node's 26 neighbours through those tables; the patches shrink to less than half."""
+    import bench
+    tot = {}
+    for ragged in (0, 1):
+        monkeypatch.setenv("HQ_BRICK_RAGGED", str(ragged))
+        acc = {"brick_nodes": 0, "patch_nodes": 0, "ragged_units": 0, "ragged_nodes": 0}
+        for rank in range(nranks):
+            box = bench.make_octbox("o4s", rank, nranks)[0]
+            rep = box.brick_plan_check()
+            box.close()
+            assert rep["faults"] == 0 and rep["units_one_nt_row"] == rep["units"] - rep["het_units"]
+            for k in acc:
+                acc[k] += rep[k]
+        tot[ragged] = acc
+    assert tot[0]["ragged_units"] == 0 and tot[0]["ragged_nodes"] == 0
+    assert tot[1]["ragged_units"] > 0 and tot[1]["ragged_nodes"] > 0.15 * (tot[1]["brick_nodes"] + tot[1]["patch_nodes"])
+    assert tot[1]["patch_nodes"] < 0.6 * tot[0]["patch_nodes"]
+    assert tot[1]["brick_nodes"] + tot[1]["patch_nodes"] == tot[0]["brick_nodes"] + tot[0]["patch_nodes"]
