@@ -1647,8 +1647,10 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
             return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
         c->d_nt = c->d_nt_rows - 7 * nt_first;
     }
+    lap("state buffers, n_t rows");
     if (h_tm1 && (rc = hq_field_to_device(c, h_tm1, c->d_u[c->now])) != HQ_OK) return bail(rc);
     if (h_tm2 && (rc = hq_field_to_device(c, h_tm2, c->d_u[c->prev])) != HQ_OK) return bail(rc);
+    lap("start fields");
 
     if (c->ldnnum) {
         int32_t na = d->dn_ptr[c->ldnnum];
@@ -1753,7 +1755,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
         c->plan.ragged_default = true;
         rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
                             dn, seed0.data(), &pb, BH.nb);
-        lap("state upload + patch plan");
+        lap("patch plan");
         if (rc == 0 && BH.nb > 0) rc = hq_brick_upload(&c->bricks, BH, &pb);
         c->bricks.mat = { 0.0, 0.0, d->deltaT, d->mat_bbase, d->mat_threshold_damping, d->mat_threshold_vpvs };
         lap("brick upload");
@@ -1766,6 +1768,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
         if ((rc = hq_build_schedule(c, &d->an_sched, &c->an)) != HQ_OK) return bail(rc);
         if ((rc = hq_build_schedule(c, &d->dn_sched, &c->dn)) != HQ_OK) return bail(rc);
         if ((rc = hq_setup_interface(c, d)) != HQ_OK) return bail(rc);
+        lap("schedules, interface");
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
     c->opt_brick_stream = hq_opt_has("HQ_BRICK_STREAM") ? (hq_opt_on("HQ_BRICK_STREAM") ? 1 : 0) : -1;

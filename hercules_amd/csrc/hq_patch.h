@@ -33,6 +33,7 @@ static inline int omp_get_thread_num(void) { return 0; }
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <string>
 #include <unordered_map>
@@ -2176,6 +2177,14 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                           const hq_dangling& dn, const char* seed0, int64_t* bytes, int64_t n0 = 0)
 {
     hq_patch_host H;
+    const bool plap_on = hq_opt_int("HQ_PATCH_VERBOSE", 0) > 1;
+    auto plap_t = std::chrono::steady_clock::now();
+    auto plap = [&](const char* what) {
+        if (!plap_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  patch plan: %-36s %6.2f s\n", what, std::chrono::duration<double>(now - plap_t).count());
+        plap_t = now;
+    };
     P->n0 = n0;
     P->cfg = hq_patch_cfg_from_env();
     P->pipe = hq_patch_kernel_choice();
@@ -2225,6 +2234,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                     P->cfg.nlmax <= HQ_PERS_THREADS && mp <= HQ_PERS_THREADS &&
                     (12 * (size_t)P->nrows + 9 * (size_t)P->max_nacc + 16) * sizeof(double) <= 160 * 1024;
     }
+    plap("patches cut");
     /* ISO patches: mass2_minusaM / mass_minusaM (psolve.c:3454-3468) equal on the three axes
      * for every owned node, i.e. no dashpot touches the patch */
     std::vector<double> nt3((size_t)N * 3);
@@ -2267,6 +2277,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             }
         }
     }
+    plap("uniform / n_t classes");
     /* stencil patches: uniform coefficients, nodes and elements a subset of the lattice, no hanging node's force to
      * distribute (full_only: only the full lattice without dashpot) */
     std::vector<uint32_t> rg_tab;
@@ -2314,6 +2325,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
                 H.desc.size(), P->nlattice, nst, H.ndistinct, nuniform, nntsame);
     }
     P->npatches = (int32_t)H.desc.size();
+    plap("stencil tables");
     P->npairs = (int64_t)H.pelem.size();
     P->nhalo = (int64_t)H.halo.size();
     P->hstride = H.hstride;
@@ -2388,6 +2400,7 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
     P->patch_nown.resize(H.desc.size());
     for (size_t p = 0; p < H.desc.size(); p++) { P->patch_base[p] = H.desc[p].base; P->patch_nown[p] = H.desc[p].nown; }
     if (hq_patch_build_order(P, nullptr, bytes) != 0) return -2;
+    plap("uploads");
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -237,12 +237,17 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     with ThreadPoolExecutor(8) as pool:
         boxes = list(pool.map(lambda r: host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, lateral_classes=ncls, lateral_amp=amp), range(8)))
     lap("8 rank boxes")
-    solvers, maps = [], []
-    for b in boxes:
+    # ... and so are the eight hq_create calls (thread-safe by design: errors and options in force are thread-local)
+    def make(b):
         g = (b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]
         m = lut[g]
+        return m, b.create_solver(tm1=u[m], tm2=0.999 * u[m])
+    with ThreadPoolExecutor(8) as pool:
+        made = list(pool.map(make, boxes))
+    solvers, maps = [], []
+    for m, sv in made:
         maps.append(m)
-        solvers.append(b.create_solver(tm1=u[m], tm2=0.999 * u[m]))
+        solvers.append(sv)
         assert solvers[-1].info()["variant"] == ha.HQ_VARIANT_PATCH
         if bricks:
             assert solvers[-1].dominant_kernel() == "hq_k_brick"
@@ -466,18 +471,19 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     solvers, maps = [], []
     # the ranks' tables are built side by side (the C host side releases the GIL; a rank alone takes ~10 s)
     from concurrent.futures import ThreadPoolExecutor
+    def make(r):                      # mesh, map to the single run's nodes and hq_create of one rank
+        b, _, _, ur = _basin("o3", r, 8)
+        m = lut[key(b.node_xyz)]
+        sv = b.create_solver(tm1=ur, tm2=0.999 * ur)
+        b.close()
+        return m, sv
     with ThreadPoolExecutor(8) as pool:
-        built = pool.map(lambda r: _basin("o3", r, 8), range(8))
-        for r in range(8):
-            b, _, _, ur = next(built)
-            m = lut[key(b.node_xyz)]
+        for m, sv in pool.map(make, range(8)):
             assert (m >= 0).all()
             maps.append(m)
-            solvers.append(b.create_solver(tm1=ur, tm2=0.999 * ur))
+            solvers.append(sv)
             assert solvers[-1].info()["brick_nodes"] > 0
-            del ur
-            b.close()
-            gc.collect()
+    gc.collect()
     del lut
     lap("8 ranks: meshes, maps, hq_create")
     capi.group_link(solvers)
@@ -707,12 +713,20 @@ def test_small_lateral_basin_in_partitions_matches_one_partition(nranks, overlap
     ref1, ref2 = _run_oct(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
     one.close()
     solvers, gids = [], []
-    for r in range(nranks):
+    bench.make_octbox("o4s", 0, nranks)[0].close()        # (fills bench's cache of the leaves and the whole-mesh field)
+
+    def make(r):
         b, _, _, itr = bench.make_octbox("o4s", r, nranks)
         assert np.array_equal(itr["field"], u[b.gid])
-        solvers.append(b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=itr["field"], tm2=0.999 * itr["field"]))
-        gids.append(b.gid.copy())
+        sv = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=itr["field"], tm2=0.999 * itr["field"])
+        gid = b.gid.copy()
         b.close()
+        return sv, gid
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nranks) as pool:
+        for sv, gid in pool.map(make, range(nranks)):
+            solvers.append(sv)
+            gids.append(gid)
     assert sum(sv.info()["brick_units_ragged"] for sv in solvers) > 0
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
