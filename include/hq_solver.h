@@ -175,7 +175,7 @@ typedef struct {
     int32_t brick_stream;        /* HQ_BRICK_STREAM       1: bricks on a stream of their own beside the patches          */
     int32_t brick_no_faces;      /* HQ_BRICK_NO_FACES     1: the domain's z faces stay with the patches instead of being stepped as
                                                           the first / last plane of the tile columns under them           */
-    int32_t brick_half_tiles;    /* HQ_BRICK_HALF_TILES   0: no second planner round with 32-wide tiles over what the 64-wide ones leave    */
+    int32_t brick_half_tiles;    /* HQ_BRICK_HALF_TILES   (only with brick_ragged = 0) 0: no second planner round with 32-wide full tiles   */
     int32_t brick_no_pack;       /* HQ_BRICK_NO_PACK      1: per-element coefficients as 24-byte (c1, c2, beta) even where
                                                           hq_desc.edata would let them travel as 12 bytes                */
     int32_t patch_pipe;          /* HQ_PATCH_PIPE         6 hq_k_patch_seed (default), 4 hq_k_patch_pers, 0 hq_k_patch_step */

@@ -464,7 +464,6 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     key = lambda xyz: (xyz[:, 2].astype(np.int64) * (far[1] + 1) + xyz[:, 1]) * (far[0] + 1) + xyz[:, 0]
     lut = np.full(int((far[0] + 1) * (far[1] + 1) * (far[2] + 1)), -1, np.int32)
     lut[key(box.node_xyz)] = np.arange(box.N, dtype=np.int32)
-    del u
     box.close()
     gc.collect()
     lap("download, anchors, node table")
@@ -472,8 +471,9 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     # the ranks' tables are built side by side (the C host side releases the GIL; a rank alone takes ~10 s)
     from concurrent.futures import ThreadPoolExecutor
     def make(r):                      # mesh, map to the single run's nodes and hq_create of one rank
-        b, _, _, ur = _basin("o3", r, 8)
+        b = bench.make_octbox("o3", r, 8)[0]
         m = lut[key(b.node_xyz)]
+        ur = u[m]                     # (the start field is a function of the coordinates: the whole mesh's values there)
         sv = b.create_solver(tm1=ur, tm2=0.999 * ur)
         b.close()
         return m, sv
@@ -484,7 +484,7 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
             solvers.append(sv)
             assert solvers[-1].info()["brick_nodes"] > 0
     gc.collect()
-    del lut
+    del lut, u
     lap("8 ranks: meshes, maps, hq_create")
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
