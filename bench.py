@@ -1056,7 +1056,7 @@ def main():
                        "patch_elements": int(info["patch_pairs"]),
                        "setup_s": round(setup_s, 1), "finite": nonfinite == 0, "rccl_ranks": rccl_ranks,
                        "transport": transport, "transport_trials_ms_per_step": trials or None,
-                       "brick_nodes": int(info["brick_nodes"]),
+                       "brick_nodes": int(info["brick_nodes"]), "brick_units_ragged": int(info.get("brick_units_ragged", 0)),
                        "preheat_s": args.preheat,
                        # oracle cone windows stepped on this very context behind the timed region (parity_windows)
                        "parity_windows": parity[0] if parity else None,
