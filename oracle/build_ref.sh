@@ -31,15 +31,18 @@ DEFS="-DHALFSPACE -DBOUNDARY -DUSECVMDB -DSCEC -DPROCPERNODE=4000"
 FWD="psolve nrutila quakesource geometrics nonlinear commutil util output io_planes io_checkpoint stiffness damping quake_util timers buildings meshformatlab drm"
 ETREE="btree buffer code dlink etree schema wrapper xplatform"
 objs=""
+objs32=""   # the same program with -DSINGLE_PRECISION_SOLVER (psolve.h:60-64: solver_float = float): oracle/_ref/psolve_f32
 for f in $FWD;   do $CC $CFLAGS $DEFS $INC -c "$REF/quake/forward/$f.c" -o "$OUT/obj/fwd_$f.o" & objs="$objs $OUT/obj/fwd_$f.o"; done
+for f in $FWD;   do $CC $CFLAGS $DEFS -DSINGLE_PRECISION_SOLVER $INC -c "$REF/quake/forward/$f.c" -o "$OUT/obj/f32_$f.o" & objs32="$objs32 $OUT/obj/f32_$f.o"; done
 eobjs=""   # etree goes into an archive, as in etree/Makefile:15-17 (wrapper.o is never pulled)
 for f in $ETREE; do $CC $CFLAGS $DEFS $INC -c "$REF/etree/$f.c"        -o "$OUT/obj/et_$f.o"  & eobjs="$eobjs $OUT/obj/et_$f.o";  done
-$CC $CFLAGS $DEFS $INC -c "$REF/octor/octor.c"   -o "$OUT/obj/octor.o" & objs="$objs $OUT/obj/octor.o"
-$CC $CFLAGS $DEFS $INC -c "$REF/quake/cvm/cvm.c" -o "$OUT/obj/cvm.o"   & objs="$objs $OUT/obj/cvm.o"
+$CC $CFLAGS $DEFS $INC -c "$REF/octor/octor.c"   -o "$OUT/obj/octor.o" & objs="$objs $OUT/obj/octor.o"; objs32="$objs32 $OUT/obj/octor.o"
+$CC $CFLAGS $DEFS $INC -c "$REF/quake/cvm/cvm.c" -o "$OUT/obj/cvm.o"   & objs="$objs $OUT/obj/cvm.o"; objs32="$objs32 $OUT/obj/cvm.o"
 wait
 ar rcs "$OUT/obj/libetree.a" $eobjs
 $CC -o "$OUT/psolve" $objs "$OUT/obj/libetree.a" -L"$MPI/lib" -Wl,-rpath,"$MPI/lib" -lmpi -lm
+$CC -o "$OUT/psolve_f32" $objs32 "$OUT/obj/libetree.a" -L"$MPI/lib" -Wl,-rpath,"$MPI/lib" -lmpi -lm
 # fixture helper: a layered CVM database writer on top of the reference's etree + cvm libraries
 $CC $CFLAGS $INC -o "$OUT/make_cvm" "$HERE/make_cvm.c" "$OUT/obj/cvm.o" "$OUT/obj/libetree.a" -lm
 rm -rf "$OUT/obj"
-echo "build_ref: built $OUT/psolve $OUT/make_cvm"
+echo "build_ref: built $OUT/psolve $OUT/psolve_f32 $OUT/make_cvm"

@@ -27,6 +27,18 @@
 
 #define HO_API __attribute__((visibility("default")))
 
+/* solver_float, psolve.h:60-64: the type of tm1 / tm2 / force (fvector_t, :102-104), of the n_t rows (:210-214) and of the
+ * locals the reference declares with them -- float when the reference is built with -DSINGLE_PRECISION_SOLVER
+ * (oracle/_ref/psolve_f32; this file then compiles to libherc_oracle_f32.so).  Everything the reference declares double
+ * (e_t, K1 / K2, atu / firstVec, dashpot, the source table) stays double: the usual arithmetic conversions then round
+ * where the reference's statements round. */
+#ifdef SINGLE_PRECISION_SOLVER
+typedef float ho_real;
+#else
+typedef double ho_real;
+#endif
+HO_API int32_t ho_real_bytes(void) { return (int32_t)sizeof(ho_real); }
+
 /* quake_util.c:36 */
 #define HO_UNDERFLOW_CAP 1e-20
 
@@ -316,12 +328,12 @@ static void ho_setboundary(float size, float Vp, float Vs, float rho, int flag, 
 HO_API int64_t ho_solver_init(int64_t E, int64_t N, const int32_t* lnid, float* edata,
                               const uint8_t* face, double dt, double freq, int damping,
                               double thr_damping, double thr_vpvs, int boundary, int halfspace,
-                              double* etable, double* ntable)
+                              double* etable, ho_real* ntable)
 {
     double aBase, bBase;
     ho_setab(freq, damping, &aBase, &bBase);
     double dt2 = dt * dt;                               /* psolve.c:998 */
-    memset(ntable, 0, sizeof(double) * 7 * (size_t)N);
+    memset(ntable, 0, sizeof(ho_real) * 7 * (size_t)N);
 
     for (int64_t e = 0; e < E; e++) {
         float* ed = &edata[4 * e];
@@ -362,7 +374,7 @@ HO_API int64_t ho_solver_init(int64_t E, int64_t N, const int32_t* lnid, float* 
         double mass = rho * h * h * h;                  /* float product, :3436 */
         double M = mass / 8;
         for (int j = 0; j < 8; j++) {
-            double* np = &ntable[7 * (int64_t)lnid[8 * e + j]];
+            ho_real* np = &ntable[7 * (int64_t)lnid[8 * e + j]];
             np[0] += M;
             for (int ax = 0; ax < 3; ax++) {            /* :3452-3469 */
                 np[4 + ax] -= (dt * a * M);
@@ -384,7 +396,7 @@ HO_API int64_t ho_solver_init(int64_t E, int64_t N, const int32_t* lnid, float* 
 /* ------------------------------------------------------------------------ */
 
 /* vector_is_zero, quake_util.c:49-68: 1 if any of the 24 entries is "non-zero" */
-static int ho_any_nonzero24(const double* v)
+static int ho_any_nonzero24(const ho_real* v)
 {
     for (int i = 0; i < 24; i++)
         if (fabs(v[i]) > HO_UNDERFLOW_CAP) return 1;
@@ -425,7 +437,7 @@ static void ho_sign_init(void)
  * aTransposeU + firstVector + au, stiffness.c:245-424.  Sums run in the
  * reference's left-to-right order so results are bit-identical.
  */
-static void ho_effective_elem(const double* u, double a, double c, double b, double* f)
+static void ho_effective_elem(const double* u, double a, double c, double b, ho_real* f)
 {
     double atu[3][8], fv[3][8];
 
@@ -477,9 +489,9 @@ static void ho_effective_elem(const double* u, double a, double c, double b, dou
 }
 
 /* lf += c * (M v), MultAddMatVec, quake_util.c:107-122 */
-static void ho_mult_add(const double* M, const double* v, double c, double* out)
+static void ho_mult_add(const double* M, const ho_real* v, double c, ho_real* out)
 {
-    double t[3] = { 0, 0, 0 };
+    ho_real t[3] = { 0, 0, 0 };                      /* fvector_t tmpV */
     for (int r = 0; r < 3; r++)
         for (int q = 0; q < 3; q++) t[r] += M[3 * r + q] * v[q];
     for (int r = 0; r < 3; r++) out[r] += c * t[r];
@@ -487,12 +499,12 @@ static void ho_mult_add(const double* M, const double* v, double c, double* out)
 
 /* compute_addforce_effective, stiffness.c:180-237 */
 HO_API void ho_addforce_effective(int64_t E, const int32_t* lnid, const double* etable,
-                                  const double* tm1, double* force, int zero_skip)
+                                  const ho_real* tm1, ho_real* force, int zero_skip)
 {
     ho_sign_init();
     for (int64_t e = 0; e < E; e++) {
         const int32_t* id = &lnid[8 * e];
-        double u[24], lf[24];
+        ho_real u[24], lf[24];                           /* fvector_t curDisp[8], localForce[8] */
         memset(lf, 0, sizeof lf);
         for (int i = 0; i < 8; i++)
             for (int d = 0; d < 3; d++) u[3 * i + d] = tm1[3 * (int64_t)id[i] + d];
@@ -501,7 +513,9 @@ HO_API void ho_addforce_effective(int64_t E, const int32_t* lnid, const double* 
             double a = -0.5625 * (c2 + 2 * c1);
             double c = -0.5625 * (c2);
             double b = -0.5625 * (c1);
-            ho_effective_elem(u, a, c, b, lf);
+            double ud[24];                               /* aTransposeU's double temp[24], stiffness.c:247-255 */
+            for (int i = 0; i < 24; i++) ud[i] = u[i];
+            ho_effective_elem(ud, a, c, b, lf);
         }
         for (int i = 0; i < 8; i++)
             for (int d = 0; d < 3; d++) force[3 * (int64_t)id[i] + d] += lf[3 * i + d];
@@ -511,17 +525,17 @@ HO_API void ho_addforce_effective(int64_t E, const int32_t* lnid, const double* 
 /* compute_addforce_conventional, stiffness.c:121-174 (per-node zero test,
  * vector_is_all_zero quake_util.c:79-96) */
 HO_API void ho_addforce_conventional(int64_t E, const int32_t* lnid, const double* etable,
-                                     const double* tm1, const double* K1, const double* K2,
-                                     double* force, int zero_skip)
+                                     const ho_real* tm1, const double* K1, const double* K2,
+                                     ho_real* force, int zero_skip)
 {
     for (int64_t e = 0; e < E; e++) {
         const int32_t* id = &lnid[8 * e];
         double c1 = etable[4 * e], c2 = etable[4 * e + 1];
-        double lf[24];
+        ho_real lf[24];
         memset(lf, 0, sizeof lf);
         for (int i = 0; i < 8; i++)
             for (int j = 0; j < 8; j++) {
-                const double* v = &tm1[3 * (int64_t)id[j]];
+                const ho_real* v = &tm1[3 * (int64_t)id[j]];
                 int nz = (fabs(v[0]) > HO_UNDERFLOW_CAP) || (fabs(v[1]) > HO_UNDERFLOW_CAP) ||
                          (fabs(v[2]) > HO_UNDERFLOW_CAP);
                 if (!zero_skip || nz) {
@@ -536,13 +550,13 @@ HO_API void ho_addforce_conventional(int64_t E, const int32_t* lnid, const doubl
 
 /* damping_addforce, damping.c:29-103 */
 HO_API void ho_damping_addforce(int64_t E, const int32_t* lnid, const double* etable,
-                                const double* tm1, const double* tm2, const double* K1,
-                                const double* K2, double* force, int zero_skip)
+                                const ho_real* tm1, const ho_real* tm2, const double* K1,
+                                const double* K2, ho_real* force, int zero_skip)
 {
     for (int64_t e = 0; e < E; e++) {
         const int32_t* id = &lnid[8 * e];
         double c3 = etable[4 * e + 2], c4 = etable[4 * e + 3];
-        double dd[24], lf[24];
+        ho_real dd[24], lf[24];                          /* fvector_t deltaDisp[8], localForce[8] */
         memset(lf, 0, sizeof lf);
         for (int i = 0; i < 8; i++)
             for (int d = 0; d < 3; d++)
@@ -567,14 +581,15 @@ HO_API void ho_damping_addforce(int64_t E, const int32_t* lnid, const double* et
  * as a cross-check of the algebra against the two reference loops above.
  */
 HO_API void ho_addforce_fused(int64_t E, const int32_t* lnid, const double* etable,
-                              const double* tm1, const double* tm2, double* force)
+                              const ho_real* tm1, const ho_real* tm2, ho_real* force)
 {
     ho_sign_init();
     for (int64_t e = 0; e < E; e++) {
         const int32_t* id = &lnid[8 * e];
         double c1 = etable[4 * e], c2 = etable[4 * e + 1];
         double beta = (c1 != 0.0) ? etable[4 * e + 2] / c1 : 0.0;
-        double w[24], lf[24];
+        double w[24];
+        ho_real lf[24];
         memset(lf, 0, sizeof lf);
         for (int i = 0; i < 8; i++)
             for (int d = 0; d < 3; d++) {
@@ -593,7 +608,7 @@ HO_API void ho_addforce_fused(int64_t E, const int32_t* lnid, const double* etab
 
 /* compute_addforce_s, psolve.c:5912-5928: assignment, not accumulation */
 HO_API void ho_addforce_source(int32_t nloaded, const int32_t* loaded_lnid, const double* F,
-                               double dt2, double* force)
+                               double dt2, ho_real* force)
 {
     for (int32_t i = 0; i < nloaded; i++)
         for (int d = 0; d < 3; d++)
@@ -601,19 +616,19 @@ HO_API void ho_addforce_source(int32_t nloaded, const int32_t* loaded_lnid, cons
 }
 
 /* solver_compute_displacement, psolve.c:4072-4114 (tm3 optional) */
-HO_API void ho_compute_displacement(int64_t N, const double* ntable, const double* tm1,
-                                    double* tm2, double* force, double* tm3)
+HO_API void ho_compute_displacement(int64_t N, const ho_real* ntable, const ho_real* tm1,
+                                    ho_real* tm2, ho_real* force, ho_real* tm3)
 {
     for (int64_t n = 0; n < N; n++) {
-        const double* np = &ntable[7 * n];
+        const ho_real* np = &ntable[7 * n];
         for (int d = 0; d < 3; d++) {
-            double f = force[3 * n + d];
+            ho_real f = force[3 * n + d];                /* fvector_t nodalForce: a copy */
             f += np[1 + d] * tm1[3 * n + d] - np[4 + d] * tm2[3 * n + d];
             if (tm3) tm3[3 * n + d] = tm2[3 * n + d];
             tm2[3 * n + d] = f / np[0];
         }
     }
-    memset(force, 0, sizeof(double) * 3 * (size_t)N);
+    memset(force, 0, sizeof(ho_real) * 3 * (size_t)N);
 }
 
 /*
@@ -621,24 +636,24 @@ HO_API void ho_compute_displacement(int64_t N, const double* ntable, const doubl
  * dn_id[k], deps = dn_ptr[k+1]-dn_ptr[k] anchors dn_anchor[dn_ptr[k]..].
  * how = 0: DISTRIBUTION (value/deps added to every anchor), else ASSIGNMENT.
  */
-HO_API void ho_compute_adjust(double* table, int32_t items, int32_t how, int32_t ldnnum,
+HO_API void ho_compute_adjust(ho_real* table, int32_t items, int32_t how, int32_t ldnnum,
                               const int32_t* dn_id, const int32_t* dn_ptr,
                               const int32_t* dn_anchor)
 {
     for (int32_t k = 0; k < ldnnum; k++) {
-        double* mine = table + (int64_t)dn_id[k] * items;
+        ho_real* mine = table + (int64_t)dn_id[k] * items;
         uint32_t deps = (uint32_t)(dn_ptr[k + 1] - dn_ptr[k]);
         if (how == 0) {
-            double part[7];
+            ho_real part[7];                             /* solver_float darray[7] */
             for (int t = 0; t < items; t++) part[t] = mine[t] / deps;
             for (int32_t p = dn_ptr[k]; p < dn_ptr[k + 1]; p++) {
-                double* anc = table + (int64_t)dn_anchor[p] * items;
+                ho_real* anc = table + (int64_t)dn_anchor[p] * items;
                 for (int t = 0; t < items; t++) anc[t] += part[t];
             }
         } else {
             for (int t = 0; t < items; t++) mine[t] = 0;
             for (int32_t p = dn_ptr[k]; p < dn_ptr[k + 1]; p++) {
-                const double* anc = table + (int64_t)dn_anchor[p] * items;
+                const ho_real* anc = table + (int64_t)dn_anchor[p] * items;
                 for (int t = 0; t < items; t++) mine[t] += anc[t] / deps;
             }
         }
@@ -665,8 +680,8 @@ HO_API void ho_compute_adjust(double* table, int32_t items, int32_t how, int32_t
  * before its swap* (tm2 = newest), exactly like the reference's arrays.
  */
 HO_API void ho_solver_run(int64_t E, int64_t N, const int32_t* lnid, const double* etable,
-                          const double* ntable, const double* K1, const double* K2,
-                          double* tm1, double* tm2, double* force, int32_t step0,
+                          const ho_real* ntable, const double* K1, const double* K2,
+                          ho_real* tm1, ho_real* tm2, ho_real* force, int32_t step0,
                           int32_t nsteps, double dt, int damping, int stiff_method,
                           int formulation, int zero_skip, int32_t nloaded,
                           const int32_t* loaded_lnid, const double* forces,
@@ -675,9 +690,9 @@ HO_API void ho_solver_run(int64_t E, int64_t N, const int32_t* lnid, const doubl
                           const int32_t* dn_ptr, const int32_t* dn_anchor)
 {
     double dt2 = dt * dt;
-    double *p1 = tm1, *p2 = tm2;
+    ho_real *p1 = tm1, *p2 = tm2;
     for (int32_t s = step0; s < step0 + nsteps; s++) {
-        double* t = p2; p2 = p1; p1 = t;                     /* psolve.c:4271-4273 */
+        ho_real* t = p2; p2 = p1; p1 = t;                    /* psolve.c:4271-4273 */
         for (int32_t c = 0; c < cap_n; c++)
             for (int d = 0; d < 3; d++)
                 cap_out[((int64_t)(s - step0) * cap_n + c) * 3 + d] = p1[3 * (int64_t)cap_lnid[c] + d];
@@ -700,8 +715,8 @@ HO_API void ho_solver_run(int64_t E, int64_t N, const int32_t* lnid, const doubl
             ho_compute_adjust(p2, 3, 1, ldnnum, dn_id, dn_ptr, dn_anchor);
     }
     if (p1 != tm1) {            /* odd number of swaps: put the roles back into the caller's arrays */
-        size_t bytes = sizeof(double) * 3 * (size_t)N;
-        double* t = (double*)malloc(bytes);
+        size_t bytes = sizeof(ho_real) * 3 * (size_t)N;
+        ho_real* t = (ho_real*)malloc(bytes);
         memcpy(t, tm1, bytes); memcpy(tm1, tm2, bytes); memcpy(tm2, t, bytes);
         free(t);
     }

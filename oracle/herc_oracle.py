@@ -18,25 +18,45 @@ DAMP_NONE, DAMP_RAYLEIGH, DAMP_MASS = 0, 1, 2
 STIFF_EFFECTIVE, STIFF_CONVENTIONAL = 0, 1
 DAMPING_BY_NAME = {"none": DAMP_NONE, "rayleigh": DAMP_RAYLEIGH, "mass": DAMP_MASS}
 
+_LIB_F32 = os.path.join(_HERE, "libherc_oracle_f32.so")      # the same file with -DSINGLE_PRECISION_SOLVER (psolve.h:60-64)
+
 _lib = None
+_lib_f32 = None
 
 
 def build(force=False):
-    """Compile the C restatement with gcc (seconds)."""
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-fvisibility=hidden",
-                               "-fopenmp", "-o", _LIB, _SRC, "-lm"])
+    """Compile the C restatement with gcc (seconds): solver_float = double, and = float as the reference's
+    -DSINGLE_PRECISION_SOLVER build has it."""
+    for out, defs in ((_LIB, []), (_LIB_F32, ["-DSINGLE_PRECISION_SOLVER"])):
+        if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(_SRC):
+            subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-fvisibility=hidden",
+                                   "-fopenmp"] + defs + ["-o", out, _SRC, "-lm"])
     return _LIB
 
 
-def lib():
-    global _lib
+def _open(path):
+    L = ctypes.CDLL(path)
+    L.ho_uniform_mesh.restype = ctypes.c_int
+    L.ho_solver_init.restype = ctypes.c_int64
+    L.ho_zvalue.restype = ctypes.c_uint64
+    L.ho_real_bytes.restype = ctypes.c_int32
+    return L
+
+
+def lib(real=np.float64):
+    """The library whose solver_float is `real` (float64: the default build; float32: -DSINGLE_PRECISION_SOLVER)."""
+    global _lib, _lib_f32
+    if np.dtype(real) == np.float32:
+        if _lib_f32 is None:
+            build()
+            _lib_f32 = _open(_LIB_F32)
+            assert _lib_f32.ho_real_bytes() == 4
+        return _lib_f32
+    assert np.dtype(real) == np.float64
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB)
-        _lib.ho_uniform_mesh.restype = ctypes.c_int
-        _lib.ho_solver_init.restype = ctypes.c_int64
-        _lib.ho_zvalue.restype = ctypes.c_uint64
+        _lib = _open(_LIB)
+        assert _lib.ho_real_bytes() == 8
     return _lib
 
 
@@ -86,15 +106,16 @@ def setab(freq, damping):
 
 
 def solver_init(lnid, edata, face, N, dt, freq, damping=DAMP_RAYLEIGH, thr_damping=0.05,
-                thr_vpvs=3.0, boundary=True, halfspace=True):
-    """-> etable [E,4], ntable [N,7]; edata [E,4] float32 (h,Vp,Vs,rho), may be modified."""
+                thr_vpvs=3.0, boundary=True, halfspace=True, real=np.float64):
+    """-> etable [E,4], ntable [N,7]; edata [E,4] float32 (h,Vp,Vs,rho), may be modified.
+    real: solver_float -- the n_t rows are accumulated in it (float32: as psolve_f32 does)."""
     lnid = _c(lnid, np.int32)
     E = lnid.shape[0]
     assert edata.dtype == np.float32 and edata.flags.c_contiguous
     face = _c(face, np.uint8)
     etable = np.zeros((E, 4))
-    ntable = np.zeros((N, 7))
-    rc = lib().ho_solver_init(ctypes.c_int64(E), ctypes.c_int64(N), _p(lnid), _p(edata), _p(face),
+    ntable = np.zeros((N, 7), real)
+    rc = lib(real).ho_solver_init(ctypes.c_int64(E), ctypes.c_int64(N), _p(lnid), _p(edata), _p(face),
                               ctypes.c_double(dt), ctypes.c_double(freq), ctypes.c_int(damping),
                               ctypes.c_double(thr_damping), ctypes.c_double(thr_vpvs),
                               ctypes.c_int(int(boundary)), ctypes.c_int(int(halfspace)),
@@ -111,10 +132,12 @@ def solver_run(lnid, etable, ntable, tm1, tm2, step0, nsteps, dt, damping=DAMP_R
     lnid = _c(lnid, np.int32)
     E = lnid.shape[0]
     N = ntable.shape[0]
-    for a in (etable, ntable, tm1, tm2):
-        assert a.dtype == np.float64 and a.flags.c_contiguous
+    real = tm1.dtype                 # solver_float: float64, or float32 = the reference's -DSINGLE_PRECISION_SOLVER
+    assert etable.dtype == np.float64 and etable.flags.c_contiguous
+    for a in (ntable, tm1, tm2):
+        assert a.dtype == real and a.flags.c_contiguous
     K1, K2 = K if K is not None else compute_K()
-    force = np.zeros((N, 3))
+    force = np.zeros((N, 3), real)
     if loaded_lnid is None or len(loaded_lnid) == 0:
         nl, ll, F, nfs = 0, None, None, 0
     else:
@@ -132,7 +155,7 @@ def solver_run(lnid, etable, ntable, tm1, tm2, step0, nsteps, dt, damping=DAMP_R
     else:
         di, dp, da = [_c(x, np.int32) for x in dangling]
         nd = len(di)
-    lib().ho_solver_run(ctypes.c_int64(E), ctypes.c_int64(N), _p(lnid), _p(etable), _p(ntable),
+    lib(real).ho_solver_run(ctypes.c_int64(E), ctypes.c_int64(N), _p(lnid), _p(etable), _p(ntable),
                         _p(K1), _p(K2), _p(tm1), _p(tm2), _p(force), ctypes.c_int32(step0),
                         ctypes.c_int32(nsteps), ctypes.c_double(dt), ctypes.c_int(damping),
                         ctypes.c_int(stiff_method), ctypes.c_int(formulation),
@@ -145,8 +168,8 @@ def solver_run(lnid, etable, ntable, tm1, tm2, step0, nsteps, dt, damping=DAMP_R
 def compute_adjust(table, how, dangling):
     """compute_adjust (psolve.c:5936-6039) in place; how 0 = DISTRIBUTION, 1 = ASSIGNMENT."""
     di, dp, da = [_c(x, np.int32) for x in dangling]
-    assert table.dtype == np.float64 and table.flags.c_contiguous
-    lib().ho_compute_adjust(_p(table), ctypes.c_int32(table.shape[1]), ctypes.c_int32(how),
+    assert table.dtype in (np.float64, np.float32) and table.flags.c_contiguous
+    lib(table.dtype).ho_compute_adjust(_p(table), ctypes.c_int32(table.shape[1]), ctypes.c_int32(how),
                             ctypes.c_int32(len(di)), _p(di), _p(dp), _p(da))
 
 

@@ -62,8 +62,9 @@ use_infinite_qk = no
 
 def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayleigh",
                   nranks=1, printk="no", freq=None, dt=None, cvm_args=None, vscut=None, planes=None,
-                  plane_rate=50, station_derivs=0, wavefield_rate=0):
-    """Run the reference in a scratch dir; return (dir, stdout)."""
+                  plane_rate=50, station_derivs=0, wavefield_rate=0, single=False):
+    """Run the reference in a scratch dir; return (dir, stdout).  single: the program built with
+    -DSINGLE_PRECISION_SOLVER (oracle/_ref/psolve_f32; psolve.h:60-64)."""
     run = tempfile.mkdtemp(prefix="herc_%s_" % tag, dir="/tmp")
     src = os.path.join(REF, "examples", "simple")
     shutil.copytree(os.path.join(src, "in"), os.path.join(run, "in"))
@@ -115,7 +116,7 @@ def run_reference(tag, end_time, ckpt_rate, stiffness="effective", damping="rayl
             "output_planes =\n" + "\n".join(" ".join(str(v) for v in p) for p in planes) + "\n")
     open(os.path.join(run, "parameters.in"), "w").write(text)
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(MPI, "lib"))
-    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", str(nranks), PSOLVE,
+    out = subprocess.run([os.path.join(MPI, "bin", "mpiexec"), "-np", str(nranks), PSOLVE + ("_f32" if single else ""),
                           "parameters.in"], cwd=run, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, universal_newlines=True)
     if out.returncode != 0:
@@ -141,17 +142,19 @@ def read_forces(run, rank=0):
     return ids, F
 
 
-def read_checkpoint(path, harbored=None):
-    """-> (step, [ (tm2, tm1) per rank ]).  io_checkpoint.c:76-112."""
+def read_checkpoint(path, harbored=None, real="<f8"):
+    """-> (step, [ (tm2, tm1) per rank ]).  io_checkpoint.c:76-112.  real: "<f4" for a file psolve_f32 wrote
+    (rows of three solver_float)."""
     b = open(path, "rb").read()
     groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+    row = 3 * np.dtype(real).itemsize
     out = []
     for r in range(groupsize):
         n = nmax if harbored is None else harbored[r]
-        off = 12 + 2 * r * nmax * 24
-        tm2 = np.frombuffer(b[off:off + n * 24], "<f8").reshape(n, 3).copy()
-        off += n * 24
-        tm1 = np.frombuffer(b[off:off + n * 24], "<f8").reshape(n, 3).copy()
+        off = 12 + 2 * r * nmax * row
+        tm2 = np.frombuffer(b[off:off + n * row], real).reshape(n, 3).copy()
+        off += n * row
+        tm1 = np.frombuffer(b[off:off + n * row], real).reshape(n, 3).copy()
         out.append((tm2, tm1))
     return step, out
 
@@ -384,6 +387,30 @@ def case_layered():
                  keep_mesh_etree=True)
 
 
+def case_single(name, end_time, ckpt_rate, cvm_args=None, vscut=None, freq=None, **kw):
+    """-DSINGLE_PRECISION_SOLVER (psolve.h:60-64): tm1 / tm2 / force and the n_t rows are floats, e_t and every local
+    the reference declares double stay double.  Same inputs as the double-precision cases; checkpoints are rows of three
+    floats, stations the usual text."""
+    run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq, single=True, **kw)
+    ids, F = read_forces(run)
+    elem_ticks, mat = read_mesh(run)
+    ck = {}
+    for f in ("checkpoint.out0", "checkpoint.out1"):
+        step, blocks = read_checkpoint(os.path.join(run, "out", "checkpoints", f), real="<f4")
+        ck[step] = blocks[0]
+    st = read_stations(run)
+    m = re.search(r"Total dangling nodes:\s+(\d+)", out)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        elem_ticks=elem_ticks, mat_vs_vp_rho=mat, loaded_lnid=ids, forces=F,
+                        ckpt_steps=np.array(sorted(ck)),
+                        ckpt_tm2=np.stack([ck[s][0] for s in sorted(ck)]),
+                        ckpt_tm1=np.stack([ck[s][1] for s in sorted(ck)]),
+                        stations=st, dt=1e-3, end_time=float(end_time), freq=5.0 if freq is None else freq,
+                        total_dangling=int(m.group(1)) if m else 0)
+    shutil.rmtree(run)
+    print(name, "ok", sorted(ck), ck[sorted(ck)[0]][0].dtype)
+
+
 BASIN_CVM = ["regions", 4, 6000, 3464, 2700, 2,
              "dip", 3.2, -0.3, -0.12, 3000, 1732, 2200,          # a sediment wedge thinning towards +x, +y
              "box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800]        # a soft box at the surface against the far-x face
@@ -476,6 +503,11 @@ CASES = {
     "c5_basin": case_basin,
     "c5_basin_np8": lambda: case_octree_np("c5_basin_np8", "c5_basin", 8, "0.3", 100, BASIN_CVM, 100, 5.0),
     "c5_basin_np5": lambda: case_octree_np("c5_basin_np5", "c5_basin", 5, "0.3", 100, BASIN_CVM, 100, 5.0),
+    # the reference's single-precision build on the uniform box (effective and conventional stiffness) and on the
+    # two-level octree (compute_adjust on float tables)
+    "c1_f32": lambda: case_single("c1_f32", "1.0", 400),
+    "c1_conv_f32": lambda: case_single("c1_conv_f32", "0.5", 200, stiffness="conventional"),
+    "c5_two_level_f32": lambda: case_single("c5_two_level_f32", "0.5", 200, [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
     # (a 5-rank run of the three-level mesh was tried and is NOT a fixture: on 5 ranks the
     #  reference's mesher refines that model uniformly, so it pins nothing the others do not)
 }

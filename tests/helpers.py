@@ -31,11 +31,12 @@ def c1_mesh():
     return lnid, node_ijk, elem_ijk, edata
 
 
-def c1_problem(damping="rayleigh"):
+def c1_problem(damping="rayleigh", real=np.float64):
+    """real: solver_float (psolve.h:60-64) -- float32 = the tables as the reference's -DSINGLE_PRECISION_SOLVER build sums them."""
     lnid, node_ijk, elem_ijk, edata = c1_mesh()
     face = ho.face_bits(elem_ijk, C1_NX, C1_NY, C1_NZ)
     etable, ntable = ho.solver_init(lnid, edata.copy(), face, len(node_ijk), 1e-3, 5.0,
-                                    damping=ho.DAMPING_BY_NAME[damping])
+                                    damping=ho.DAMPING_BY_NAME[damping], real=real)
     return dict(lnid=lnid, node_ijk=node_ijk, elem_ijk=elem_ijk, edata=edata, face=face,
                 etable=etable, ntable=ntable, N=len(node_ijk), E=len(lnid), dt=1e-3,
                 damping=ho.DAMPING_BY_NAME[damping])
@@ -45,7 +46,7 @@ def rel_linf(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300))
 
 
-def c5_problem(name="c5_two_level"):
+def c5_problem(name="c5_two_level", real=np.float64):
     """One of the reference's own octree meshes (c5_two_level: soft layer refined one level
     deeper, 800 hanging nodes; c5_three_level: three element sizes and three materials that
     take every branch of mu_and_lambda) rebuilt from its flat dump, with eTable / nTable as
@@ -58,7 +59,7 @@ def c5_problem(name="c5_two_level"):
     edata = np.empty((E, 4), np.float32)
     edata[:, 0] = (tick * m["emin"] * m["elem_size"].astype(np.float64)).astype(np.float32)
     edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
-    etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, 1e-3, float(g["freq"]))
+    etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, 1e-3, float(g["freq"]), real=real)
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
                 N=N, E=E, dt=1e-3, emin=m["emin"], golden=g, elem_size=m["elem_size"])
