@@ -3,6 +3,7 @@
     python -m hercules_amd.build [--force]
 
 libhq_solver.so : HIP kernels + C-ABI (include/hq_solver.h)
+libhq_solver_f32.so : the same sources with -DHQ_SINGLE_PRECISION_SOLVER (hq_real = float; never the default)
 libhq_host.so   : C host side mirroring the reference's solver_init/solver_run
                   for uniform boxes (include/hq_host.h), links libhq_solver.so
 """
@@ -38,6 +39,23 @@ def build_solver(force=False):
     return SOLVER_LIB
 
 
+SOLVER_LIB_F32 = os.path.join(CSRC, "libhq_solver_f32.so")
+
+
+def build_solver_f32(force=False):
+    """The same sources with -DHQ_SINGLE_PRECISION_SOLVER: hq_real = float (the reference's -DSINGLE_PRECISION_SOLVER,
+    psolve.h:60-64) -- a separately named library, never the default."""
+    srcs = [os.path.join(CSRC, f) for f in ("hq_engine.hip", "hq_kernels.h", "hq_opts.h", "hq_patch.h", "hq_brick.h")]
+    srcs.append(os.path.join(ROOT, "include", "hq_solver.h"))
+    if force or _newer(SOLVER_LIB_F32, srcs):
+        cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DHQ_SINGLE_PRECISION_SOLVER",
+               "-fvisibility=hidden", "-fopenmp", "-Wno-unused-value"] + \
+              os.environ.get("HQ_EXTRA_FLAGS", "").split() + \
+              ["-o", SOLVER_LIB_F32, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return SOLVER_LIB_F32
+
+
 def build_host(force=False):
     src = os.path.join(CSRC, "hq_host.c")
     if not os.path.exists(src):
@@ -70,6 +88,7 @@ def build_example(force=False):
 
 def build(force=False):
     out = build_solver(force), build_host(force)
+    build_solver_f32(force)
     build_example(force)
     return out
 

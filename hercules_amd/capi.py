@@ -15,7 +15,7 @@ HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 IPC_BLOB_BYTES = 4096                   # HQ_IPC_BLOB_BYTES
 
 EXPORTS = ["hq_device_count", "hq_last_error", "hq_create", "hq_destroy", "hq_get_info", "hq_get_info_sized", "hq_abi_version", "hq_comm_init_ipc_n",
-           "hq_options_init", "hq_create_opts", "hq_get_options",
+           "hq_options_init", "hq_create_opts", "hq_get_options", "hq_real_bytes",
            "hq_comm_unique_id", "hq_comm_init", "hq_comm_selftest", "hq_group_link", "hq_group_run", "hq_set_source", "hq_run", "hq_sync", "hq_gather", "hq_gather3",
            "hq_download", "hq_upload", "hq_phase_force", "hq_phase_update", "hq_download_force",
            "hq_run_timed", "hq_dominant_kernel", "hq_plan_check", "hq_stencil_plan_check", "hq_check_finite",
@@ -98,11 +98,21 @@ class Options(ctypes.Structure):
 
 
 _lib = None
+_lib_f32 = None
+_LIBPATH_F32 = os.path.join(os.path.dirname(_LIBPATH), "libhq_solver_f32.so")
 
 
-def load_library(path=None):
-    """dlopen libhq_solver.so; raises HqError if it was not built."""
-    global _lib
+def load_library(path=None, precision="f64"):
+    """dlopen libhq_solver.so; raises HqError if it was not built.
+    precision="f32": libhq_solver_f32.so -- the same sources with -DHQ_SINGLE_PRECISION_SOLVER (hq_real = float: the
+    reference's -DSINGLE_PRECISION_SOLVER, psolve.h:60-64); a separately named build, never the default."""
+    global _lib, _lib_f32
+    if precision == "f32" and path is None:
+        if _lib_f32 is None:
+            _lib_f32 = load_library(_LIBPATH_F32)
+            if _lib_f32.hq_real_bytes() != 4:
+                raise HqError("%s was not built with -DHQ_SINGLE_PRECISION_SOLVER" % _LIBPATH_F32)
+        return _lib_f32
     if _lib is not None and path is None:
         return _lib
     p = path or _LIBPATH
@@ -124,9 +134,9 @@ def device_count():
     return int(load_library().hq_device_count())
 
 
-def _check(rc):
+def _check(rc, lib=None):
     if rc != 0:
-        raise HqError("hq error %d: %s" % (rc, load_library().hq_last_error().decode()))
+        raise HqError("hq error %d: %s" % (rc, (lib or load_library()).hq_last_error().decode()))
 
 
 def _ptr(a):
@@ -158,17 +168,22 @@ class Solver:
 
     def __init__(self, lnid, etable, ntable, dt, tm1=None, tm2=None, node_xyz=None,
                  dangling=None, an_sched=None, dn_sched=None, rank=0, nranks=1,
-                 variant=HQ_VARIANT_AUTO, device=0, options=None, edata=None, material=None):
+                 variant=HQ_VARIANT_AUTO, device=0, options=None, edata=None, material=None, precision="f64"):
         """options: an Options (hq_options) or a dict of its fields; None = hq_create's defaults.
+        precision: "f64", or "f32" = libhq_solver_f32.so (hq_real = float: ntable, tm1, tm2 and everything gathered or
+        downloaded are float32 arrays, as the reference's -DSINGLE_PRECISION_SOLVER arrays are).
         edata [E,4] float32 (edgesize, Vp, Vs, rho as solver_init left them) + material = (bBase, threshold_damping,
         threshold_vpvs): hq_desc.edata / mat_* -- lets hq_k_brick_het keep 12 bytes per element."""
-        lib = load_library()
+        lib = load_library(precision=precision)
+        self.real = np.float32 if precision == "f32" else np.float64
+        if lib.hq_real_bytes() != np.dtype(self.real).itemsize:
+            raise HqError("library and precision %r disagree about sizeof(hq_real)" % precision)
         if isinstance(options, dict):
             options = Options(**options)
         keep = []
         lnid = np.ascontiguousarray(lnid, np.int32)
         etable = np.ascontiguousarray(etable, np.float64)
-        ntable = np.ascontiguousarray(ntable, np.float64)
+        ntable = np.ascontiguousarray(ntable, self.real)
         d = _Desc()
         d.lenum, d.nharbored = lnid.shape[0], ntable.shape[0]
         d.lnid, d.eTable, d.nTable = _ptr(lnid), _ptr(etable), _ptr(ntable)
@@ -179,7 +194,7 @@ class Solver:
             d.node_xyz = _ptr(node_xyz)
         for name, a in (("tm1", tm1), ("tm2", tm2)):
             if a is not None:
-                a = np.ascontiguousarray(a, np.float64)
+                a = np.ascontiguousarray(a, self.real)
                 keep.append(a)
                 setattr(d, name, _ptr(a))
         if dangling is not None:
@@ -198,11 +213,11 @@ class Solver:
         d.deltaT, d.rank, d.nranks, d.variant = dt, rank, nranks, variant
         self._h = ctypes.c_void_p()
         self.N, self.E = d.nharbored, d.lenum
-        if options is None:
-            _check(lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(self._h)))
-        else:
-            _check(lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(self._h)))
         self._lib = lib
+        if options is None:
+            _check(lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(self._h)), lib)
+        else:
+            _check(lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(self._h)), lib)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -213,13 +228,13 @@ class Solver:
 
     def info(self):
         i = _Info()
-        _check(self._lib.hq_get_info_sized(self._h, ctypes.byref(i), ctypes.c_uint64(ctypes.sizeof(i))))
+        _check(self._lib.hq_get_info_sized(self._h, ctypes.byref(i), ctypes.c_uint64(ctypes.sizeof(i))), self._lib)
         return {k: getattr(i, k) for k, _ in _Info._fields_}
 
     def options(self):
         """hq_get_options: what the context runs with (its options with the environment's overrides applied)."""
         o = Options()
-        _check(self._lib.hq_get_options(self._h, ctypes.byref(o), ctypes.c_uint64(ctypes.sizeof(o))))
+        _check(self._lib.hq_get_options(self._h, ctypes.byref(o), ctypes.c_uint64(ctypes.sizeof(o))), self._lib)
         return o.as_dict()
 
     def set_source(self, loaded_lnid, forces, step0=0):
@@ -231,7 +246,7 @@ class Solver:
 
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
-        _check(self._lib.hq_comm_init(self._h, buf))
+        _check(self._lib.hq_comm_init(self._h, buf), self._lib)
 
     def comm_init_host(self, exchange):
         """hq_comm_init_host: `exchange(recvs, sends, tag)` is called at every halo exchange with
@@ -252,12 +267,12 @@ class Solver:
                 traceback.print_exc()
                 return 1
         self._host_exchange = HOST_EXCHANGE_FN(trampoline)          # keep the thunk alive with the context
-        _check(self._lib.hq_comm_init_host(self._h, self._host_exchange, None))
+        _check(self._lib.hq_comm_init_host(self._h, self._host_exchange, None), self._lib)
 
     def comm_ipc_export(self):
         """hq_comm_ipc_export: this rank's HQ_IPC_BLOB_BYTES blob (bytes) for the host to all-gather."""
         buf = (ctypes.c_char * IPC_BLOB_BYTES)()
-        _check(self._lib.hq_comm_ipc_export(self._h, buf))
+        _check(self._lib.hq_comm_ipc_export(self._h, buf), self._lib)
         return bytes(buf)
 
     def comm_init_ipc(self, blobs):
@@ -266,29 +281,29 @@ class Solver:
         if len(raw) % IPC_BLOB_BYTES:
             raise HqError("comm_init_ipc: %d bytes is not a whole number of %d-byte blobs" % (len(raw), IPC_BLOB_BYTES))
         buf = (ctypes.c_char * len(raw)).from_buffer_copy(bytes(raw))
-        _check(self._lib.hq_comm_init_ipc_n(self._h, buf, ctypes.c_int32(len(raw) // IPC_BLOB_BYTES)))
+        _check(self._lib.hq_comm_init_ipc_n(self._h, buf, ctypes.c_int32(len(raw) // IPC_BLOB_BYTES)), self._lib)
 
     def comm_init_loopback(self):
-        _check(self._lib.hq_comm_init_loopback(self._h))
+        _check(self._lib.hq_comm_init_loopback(self._h), self._lib)
 
     def comm_selftest(self, count=1024):
-        _check(self._lib.hq_comm_selftest(self._h, ctypes.c_int32(count)))
+        _check(self._lib.hq_comm_selftest(self._h, ctypes.c_int32(count)), self._lib)
 
     def run(self, nsteps):
-        _check(self._lib.hq_run(self._h, ctypes.c_int32(nsteps)))
+        _check(self._lib.hq_run(self._h, ctypes.c_int32(nsteps)), self._lib)
 
     def sync(self):
-        _check(self._lib.hq_sync(self._h))
+        _check(self._lib.hq_sync(self._h), self._lib)
 
     def check_finite(self):
         """Count of NaN / infinite values in tm1, tm2 (solver_check_nan, psolve.c:3769-3782)."""
         n = ctypes.c_int64()
-        _check(self._lib.hq_check_finite(self._h, ctypes.byref(n)))
+        _check(self._lib.hq_check_finite(self._h, ctypes.byref(n)), self._lib)
         return int(n.value)
 
     def run_timed(self, nsteps):
         tot, ker = ctypes.c_double(), ctypes.c_double()
-        _check(self._lib.hq_run_timed(self._h, ctypes.c_int32(nsteps), ctypes.byref(tot), ctypes.byref(ker)))
+        _check(self._lib.hq_run_timed(self._h, ctypes.c_int32(nsteps), ctypes.byref(tot), ctypes.byref(ker)), self._lib)
         return tot.value, ker.value
 
     def dominant_kernel(self):
@@ -296,39 +311,39 @@ class Solver:
 
     def download(self, want_tm2=True):
         """(tm1, tm2) = u(step dt), u((step - 1) dt); tm2 is None with want_tm2=False."""
-        tm1 = np.empty((self.N, 3))
-        tm2 = np.empty((self.N, 3)) if want_tm2 else None
-        _check(self._lib.hq_download(self._h, _ptr(tm1), _ptr(tm2)))
+        tm1 = np.empty((self.N, 3), self.real)
+        tm2 = np.empty((self.N, 3), self.real) if want_tm2 else None
+        _check(self._lib.hq_download(self._h, _ptr(tm1), _ptr(tm2)), self._lib)
         return tm1, tm2
 
     def upload(self, tm1, tm2, step):
-        a = np.ascontiguousarray(tm1, np.float64)
-        b = np.ascontiguousarray(tm2, np.float64)
-        _check(self._lib.hq_upload(self._h, _ptr(a), _ptr(b), ctypes.c_int32(step)))
+        a = np.ascontiguousarray(tm1, self.real)
+        b = np.ascontiguousarray(tm2, self.real)
+        _check(self._lib.hq_upload(self._h, _ptr(a), _ptr(b), ctypes.c_int32(step)), self._lib)
 
     def gather(self, lnid):
         ids = np.ascontiguousarray(np.asarray(lnid).reshape(-1), np.int32)
-        o1 = np.empty((len(ids), 3))
-        o2 = np.empty((len(ids), 3))
-        _check(self._lib.hq_gather(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o1), _ptr(o2)))
+        o1 = np.empty((len(ids), 3), self.real)
+        o2 = np.empty((len(ids), 3), self.real)
+        _check(self._lib.hq_gather(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o1), _ptr(o2)), self._lib)
         return o1, o2
 
     def gather3(self, lnid):
         """tm1, tm2 and tm3 = u((step - 2) dt) at the given nodes (patch variant)."""
         ids = np.ascontiguousarray(np.asarray(lnid).reshape(-1), np.int32)
-        o = [np.empty((len(ids), 3)) for _ in range(3)]
-        _check(self._lib.hq_gather3(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o[0]), _ptr(o[1]), _ptr(o[2])))
+        o = [np.empty((len(ids), 3), self.real) for _ in range(3)]
+        _check(self._lib.hq_gather3(self._h, ctypes.c_int32(len(ids)), _ptr(ids), _ptr(o[0]), _ptr(o[1]), _ptr(o[2])), self._lib)
         return tuple(o)
 
     def phase_force(self):
-        _check(self._lib.hq_phase_force(self._h))
+        _check(self._lib.hq_phase_force(self._h), self._lib)
 
     def phase_update(self):
-        _check(self._lib.hq_phase_update(self._h))
+        _check(self._lib.hq_phase_update(self._h), self._lib)
 
     def download_force(self):
         f = np.empty((self.N, 3))
-        _check(self._lib.hq_download_force(self._h, _ptr(f)))
+        _check(self._lib.hq_download_force(self._h, _ptr(f)), self._lib)
         return f
 
 
@@ -373,11 +388,13 @@ def comm_unique_id():
 def group_link(solvers):
     """hq_group_link: solvers[i] must hold rank i of len(solvers)."""
     arr = (ctypes.c_void_p * len(solvers))(*[s._h for s in solvers])
-    _check(load_library().hq_group_link(arr, ctypes.c_int32(len(solvers))))
+    lib = solvers[0]._lib                       # (the group's library: libhq_solver.so or its _f32 build)
+    _check(lib.hq_group_link(arr, ctypes.c_int32(len(solvers))), lib)
 
 
 def group_run(solvers, nsteps):
     arr = (ctypes.c_void_p * len(solvers))(*[s._h for s in solvers])
-    _check(load_library().hq_group_run(arr, ctypes.c_int32(len(solvers)), ctypes.c_int32(nsteps)))
+    lib = solvers[0]._lib
+    _check(lib.hq_group_run(arr, ctypes.c_int32(len(solvers)), ctypes.c_int32(nsteps)), lib)
     for s in solvers:
         s.sync()

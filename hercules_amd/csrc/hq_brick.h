@@ -866,7 +866,7 @@ template <bool PERNODE, bool BYCOMP, bool RAGGED = false>
  * numbers in scalar registers it fits 128 VGPRs too (round 3: 33 spilled) */
 __global__ void HQ_BK_ATTR __launch_bounds__(HQ_BK_THREADS, 4)   /* 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs */
 hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
-           const double* __restrict__ u1g, const double* __restrict__ u2g, double* __restrict__ ung,
+           const hq_real* __restrict__ u1g, const hq_real* __restrict__ u2g, hq_real* __restrict__ ung,
            const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
            const double* __restrict__ F, double dt2, hq_stencil_coef sc)
 {
@@ -1047,7 +1047,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
                         for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
                     }
             }
-            double* out = ung + 3 * (int64_t)cap[nxy + sidx];
+            hq_real* out = ung + 3 * (int64_t)cap[nxy + sidx];
             const double rm = 1.0 / U.fb[0];
 #pragma unroll
             for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
@@ -1065,7 +1065,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
                         for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
                     }
             }
-            double* out = ung + 3 * (RAGGED ? (int64_t)vOut : (outface ? (int64_t)cap[sidx] : U.base + (int64_t)local));
+            hq_real* out = ung + 3 * (RAGGED ? (int64_t)vOut : (outface ? (int64_t)cap[sidx] : U.base + (int64_t)local));
             const double rm = outface ? 1.0 / U.ft[0] : m0A;
 #pragma unroll
             for (int d = 0; d < 3; d++) out[d] = f[d] * rm;
@@ -1117,8 +1117,8 @@ static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
 template <bool PACKED>
 __global__ void __launch_bounds__(HQ_BH_THREADS, HQ_BH_WAVES == 12 ? 3 : 4)   /* 8 waves: 4 per SIMD = two workgroups per CU, <= 128 VGPRs */
 hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
-               const void* __restrict__ coef_any, const double* __restrict__ u1g, const double* __restrict__ u2g,
-               double* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
+               const void* __restrict__ coef_any, const hq_real* __restrict__ u1g, const hq_real* __restrict__ u2g,
+               hq_real* __restrict__ ung, const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
                const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2, hq_mat_const mat)
 {
     extern __shared__ __align__(16) double s_het[];
@@ -1172,9 +1172,14 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 #define HQ_BH_LOAD(node_)                                                                             \
     {                                                                                                 \
         const int64_t a_ = owner ? (int64_t)(node_) : (int64_t)ridA;                                  \
-        const double* __restrict__ pb_ = owner ? nt3 + (PACKED ? 2 : 3) * a_ : u1g + 3 * (int64_t)ridB; \
+        const double* __restrict__ pb_ = (owner || sizeof(hq_real) != sizeof(double)) ? nt3 + (PACKED ? 2 : 3) * a_ : (const double*)(const void*)(u1g + 3 * (int64_t)ridB); \
         _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
-        if (HQ_BH_ABL != 4) { mn[0] = pb_[0]; mn[1] = pb_[1]; mn[2] = pb_[third]; }                    \
+        if (sizeof(hq_real) == sizeof(double) || owner) {                                             \
+            if (HQ_BH_ABL != 4) { mn[0] = pb_[0]; mn[1] = pb_[1]; mn[2] = pb_[third]; }                \
+        } else {                     /* (a float state: the n_t row and ring node B are loads of two types) */ \
+            const hq_real* __restrict__ pu_ = u1g + 3 * (int64_t)ridB;                                \
+            mn[0] = pu_[0]; mn[1] = pu_[1]; mn[2] = pu_[2];                                            \
+        }                                                                                             \
     }
 #define HQ_BH_LOAD_B()                                                                                \
     {                                                                                                 \
@@ -1269,7 +1274,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                                 for (int d = 0; d < 3; d++) f[d] += F[3 * li + d] * dt2;
                             }
                     }
-                    double* out = ung + 3 * (U.base + (int64_t)local);
+                    hq_real* out = ung + 3 * (U.base + (int64_t)local);
 #pragma unroll
                     for (int d = 0; d < 3; d++) out[d] = f[d] * m0A;
                 }
@@ -1392,7 +1397,7 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
 }
 
 /* one step of all units: the HQ_BK_NTSAME units, then (a launch each) the units with per-node n_t rows and the HET units */
-static void hq_brick_launch(const hq_brick_plan* P, const double* u1, const double* u2, double* un, const double* nt3,
+static void hq_brick_launch(const hq_brick_plan* P, const hq_real* u1, const hq_real* u2, hq_real* un, const double* nt3,
                             const double* F, double dt2, hipStream_t stream, bool light = false)
 {
     const int32_t cnt[5] = { P->nsame - P->nrag, P->nunits - P->nsame - P->nhet, P->nhet - P->npacked, P->npacked, P->nrag };

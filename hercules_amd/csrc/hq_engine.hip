@@ -166,7 +166,7 @@ struct hq_ctx {
     int64_t bytes = 0;
     int64_t h2d_bytes = 0, d2h_bytes = 0;    /* what crossed PCIe through the entry points since hq_create returned (hq_info) */
     int32_t* d_gather_ids = nullptr;         /* hq_gather's scratch */
-    double* d_gather_out = nullptr;
+    hq_real* d_gather_out = nullptr;
     int32_t gather_cap = 0;
 
     /* element data, SoA */
@@ -178,7 +178,7 @@ struct hq_ctx {
     /* node data */
     double* d_nt = nullptr;         /* [N][7]; behind bricks only the rows of the nodes nt_first .. N - 1 exist (d_nt_rows), */
     double* d_nt_rows = nullptr;    /* d_nt = d_nt_rows - 7 nt_first: no kernel reads a brick node's 7-double row */
-    double* d_u[3] = { nullptr, nullptr, nullptr };
+    hq_real* d_u[3] = { nullptr, nullptr, nullptr };     /* the state in solver_float (psolve.h:60-64) */
     int now = 0, prev = 1, spare = 2;
     double* d_force = nullptr;
     /* source window */
@@ -331,8 +331,8 @@ __global__ void hq_k_source(int32_t nloaded, const int32_t* __restrict__ loaded,
 __global__ void __launch_bounds__(256)
 hq_k_element_scatter(int32_t E, int32_t Epad, const int32_t* __restrict__ lnid,
                      const double* __restrict__ c1v, const double* __restrict__ c2v,
-                     const double* __restrict__ betav, const double* __restrict__ u1,
-                     const double* __restrict__ u2, double* __restrict__ force)
+                     const double* __restrict__ betav, const hq_real* __restrict__ u1,
+                     const hq_real* __restrict__ u2, double* __restrict__ force)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -343,8 +343,8 @@ hq_k_element_scatter(int32_t E, int32_t Epad, const int32_t* __restrict__ lnid,
     for (int n = 0; n < 8; n++) id[n] = lnid[(int64_t)n * Epad + e];
 #pragma unroll
     for (int n = 0; n < 8; n++) {
-        const double* p1 = u1 + 3 * (int64_t)id[n];
-        const double* p2 = u2 + 3 * (int64_t)id[n];
+        const hq_real* p1 = u1 + 3 * (int64_t)id[n];
+        const hq_real* p2 = u2 + 3 * (int64_t)id[n];
         double a0 = p1[0], a1 = p1[1], a2 = p1[2];
         X[n] = a0 + beta * (a0 - p2[0]);
         Y[n] = a1 + beta * (a1 - p2[1]);
@@ -362,8 +362,8 @@ hq_k_element_scatter(int32_t E, int32_t Epad, const int32_t* __restrict__ lnid,
 
 /* solver_compute_displacement (psolve.c:4078-4111): one thread per scalar */
 __global__ void __launch_bounds__(256)
-hq_k_update(int64_t n3, const double* __restrict__ nt, const double* __restrict__ u1,
-            double* __restrict__ u2, double* __restrict__ force)
+hq_k_update(int64_t n3, const double* __restrict__ nt, const hq_real* __restrict__ u1,
+            hq_real* __restrict__ u2, double* __restrict__ force)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n3) return;
@@ -371,8 +371,8 @@ hq_k_update(int64_t n3, const double* __restrict__ nt, const double* __restrict_
     int d = (int)(t - 3 * n);
     const double* np = nt + 7 * n;
     double f = force[t];
-    f += np[1 + d] * u1[t] - np[4 + d] * u2[t];
-    u2[t] = f / np[0];
+    f += np[1 + d] * (double)u1[t] - np[4 + d] * (double)u2[t];
+    u2[t] = (hq_real)(f / np[0]);
     force[t] = 0.0;
 }
 
@@ -398,7 +398,7 @@ __global__ void hq_k_distribute(int32_t ndst, const int32_t* __restrict__ dst, c
 /* compute_adjust ASSIGNMENT (psolve.c:5992-6035) */
 __global__ void hq_k_adjust_assign(int32_t ldnnum, const int32_t* __restrict__ dn_id,
                                    const int32_t* __restrict__ dn_ptr,
-                                   const int32_t* __restrict__ dn_anchor, double* __restrict__ table)
+                                   const int32_t* __restrict__ dn_anchor, hq_real* __restrict__ table)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ldnnum * 3) return;
@@ -406,28 +406,31 @@ __global__ void hq_k_adjust_assign(int32_t ldnnum, const int32_t* __restrict__ d
     int32_t lo = dn_ptr[k], hi = dn_ptr[k + 1];
     double deps = (double)(uint32_t)(hi - lo);
     double s = 0.0;
-    for (int32_t p = lo; p < hi; p++) s += table[3 * (int64_t)dn_anchor[p] + d] / deps;
-    table[3 * (int64_t)dn_id[k] + d] = s;
+    for (int32_t p = lo; p < hi; p++) s += (double)table[3 * (int64_t)dn_anchor[p] + d] / deps;
+    table[3 * (int64_t)dn_id[k] + d] = (hq_real)s;
 }
 
 /* schedule_senddata pack (psolve.c:4985-5011) / unpack (:5035-5073) */
+/* (T: the table's type -- forces are doubles, displacements hq_real; the records travel as doubles either way) */
+template <typename T>
 __global__ void hq_k_pack(int32_t count, const int32_t* __restrict__ map,
-                          const double* __restrict__ table, double* __restrict__ out)
+                          const T* __restrict__ table, double* __restrict__ out)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * 3) return;
     int i = t / 3, d = t - 3 * i;
-    out[t] = table[3 * (int64_t)map[i] + d];
+    out[t] = (double)table[3 * (int64_t)map[i] + d];
 }
 
 /* in-process transport: record i goes where its peer expects it (dst[i]: base of the record in the peer's buffer) */
-__global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
+template <typename T>
+__global__ void hq_k_pack_to_peers(int32_t count, const int32_t* __restrict__ map, const T* __restrict__ table,
                                    double* const* __restrict__ dst)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * 3) return;
     int i = t / 3, d = t - 3 * i;
-    dst[i][d] = table[3 * (int64_t)map[i] + d];
+    dst[i][d] = (double)table[3 * (int64_t)map[i] + d];
 }
 
 /*
@@ -451,7 +454,8 @@ static __device__ __forceinline__ void hq_ipc_delay(unsigned long long ticks)
     while ((unsigned long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-__global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict__ map, const double* __restrict__ table,
+template <typename T>
+__global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict__ map, const T* __restrict__ table,
                                        double* const* __restrict__ dst, uint32_t* __restrict__ done, int32_t nsig,
                                        unsigned long long* const* __restrict__ sig, unsigned long long epoch,
                                        unsigned long long delay_ticks)
@@ -459,7 +463,7 @@ __global__ void hq_k_pack_to_peers_sig(int32_t count, const int32_t* __restrict_
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < count * 3) {
         int i = t / 3, d = t - 3 * i;
-        __hip_atomic_store(dst[i] + d, table[3 * (int64_t)map[i] + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst[i] + d, (double)table[3 * (int64_t)map[i] + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -490,20 +494,22 @@ __global__ void hq_k_ipc_wait(const unsigned long long* __restrict__ flags, unsi
     }
 }
 
+template <typename T>
 __global__ void hq_k_unpack(int32_t count, const int32_t* __restrict__ map,
-                            const double* __restrict__ in, double* __restrict__ table, int add)
+                            const double* __restrict__ in, T* __restrict__ table, int add)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * 3) return;
     int i = t / 3, d = t - 3 * i;
-    double* p = &table[3 * (int64_t)map[i] + d];
-    *p = add ? (*p + in[t]) : in[t];
+    T* p = &table[3 * (int64_t)map[i] + d];
+    *p = (T)(add ? ((double)*p + in[t]) : in[t]);
 }
 
 /* the sharing unpack of the IPC transport with the wait folded in: every workgroup polls the senders' flags before it
  * reads a record, and reads the records system-scope (hq_k_interface_update<1> has the reasoning) */
+template <typename T>
 __global__ void __launch_bounds__(256)
-hq_k_unpack_ipc(int32_t count, const int32_t* __restrict__ map, const double* in, double* __restrict__ table,
+hq_k_unpack_ipc(int32_t count, const int32_t* __restrict__ map, const double* in, T* __restrict__ table,
                 const unsigned long long* __restrict__ flags, unsigned long long mask, unsigned long long epoch,
                 unsigned long long timeout_ticks, int32_t* __restrict__ err)
 {
@@ -519,7 +525,7 @@ hq_k_unpack_ipc(int32_t count, const int32_t* __restrict__ map, const double* in
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * 3) return;
     int i = t / 3, d = t - 3 * i;
-    table[3 * (int64_t)map[i] + d] = __hip_atomic_load(in + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    table[3 * (int64_t)map[i] + d] = (T)__hip_atomic_load(in + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* HQ_DEBUG_HALO: the sender's node identities beside the records, checked on receipt */
@@ -551,14 +557,15 @@ static __device__ __forceinline__ int64_t hq_check_word(int64_t id, unsigned lon
 /* vmap: the rows of `table` the records are packed from (node ids or interface slots); nmap: the nodes they belong to.
  * dst != NULL: every word goes where the peer reads it (system-scope store; the flags are raised by the record kernel
  * enqueued BEHIND this one); else out[i] */
+template <typename T>
 __global__ void hq_k_pack_check(int32_t count, const int32_t* __restrict__ vmap, const int32_t* __restrict__ nmap,
-                                const double* __restrict__ table, const int64_t* __restrict__ gkey, unsigned long long epoch,
+                                const T* __restrict__ table, const int64_t* __restrict__ gkey, unsigned long long epoch,
                                 int64_t* const* __restrict__ dst, int64_t* __restrict__ out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const double* r = table + 3 * (int64_t)vmap[i];
-    const int64_t w = hq_check_word(gkey[nmap[i]], epoch, r[0], r[1], r[2]);
+    const T* r = table + 3 * (int64_t)vmap[i];
+    const int64_t w = hq_check_word(gkey[nmap[i]], epoch, (double)r[0], (double)r[1], (double)r[2]);   /* as the record travels */
     if (dst) __hip_atomic_store(dst[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else out[i] = w;
 }
@@ -576,19 +583,20 @@ __global__ void hq_k_verify_check(int32_t count, const int32_t* __restrict__ nma
 }
 
 /* solver_check_nan (psolve.c:3769-3782): count the values that are not finite */
-__global__ void hq_k_count_nonfinite(int64_t n, const double* __restrict__ a, int32_t* __restrict__ cnt)
+template <typename T>
+__global__ void hq_k_count_nonfinite(int64_t n, const T* __restrict__ a, int32_t* __restrict__ cnt)
 {
     int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double v = a[i];
+        const double v = (double)a[i];
         bad += !(fabs(v) <= 1.7976931348623157e308);          /* NaN and +-inf fail the comparison */
     }
     if (bad) atomicAdd(cnt, bad);
 }
 
 __global__ void hq_k_gather(int32_t n, const int32_t* __restrict__ ids,
-                            const double* __restrict__ a, const double* __restrict__ b,
-                            double* __restrict__ oa, double* __restrict__ ob)
+                            const hq_real* __restrict__ a, const hq_real* __restrict__ b,
+                            hq_real* __restrict__ oa, hq_real* __restrict__ ob)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 3) return;
@@ -663,7 +671,9 @@ static hq_dev_schedule* hq_peer_schedule(hq_ctx* peer, hq_ctx* me, hq_dev_schedu
  * Transport: RCCL grouped send/recv over xGMI (hq_comm_init) or device-to-device
  * copies between contexts of one process (hq_group_link).
  */
-static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const double* table, bool contribution, bool force_table)
+/* (T: double for a force table, hq_real for a displacement field) */
+template <typename T>
+static int hq_xchg_send(hq_ctx* c, hq_dev_schedule* s, const T* table, bool contribution, bool force_table)
 {
     hipStream_t xs = c->overlap ? c->cstream : c->stream;
     std::vector<hq_dev_messenger>& snd = contribution ? s->c : s->s;
@@ -833,7 +843,8 @@ static void hq_ipc_wait(hq_ctx* c, hq_dev_schedule* s, bool contribution, hipStr
                                    c->d_halo_err + 2);
 }
 
-static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, double* table, bool contribution, bool force_table)
+template <typename T>
+static int hq_xchg_recv(hq_ctx* c, hq_dev_schedule* s, T* table, bool contribution, bool force_table)
 {
     hipStream_t xs = c->overlap ? c->cstream : c->stream;
     std::vector<hq_dev_messenger>& rcv = contribution ? s->s : s->c;
@@ -951,8 +962,8 @@ __global__ void __launch_bounds__(256)
 hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t* __restrict__ slot,
                       const int32_t* __restrict__ ptr, const int32_t* __restrict__ pos, const int32_t* __restrict__ fcv,
                       const double* __restrict__ iforce, const double* rec,
-                      const double* __restrict__ nt, const double* __restrict__ u1,
-                      const double* __restrict__ u2, double* __restrict__ un, double* __restrict__ s_out,
+                      const double* __restrict__ nt, const hq_real* __restrict__ u1,
+                      const hq_real* __restrict__ u2, hq_real* __restrict__ un, double* __restrict__ s_out,
                       double* const* __restrict__ s_dst, hq_ipc_args ia)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -986,9 +997,9 @@ hq_k_interface_update(int32_t n, const int32_t* __restrict__ node, const int32_t
         for (int32_t k = 1; k < cnt; k++)                            /* messenger order: pos[k0] == first */
             f += IPC ? __hip_atomic_load(rec + 3 * (int64_t)pos[k0 + k] + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                      : rec[3 * (int64_t)pos[k0 + k] + d];
-        f += (np[1 + d] * u1[3 * g + d] - np[4 + d] * u2[3 * g + d]);
-        const double v = f / np[0];
-        un[3 * g + d] = v;
+        f += (np[1 + d] * (double)u1[3 * g + d] - np[4 + d] * (double)u2[3 * g + d]);
+        const double v = (double)(hq_real)(f / np[0]);        /* what the owner keeps is what its sharers get */
+        un[3 * g + d] = (hq_real)v;
         if (s_dst) {
             if (cnt) {
                 if (IPC) __hip_atomic_store(p0 + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1059,7 +1070,7 @@ static int hq_phase(hq_ctx* c, int ph)
 {
     const bool patch = (c->variant == HQ_VARIANT_PATCH);
     double* ftab = patch ? c->d_iforce : c->d_force;
-    double* unew = patch ? c->d_u[c->spare] : c->d_u[c->prev];
+    hq_real* unew = patch ? c->d_u[c->spare] : c->d_u[c->prev];
     switch (ph) {
     case 0:
         if (patch) {
@@ -1393,15 +1404,15 @@ extern "C" int hq_device_count(void)
 static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl);
 
 /* a node-ordered field [N][3] between the caller's numbering and the device's (c->perm; empty: the same) */
-static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
+static int hq_field_to_device(hq_ctx* c, const hq_real* host, hq_real* dev)
 {
-    const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    const size_t bytes = sizeof(hq_real) * 3 * (size_t)c->N;
     c->h2d_bytes += (int64_t)bytes;
     if (c->perm.empty()) {
         HQ_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
         return HQ_OK;
     }
-    std::vector<double> tmp;
+    std::vector<hq_real> tmp;
     try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
     const int32_t* pm = c->perm.data();
 #pragma omp parallel for schedule(static) if (c->N > 262144)     /* small fields: a parallel region costs more than the loop */
@@ -1413,15 +1424,15 @@ static int hq_field_to_device(hq_ctx* c, const double* host, double* dev)
     return HQ_OK;
 }
 
-static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
+static int hq_field_to_host(hq_ctx* c, const hq_real* dev, hq_real* host)
 {
-    const size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    const size_t bytes = sizeof(hq_real) * 3 * (size_t)c->N;
     c->d2h_bytes += (int64_t)bytes;
     if (c->perm.empty()) {
         HQ_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return HQ_OK;
     }
-    std::vector<double> tmp;
+    std::vector<hq_real> tmp;
     try { tmp.resize(3 * (size_t)c->N); } catch (...) { return hq_fail(HQ_ERR_NOMEM, "out of host memory%s", ""); }
     HQ_HIP(hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost));
     const int32_t* pm = c->perm.data();
@@ -1434,6 +1445,18 @@ static int hq_field_to_host(hq_ctx* c, const double* dev, double* host)
 }
 
 static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out);
+
+/* the caller's n_t rows (solver_float at the ABI) as the doubles the planners and kernels work with: the caller's own
+ * array where hq_real is double, a widened copy in `store` otherwise */
+static const double* hq_ntable64(const hq_desc* d, std::vector<double>& store)
+{
+    if (sizeof(hq_real) == sizeof(double)) return reinterpret_cast<const double*>(d->nTable);
+    const size_t n = 7 * (size_t)d->nharbored;
+    store.resize(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) store[(size_t)i] = (double)d->nTable[i];
+    return store.data();
+}
 
 extern "C" void hq_options_init(hq_options* o, uint64_t size)
 {
@@ -1562,18 +1585,19 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
     };
     hq_desc dd = *d;
     std::vector<int32_t> p_lnid, p_xyz, p_dn_id, p_dn_anchor;
-    std::vector<double> p_nt;
+    std::vector<double> p_nt, nt64;
+    const double* ntab = hq_ntable64(d, nt64);       /* [N][7] doubles, in the numbering `d` has at the moment */
     std::vector<int64_t> p_gnid;
     std::vector<std::vector<int32_t>> p_maps;
     std::vector<hq_messenger> p_msg[4];
     hq_brick_host BH;
-    const double *h_tm1 = d->tm1, *h_tm2 = d->tm2;
+    const hq_real *h_tm1 = d->tm1, *h_tm2 = d->tm2;
     if (variant == HQ_VARIANT_PATCH && d->node_xyz && !(hq_opt_on("HQ_NO_BRICKS"))) {
         std::vector<char> excl;
         if ((rc = hq_brick_excluded(d, excl)) != HQ_OK) return bail(rc);
         hq_mat_src ms;
         ms.edata = d->edata; ms.dt = d->deltaT; ms.bbase = d->mat_bbase; ms.thr_damp = d->mat_threshold_damping; ms.thr_vpvs = d->mat_threshold_vpvs;
-        if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &BH, &ms) != 0)
+        if (hq_brick_plan_host(c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), ntab, excl.data(), &BH, &ms) != 0)
             return bail(hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error()));
         lap("brick plan");
     }
@@ -1589,9 +1613,10 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
         for (int64_t n = 0; n < N; n++) {
             const int64_t q = pm[(size_t)n];
             for (int k = 0; k < 3; k++) p_xyz[(size_t)(3 * q + k)] = d->node_xyz[3 * n + k];
-            for (int k = 0; k < 7; k++) p_nt[(size_t)(7 * q + k)] = d->nTable[7 * n + k];
+            for (int k = 0; k < 7; k++) p_nt[(size_t)(7 * q + k)] = ntab[7 * n + k];
         }
-        dd.lnid = p_lnid.data(); dd.node_xyz = p_xyz.data(); dd.nTable = p_nt.data();
+        dd.lnid = p_lnid.data(); dd.node_xyz = p_xyz.data(); dd.nTable = nullptr; ntab = p_nt.data();
+        std::vector<double>().swap(nt64);
         if (d->node_gnid) {
             p_gnid.resize((size_t)N);
             for (int64_t n = 0; n < N; n++) p_gnid[(size_t)pm[(size_t)n]] = d->node_gnid[n];
@@ -1634,7 +1659,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
     int nbuf = (variant == HQ_VARIANT_PATCH) ? 3 : 2;
     for (int b = 0; b < nbuf; b++) {
         if ((rc = hq_dev_alloc(c, &c->d_u[b], n3)) != HQ_OK) return bail(rc);
-        if (hipMemset(c->d_u[b], 0, sizeof(double) * n3) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
+        if (hipMemset(c->d_u[b], 0, sizeof(hq_real) * n3) != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "memset%s", ""));
     }
     {
         /* brick nodes are updated from the 3-double rows (plan.d_nt3) or the unit's record: their 7-double rows stay on
@@ -1643,7 +1668,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
         const size_t rows = (size_t)std::max<int64_t>(c->N - nt_first, 1);
         if ((rc = hq_dev_alloc(c, &c->d_nt_rows, rows * 7)) != HQ_OK) return bail(rc);
         if (c->N > nt_first &&
-            hipMemcpy(c->d_nt_rows, d->nTable + 7 * nt_first, sizeof(double) * 7 * (size_t)(c->N - nt_first), hipMemcpyHostToDevice) != hipSuccess)
+            hipMemcpy(c->d_nt_rows, ntab + 7 * nt_first, sizeof(double) * 7 * (size_t)(c->N - nt_first), hipMemcpyHostToDevice) != hipSuccess)
             return bail(hq_fail(HQ_ERR_DEVICE, "nTable upload failed%s", ""));
         c->d_nt = c->d_nt_rows - 7 * nt_first;
     }
@@ -1753,7 +1778,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
                     }
             }
         c->plan.ragged_default = true;
-        rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable,
+        rc = hq_patch_build(&c->plan, c->E, c->N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), ntab,
                             dn, seed0.data(), &pb, BH.nb);
         lap("patch plan");
         if (rc == 0 && BH.nb > 0) rc = hq_brick_upload(&c->bricks, BH, &pb);
@@ -2071,7 +2096,9 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
     hq_brick_host B;
     hq_mat_src ms;
     ms.edata = d->edata; ms.dt = d->deltaT; ms.bbase = d->mat_bbase; ms.thr_damp = d->mat_threshold_damping; ms.thr_vpvs = d->mat_threshold_vpvs;
-    if (hq_brick_plan_host(E, N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), d->nTable, excl.data(), &B, &ms) != 0)
+    std::vector<double> nt64;
+    const double* ntab = hq_ntable64(d, nt64);
+    if (hq_brick_plan_host(E, N, d->lnid, d->node_xyz, c1.data(), c2.data(), beta.data(), ntab, excl.data(), &B, &ms) != 0)
         return hq_fail(HQ_ERR_ARG, "brick plan: %s", hq_patch_error());
     int64_t bad = 0, nchecked = 0;
     for (int k = 0; k < 8; k++) report[k] = 0;
@@ -2142,7 +2169,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                     const int32_t n = inv[(size_t)q];
                     if (n < 0) { bad++; continue; }
                     if (excl[(size_t)n]) bad++;
-                    const double* t7 = d->nTable + 7 * (int64_t)n;
+                    const double* t7 = ntab + 7 * (int64_t)n;
                     if (!((t7[1] == t7[2]) && (t7[1] == t7[3]) && (t7[4] == t7[5]) && (t7[4] == t7[6]))) bad++;
                     if ((U.flags & HQ_BK_NTSAME) && (t7[0] != U.m0 || t7[1] != U.m2 || t7[4] != U.m1)) bad++;
                     int64_t el[8];
@@ -2212,7 +2239,7 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
                     const int32_t n = inv[(size_t)q];
                     if (n < 0) { bad++; continue; }
                     if (excl[(size_t)n]) bad++;
-                    if (memcmp(d->nTable + 7 * (int64_t)n, row, 7 * sizeof(double)) != 0) bad++;
+                    if (memcmp(ntab + 7 * (int64_t)n, row, 7 * sizeof(double)) != 0) bad++;
                     int64_t el[8];
                     for (int o = 0; o < 8; o++) el[o] = -1;
                     if (aptr[(size_t)n + 1] - aptr[(size_t)n] != 4) { bad++; continue; }
@@ -2383,6 +2410,8 @@ extern "C" int hq_destroy(hq_ctx* c)
     delete c;
     return HQ_OK;
 }
+
+extern "C" int hq_real_bytes(void) { return (int)sizeof(hq_real); }
 
 extern "C" int hq_abi_version(void) { return HQ_ABI_VERSION; }
 
@@ -2978,9 +3007,10 @@ extern "C" int hq_check_finite(hq_ctx* c, int64_t* nonfinite)
     HQ_HIP(hq_quiesce(c));
     HQ_HIP(hipMemsetAsync(c->d_halo_err + 1, 0, sizeof(int32_t), c->stream));
     const int64_t n3 = 3 * (int64_t)c->N;
-    const double* arr[3] = { c->d_u[c->now], c->d_u[c->prev], c->d_force };
-    for (const double* a : arr)
+    const hq_real* arr[2] = { c->d_u[c->now], c->d_u[c->prev] };
+    for (const hq_real* a : arr)
         if (a) hq_k_count_nonfinite<<<2048, 256, 0, c->stream>>>(n3, a, c->d_halo_err + 1);
+    if (c->d_force) hq_k_count_nonfinite<<<2048, 256, 0, c->stream>>>(n3, (const double*)c->d_force, c->d_halo_err + 1);
     int32_t bad = 0;
     HQ_HIP(hipMemcpyAsync(&bad, c->d_halo_err + 1, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     HQ_HIP(hipStreamSynchronize(c->stream));
@@ -3038,21 +3068,21 @@ extern "C" const char* hq_dominant_kernel(hq_ctx* c)
     return c->plan.seeded ? "hq_k_patch_seed" : "hq_k_patch_pers";
 }
 
-static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3);
+static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, hq_real* o1, hq_real* o2, hq_real* o3);
 
-extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2)
+extern "C" int hq_gather(hq_ctx* c, int32_t n, const int32_t* lnid, hq_real* o1, hq_real* o2)
 {
     return hq_gather_impl(c, n, lnid, o1, o2, nullptr);
 }
 
-extern "C" int hq_gather3(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3)
+extern "C" int hq_gather3(hq_ctx* c, int32_t n, const int32_t* lnid, hq_real* o1, hq_real* o2, hq_real* o3)
 {
     if (c && o3 && c->variant != HQ_VARIANT_PATCH)
         return hq_fail(HQ_ERR_STATE, "u(t - 2 dt) is kept by the patch variant only%s", "");
     return hq_gather_impl(c, n, lnid, o1, o2, o3);
 }
 
-static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1, double* o2, double* o3)
+static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, hq_real* o1, hq_real* o2, hq_real* o3)
 {
     if (!c || n < 0 || (n && !lnid)) return hq_fail(HQ_ERR_ARG, "bad argument%s", "");
     if (n == 0) return HQ_OK;
@@ -3068,17 +3098,17 @@ static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1,
         c->gather_cap = 0;
         const int32_t cap = std::max(n, 1024);
         HQ_HIP(hipMalloc((void**)&c->d_gather_ids, sizeof(int32_t) * (size_t)cap));
-        if (hipMalloc((void**)&c->d_gather_out, sizeof(double) * 9 * (size_t)cap) != hipSuccess) {
+        if (hipMalloc((void**)&c->d_gather_out, sizeof(hq_real) * 9 * (size_t)cap) != hipSuccess) {
             hipFree(c->d_gather_ids); c->d_gather_ids = nullptr;
             return hq_fail(HQ_ERR_NOMEM, "hipMalloc failed%s", "");
         }
         c->gather_cap = cap;
     }
     int32_t* d_ids = c->d_gather_ids;
-    double* d_o = c->d_gather_out;
+    hq_real* d_o = c->d_gather_out;
     hipError_t e;
     c->h2d_bytes += 4 * (int64_t)n;
-    c->d2h_bytes += 24 * (int64_t)n * ((o1 ? 1 : 0) + (o2 ? 1 : 0) + (o3 ? 1 : 0));
+    c->d2h_bytes += 3 * (int64_t)sizeof(hq_real) * (int64_t)n * ((o1 ? 1 : 0) + (o2 ? 1 : 0) + (o3 ? 1 : 0));
     std::vector<int32_t> dev_ids;
     if (!c->perm.empty()) {
         dev_ids.resize((size_t)n);
@@ -3088,19 +3118,19 @@ static int hq_gather_impl(hq_ctx* c, int32_t n, const int32_t* lnid, double* o1,
     hipMemcpyAsync(d_ids, lnid, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream);
     hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->now], c->d_u[c->prev],
                                                                          d_o, d_o + 3 * (size_t)n);
-    if (o1) hipMemcpyAsync(o1, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
-    if (o2) hipMemcpyAsync(o2, d_o + 3 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (o1) hipMemcpyAsync(o1, d_o, sizeof(hq_real) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (o2) hipMemcpyAsync(o2, d_o + 3 * (size_t)n, sizeof(hq_real) * 3 * n, hipMemcpyDeviceToHost, c->stream);
     if (o3) {
         hq_k_gather<<<hq_blocks((int64_t)n * 3, 256), 256, 0, c->stream>>>(n, d_ids, c->d_u[c->spare], c->d_u[c->spare],
                                                                              d_o + 6 * (size_t)n, d_o + 6 * (size_t)n);
-        hipMemcpyAsync(o3, d_o + 6 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+        hipMemcpyAsync(o3, d_o + 6 * (size_t)n, sizeof(hq_real) * 3 * n, hipMemcpyDeviceToHost, c->stream);
     }
     e = hq_quiesce(c);
     if (e != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "gather failed: %s", hipGetErrorString(e));
     return HQ_OK;
 }
 
-extern "C" int hq_download(hq_ctx* c, double* tm1, double* tm2)
+extern "C" int hq_download(hq_ctx* c, hq_real* tm1, hq_real* tm2)
 {
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
@@ -3110,12 +3140,12 @@ extern "C" int hq_download(hq_ctx* c, double* tm1, double* tm2)
     return HQ_OK;
 }
 
-extern "C" int hq_upload(hq_ctx* c, const double* tm1, const double* tm2, int32_t step)
+extern "C" int hq_upload(hq_ctx* c, const hq_real* tm1, const hq_real* tm2, int32_t step)
 {
     if (!c || !tm1 || !tm2) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
-    size_t bytes = sizeof(double) * 3 * (size_t)c->N;
+    size_t bytes = sizeof(hq_real) * 3 * (size_t)c->N;
     HQ_TRY(hq_field_to_device(c, tm1, c->d_u[c->now]));
     HQ_TRY(hq_field_to_device(c, tm2, c->d_u[c->prev]));
     if (c->d_u[2]) HQ_HIP(hipMemset(c->d_u[c->spare], 0, bytes));          /* tm3 after a restart: calloc, psolve.c:3347 */

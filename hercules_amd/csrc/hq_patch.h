@@ -1003,8 +1003,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
-                const int32_t* __restrict__ halo, const double* __restrict__ u1g,
-                const double* __restrict__ u2g, double* __restrict__ ung,
+                const int32_t* __restrict__ halo, const hq_real* __restrict__ u1g,
+                const hq_real* __restrict__ u2g, hq_real* __restrict__ ung,
                 const double* __restrict__ nt, const double* __restrict__ nt3,
                 const int32_t* __restrict__ src_ptr,
                 const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
@@ -1044,8 +1044,8 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
     if (tid < D.npairs) cur = hq_pair_load<NT>(pidx, pc1, pc2, pbeta, D.pidx_off + tid, D.pair_off + cstep * tid);
 
     {   /* stage: owned nodes are one contiguous run of doubles, halo nodes a gather */
-        const double* g1 = u1g + 3 * (int64_t)D.base;
-        const double* g2 = u2g + 3 * (int64_t)D.base;
+        const hq_real* g1 = u1g + 3 * (int64_t)D.base;
+        const hq_real* g2 = u2g + 3 * (int64_t)D.base;
         for (int i0 = 0; i0 < own3 || i0 < halo3; i0 += 4 * T) {
             double a1[4], a2[4], b1[4], b2[4];
 #pragma unroll
@@ -1163,13 +1163,13 @@ hq_k_patch_step(int32_t npatches, int32_t per_xcd, const int32_t* __restrict__ o
                 for (int k = 0; k < 7; k++) np[k] = q[k];
             }
         }
-        double* out = ung + 3 * ((int64_t)D.base + n);
+        hq_real* out = ung + 3 * ((int64_t)D.base + n);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const double m2 = iso ? np[1] : np[1 + d], m1 = iso ? np[4] : np[4 + d];
             const double x1 = wf ? s_u2[3 * n + d] : s_u1[3 * n + d], x2 = wf ? s_u2[o2off + 3 * n + d] : s_u2[3 * n + d];
             double f = s_f[3 * n + d] + (m2 * x1 - m1 * x2);
-            if (NT) __builtin_nontemporal_store(f / np[0], out + d);
+            if (NT) __builtin_nontemporal_store((hq_real)(f / np[0]), out + d);
             else out[d] = f / np[0];
         }
     }
@@ -1228,8 +1228,8 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 int32_t nfacc, const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
-                const int32_t* __restrict__ halo, const double* __restrict__ u1g,
-                const double* __restrict__ u2g, double* __restrict__ ung,
+                const int32_t* __restrict__ halo, const hq_real* __restrict__ u1g,
+                const hq_real* __restrict__ u2g, hq_real* __restrict__ ung,
                 const double* __restrict__ nt, const double* __restrict__ nt3,
                 const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
                 const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
@@ -1478,7 +1478,7 @@ hq_k_patch_pers(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
         }
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
             const int n = tid;
-            double* out = ung + 3 * ((int64_t)D0.base + n);
+            hq_real* out = ung + 3 * ((int64_t)D0.base + n);
             /* u1, u2 of the owned node: compact by owned index behind w (w-form), else its image row */
             const hq_lds_double* __restrict__ o_u1 = wf0 ? s_u2 + 3 * n : s_u1 + 3 * row0;
             const hq_lds_double* __restrict__ o_u2 = wf0 ? s_u2 + 3 * (nrows / 2) + 3 * n : s_u2 + 3 * row0;
@@ -1537,8 +1537,8 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
                 int32_t nfacc, const hq_patch_desc* __restrict__ desc,
                 const uint4* __restrict__ pidx, const double* __restrict__ pc1,
                 const double* __restrict__ pc2, const double* __restrict__ pbeta,
-                const int32_t* __restrict__ halo, const double* __restrict__ u1g,
-                const double* __restrict__ u2g, double* __restrict__ ung,
+                const int32_t* __restrict__ halo, const hq_real* __restrict__ u1g,
+                const hq_real* __restrict__ u2g, hq_real* __restrict__ ung,
                 const double* __restrict__ nt, const double* __restrict__ nt3,
                 const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_ent,
                 const double* __restrict__ F, double dt2, const int32_t* __restrict__ if_ptr,
@@ -1775,7 +1775,7 @@ hq_k_patch_seed(int32_t count, int32_t per_xcd, const int32_t* __restrict__ orde
             }
         }
         if (tid < D0.nown) {                             /* solver_compute_displacement, psolve.c:4078-4106 */
-            double* out = ung + 3 * ((int64_t)D0.base + tid);
+            hq_real* out = ung + 3 * ((int64_t)D0.base + tid);
             const hq_lds_double* __restrict__ acc = s_f + 3 * row0;
 #pragma unroll
             for (int d = 0; d < 3; d++) out[d] = acc[d] / m0;
@@ -1881,8 +1881,8 @@ __device__ unsigned long long* g_hq_st_time = nullptr;
 template <int NT>                /* 512, or 768 for the far-face patches of 513 .. 729 owned nodes */
 __global__ void __launch_bounds__(NT)
 hq_k_patch_stencil(int32_t count, int32_t per_xcd, const hq_st_desc* __restrict__ st_desc,
-                   const int2* __restrict__ st_halo, const double* __restrict__ u1g,
-                   const double* __restrict__ u2g, double* __restrict__ ung, const double* __restrict__ nt,
+                   const int2* __restrict__ st_halo, const hq_real* __restrict__ u1g,
+                   const hq_real* __restrict__ u2g, hq_real* __restrict__ ung, const double* __restrict__ nt,
                    const double* __restrict__ nt3, const int32_t* __restrict__ src_ptr,
                    const int32_t* __restrict__ src_ent, const double* __restrict__ F, double dt2,
                    const uint32_t* __restrict__ rg_tab,
@@ -2038,7 +2038,7 @@ hq_k_patch_stencil(int32_t count, int32_t per_xcd, const hq_st_desc* __restrict_
         const int32_t sl = if_slot[(int64_t)D.base + t];
         if (sl >= 0) { double* o = iforce + 3 * (int64_t)sl; o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; }
     }
-    double* out = ung + 3 * ((int64_t)D.base + t);
+    hq_real* out = ung + 3 * ((int64_t)D.base + t);
 #pragma unroll
     for (int d = 0; d < 3; d++) out[d] = (f[d] + rs[d]) / m0;
     HQ_ST_STAMP(3);
@@ -2537,8 +2537,8 @@ static bool hq_patch_uses_pers(const hq_patch_plan* P)
 }
 
 /* launch patches order[first .. first+count) (order == identity when there is no interface) */
-static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const double* u1,
-                            const double* u2, double* un, const double* nt, const double* F, double dt2,
+static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count, const hq_real* u1,
+                            const hq_real* u2, hq_real* un, const double* nt, const double* F, double dt2,
                             double* iforce, hipStream_t stream, int reserve_cus = 0)
 {
     if (count <= 0) return;
@@ -2606,7 +2606,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
 
 /* the stencil patches: part 0 = those that own interface nodes, d_order[nb + ne .. nb + ne + nr) (they also hand their
  * pure force to the exchange), part 1 = the others, d_order[nb + ne + nr .. nb + ne + nr + ns) */
-static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const double* u1, const double* u2, double* un,
+static void hq_patch_launch_stencil(const hq_patch_plan* P, int part, const hq_real* u1, const hq_real* u2, hq_real* un,
                                     const double* nt, const double* F, double dt2, double* iforce, hipStream_t stream)
 {
     const int32_t total = part == 0 ? P->nr : P->ns, nbig = part == 0 ? P->nr_big : P->ns_big;

@@ -284,30 +284,13 @@ class Box:
             raise capi.HqError("hqh_box_desc failed: %d" % rc)
         return capi.brick_plan_check(d)
 
-    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None):
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None, precision="f64"):
         """hq_create[_opts] on the arrays the C host side built (no copies through Python)."""
         d = capi._Desc()
         rc = self._lib.hqh_box_desc(self._h, ctypes.byref(d))
         if rc != 0:
             raise capi.HqError("hqh_box_desc failed: %d" % rc)
-        d.variant = variant
-        keep = []
-        for name, a in (("tm1", tm1), ("tm2", tm2)):
-            if a is not None:
-                a = np.ascontiguousarray(a, np.float64)
-                keep.append(a)
-                setattr(d, name, a.ctypes.data)
-        s = capi.Solver.__new__(capi.Solver)
-        s._lib = capi.load_library()
-        s._h = ctypes.c_void_p()
-        s.N, s.E = d.nharbored, d.lenum
-        if isinstance(options, dict):
-            options = capi.Options(**options)
-        if options is None:
-            capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
-        else:
-            capi._check(s._lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(s._h)))
-        return s
+        return _solver_from_desc(d, self.ntable, variant, device, tm1, tm2, options, precision)
 
     def point_source(self, x, y, z, strike=0.0, dip=90.0, rake=0.0):
         n = ctypes.c_int32()
@@ -547,29 +530,42 @@ class OctBox:
             raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
         return capi.brick_plan_check(d)
 
-    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None):
+    def create_solver(self, variant=capi.HQ_VARIANT_AUTO, device=0, tm1=None, tm2=None, options=None, precision="f64"):
         d = capi._Desc()
         rc = self._lib.hqh_octbox_desc(self._h, ctypes.byref(d))
         if rc != 0:
             raise capi.HqError("hqh_octbox_desc failed: %d" % rc)
-        d.variant = variant
-        keep = []
-        for name, a in (("tm1", tm1), ("tm2", tm2)):
-            if a is not None:
-                a = np.ascontiguousarray(a, np.float64)
-                keep.append(a)
-                setattr(d, name, a.ctypes.data)
-        s = capi.Solver.__new__(capi.Solver)
-        s._lib = capi.load_library()
-        s._h = ctypes.c_void_p()
-        s.N, s.E = d.nharbored, d.lenum
-        if isinstance(options, dict):
-            options = capi.Options(**options)
-        if options is None:
-            capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)))
-        else:
-            capi._check(s._lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(s._h)))
-        return s
+        return _solver_from_desc(d, self.ntable, variant, device, tm1, tm2, options, precision)
+
+
+def _solver_from_desc(d, ntable, variant, device, tm1, tm2, options, precision):
+    """capi.Solver on a description the C host side filled.  precision "f32": libhq_solver_f32.so -- the C host side builds
+    its tables in double (it mirrors the double-precision reference), so the n_t rows are handed over ROUNDED to float;
+    tm1 / tm2 are taken as float32."""
+    d.variant = variant
+    real = np.float32 if precision == "f32" else np.float64
+    keep = []
+    if precision == "f32":
+        nt = np.ascontiguousarray(ntable, np.float32)
+        keep.append(nt)
+        d.nTable = nt.ctypes.data
+    for name, a in (("tm1", tm1), ("tm2", tm2)):
+        if a is not None:
+            a = np.ascontiguousarray(a, real)
+            keep.append(a)
+            setattr(d, name, a.ctypes.data)
+    s = capi.Solver.__new__(capi.Solver)
+    s._lib = capi.load_library(precision=precision)
+    s.real = real
+    s._h = ctypes.c_void_p()
+    s.N, s.E = d.nharbored, d.lenum
+    if isinstance(options, dict):
+        options = capi.Options(**options)
+    if options is None:
+        capi._check(s._lib.hq_create(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(s._h)), s._lib)
+    else:
+        capi._check(s._lib.hq_create_opts(ctypes.byref(d), ctypes.c_int(device), ctypes.byref(options), ctypes.byref(s._h)), s._lib)
+    return s
 
 
 class _GridModel(ctypes.Structure):

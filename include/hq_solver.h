@@ -59,6 +59,21 @@ typedef struct {
 } hq_messenger;
 
 /*
+ * solver_float (psolve.h:60-64): the type of the caller's tm1 / tm2 arrays and n_t rows.  The reference's
+ * -DSINGLE_PRECISION_SOLVER makes it float; the library built with -DHQ_SINGLE_PRECISION_SOLVER
+ * (libhq_solver_f32.so, same sources) then takes and returns floats at these places and keeps the device-resident
+ * state in floats (36 instead of 72 compulsory bytes per node and step); e_t, the source table and every sum inside
+ * a kernel stay double, as the reference's own locals do.  A client compiles with the same macro and checks
+ * hq_real_bytes() == sizeof(hq_real).  A separately named dtype with its own oracle build and tolerance
+ * (tests/test_gpu_single_precision.py); never the headline.
+ */
+#ifdef HQ_SINGLE_PRECISION_SOLVER
+typedef float hq_real;
+#else
+typedef double hq_real;
+#endif
+
+/*
  * One communication schedule: schedule_t (psolve.h:255-274).
  * c-list: ranks that OWN nodes I harbor -- I send them force contributions and
  *         receive displacements from them.
@@ -89,9 +104,9 @@ typedef struct {
     const int32_t* dn_lanid;
     /* mysolver_t */
     const double*  eTable;       /* [lenum][4]      e_t  c1..c4 (psolve.h:196-198) */
-    const double*  nTable;       /* [nharbored][7]  n_t  (psolve.h:210-214)   */
-    const double*  tm1;          /* [nharbored][3]  u(t)      or NULL = 0     */
-    const double*  tm2;          /* [nharbored][3]  u(t-dt)   or NULL = 0     */
+    const hq_real* nTable;       /* [nharbored][7]  n_t  (psolve.h:210-214)   */
+    const hq_real* tm1;          /* [nharbored][3]  u(t)      or NULL = 0     */
+    const hq_real* tm2;          /* [nharbored][3]  u(t-dt)   or NULL = 0     */
     hq_schedule    an_sched;     /* anchored-node schedule  (mysolver_t.an_sched) */
     hq_schedule    dn_sched;     /* dangling-node schedule  (mysolver_t.dn_sched) */
     /* Param */
@@ -235,6 +250,8 @@ HQ_API int hq_destroy(hq_ctx* ctx);
  */
 #define HQ_ABI_VERSION 5
 HQ_API int hq_abi_version(void);
+/* sizeof(hq_real) of the library that is loaded: 8 (libhq_solver.so), 4 (libhq_solver_f32.so) */
+HQ_API int hq_real_bytes(void);
 HQ_API int hq_get_info_sized(hq_ctx* ctx, hq_info* info, uint64_t size);
 HQ_API int hq_get_info(hq_ctx* ctx, hq_info* info);
 #ifndef HQ_SOLVER_IMPLEMENTATION
@@ -350,18 +367,18 @@ HQ_API int hq_check_finite(hq_ctx* ctx, int64_t* nonfinite);
  * (psolve.c:6679-6710) / planes; hq_download those of checkpoint_write
  * (io_checkpoint.c:98-112) and the 4D output (output.c:1265).
  */
-HQ_API int hq_gather(hq_ctx* ctx, int32_t n, const int32_t* lnid, double* tm1_out, double* tm2_out);
+HQ_API int hq_gather(hq_ctx* ctx, int32_t n, const int32_t* lnid, hq_real* tm1_out, hq_real* tm2_out);
 /*
  * The same with tm3 = u((step-2)*dt), which the reference keeps when station accelerations are
  * printed (solver_compute_displacement psolve.c:4093-4101; read at :6762-6778).  The patch variant
  * has it for free -- it is the buffer the next step overwrites; zero before the second step and
  * after hq_upload, as the reference's calloc'ed tm3 is.  HQ_ERR_STATE in the scatter variant.
  */
-HQ_API int hq_gather3(hq_ctx* ctx, int32_t n, const int32_t* lnid, double* tm1_out, double* tm2_out,
-                      double* tm3_out);
-HQ_API int hq_download(hq_ctx* ctx, double* tm1, double* tm2);
+HQ_API int hq_gather3(hq_ctx* ctx, int32_t n, const int32_t* lnid, hq_real* tm1_out, hq_real* tm2_out,
+                      hq_real* tm3_out);
+HQ_API int hq_download(hq_ctx* ctx, hq_real* tm1, hq_real* tm2);
 /* checkpoint_read (io_checkpoint.c:134-236): overwrite the fields, set the step. */
-HQ_API int hq_upload(hq_ctx* ctx, const double* tm1, const double* tm2, int32_t step);
+HQ_API int hq_upload(hq_ctx* ctx, const hq_real* tm1, const hq_real* tm2, int32_t step);
 
 /*
  * Single phases, for per-function parity tests against the reference loops

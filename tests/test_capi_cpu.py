@@ -34,6 +34,19 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(names) == sorted(capi.EXPORTS)
 
 
+def test_single_precision_build_exports_the_same_interface(lib):
+    """libhq_solver_f32.so: the same sources with -DHQ_SINGLE_PRECISION_SOLVER (hq_real = float, the reference's
+    -DSINGLE_PRECISION_SOLVER psolve.h:60-64): every declared symbol, sizeof(hq_real) = 4; the default library says 8."""
+    f32 = capi.load_library(precision="f32")
+    for n in _declared("hq_solver.h"):
+        assert hasattr(f32, n), n
+    assert f32.hq_real_bytes() == 4 and lib.hq_real_bytes() == 8
+    assert f32.hq_abi_version() == lib.hq_abi_version()
+    if ha.device_count() == 0:          # no CPU path in this build either
+        with pytest.raises(capi.HqError):
+            ha.Solver(np.zeros((1, 8), np.int32), np.ones((1, 4)), np.ones((8, 7)), 1e-3, precision="f32")
+
+
 def test_host_library_exports(lib):
     path = hbuild.build_host()
     if path is None:

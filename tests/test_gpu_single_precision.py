@@ -1,0 +1,159 @@
+"""The reference's -DSINGLE_PRECISION_SOLVER (psolve.h:60-64: solver_float = float) as a separately named dtype:
+libhq_solver_f32.so = the same sources with -DHQ_SINGLE_PRECISION_SOLVER -- the C-ABI takes and returns floats where the
+reference's arrays are solver_float (tm1 / tm2, the n_t rows), the device keeps the state in floats (36 instead of 72
+compulsory bytes per node and step), every sum inside a kernel stays double.
+
+Checked against (i) checkpoints the REAL reference built with the switch wrote (oracle/_ref/psolve_f32, tests/golden/*_f32.npz)
+and (ii) the oracle's own float build (oracle/libherc_oracle_f32.so, pinned on those checkpoints bit for bit in
+tests/test_oracle_single_precision.py).
+
+TOLERANCE, stated: the reference's float build rounds every local force, every n_t sum and the state; this path rounds the
+state only.  On the 800-step run of examples/simple the reference's float build is 7.3e-6 (relative, L-inf) away from its own
+double build; this path must stay within 2e-5 of the float reference there, and within 2e-6 of the float oracle over a few
+steps from a seeded field.  Never the headline: the fp64 library is byte-for-byte what it was."""
+import numpy as np
+import pytest
+
+import hercules_amd as ha
+from hercules_amd import host
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_RUN = 2e-5       # hundreds of steps, against the reference's own float checkpoints
+TOL_STEPS = 2e-6     # a few steps from a seeded field, against the float oracle on the same tables
+
+
+def _ticks(node_ijk, edge=1 << 26):
+    return (np.asarray(node_ijk, np.int64) * edge).astype(np.int32)
+
+
+@pytest.mark.parametrize("variant", [ha.HQ_VARIANT_SCATTER, ha.HQ_VARIANT_PATCH])
+def test_uniform_box_against_the_float_references_checkpoints(variant):
+    g = H.load("c1_f32")
+    p = H.c1_problem("rayleigh", real=np.float32)
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], node_xyz=_ticks(p["node_ijk"]), variant=variant, precision="f32")
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done, worst = 0, 0.0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert tm1.dtype == np.float32 and tm2.dtype == np.float32
+        worst = max(worst, H.rel_linf(tm1.astype(np.float64), g["ckpt_tm1"][k].astype(np.float64)),
+                    H.rel_linf(tm2.astype(np.float64), g["ckpt_tm2"][k].astype(np.float64)))
+    assert s.check_finite() == 0
+    s.close()
+    assert worst < TOL_RUN, worst
+    # ... and closer to the DOUBLE reference than the float reference is (double sums, float state)
+    g64 = H.load("c1_short")
+    assert H.rel_linf(tm1.astype(np.float64), g64["ckpt_tm1"][-1]) < 2e-5
+
+
+def test_two_level_octree_against_the_float_references_checkpoints():
+    """compute_adjust on float tables: 800 hanging nodes, the reference's own float run of the two-level mesh."""
+    p = H.c5_problem("c5_two_level_f32", real=np.float32)
+    g = p["golden"]
+    for variant in (ha.HQ_VARIANT_SCATTER, ha.HQ_VARIANT_PATCH):
+        s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"],
+                      node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32), variant=variant, precision="f32")
+        s.set_source(g["loaded_lnid"], g["forces"])
+        done = 0
+        for k, step in enumerate(g["ckpt_steps"]):
+            s.run(int(step) - done)
+            done = int(step)
+            tm1, tm2 = s.download()
+            assert H.rel_linf(tm1.astype(np.float64), g["ckpt_tm1"][k].astype(np.float64)) < TOL_RUN
+            assert H.rel_linf(tm2.astype(np.float64), g["ckpt_tm2"][k].astype(np.float64)) < TOL_RUN
+        s.close()
+
+
+def _field32(box, seed, amp=1e-3):
+    ijk = box.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (box.ny + 1) + ijk[:, 1]) * (box.nx + 1) + ijk[:, 0]
+    u = np.empty((len(gid), 3))
+    for d in range(3):
+        x = (gid * 3 + d + seed) * np.int64(2654435761) % np.int64(2 ** 31)
+        u[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * amp
+    return u.astype(np.float32)
+
+
+def test_one_million_elements_bricks_against_the_float_oracle_and_in_eight_partitions():
+    """The 1 M-element box: hq_k_brick on a float state (z faces with their columns), the shell's patches, gather /
+    gather3 / upload in floats -- against the oracle's float build stepping the same (rounded) tables; then cut 8 ways
+    (in-process transport: the records travel as doubles, what arrives is rounded as the owner's own copy is)."""
+    from hercules_amd import capi
+    nx, ny, nz, h, dt, freq = 128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    u = _field32(box, 4242)
+    u2 = (0.999 * u.astype(np.float64)).astype(np.float32)
+    nsteps = 3
+    nt32 = np.ascontiguousarray(box.ntable, np.float32)
+    o1, o2 = u2.copy(), u.copy()                                    # oracle arrays are pre-swap
+    ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, nsteps, dt)
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=u2, precision="f32")
+    assert s.dominant_kernel() == "hq_k_brick" and s.info()["brick_nodes"] > 0.9 * len(u)
+    s.run(nsteps)
+    tm1, tm2 = s.download()
+    assert tm1.dtype == np.float32
+    assert H.rel_linf(tm1.astype(np.float64), o2.astype(np.float64)) < TOL_STEPS
+    assert H.rel_linf(tm2.astype(np.float64), o1.astype(np.float64)) < TOL_STEPS
+    ids = np.array([0, 17, len(u) // 2, len(u) - 1], np.int32)
+    g1, g2, g3 = s.gather3(ids)
+    assert g1.dtype == np.float32 and np.array_equal(g1, tm1[ids]) and np.array_equal(g2, tm2[ids])
+    s.upload(u, u2, 0)
+    s.run(nsteps)
+    again, _ = s.download()
+    assert np.array_equal(again, tm1)                                 # the same floats from the same start
+    s.close()
+    # the scatter kernels on the float state
+    sc = box.create_solver(variant=ha.HQ_VARIANT_SCATTER, tm1=u, tm2=u2, precision="f32")
+    sc.run(nsteps)
+    s1, _ = sc.download()
+    sc.close()
+    assert H.rel_linf(s1.astype(np.float64), o2.astype(np.float64)) < TOL_STEPS
+    gid = (box.node_ijk[:, 2].astype(np.int64) * (ny + 1) + box.node_ijk[:, 1]) * (nx + 1) + box.node_ijk[:, 0]
+    lut = np.empty(gid.max() + 1, np.int64)
+    lut[gid] = np.arange(len(gid))
+    box.close()
+    parts = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8) for r in range(8)]
+    maps = [lut[(b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]] for b in parts]
+    solvers = [b.create_solver(tm1=u[m], tm2=u2[m], precision="f32") for b, m in zip(parts, maps)]
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for sv, m in zip(solvers, maps):
+        p1, p2 = sv.download()
+        assert H.rel_linf(p1.astype(np.float64), o2[m].astype(np.float64)) < TOL_STEPS
+        assert H.rel_linf(p1.astype(np.float64), tm1[m].astype(np.float64)) < 5e-7      # a float ulp or two from the single run
+        sv.close()
+    for b in parts:
+        b.close()
+
+
+def test_small_lateral_basin_float_state_against_the_float_oracle():
+    """o4s (laterally refined: full and ragged tile columns, element-form patches with hanging-node accumulators,
+    hq_k_adjust_assign) on a float state, forces on 3 000 nodes, against the float oracle with compute_adjust."""
+    import bench
+    box, E, N, it = bench.make_octbox("o4s", 0, 1)
+    u = it["field"].astype(np.float32)
+    u2 = (0.999 * it["field"]).astype(np.float32)
+    nsteps = 3
+    free = np.setdiff1d(np.arange(N, dtype=np.int64), box.dangling[0])
+    loaded = free[np.linspace(0, len(free) - 1, 3000).astype(np.int64)].astype(np.int32)
+    rng = np.random.default_rng(99)
+    F = rng.uniform(-1.0, 1.0, (nsteps, len(loaded), 3)) * (1e-4 * np.abs(u).max() / box.dt ** 2) * box.ntable[loaded, 0][None, :, None]
+    nt32 = np.ascontiguousarray(box.ntable, np.float32)
+    o1, o2 = u2.copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, nsteps, box.dt, dangling=box.dangling, loaded_lnid=loaded, forces=F)
+    for variant in (ha.HQ_VARIANT_PATCH, ha.HQ_VARIANT_SCATTER):
+        s = box.create_solver(variant=variant, tm1=u, tm2=u2, precision="f32")
+        if variant == ha.HQ_VARIANT_PATCH:
+            assert s.info()["brick_units_ragged"] > 0
+        s.set_source(loaded, F)
+        s.run(nsteps)
+        tm1, tm2 = s.download()
+        s.close()
+        assert H.rel_linf(tm1.astype(np.float64), o2.astype(np.float64)) < TOL_STEPS
+        assert H.rel_linf(tm2.astype(np.float64), o1.astype(np.float64)) < TOL_STEPS
+    box.close()
