@@ -123,7 +123,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(seconds_target=6.0):
+def cpu_baseline(seconds_target=6.0, single=False):
     """The oracle's reference-formulation loops (effective stiffness + the 8x8
     conventional damping loop + nodal update) on the host cores: one independent
     64x64x32 partition per core, seeded random field (all elements active)."""
@@ -176,6 +176,8 @@ def cpu_baseline(seconds_target=6.0):
         return port
     try:
         from oracle import ref_baseline as rb
+        if single:                       # --precision f32: the reference built with -DSINGLE_PRECISION_SOLVER beside it
+            rb.PSOLVE = rb.PSOLVE + "_f32" if not rb.PSOLVE.endswith("_f32") else rb.PSOLVE
         if not rb.available():
             return port
         why_not_c2 = None
@@ -190,7 +192,7 @@ def cpu_baseline(seconds_target=6.0):
             "unit": "element-updates/s",
             "cores": cores,
             "kind": "reference",
-            "sample": "CMU-Quake/hercules psolve itself (oracle/_ref/psolve, MPICH, %d ranks): examples/simple "
+            "sample": "CMU-Quake/hercules psolve itself (oracle/_ref/" + os.path.basename(rb.PSOLVE) + ", MPICH, %d ranks): examples/simple "
                       "material refined by its own mesher to %d elements (f = %s Hz), effective stiffness + "
                       "Rayleigh damping, %d point sources so that no element is quiescent; the solver's own "
                       "wall clock over steps %d..%d of one run"
@@ -366,7 +368,7 @@ def inproc_diagnostic(args):
             ncls, amp = LATERAL.get(args.workload, (0, 0.0))
             b = hhost.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=P, lateral_classes=ncls, lateral_amp=amp)
             u1 = seeded_field(b.node_ijk, nx, ny)
-        solvers.append(b.create_solver(variant=variant, tm1=u1, tm2=u1 * (1.0 - 1e-3)))
+        solvers.append(b.create_solver(variant=variant, tm1=u1, tm2=u1 * (1.0 - 1e-3), precision=args.precision))
         boxes.append(b)
     capi.group_link(solvers)
     capi.group_run(solvers, args.warmup)
@@ -540,7 +542,7 @@ def build_problem(args, rank, world, device):
     # because it is a function of the global node coordinates
     u1 = seeded_field(box.node_ijk, nx, ny, interfaces)
     u2 = u1 * (1.0 - 1e-3)
-    solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2)
+    solver = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u2, precision=args.precision)
     del u1, u2
     return box, solver, N, octree
 
@@ -586,7 +588,8 @@ def measure_traffic(args, keep_dir=None):
             d = os.path.join(out_root, counter.lower())
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                    os.path.realpath(sys.executable), os.path.abspath(__file__), "--pmc-child",
-                   "--workload", args.workload, "--variant", args.variant, "--steps", str(PMC_STEPS - 1), "--warmup", "1"]
+                   "--workload", args.workload, "--variant", args.variant, "--precision", args.precision,
+                   "--steps", str(PMC_STEPS - 1), "--warmup", "1"]
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -636,6 +639,12 @@ def traffic_of(pmc, kernel, steps=PMC_STEPS):
 PARITY_STEPS = 3                # steps of the parity run behind the timed region
 PARITY_EDGE = 16                # elements per axis of a window (a power of two: hqh_box_create)
 PARITY_TOL = 1e-9               # the GPU parity bar: relative L-inf on nodal displacement
+PARITY_TOL_F32 = 2e-6           # --precision f32: a float state against the oracle's float build over a few steps
+                                # (tests/test_gpu_single_precision.py states where the figure comes from)
+
+
+def parity_tol(args):
+    return PARITY_TOL_F32 if getattr(args, "precision", "f64") == "f32" else PARITY_TOL
 PARITY_WORKLOADS = ("c1", "c2", "c3", "m1", "c3h", "c2h", "m1h")     # boxes: a window of them is a small box of the same
                                                                      # material (hqh_box_params.origin: classes at the big box's indices)
 
@@ -649,8 +658,10 @@ def parity_windows(args, box, solver, rank, world):
     this rank SHARES with others (its partition interfaces: pack, transport, interface update and unpack are inside the
     checked cones), plus brick-tile borders and domain faces.
     -> (windows, nodes checked, worst relative error) of this rank; None for workloads without a window oracle."""
+    single = getattr(args, "precision", "f64") == "f32"
+    real = np.float32 if single else np.float64
     if args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED or args.workload in OCT_BASIN:
-        return parity_windows_octree(args, box, solver) if world == 1 else None
+        return parity_windows_octree(args, box, solver) if (world == 1 and not single) else None
     if args.workload not in PARITY_WORKLOADS:
         return None
     from hercules_amd import host as hhost
@@ -690,8 +701,9 @@ def parity_windows(args, box, solver, rank, world):
         sub = hhost.Box(W, W, W, h, dt, freq, lateral_classes=ncls, lateral_amp=amp, origin=lo)
         g = sub.node_ijk.astype(np.int64) + np.array(lo)
         w1 = seeded_field(g, nx, ny)
-        o1, o2 = w1 * (1.0 - 1e-3), w1.copy()
-        ho.solver_run(sub.lnid, sub.etable.copy(), sub.ntable.copy(), o1, o2, 0, k, dt)
+        # (f32: the oracle's float build on the tables the context was handed -- the n_t rows rounded to float)
+        o1, o2 = (w1 * (1.0 - 1e-3)).astype(real), w1.astype(real)
+        ho.solver_run(sub.lnid, sub.etable.copy(), np.ascontiguousarray(sub.ntable, real), o1, o2, 0, k, dt)
         ok = np.ones(len(g), bool)
         for d in range(3):
             if lo[d] > 0:                                   # a cut face unless it is the domain's own near face
@@ -706,7 +718,8 @@ def parity_windows(args, box, solver, rank, world):
         if not mine.any():
             continue
         tm1, tm2 = solver.gather(order[pos[mine]].astype(np.int32))
-        worst = max(worst, float(np.abs(tm1 - o2[mine]).max() / scale), float(np.abs(tm2 - o1[mine]).max() / scale))
+        worst = max(worst, float(np.abs(tm1.astype(np.float64) - o2[mine]).max() / scale),
+                    float(np.abs(tm2.astype(np.float64) - o1[mine]).max() / scale))
         nwin += 1
         nchecked += int(mine.sum())
     return nwin, nchecked, worst
@@ -762,6 +775,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
+                    help="f32: libhq_solver_f32.so (hq_real = float, the reference's -DSINGLE_PRECISION_SOLVER) -- a separately "
+                         "named dtype with its own oracle build and tolerance; never the headline")
     ap.add_argument("--pmc-dir", default=None, help="keep the rocprofv3 counter CSVs of the traffic passes here")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle cone windows behind the timed region (config.parity_*)")
@@ -801,7 +817,7 @@ def main():
         pmc = measure_traffic(args, args.pmc_dir)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(single=args.precision == "f32")
 
     import torch
     import torch.distributed as dist
@@ -861,7 +877,7 @@ def main():
         sv, why = None, ""
         try:
             u1 = start_field()
-            sv = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3))
+            sv = box.create_solver(variant=variant, device=device, tm1=u1, tm2=u1 * (1.0 - 1e-3), precision=args.precision)
         except Exception as exc:
             why = str(exc)
         if not everywhere(sv is not None):
@@ -937,7 +953,7 @@ def main():
             sample = np.unique(np.linspace(0, n_here - 1, min(n_here, 65536)).astype(np.int32))
             ga, gb = a.gather(sample)[0], b.gather(sample)[0]
             err = float(np.abs(ga - gb).max() / max(np.abs(ga).max(), 1e-300))
-            return everywhere(err <= PARITY_TOL)
+            return everywhere(err <= parity_tol(args))
 
         solver, chosen = select_transport(want, solver, new_solver, bring_up, trial, trials, agree)
         if trials:
@@ -999,7 +1015,7 @@ def main():
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             if have:
                 parity = (int(t[0]), int(t[1]), float(w[0]))
-    parity_failed = parity is not None and not (parity[0] > 0 and parity[2] <= PARITY_TOL)
+    parity_failed = parity is not None and not (parity[0] > 0 and parity[2] <= parity_tol(args))
 
     if rank == 0:
         E_total = box.info["total_elements"]
@@ -1009,7 +1025,7 @@ def main():
         kernel = solver.dominant_kernel()
         # ONE basis for every workload (round-3 advisor finding): 72 B per node and step.  What a mesh with material of
         # its own in every element reads on top (24 B n_t row + 24 B coefficients) is reported beside it, not in `frac`.
-        per_node = COMPULSORY_BYTES_PER_NODE
+        per_node = COMPULSORY_BYTES_PER_NODE * (0.5 if args.precision == "f32" else 1.0)      # a float state: 36 B
         compulsory = per_node * N                          # this rank's nodes: read u(t), u(t-dt), write u(t+dt)
         traffic = rd = wr = None
         source = None
@@ -1046,9 +1062,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.precision == "f64" else "f32 state, f64 sums (the reference's -DSINGLE_PRECISION_SOLVER; libhq_solver_f32.so)",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD_NAMES[args.workload], "elements": int(E_total),
+            "config": {"workload": WORKLOAD_NAMES[args.workload] + ("" if args.precision == "f64" else " -- SINGLE-PRECISION state (a separately named dtype, not the headline)"),
+                       "elements": int(E_total),
                        "nodes": int(box.info["total_nodes"]), "partition": "octor block x%d" % world,
                        "kernel_variant": "patch" if is_patch else "scatter",
                        "patches": int(info["npatches"]), "stencil_patches": int(info["stencil_patches"]),
@@ -1062,7 +1079,7 @@ def main():
                        "parity_windows": parity[0] if parity else None,
                        "parity_nodes": parity[1] if parity else None,
                        "parity_worst": parity[2] if parity else None,
-                       "parity_steps": (2 if octree else PARITY_STEPS) if parity else None, "parity_tol": PARITY_TOL},
+                       "parity_steps": (2 if octree else PARITY_STEPS) if parity else None, "parity_tol": parity_tol(args)},
             # achieved = HBM bytes the kernel really moved per launch (PMC, this session) / its mean launch
             # time (HIP events on its stream); where the counters are unavailable, the compulsory bytes
             # (a lower bound).  The reference formulation's 336 B per element-update is kept only as
@@ -1089,7 +1106,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
         if parity_failed:
-            print("bench.py: PARITY FAILED: %s windows, worst relative error %s (bar %g)" % (parity[0], parity[2], PARITY_TOL),
+            print("bench.py: PARITY FAILED: %s windows, worst relative error %s (bar %g)" % (parity[0], parity[2], parity_tol(args)),
                   file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
