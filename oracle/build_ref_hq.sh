@@ -49,4 +49,16 @@ ar rcs "$TMP/obj/libetree.a" $eobjs
 SYSLIB=$(dirname "$($CC -print-file-name=libstdc++.so.6)")
 $CC -o "$OUT/psolve_hq" $objs "$TMP/obj/libetree.a" "$SYSLIB/libstdc++.so.6" -L"$LIB" -lhq_solver \
     "$MPI/lib/libmpi.so" -Wl,-rpath-link,"$MPI/lib" -Wl,-rpath,'$ORIGIN/../../hercules_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lm
+# the same program in the reference's single precision (psolve.h:60-64) on libhq_solver_f32.so: only the files that see
+# solver_float are compiled again (everything under quake/forward includes psolve.h)
+objs32="$TMP/obj/f32_psolve_hq.o"
+D32="-DSINGLE_PRECISION_SOLVER -DHQ_SINGLE_PRECISION_SOLVER"
+$CC $CFLAGS $DEFS $D32 $INC -c "$TMP/psolve_hq.c" -o "$TMP/obj/f32_psolve_hq.o" &
+for f in $FWD;   do $CC $CFLAGS $DEFS $D32 $INC -c "$REF/quake/forward/$f.c" -o "$TMP/obj/f32_$f.o" & objs32="$objs32 $TMP/obj/f32_$f.o"; done
+wait
+if [ -f "$LIB/libhq_solver_f32.so" ]; then
+    $CC -o "$OUT/psolve_hq_f32" $objs32 "$TMP/obj/octor.o" "$TMP/obj/cvm.o" "$TMP/obj/libetree.a" "$SYSLIB/libstdc++.so.6" -L"$LIB" -lhq_solver_f32 \
+        "$MPI/lib/libmpi.so" -Wl,-rpath-link,"$MPI/lib" -Wl,-rpath,'$ORIGIN/../../hercules_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lm
+    echo "build_ref_hq: built $OUT/psolve_hq_f32"
+fi
 echo "build_ref_hq: built $OUT/psolve_hq"

@@ -222,3 +222,37 @@ def test_station_accelerations_at_steps_that_also_write_a_checkpoint():
         assert np.abs(ref[:, 10::10, 7:]).max() > 1.0        # the lines written at checkpoint steps carry real accelerations
     finally:
         shutil.rmtree(run_hq, ignore_errors=True)
+
+
+PSOLVE_HQ_F32 = os.path.join(ROOT, "oracle", "_ref", "psolve_hq_f32")
+
+
+@pytest.mark.skipif(not (os.path.exists(PSOLVE_HQ_F32) and rb.available()),
+                    reason="oracle/_ref/psolve_hq_f32 (oracle/build_ref_hq.sh, build container) or mpiexec missing")
+def test_the_single_precision_reference_program_on_the_float_library():
+    """The reference built with -DSINGLE_PRECISION_SOLVER (psolve.h:60-64) with the same stub, compiled with
+    -DHQ_SINGLE_PRECISION_SOLVER and linked against libhq_solver_f32.so: its float arrays go through the C-ABI as they are
+    (hq_real = solver_float; hq_attach checks the pairing).  Checkpoints (rows of three floats, io_checkpoint.c:98-112) and
+    station files against what the unmodified float reference wrote for tests/golden/c1_f32.npz: within the tolerance the
+    f32 dtype states (tests/test_gpu_single_precision.py: 2e-5 over this 800-step run)."""
+    g = H.load("c1_f32")
+    run_hq, log = _run(PSOLVE_HQ_F32, _params(float(g["end_time"]), 400, 1))
+    try:
+        assert int(re.search(r"Total elements:\s+(\d+)", log).group(1)) == 2048
+        seen = []
+        for k in (0, 1):
+            b = open(os.path.join(run_hq, "out", "checkpoints", "checkpoint.out%d" % k), "rb").read()
+            groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
+            assert groupsize == 1 and len(b) == 12 + 2 * nmax * 12              # float rows
+            tm2 = np.frombuffer(b[12:12 + nmax * 12], "<f4").reshape(nmax, 3).astype(np.float64)
+            tm1 = np.frombuffer(b[12 + nmax * 12:], "<f4").reshape(nmax, 3).astype(np.float64)
+            i = list(g["ckpt_steps"]).index(step)
+            assert H.rel_linf(tm1, g["ckpt_tm1"][i].astype(np.float64)) < 2e-5
+            assert H.rel_linf(tm2, g["ckpt_tm2"][i].astype(np.float64)) < 2e-5
+            seen.append(step)
+        assert sorted(seen) == [int(s) for s in g["ckpt_steps"]]
+        st = _stations(run_hq)
+        scale = np.abs(g["stations"][:, :, 1:]).max()
+        assert st.shape == g["stations"].shape and np.abs(st - g["stations"]).max() <= 2e-5 * scale
+    finally:
+        shutil.rmtree(run_hq, ignore_errors=True)
