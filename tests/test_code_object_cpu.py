@@ -4,6 +4,7 @@ occupancy their launch bounds promise (<= 128 VGPRs: two 512-thread workgroups p
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -61,3 +62,26 @@ def test_exchange_chain_kernels_are_small(tmp_path):
             seen += 1
             assert v["vgpr_count"] <= 32 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
     assert seen >= 5
+
+
+def test_single_precision_build_keeps_the_register_budget(tmp_path, monkeypatch):
+    """libhq_solver_f32.so (hq_real = float): the same kernels on a float state.  Two workgroups per CU as in the fp64
+    build: <= 128 VGPRs, no scratch -- except hq_k_brick_het<false> (24-byte coefficients, no hq_desc.edata), whose
+    "one load, address chosen per lane" of n_t row / ring node needs ONE type and branches in the float build: 2 spilled
+    registers, accepted for a form the packed one replaces wherever the caller hands over edata."""
+    so = os.path.join(ROOT, "hercules_amd", "csrc", "libhq_solver_f32.so")
+    if not os.path.exists(so):
+        pytest.skip("libhq_solver_f32.so is not built")
+    monkeypatch.setattr(sys.modules[__name__], "SO", so)
+    k = _kernel_notes(tmp_path)
+    seen = 0
+    for name, v in k.items():
+        if "hq_k_brick" not in name and "hq_k_patch" not in name:
+            continue
+        seen += 1
+        assert v["vgpr_count"] <= 128, (name, v)
+        if "hq_k_brick_hetILb0E" in name:
+            assert v["vgpr_spill_count"] <= 2, (name, v)
+        else:
+            assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
+    assert seen >= 10
