@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "csrc", "libhq_solver.so")
+_LIBPATH = os.environ.get("HQ_SOLVER_LIB") or os.path.join(_HERE, "csrc", "libhq_solver.so")   # (HQ_SOLVER_LIB: experiment builds, profiles/tools)
 
 HQ_VARIANT_AUTO, HQ_VARIANT_SCATTER, HQ_VARIANT_PATCH = 0, 1, 2
 IPC_BLOB_BYTES = 4096                   # HQ_IPC_BLOB_BYTES
