@@ -16,6 +16,12 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct coef { double P[6], Q[2], beta, m0, m1, m2; };
+// (round 5) -DREAL=float: the STATE (u1, u2, un and the registers the loads land in) in floats, every sum in doubles -- the
+// question behind libhq_solver_f32.so's 3 %: does the march get faster with half the bytes once TWO planes are in flight?
+#ifndef REAL
+#define REAL double
+#endif
+typedef REAL real;
 
 template <int TX, int TY>
 __device__ __host__ inline int64_t node_addr(int gx, int gy, int gz, int NX, int NY, int NZ)
@@ -51,7 +57,7 @@ __device__ __forceinline__ void stencil27(const double* __restrict__ ctr, int px
 
 // reference: one thread per node, gathers from global
 template <int TX, int TY>
-__global__ void k_ref(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ un, int NX, int NY, int NZ, coef c)
+__global__ void k_ref(const real* __restrict__ u1, const real* __restrict__ u2, real* __restrict__ un, int NX, int NY, int NZ, coef c)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)NX * NY * NZ) return;
@@ -79,7 +85,7 @@ __global__ void k_ref(const double* __restrict__ u1, const double* __restrict__ 
 // marching kernel. SLOTS = 4: one barrier per plane; SLOTS = 3: two.
 template <int TX, int TY, int SLOTS>
 __global__ void __launch_bounds__(TX * TY)
-k_march(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ un, int NX, int NY, int NZ, int CZ,
+k_march(const real* __restrict__ u1, const real* __restrict__ u2, real* __restrict__ un, int NX, int NY, int NZ, int CZ,
         int units_per_xcd, int nunits, coef c)
 {
     constexpr int PX = 1, PY = TX + 2, PLANE = (TX + 2) * (TY + 2);
@@ -110,7 +116,7 @@ k_march(const double* __restrict__ u1, const double* __restrict__ u2, double* __
     const int rtile = (rgy / TY) * ntx + rgx / TX;
     const int64_t ring_base = (int64_t)rtile * NZ * (TX * TY) + (rgy % TY) * TX + (rgx % TX);
 
-    double x1[3], x2[3], y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
+    real x1[3], x2[3], y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
     double rsA[3], rsB[3];           // m2 u1 - m1 u2 of the planes k and k+1
     auto load = [&](int z) {
         const int zc = min(max(z, 0), NZ - 1);
@@ -158,7 +164,7 @@ k_march(const double* __restrict__ u1, const double* __restrict__ u2, double* __
 // per node instead of 81 / 153+; only the arriving plane has to be in LDS (2 slots, one barrier per plane).
 template <int TX, int TY, int ABL>
 __global__ void __launch_bounds__(TX * TY)
-k_march2(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ un, int NX, int NY, int NZ, int CZ,
+k_march2(const real* __restrict__ u1, const real* __restrict__ u2, real* __restrict__ un, int NX, int NY, int NZ, int CZ,
          int units_per_xcd, int nunits, coef c)
 {
     constexpr int PY = TX + 2, PLANE = (TX + 2) * (TY + 2);
@@ -186,7 +192,7 @@ k_march2(const double* __restrict__ u1, const double* __restrict__ u2, double* _
     const int rtile = (rgy / TY) * ntx + rgx / TX;
     const int64_t ring_base = (int64_t)rtile * NZ * (TX * TY) + (rgy % TY) * TX + (rgx % TX);
 
-    double x1[3], x2[3], y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
+    real x1[3], x2[3], y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
     double fA[3] = { 0, 0, 0 }, fB[3] = { 0, 0, 0 }, fC[3];
     auto load = [&](int z) {
         const int zc = min(max(z, 0), NZ - 1);
@@ -266,7 +272,7 @@ k_march2(const double* __restrict__ u1, const double* __restrict__ u2, double* _
 // unconditional (lanes without a ring node re-read their own row), so that the compiler can count them.
 template <int TX, int TY, int BYCOMP>
 __global__ void __launch_bounds__(TX * TY, 4)
-k_march3(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ un, int NX, int NY, int NZ, int CZ,
+k_march3(const real* __restrict__ u1, const real* __restrict__ u2, real* __restrict__ un, int NX, int NY, int NZ, int CZ,
          int units_per_xcd, int nunits, coef cin)
 {
     constexpr int PY = TX + 2, PLANE = (TX + 2) * (TY + 2);
@@ -305,8 +311,8 @@ k_march3(const double* __restrict__ u1, const double* __restrict__ u2, double* _
     const int64_t ring_base = (int64_t)rtile * NZ * (TX * TY) + (rgy % TY) * TX + (rgx % TX);
     constexpr int ZS = TX * TY;
 
-    double a1[3], a2[3], c1[3], c2[3];          // the own node's u1, u2: two sets, loaded two planes ahead
-    double b1[3], b2[3];                        // the ring node's: one set, loaded one plane ahead (mostly L2 hits)
+    real a1[3], a2[3], c1[3], c2[3];          // the own node's u1, u2: two sets, loaded two planes ahead
+    real b1[3], b2[3];                        // the ring node's: one set, loaded one plane ahead (mostly L2 hits)
     double fA[3] = { 0, 0, 0 }, fB[3] = { 0, 0, 0 };
 #define LOADOWN(z_, x1_, x2_)                                                                      \
     {                                                                                              \
@@ -420,15 +426,16 @@ int main(int argc, char** argv)
 {
     const int NX = 512, NY = 512, NZ = argc > 1 ? atoi(argv[1]) : 256;
     const int64_t N = (int64_t)NX * NY * NZ;
-    double *u1, *u2, *un, *ur;
-    CK(hipMalloc(&u1, N * 24)); CK(hipMalloc(&u2, N * 24)); CK(hipMalloc(&un, N * 24)); CK(hipMalloc(&ur, N * 24));
+    real *u1, *u2, *un, *ur;
+    const size_t RB = 3 * sizeof(real);
+    CK(hipMalloc(&u1, N * RB)); CK(hipMalloc(&u2, N * RB)); CK(hipMalloc(&un, N * RB)); CK(hipMalloc(&ur, N * RB));
     {
-        std::vector<double> h((size_t)N * 3);
+        std::vector<real> h((size_t)N * 3);
         uint64_t s = 88172645463325252ull;
-        for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-        CK(hipMemcpy(u1, h.data(), N * 24, hipMemcpyHostToDevice));
-        for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-        CK(hipMemcpy(u2, h.data(), N * 24, hipMemcpyHostToDevice));
+        for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (real)((double)(s >> 11) / 9007199254740992.0 - 0.5); }
+        CK(hipMemcpy(u1, h.data(), N * RB, hipMemcpyHostToDevice));
+        for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (real)((double)(s >> 11) / 9007199254740992.0 - 0.5); }
+        CK(hipMemcpy(u2, h.data(), N * RB, hipMemcpyHostToDevice));
     }
     coef c;
     for (int i = 0; i < 6; i++) c.P[i] = 0.1 * (i + 1) - 0.3;
@@ -440,70 +447,70 @@ int main(int argc, char** argv)
     {                                                                                                                  \
         const int ntiles = (NX / TX_) * (NY / TY_), nch = (NZ + CZ_ - 1) / CZ_, nunits = ntiles * nch, upx = nunits / 8; \
         k_ref<TX_, TY_><<<(unsigned)((N + 255) / 256), 256>>>(u1, u2, ur, NX, NY, NZ, c);                                \
-        CK(hipMemset(un, 0, N * 24));                                                                                  \
+        CK(hipMemset(un, 0, N * RB));                                                                                  \
         k_march<TX_, TY_, SL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c);                     \
         CK(hipDeviceSynchronize());                                                                                    \
         {                                                                                                              \
-            std::vector<double> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
+            std::vector<real> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
             double worst = 0;                                                                                          \
             for (int64_t off : { (int64_t)0, N * 3 / 2, N * 3 - ((int64_t)1 << 22) }) {                                \
-                CK(hipMemcpy(a.data(), un + off, a.size() * 8, hipMemcpyDeviceToHost));                                \
-                CK(hipMemcpy(b.data(), ur + off, b.size() * 8, hipMemcpyDeviceToHost));                                \
-                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs(a[i] - b[i]));                          \
+                CK(hipMemcpy(a.data(), un + off, a.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                CK(hipMemcpy(b.data(), ur + off, b.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs((double)a[i] - (double)b[i]));                          \
             }                                                                                                          \
             printf("tile %2dx%-2d slots %d chunk %3d  max|march - ref| = %.2e  ", TX_, TY_, SL_, CZ_, worst);          \
         }                                                                                                              \
         CK(hipEventRecord(e0));                                                                                        \
         for (int r = 0; r < reps; r++) k_march<TX_, TY_, SL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c); \
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));                     \
-        printf("%7.3f ms  (%.0f GB/s of the compulsory 72 B/node; 67.6M-node box: %.3f ms)\n", ms / reps,              \
-               72.0 * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
+        printf("%7.3f ms  (%.0f GB/s of the compulsory bytes; 67.6M-node box: %.3f ms)\n", ms / reps,              \
+               3.0 * RB * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
     }
 #define RUN2(TX_, TY_, CZ_, ABL_)                                                                                    \
     {                                                                                                                  \
         const int ntiles = (NX / TX_) * (NY / TY_), nch = (NZ + CZ_ - 1) / CZ_, nunits = ntiles * nch, upx = nunits / 8; \
         k_ref<TX_, TY_><<<(unsigned)((N + 255) / 256), 256>>>(u1, u2, ur, NX, NY, NZ, c);                                \
-        CK(hipMemset(un, 0, N * 24));                                                                                  \
+        CK(hipMemset(un, 0, N * RB));                                                                                  \
         k_march2<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c);                   \
         CK(hipDeviceSynchronize());                                                                                    \
         {                                                                                                              \
-            std::vector<double> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
+            std::vector<real> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
             double worst = 0;                                                                                          \
             for (int64_t off : { (int64_t)0, N * 3 / 2, N * 3 - ((int64_t)1 << 22) }) {                                \
-                CK(hipMemcpy(a.data(), un + off, a.size() * 8, hipMemcpyDeviceToHost));                                \
-                CK(hipMemcpy(b.data(), ur + off, b.size() * 8, hipMemcpyDeviceToHost));                                \
-                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs(a[i] - b[i]));                          \
+                CK(hipMemcpy(a.data(), un + off, a.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                CK(hipMemcpy(b.data(), ur + off, b.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs((double)a[i] - (double)b[i]));                          \
             }                                                                                                          \
             printf("plane sums: tile %2dx%-2d chunk %3d abl %d  max|march - ref| = %.2e  ", TX_, TY_, CZ_, ABL_, worst); \
         }                                                                                                              \
         CK(hipEventRecord(e0));                                                                                        \
         for (int r = 0; r < reps; r++) k_march2<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c); \
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));                     \
-        printf("%7.3f ms  (%.0f GB/s of the compulsory 72 B/node; 67.6M-node box: %.3f ms)\n", ms / reps,              \
-               72.0 * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
+        printf("%7.3f ms  (%.0f GB/s of the compulsory bytes; 67.6M-node box: %.3f ms)\n", ms / reps,              \
+               3.0 * RB * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
     }
 #define RUN3(TX_, TY_, CZ_, ABL_)                                                                                    \
     {                                                                                                                  \
         const int ntiles = (NX / TX_) * (NY / TY_), nch = (NZ + CZ_ - 1) / CZ_, nunits = ntiles * nch, upx = nunits / 8; \
         k_ref<TX_, TY_><<<(unsigned)((N + 255) / 256), 256>>>(u1, u2, ur, NX, NY, NZ, c);                                \
-        CK(hipMemset(un, 0, N * 24));                                                                                  \
+        CK(hipMemset(un, 0, N * RB));                                                                                  \
         k_march3<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c);                   \
         CK(hipDeviceSynchronize());                                                                                    \
         {                                                                                                              \
-            std::vector<double> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
+            std::vector<real> a((size_t)1 << 22), b((size_t)1 << 22);                                                \
             double worst = 0;                                                                                          \
             for (int64_t off : { (int64_t)0, N * 3 / 2, N * 3 - ((int64_t)1 << 22) }) {                                \
-                CK(hipMemcpy(a.data(), un + off, a.size() * 8, hipMemcpyDeviceToHost));                                \
-                CK(hipMemcpy(b.data(), ur + off, b.size() * 8, hipMemcpyDeviceToHost));                                \
-                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs(a[i] - b[i]));                          \
+                CK(hipMemcpy(a.data(), un + off, a.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                CK(hipMemcpy(b.data(), ur + off, b.size() * sizeof(real), hipMemcpyDeviceToHost));                                \
+                for (size_t i = 0; i < a.size(); i++) worst = fmax(worst, fabs((double)a[i] - (double)b[i]));                          \
             }                                                                                                          \
             printf("plane sums, loads two planes ahead (bycomp = abl): tile %2dx%-2d chunk %3d abl %d  max|march - ref| = %.2e  ", TX_, TY_, CZ_, ABL_, worst); \
         }                                                                                                              \
         CK(hipEventRecord(e0));                                                                                        \
         for (int r = 0; r < reps; r++) k_march3<TX_, TY_, ABL_><<<upx * 8, TX_ * TY_>>>(u1, u2, un, NX, NY, NZ, CZ_, upx, nunits, c); \
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));                     \
-        printf("%7.3f ms  (%.0f GB/s of the compulsory 72 B/node; 67.6M-node box: %.3f ms)\n", ms / reps,              \
-               72.0 * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
+        printf("%7.3f ms  (%.0f GB/s of the compulsory bytes; 67.6M-node box: %.3f ms)\n", ms / reps,              \
+               3.0 * RB * N / (ms / reps * 1e-3) / 1e9, ms / reps * 67634433.0 / N);                                       \
     }
     RUN3(64, 8, 32, 1)
     RUN3(64, 8, 64, 1)
