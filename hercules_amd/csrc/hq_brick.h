@@ -909,7 +909,10 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
     for (int i = 0; i < 2; i++) Q[i] = hq_uniform(U.c1 * sc.q1[i] + U.c2 * sc.q2[i]);
     const bool has_src = F && src_ptr[slot + 1] > src_ptr[slot];
 
-    double x1[3] = { 0.0, 0.0, 0.0 }, x2[3] = { 0.0, 0.0, 0.0 }, y1[3] = { 0.0, 0.0, 0.0 }, y2[3] = { 0.0, 0.0, 0.0 };
+    /* (the registers the loads land in have the STATE's type: a float state is widened where it is used, at the PUT --
+     *  a conversion beside the load would wait for it there and then, and the loads of a plane are meant to stay in flight
+     *  while the plane before is worked on: float build 0.95 -> see DESIGN.md s8.5) */
+    hq_real x1[3] = { 0, 0, 0 }, x2[3] = { 0, 0, 0 }, y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
     double m0A = hq_uniform(1.0 / U.m0), m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */
     double fA[3] = { 0.0, 0.0, 0.0 }, fB[3] = { 0.0, 0.0, 0.0 };
@@ -935,11 +938,12 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
         hq_lds_double* img_ = (hq_lds_double*)s_w + 3 * HQ_BK_PLANE * (s_);                            \
         if (active) {                                                                                 \
             _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
-                img_[3 * myrow + d] = x1[d] + beta * (x1[d] - x2[d]);                                 \
-                acc_[d] += (M2_) * x1[d] - (M1_) * x2[d];                                             \
+                const double a1_ = x1[d], a2_ = x2[d];                                                \
+                img_[3 * myrow + d] = a1_ + beta * (a1_ - a2_);                                       \
+                acc_[d] += (M2_) * a1_ - (M1_) * a2_;                                                 \
             }                                                                                         \
         }                                                                                             \
-        if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) img_[3 * rrow + d] = y1[d] + beta * (y1[d] - y2[d]); } \
+        if (ring) { _Pragma("unroll") for (int d = 0; d < 3; d++) { const double b1_ = y1[d], b2_ = y2[d]; img_[3 * rrow + d] = b1_ + beta * (b1_ - b2_); } } \
     }
 
     /* face planes (HQ_BK_TOPFACE / BOTFACE): uniform per unit */
@@ -1159,7 +1163,10 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     /* an owner's registers: x1, x2 = u1, u2 of its node of the plane in flight, mn = its n_t row, accA / accB = the
      * accumulators of its two unfinished planes.  A ring thread's: x1, x2 = u1, u2 of ring node A, mn / accB = u1 / u2
      * of ring node B (the same registers: a thread is either the one or the other) */
-    double x1[3] = { 0.0, 0.0, 0.0 }, x2[3] = { 0.0, 0.0, 0.0 };
+    /* (x1, x2 in the state's type, widened where they are used: see hq_k_brick.  A FLOAT state cannot share mn / accB
+     *  -- doubles -- with ring node B: its lanes land that node in rb1, rb2) */
+    hq_real x1[3] = { 0, 0, 0 }, x2[3] = { 0, 0, 0 }, rb1[3] = { 0, 0, 0 }, rb2[3] = { 0, 0, 0 };
+    constexpr bool SAME = sizeof(hq_real) == sizeof(double);
     double mn[3] = { 1.0, 0.0, 0.0 };
     double accA[3] = { 0.0, 0.0, 0.0 }, accB[3] = { 0.0, 0.0, 0.0 }, m0A = 1.0, m0B = 1.0;    /* m0: 1 / mass_simple */
     int32_t ridA = rtabA[0], ridB = rtabB[0];
@@ -1174,18 +1181,18 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
         const int64_t a_ = owner ? (int64_t)(node_) : (int64_t)ridA;                                  \
         const double* __restrict__ pb_ = (owner || sizeof(hq_real) != sizeof(double)) ? nt3 + (PACKED ? 2 : 3) * a_ : (const double*)(const void*)(u1g + 3 * (int64_t)ridB); \
         _Pragma("unroll") for (int d = 0; d < 3; d++) { x1[d] = u1g[3 * a_ + d]; x2[d] = u2g[3 * a_ + d]; } \
-        if (sizeof(hq_real) == sizeof(double) || owner) {                                             \
+        if (SAME || owner) {                                                                          \
             if (HQ_BH_ABL != 4) { mn[0] = pb_[0]; mn[1] = pb_[1]; mn[2] = pb_[third]; }                \
         } else {                     /* (a float state: the n_t row and ring node B are loads of two types) */ \
             const hq_real* __restrict__ pu_ = u1g + 3 * (int64_t)ridB;                                \
-            mn[0] = pu_[0]; mn[1] = pu_[1]; mn[2] = pu_[2];                                            \
+            rb1[0] = pu_[0]; rb1[1] = pu_[1]; rb1[2] = pu_[2];                                         \
         }                                                                                             \
     }
 #define HQ_BH_LOAD_B()                                                                                \
     {                                                                                                 \
         if (ringB && HQ_BH_ABL != 1) {                                                                \
             const int64_t b_ = (int64_t)ridB;                                                         \
-            _Pragma("unroll") for (int d = 0; d < 3; d++) accB[d] = u2g[3 * b_ + d];                  \
+            _Pragma("unroll") for (int d = 0; d < 3; d++) { if (SAME) accB[d] = u2g[3 * b_ + d]; else rb2[d] = u2g[3 * b_ + d]; } \
         }                                                                                             \
     }
     /* the loaded plane -> slot s_; acc_ / m0_: seed m2 u1 - m1 u2 and 1 / mass_simple of its owned node (one division per
@@ -1197,13 +1204,14 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
         if (owner) {                                                                                  \
             const double m2_ = PACKED ? 2.0 * mn[0] - mn[1] : mn[1], m1_ = PACKED ? mn[0] - mn[1] : mn[2]; \
             _Pragma("unroll") for (int d = 0; d < 3; d++) {                                           \
-                iu_[3 * myrow + d] = x1[d]; iv_[3 * myrow + d] = x1[d] - x2[d];                       \
-                acc_[d] = m2_ * x1[d] - m1_ * x2[d];                                                  \
+                const double a1_ = x1[d], a2_ = x2[d];                                                \
+                iu_[3 * myrow + d] = a1_; iv_[3 * myrow + d] = a1_ - a2_;                             \
+                acc_[d] = m2_ * a1_ - m1_ * a2_;                                                      \
             }                                                                                         \
             m0_ = 1.0 / mn[0];                                                                        \
         }                                                                                             \
-        if (ringA) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowA + d] = x1[d]; iv_[3 * rrowA + d] = x1[d] - x2[d]; } } \
-        if (ringB) { _Pragma("unroll") for (int d = 0; d < 3; d++) { iu_[3 * rrowB + d] = mn[d]; iv_[3 * rrowB + d] = mn[d] - accB[d]; } } \
+        if (ringA) { _Pragma("unroll") for (int d = 0; d < 3; d++) { const double a1_ = x1[d], a2_ = x2[d]; iu_[3 * rrowA + d] = a1_; iv_[3 * rrowA + d] = a1_ - a2_; } } \
+        if (ringB) { _Pragma("unroll") for (int d = 0; d < 3; d++) { const double b1_ = SAME ? mn[d] : (double)rb1[d], b2_ = SAME ? accB[d] : (double)rb2[d]; iu_[3 * rrowB + d] = b1_; iv_[3 * rrowB + d] = b1_ - b2_; } } \
     }
 
     /* request plane p_ (1 .. np + 1) of the march, the ring ids of the plane after it and the coefficients of layer p_ - 1 */
