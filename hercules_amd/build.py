@@ -34,7 +34,7 @@ def build_solver(force=False):
         cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
                "-fvisibility=hidden", "-fopenmp", "-Wno-unused-value"] + \
               os.environ.get("HQ_EXTRA_FLAGS", "").split() + \
-              ["-o", SOLVER_LIB, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+              ["-o", SOLVER_LIB, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-Wl,-Bsymbolic", "-ldl"]
         subprocess.check_call(cmd, cwd=CSRC)
     return SOLVER_LIB
 
@@ -51,7 +51,7 @@ def build_solver_f32(force=False):
         cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DHQ_SINGLE_PRECISION_SOLVER",
                "-fvisibility=hidden", "-fopenmp", "-Wno-unused-value"] + \
               os.environ.get("HQ_EXTRA_FLAGS", "").split() + \
-              ["-o", SOLVER_LIB_F32, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+              ["-o", SOLVER_LIB_F32, srcs[0], "-Wl,-rpath,/opt/rocm/lib", "-Wl,-Bsymbolic", "-ldl"]
         subprocess.check_call(cmd, cwd=CSRC)
     return SOLVER_LIB_F32
 

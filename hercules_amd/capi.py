@@ -119,7 +119,10 @@ def load_library(path=None, precision="f64"):
     if not os.path.exists(p):
         raise HqError("native library %s is missing: run `python -m hercules_amd.build` "
                       "(there is no Python/CPU fallback)" % p)
-    lib = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    # libhq_solver.so and its _f32 build export the same names: only the fp64 one joins the global scope (libhq_host.so's
+    # references must never bind to the float build, whichever was loaded first); both are linked -Bsymbolic, so calls
+    # between their own entry points stay inside the library they belong to
+    lib = ctypes.CDLL(p, mode=ctypes.RTLD_LOCAL if os.path.basename(p) == os.path.basename(_LIBPATH_F32) else ctypes.RTLD_GLOBAL)
     lib.hq_last_error.restype = ctypes.c_char_p
     lib.hq_dominant_kernel.restype = ctypes.c_char_p
     lib.hq_dominant_kernel.argtypes = [ctypes.c_void_p]

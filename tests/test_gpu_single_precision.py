@@ -157,3 +157,43 @@ def test_small_lateral_basin_float_state_against_the_float_oracle():
         assert H.rel_linf(tm1.astype(np.float64), o2.astype(np.float64)) < TOL_STEPS
         assert H.rel_linf(tm2.astype(np.float64), o1.astype(np.float64)) < TOL_STEPS
     box.close()
+
+
+def test_the_two_libraries_keep_their_symbols_apart():
+    """libhq_solver.so and libhq_solver_f32.so export the same names.  In a fresh process that loads the FLOAT build first,
+    the C host side (libhq_host.so: hqh_solver_run calls hq_run / hq_gather / hq_download through its own references) must
+    still drive the fp64 library -- the float build never joins the global symbol scope, and both are linked -Bsymbolic."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+import hercules_amd as ha
+from hercules_amd import capi, host
+f32 = capi.load_library(precision="f32")                       # first in this process
+assert f32.hq_real_bytes() == 4
+box = host.Box(16, 16, 8, 62.5, 1e-3, 5.0)
+loaded, pattern = box.point_source(500.0, 500.0, 100.0, 0.0, 90.0, 0.0)
+rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e15, rise_time=0.02, source_window=32)
+F = box.source_table(rp, 0, 40)
+a = box.create_solver()
+box.solver_run(a, rp, 0, 40)                                   # libhq_host.so -> hq_* of the fp64 library
+t1, t2 = a.download()
+b = box.create_solver()
+b.set_source(loaded, F)
+b.run(40)                                                      # the same steps through ctypes
+u1, u2 = b.download()
+scale = np.abs(u1).max()
+assert t1.dtype == np.float64 and scale > 0, (t1.dtype, scale)
+assert np.isfinite(t1).all() and np.abs(t1 - u1).max() <= 1e-12 * scale and np.abs(t2 - u2).max() <= 1e-12 * scale, (np.abs(t1).max(), np.abs(t1 - u1).max(), scale)
+c = box.create_solver(precision="f32")                         # and the float library still is the float library
+c.set_source(loaded, F)
+c.run(40)
+w1, _ = c.download()
+assert w1.dtype == np.float32 and np.abs(w1.astype(np.float64) - u1).max() < 1e-5 * np.abs(u1).max()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:]
