@@ -2076,7 +2076,7 @@ static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl)
  * the unit, an entry of the unit's ring table or of its first / last plane's id list.
  * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}
  */
-static int64_t g_brick_check_extra[2];    /* the last check's ragged units and the nodes they own (hq_brick_plan_check_n) */
+static thread_local int64_t g_brick_check_extra[2];    /* the last check's ragged units and the nodes they own (hq_brick_plan_check_n) */
 
 extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
 {
