@@ -183,3 +183,19 @@ def lap_timer(name):
             sys.stderr.write("  [%s] %-40s %7.1f s\n" % (name, what, now - t[0]))
             t[0] = now
     return lap
+
+
+def two_material_leaves(nx=128, ny=32, nz=32, split=37, h=100.0):
+    """Leaves (pre-order) of a uniform nx x ny x nz box whose material changes at the element column i = split -- a material
+    boundary INSIDE a level that is not aligned with the 64-wide brick tiles: the tile that straddles it holds simple nodes
+    of two materials.  -> (elem_ticks, elem_edge, edata [E,4] = h, Vp, Vs, rho, far_ticks)"""
+    e = 1 << 23
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    order = np.argsort(ho.zvalue(i, j, k), kind="stable")
+    i, j, k = i[order], j[order], k[order]
+    ticks = (np.stack([i, j, k], 1).astype(np.int64) * e).astype(np.uint32)
+    edata = np.empty((len(i), 4), np.float32)
+    edata[:] = (h, 6000.0, 3464.0, 2700.0)
+    edata[i < split] = (h, 3000.0, 1732.0, 2200.0)
+    return ticks, np.full(len(i), e, np.uint32), edata, (nx * e, ny * e, nz * e)

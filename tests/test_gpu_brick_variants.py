@@ -183,3 +183,31 @@ def test_typed_options_select_kernels_per_context(monkeypatch):
     d = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH, options={"no_bricks": 0})
     assert d.info()["brick_nodes"] == 0 and d.options()["no_bricks"] == 1
     d.close()
+
+
+def test_two_materials_in_one_tile_footprint_against_the_oracle():
+    """tests/helpers.two_material_leaves: a material boundary inside one level, off the tile grid -- the footprints that
+    straddle it carry two ragged columns (HQ_BK_RAGGED), one per material; the boundary plane itself is the patches'.
+    Three steps from a seeded field against the oracle's reference loops, with and without ragged columns."""
+    from hercules_amd import host
+    ticks, edge, edata, far = H.two_material_leaves()
+    box = host.OctBox.from_leaves(ticks, edge, edata, far, 1e-3, 2.0)
+    xyz = box.node_xyz.astype(np.int64)
+    gid = (xyz[:, 2] * 1000003 + xyz[:, 1]) * 1000003 + xyz[:, 0]
+    u = np.empty((box.N, 3))
+    for d in range(3):
+        x = (gid * 3 + d + 7) * np.int64(2654435761) % np.int64(2 ** 31)
+        u[:, d] = (x.astype(np.float64) / 2 ** 30 - 1.0) * 1e-3
+    nsteps = 3
+    o1, o2 = (0.999 * u).copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt)
+    for ragged in (1, 0):
+        s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u, options={"brick_ragged": ragged})
+        info = s.info()
+        # (without ragged columns the 32-wide round and then the per-element units take what they can of the straddling tiles)
+        assert (info["brick_units_ragged"] >= 8) == bool(ragged) and (info["brick_units_het"] == 0) == bool(ragged)
+        s.run(nsteps)
+        tm1, tm2 = s.download()
+        s.close()
+        assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    box.close()

@@ -192,3 +192,20 @@ def test_ragged_brick_units_beside_lateral_level_interfaces(nranks, monkeypatch)
     assert tot[1]["ragged_units"] > 0 and tot[1]["ragged_nodes"] > 0.15 * (tot[1]["brick_nodes"] + tot[1]["patch_nodes"])
     assert tot[1]["patch_nodes"] < 0.6 * tot[0]["patch_nodes"]
     assert tot[1]["brick_nodes"] + tot[1]["patch_nodes"] == tot[0]["brick_nodes"] + tot[0]["patch_nodes"]
+
+
+def test_ragged_columns_of_two_materials_share_a_footprint():
+    """A material boundary inside one level, off the tile grid (element column 37 of a 128 x 32 x 32 box): the 64 x 8
+    footprints that straddle it hold simple nodes of TWO materials -- two ragged columns per footprint, one material and one
+    n_t row each (the planner's second and later passes over a tile); the nodes ON the boundary plane stay with the patches.
+    hq_brick_plan_check compares every owned node's eight elements with its unit's coefficients."""
+    from tests import helpers as H
+    ticks, edge, edata, far = H.two_material_leaves()
+    box = host.OctBox.from_leaves(ticks, edge, edata, far, 1e-3, 2.0)
+    rep = box.brick_plan_check()
+    box.close()
+    assert rep["faults"] == 0 and rep["het_units"] == 0
+    # x = 1 .. 36 of the one material and 38 .. 64 of the other, in every one of the 31 x 31 interior rows and planes
+    assert rep["ragged_nodes"] == (36 + 27) * 31 * 31 and rep["ragged_units"] >= 8
+    # ... beside the full tiles of x = 65 .. 127 (with the z faces of their columns: 33 planes)
+    assert rep["brick_nodes"] == rep["ragged_nodes"] + 63 * 31 * 33
