@@ -28,15 +28,17 @@ def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin, 
     nodes, inv = np.unique(lnid[elems], return_inverse=True)
     lnid_w = inv.reshape(-1, 8).astype(np.int32)
     ids, ptr, anchors = dangling
-    pos = np.full(int(max(nodes.max(), ids.max() if len(ids) else 0)) + 2, -1, np.int64)
-    pos[nodes] = np.arange(len(nodes))
-    sel = np.nonzero(pos[np.minimum(ids, len(pos) - 1)] >= 0)[0] if len(ids) else np.zeros(0, np.int64)
+
+    def pos(v):                      # place of the mesh's nodes v among the window's (sorted) nodes, -1 where absent
+        v = np.asarray(v)            # (a search, not a table over all nodes of a 100 M-element mesh per window)
+        i = np.minimum(np.searchsorted(nodes, v), len(nodes) - 1)
+        return np.where(nodes[i] == v, i, -1).astype(np.int64)
+    sel = np.nonzero(pos(ids) >= 0)[0] if len(ids) else np.zeros(0, np.int64)
     w_ids, w_ptr, w_anc = [], [0], []
     for k in sel:
-        a = anchors[ptr[k]:ptr[k + 1]]
-        la = pos[np.minimum(a, len(pos) - 1)]
+        la = pos(anchors[ptr[k]:ptr[k + 1]])
         assert (la >= 0).all(), "a hanging node of the window has an anchor outside it: window not aligned to the coarse grid"
-        w_ids.append(pos[ids[k]])
+        w_ids.append(int(pos(ids[k:k + 1])[0]))
         w_anc += [int(v) for v in la]
         w_ptr.append(len(w_anc))
     dom_hi = node_xyz.max(axis=0).astype(np.int64)
@@ -95,10 +97,11 @@ def lateral_windows(node_xyz, dangling, elem_lo, elem_edge, k, per_kind=1, seed=
             c = 2 * int(key[1])
             # ONE pass over the mesh per window: the elements that can lie in the largest window this node may get
             reach = 2 * k * A + 2 * A
-            near = np.ones(len(elem_edge), bool)
-            for d in range(3):
-                near &= (elem_lo[:, d] >= q[d] - reach - A) & (elem_lo[:, d] <= q[d] + reach)
-            cand = np.nonzero(near)[0]
+            # (the slab in x over the whole mesh, then y and z on what is left of it)
+            cand = np.nonzero((elem_lo[:, 0] >= q[0] - reach - A) & (elem_lo[:, 0] <= q[0] + reach))[0]
+            for d in (1, 2):
+                v = elem_lo[cand, d]
+                cand = cand[(v >= q[d] - reach - A) & (v <= q[d] + reach)]
             c_lo = elem_lo[cand].astype(np.int64)
             c_hi = c_lo + elem_edge[cand].astype(np.int64)[:, None]
             for _ in range(3):
