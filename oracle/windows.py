@@ -17,7 +17,7 @@ def octree_window(lnid, node_xyz, dangling, elem_lo, elem_edge, lo, hi, margin, 
     on the window gives the exact values of those nodes."""
     lo, hi = np.asarray(lo, np.int64), np.asarray(hi, np.int64)
     if cand is None:                                            # (cand: elements known to hold every element of the window)
-        cand = np.arange(len(elem_edge))
+        cand = np.nonzero((elem_lo[:, 0] >= lo[0]) & (elem_lo[:, 0] < hi[0]))[0]   # the x slab; y, z and the edges below
     c_lo, c_edge = elem_lo[cand], elem_edge[cand]
     inside = np.ones(len(cand), bool)
     for d in range(3):
