@@ -698,8 +698,18 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
                               const int32_t* xyz, const hq_dangling& dn, bool want_lattice, hq_patch_host* H, int64_t n0 = 0,
                               std::vector<int32_t>* cand_cache = nullptr)
 {
+    /* HQ_PATCH_VERBOSE >= 3: where the planner's own time goes */
+    const bool lap_on = hq_opt_int("HQ_PATCH_VERBOSE", 0) > 2;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!lap_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "    patch planner: %-30s %6.3f s\n", what, std::chrono::duration<double>(now - lap_t).count());
+        lap_t = now;
+    };
     std::vector<int32_t> cuts;
     hq_patch_cuts(cfg, N, xyz, cuts, n0);
+    lap("cuts");
     /* hanging nodes: dn_of[n] = index into the dangling table or -1 */
     std::vector<int32_t> dn_of;
     if (dn.n > 0) {
@@ -719,6 +729,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
     }
     const int64_t NE = cand ? (int64_t)cand->size() : E;
     auto elem_at = [&](int64_t i) -> int64_t { return cand ? (int64_t)(*cand)[(size_t)i] : i; };
+    lap("hanging-node table, candidates");
 
     for (int attempt = 0; attempt < 12; attempt++) {
         int32_t P = (int32_t)cuts.size() - 1;
@@ -753,6 +764,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
         }
         for (int32_t p = 0; p < P; p++) off[p + 1] += off[p];
         int64_t npairs = off[P];
+        lap("patch_of, pair counts");
         H->pelem.assign((size_t)npairs, 0);
         {
             std::vector<int64_t> fill(off.begin(), off.end() - 1);
@@ -764,6 +776,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
             }
         }
 
+        lap("pair lists");
         /* halo lists */
         std::vector<int64_t> hoff((size_t)P + 1, 0);
         std::vector<std::vector<int32_t>> halos((size_t)P);
@@ -799,6 +812,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
                 bad[p] = 1;
         }
         for (int32_t p = 0; p < P; p++) any_bad |= (bad[p] != 0);
+        lap("halo lists");
         if (any_bad) {
             std::vector<int32_t> nc;
             for (int32_t p = 0; p < P; p++) {
@@ -865,6 +879,7 @@ static int hq_patch_plan_host(const hq_patch_cfg& cfg, int64_t E, int64_t N, con
                 }
             }
         }
+        lap("element rows");
         /* regular regions repeat one local connectivity: a patch whose rows equal those of an
          * earlier patch reads that patch's rows (which then stay in L2) instead of its own */
         {
