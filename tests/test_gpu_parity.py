@@ -324,6 +324,28 @@ def test_two_level_mesh_with_hanging_nodes_against_reference(variant, mesh):
     s.close()
 
 
+def test_ragged_tile_columns_on_the_references_lateral_mesh_against_its_checkpoints():
+    """c5_basin -- the mesh the REAL reference refined laterally, hanging nodes of every orientation -- with the planner's
+    thresholds lowered (hq_options: 12 nodes per plane, 48 per column, 2 planes) until this 5 429-element mesh carries ragged
+    tile columns (HQ_BK_RAGGED) beside its x-, y- and z-normal level interfaces: against the reference's own checkpoints."""
+    p = H.c5_problem("c5_basin")
+    g = p["golden"]
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"], variant=ha.HQ_VARIANT_PATCH,
+                  node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32),
+                  options={"brick_ragged_minfill": 12, "brick_minnodes": 48, "brick_minz": 2})
+    import os
+    assert s.info()["brick_units_ragged"] >= (0 if os.environ.get("HQ_NO_BRICKS") else 2)      # (this file runs twice: see its fixture)
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL
+        assert H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("shape", [(64, 64, 8, 12), (128, 96, 16, 20)])
 def test_larger_two_level_meshes_against_oracle(variant, shape):

@@ -209,3 +209,25 @@ def test_ragged_columns_of_two_materials_share_a_footprint():
     assert rep["ragged_nodes"] == (36 + 27) * 31 * 31 and rep["ragged_units"] >= 8
     # ... beside the full tiles of x = 65 .. 127 (with the z faces of their columns: 33 planes)
     assert rep["brick_nodes"] == rep["ragged_nodes"] + 63 * 31 * 33
+
+
+def test_ragged_columns_on_the_references_own_lateral_mesh(monkeypatch):
+    """tests/golden/c5_basin (meshed by the real reference: three levels, hanging nodes of all six kinds) with the planner's
+    thresholds lowered until this small mesh carries ragged tile columns beside its level interfaces: every owned node's 26
+    neighbours through the id tables, none of them a hanging node or an anchor."""
+    from hercules_amd import capi
+    from tests import helpers as H
+    p = H.c5_problem("c5_basin")
+    for k, v in (("HQ_BRICK_RAGGED_MINFILL", "12"), ("HQ_BRICK_MINNODES", "48"), ("HQ_BRICK_MINZ", "2")):
+        monkeypatch.setenv(k, v)
+    lnid, et, nt = [np.ascontiguousarray(a) for a in (p["lnid"].astype(np.int32), p["etable"], p["ntable"])]
+    xyz = (p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32)
+    ids, ptr, anc = [np.ascontiguousarray(x, np.int32) for x in p["dangling"]]
+    d = capi._Desc()
+    d.lenum, d.nharbored, d.ldnnum = len(lnid), len(nt), len(ids)
+    d.lnid, d.eTable, d.nTable, d.node_xyz = capi._ptr(lnid), capi._ptr(et), capi._ptr(nt), capi._ptr(xyz)
+    d.dn_ldnid, d.dn_ptr, d.dn_lanid = capi._ptr(ids), capi._ptr(ptr), capi._ptr(anc)
+    d.deltaT, d.rank, d.nranks = 1e-3, 0, 1
+    rep = capi.brick_plan_check(d)
+    assert rep["faults"] == 0 and rep["ragged_units"] >= 2 and rep["ragged_nodes"] > 500
+    assert rep["brick_nodes"] + rep["patch_nodes"] == p["N"]
