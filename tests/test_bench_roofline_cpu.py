@@ -241,3 +241,44 @@ def test_octree_parity_windows_of_the_bench_line_against_a_whole_mesh_oracle():
     assert nwin >= 4 and nchecked > 1000 and worst < 1e-12
     assert bench.parity_windows(argparse.Namespace(workload="o4s"), box, None, 0, 2) is None     # partitions: no windows
     box.close()
+
+
+def test_parity_windows_of_a_single_precision_line(monkeypatch):
+    """bench.parity_windows with `--precision f32`: the stand-in keeps a FLOAT state and steps the whole box with the
+    oracle's float build on the n_t rows rounded to float (what host._solver_from_desc hands libhq_solver_f32.so); the
+    windows must use the same build, tables and start values -- agreement to rounding, tolerance 2e-6 in the line."""
+    import argparse
+    import numpy as np
+    import bench
+    from hercules_amd import host
+    from oracle import herc_oracle as ho
+    monkeypatch.setitem(bench.WORKLOADS, "c1", (128, 32, 32, 62.5, 1e-3, 5.0))
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS["c1"]
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    nt32 = np.ascontiguousarray(box.ntable, np.float32)
+
+    class FloatBoxOracle:
+        def set_source(self, ids, F):
+            assert len(ids) == 0
+
+        def upload(self, tm1, tm2, step):                       # (capi.Solver.upload casts to the library's hq_real)
+            self.u1, self.u2 = np.ascontiguousarray(tm1, np.float32), np.ascontiguousarray(tm2, np.float32)
+
+        def run(self, k):
+            o1, o2 = self.u2.copy(), self.u1.copy()
+            ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, k, dt)
+            self.u1, self.u2 = o2, o1
+
+        def sync(self):
+            pass
+
+        def gather(self, ids):
+            return self.u1[ids], self.u2[ids]
+
+    args = argparse.Namespace(workload="c1", precision="f32")
+    nwin, nchecked, worst = bench.parity_windows(args, box, FloatBoxOracle(), 0, 1)
+    assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-6 and bench.parity_tol(args) == 2e-6
+    assert bench.parity_tol(argparse.Namespace(workload="c1", precision="f64")) == 1e-9
+    # an octree workload has no float windows (reported as null)
+    assert bench.parity_windows(argparse.Namespace(workload="o3", precision="f32"), box, FloatBoxOracle(), 0, 1) is None
+    box.close()
