@@ -661,7 +661,7 @@ def parity_windows(args, box, solver, rank, world):
     single = getattr(args, "precision", "f64") == "f32"
     real = np.float32 if single else np.float64
     if args.workload in OCT_COARSE_LAYERS or args.workload in OCT_LAYERED or args.workload in OCT_BASIN:
-        return parity_windows_octree(args, box, solver) if (world == 1 and not single) else None
+        return parity_windows_octree(args, box, solver) if world == 1 else None
     if args.workload not in PARITY_WORKLOADS:
         return None
     from hercules_amd import host as hhost
@@ -751,13 +751,18 @@ def parity_windows_octree(args, box, solver):
     kinds = sorted(set(zip(mask.tolist(), dist.tolist())))
     pick = [kinds[i] for i in np.unique(np.linspace(0, len(kinds) - 1, PARITY_OCTREE_WINDOWS).astype(int))]
     scale = np.abs(u1).max()
+    # (--precision f32: the oracle's float build on the values and rows the context was handed -- rounded to float)
+    real = np.float32 if getattr(args, "precision", "f64") == "f32" else np.float64
+    w1, w2 = u1.astype(real), (u1 * (1.0 - 1e-3)).astype(real)
+    ntab = np.ascontiguousarray(box.ntable, real)
     nwin, nchecked, worst = 0, 0, 0.0
     for lo, hi, margin, centre, cand in ow.lateral_windows(xyz, box.dangling, elem_lo, elem_edge, k, per_kind=1, kinds=set(pick)):
         win = ow.octree_window(box.lnid, xyz, box.dangling, elem_lo, elem_edge, lo, hi, margin, cand)
-        g1, g2 = ow.octree_window_oracle(win, box.etable, box.ntable, u1, 1.0 - 1e-3, k, box.dt)
+        g1, g2 = ow.octree_window_oracle(win, box.etable, ntab, w1, w2, k, box.dt)
         ok, nodes = win["ok"], win["nodes"]
         tm1, tm2 = solver.gather(nodes[ok])
-        worst = max(worst, float(np.abs(tm1 - g1[ok]).max() / scale), float(np.abs(tm2 - g2[ok]).max() / scale))
+        worst = max(worst, float(np.abs(tm1.astype(np.float64) - g1[ok]).max() / scale),
+                    float(np.abs(tm2.astype(np.float64) - g2[ok]).max() / scale))
         nwin += 1
         nchecked += int(ok.sum())
     return nwin, nchecked, worst

@@ -240,6 +240,22 @@ def test_octree_parity_windows_of_the_bench_line_against_a_whole_mesh_oracle():
     nwin, nchecked, worst = bench.parity_windows(argparse.Namespace(workload="o4s"), box, WholeMeshOracle(), 0, 1)
     assert nwin >= 4 and nchecked > 1000 and worst < 1e-12
     assert bench.parity_windows(argparse.Namespace(workload="o4s"), box, None, 0, 2) is None     # partitions: no windows
+
+    # --precision f32: a float state stepped by the oracle's float build (compute_adjust on floats) on the rounded n_t rows
+    import numpy as np
+    nt32 = np.ascontiguousarray(box.ntable, np.float32)
+
+    class FloatMeshOracle(WholeMeshOracle):
+        def upload(self, tm1, tm2, step):
+            self.u1, self.u2 = np.ascontiguousarray(tm1, np.float32), np.ascontiguousarray(tm2, np.float32)
+
+        def run(self, k):
+            o1, o2 = self.u2.copy(), self.u1.copy()
+            ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, k, box.dt, dangling=box.dangling)
+            self.u1, self.u2 = o2, o1
+
+    nwin, nchecked, worst = bench.parity_windows(argparse.Namespace(workload="o4s", precision="f32"), box, FloatMeshOracle(), 0, 1)
+    assert nwin >= 4 and nchecked > 1000 and worst < 1e-6
     box.close()
 
 
@@ -279,6 +295,6 @@ def test_parity_windows_of_a_single_precision_line(monkeypatch):
     nwin, nchecked, worst = bench.parity_windows(args, box, FloatBoxOracle(), 0, 1)
     assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-6 and bench.parity_tol(args) == 2e-6
     assert bench.parity_tol(argparse.Namespace(workload="c1", precision="f64")) == 1e-9
-    # an octree workload has no float windows (reported as null)
-    assert bench.parity_windows(argparse.Namespace(workload="o3", precision="f32"), box, FloatBoxOracle(), 0, 1) is None
+    # a PARTITION of an octree workload carries no windows in either precision (reported as null)
+    assert bench.parity_windows(argparse.Namespace(workload="o3", precision="f32"), box, FloatBoxOracle(), 0, 2) is None
     box.close()
