@@ -488,10 +488,11 @@ def multi_rank_init(parts, edata_by_rank, face_by_rank, dt, freq, **kw):
 def multi_rank_run(parts, ets, nts, tm1s, tm2s, step0, nsteps, dt, loaded, forces):
     """solver_run (psolve.c:4265-4319) for all ranks in lockstep; tm1s/tm2s are the
     reference's pre-swap arrays per rank, updated in place."""
-    L = lib()
+    real = tm1s[0].dtype                  # solver_float: the records of every exchange have it (psolve.c:4985-5073)
+    L = lib(real)
     K1, K2 = compute_K()
     c64 = ctypes.c_int64
-    frc = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    frc = [np.zeros((len(p["nodes"]), 3), real) for p in parts]
     a = [t for t in tm1s]
     b = [t for t in tm2s]
     for step in range(step0, step0 + nsteps):

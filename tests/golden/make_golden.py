@@ -426,11 +426,12 @@ def case_basin():
     _octree_case("c5_basin", "0.3", 100, BASIN_CVM, 100, 5.0)
 
 
-def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq):
+def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, freq, single=False):
     """The same octree models on `nranks` MPI ranks: per-rank element dumps, force files and
     checkpoint stripes pin octor's multi-rank tables (block partition, ownership by containing
     leaf, direct + indirect sharing octor.c:5516-6040, dnodeTable of owned hanging nodes)."""
-    run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq, nranks=nranks)
+    run, out = run_reference(name, end_time, ckpt_rate, cvm_args=cvm_args, vscut=vscut, freq=freq, nranks=nranks, single=single)
+    real, row = ("<f4", 12) if single else ("<f8", 24)          # -DSINGLE_PRECISION_SOLVER: rows of three floats
     # A rank's stripe holds nharbored (not nharboredmax) records per field, so the raw stripes
     # are kept and parsed by whoever knows each rank's nharbored (io_checkpoint.c:93-118).
     ckfiles = {}
@@ -438,7 +439,7 @@ def case_octree_np(name, base, nranks, end_time, ckpt_rate, cvm_args, vscut, fre
     for f in ("checkpoint.out0", "checkpoint.out1"):
         b = open(os.path.join(run, "out", "checkpoints", f), "rb").read()
         groupsize, step, nmax = [int(v) for v in np.frombuffer(b[:12], "<i4")]
-        ckfiles[step] = [np.frombuffer(b[12 + 2 * r * nmax * 24: 12 + 2 * (r + 1) * nmax * 24], "<f8").copy()
+        ckfiles[step] = [np.frombuffer(b[12 + 2 * r * nmax * row: 12 + 2 * (r + 1) * nmax * row], real).copy()
                          for r in range(groupsize)]
     arrays = {"nharboredmax": nmax}
     for r in range(nranks):
@@ -508,6 +509,10 @@ CASES = {
     "c1_f32": lambda: case_single("c1_f32", "1.0", 400),
     "c1_conv_f32": lambda: case_single("c1_conv_f32", "0.5", 200, stiffness="conventional"),
     "c5_two_level_f32": lambda: case_single("c5_two_level_f32", "0.5", 200, [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
+    # ... and on 8 MPI ranks: the reference's exchanges of float records (schedule_senddata on solver_float, psolve.c:4985-5073),
+    # the mass exchange on float n_t rows at init, shared hanging nodes
+    "c5_two_level_np8_f32": lambda: case_octree_np("c5_two_level_np8_f32", "c5_two_level", 8, "0.3", 100,
+                                                   [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0, single=True),
     # (a 5-rank run of the three-level mesh was tried and is NOT a fixture: on 5 ranks the
     #  reference's mesher refines that model uniformly, so it pins nothing the others do not)
 }

@@ -97,7 +97,7 @@ def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), ha
                 N=N, E=E, dt=dt, emin=1, mesh=m)
 
 
-def c5_np8_problem(name="c5_two_level_np8"):
+def c5_np8_problem(name="c5_two_level_np8", real=np.float64):
     """One of the reference's octree meshes on several MPI ranks (c5_two_level_np8; c5_basin_np8 /
     c5_basin_np5: the laterally refined basin): octor's per-rank tables restated
     from the global view (ho.octree_partition), per-rank eTable / nTable after the mass
@@ -116,7 +116,7 @@ def c5_np8_problem(name="c5_two_level_np8"):
     edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
     eds = [np.ascontiguousarray(edata[p["elems"]]) for p in parts]
     fcs = [np.ascontiguousarray(m["face"][p["elems"]]) for p in parts]
-    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, float(base["freq"]))
+    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, float(base["freq"]), real=real)
     return dict(golden=g, base=base, mesh=m, parts=parts, ets=ets, nts=nts, dt=1e-3, nranks=nranks, edata=edata,
                 loaded=[g["loaded_lnid_%d" % r] for r in range(nranks)],
                 forces=[g["forces_%d" % r] for r in range(nranks)])

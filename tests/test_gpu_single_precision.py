@@ -197,3 +197,37 @@ print("ok")
     out = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          universal_newlines=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("variant", [ha.HQ_VARIANT_SCATTER, ha.HQ_VARIANT_PATCH])
+def test_eight_partitions_against_the_float_references_eight_rank_stripes(variant):
+    """The float reference ran its two-level octree on 8 MPI ranks (tests/golden/c5_two_level_np8_f32: hanging nodes shared
+    between ranks, float records in all four exchanges, the mass exchange on float n_t rows): eight float contexts in one
+    process (in-process transport; the records travel as doubles and are rounded where the reference's land) against its
+    per-rank checkpoint stripes, relative to the field's scale."""
+    from hercules_amd import capi
+    pr = H.c5_np8_problem("c5_two_level_np8_f32", real=np.float32)
+    g, parts, mesh = pr["golden"], pr["parts"], pr["mesh"]
+    solvers = []
+    for p in parts:
+        r = p["rank"]
+        s = ha.Solver(p["lnid"], pr["ets"][r], pr["nts"][r], pr["dt"], dangling=p["dangling"], an_sched=p["an_sched"],
+                      dn_sched=p["dn_sched"], rank=r, nranks=pr["nranks"], variant=variant,
+                      node_xyz=mesh["node_q"][p["nodes"]], precision="f32")
+        if len(pr["loaded"][r]):
+            s.set_source(pr["loaded"][r], pr["forces"][r])
+        solvers.append(s)
+    capi.group_link(solvers)
+    done = 0
+    for step in g["ckpt_steps"]:
+        capi.group_run(solvers, int(step) - done)
+        done = int(step)
+        stripes = [H.np8_stripe(g, step, p["rank"], len(p["nodes"])) for p in parts]
+        scale = max(float(np.abs(ref1).max()) for _, ref1 in stripes)
+        for (ref2, ref1), s in zip(stripes, solvers):
+            tm1, tm2 = s.download()
+            assert tm1.dtype == np.float32
+            assert np.abs(tm1.astype(np.float64) - ref1).max() <= TOL_RUN * scale
+            assert np.abs(tm2.astype(np.float64) - ref2).max() <= TOL_RUN * scale
+    for s in solvers:
+        s.close()
