@@ -81,7 +81,8 @@ def main():
         s = ha.Solver(b.lnid, b.etable, b.ntable, b.dt, tm1=g1[gid], tm2=g2[gid], node_xyz=b.node_xyz, dangling=b.dangling,
                       an_sched=sch["an"], dn_sched=sch["dn"], rank=rank, nranks=world, variant=ha.HQ_VARIANT_PATCH)
     else:
-        s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid])
+        # HQ_TEST_PRECISION=f32: libhq_solver_f32.so -- a float state on every rank, the records still travel as doubles
+        s = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=g1[gid], tm2=g2[gid], precision=os.environ.get("HQ_TEST_PRECISION", "f64"))
     if os.environ.get("HQ_TEST_TRANSPORT", "host") == "ipc":
         # device-to-device between the processes: blobs all-gathered over gloo (MPI_Allgather in the reference's world)
         mine = torch.frombuffer(bytearray(s.comm_ipc_export()), dtype=torch.uint8)

@@ -79,6 +79,37 @@ def test_ranks_in_their_own_processes_on_one_gpu_uniform_box(tmp_path, world, ov
         assert all(int(z["ipc_arena_coarse"]) == 0 and int(z["ipc_arena_kind"]) == 0 for z in parts)
 
 
+@pytest.mark.parametrize("transport", ["ipc", "host"])
+def test_float_state_between_processes(tmp_path, transport):
+    """libhq_solver_f32.so on ranks in their own processes: the templated forms of the chain's kernels on a float table
+    (pack to the peers / to the staging buffers, the interface update with the sharing fused in, the IPC unpack) with the
+    check words of hq_options.debug_halo on -- against the oracle's float build on the rounded n_t rows, tolerance as in
+    tests/test_gpu_single_precision.py."""
+    nx, ny, nz, h, dt, freq, nsteps = 64, 64, 32, 15.0, 3e-4, 30.0, 20
+    parts = _launch(tmp_path, 2, "box", nsteps, {"HQ_OVERLAP": "1", "HQ_TEST_TRANSPORT": transport, "HQ_TEST_PRECISION": "f32",
+                                                 "HQ_DEBUG_HALO": "1"})
+    from hercules_amd import host
+    b = host.Box(nx, ny, nz, h, dt, freq)
+    ijk = b.node_ijk.astype(np.int64)
+    gid = (ijk[:, 2] * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    Ng = (nx + 1) * (ny + 1) * (nz + 1)
+    rng = np.random.default_rng(4321)
+    g1 = rng.uniform(-1, 1, (Ng, 3)) * 1e-3
+    g2 = g1 + rng.uniform(-1, 1, (Ng, 3)) * 1e-6
+    loaded, pattern = b.point_source(nx * h / 2 + 3.0, ny * h / 2 - 2.0, nz * h / 3, 30.0, 70.0, 10.0)
+    rp = b.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=10 * dt)
+    F = b.source_table(rp, 0, nsteps)
+    o1, o2 = g2[gid].astype(np.float32), g1[gid].astype(np.float32)
+    ho.solver_run(b.lnid, b.etable.copy(), np.ascontiguousarray(b.ntable, np.float32), o1, o2, 0, nsteps, dt, loaded_lnid=loaded, forces=F)
+    ref1, ref2 = np.zeros((Ng, 3)), np.zeros((Ng, 3))
+    ref1[gid], ref2[gid] = o2, o1
+    b.close()
+    for z in parts:
+        assert z["tm1"].dtype == np.float32 and int(z["debug_halo"]) == 1
+        assert H.rel_linf(z["tm1"].astype(np.float64), ref1[z["gid"]]) < 2e-5 and H.rel_linf(z["tm2"].astype(np.float64), ref2[z["gid"]]) < 2e-5
+        assert int(z["transport"]) == (2 if transport == "ipc" else 3)
+
+
 @pytest.mark.parametrize("transport,env", [("ipc", {"HQ_NO_FUSED_SHARE": "1", "HQ_PATCH_MERGE_ROUNDS": "0"}),
                                            ("host", {"HQ_NO_FUSED_SHARE": "1"}), ("ipc", {"HQ_IPC_COARSE": "1"}),
                                            ("ipc", {"HQ_BRICK_BY_COMPONENT": "0", "HQ_BRICK_STREAM": "1"})])
