@@ -67,7 +67,10 @@ class _Info(ctypes.Structure):
                 ("brick_units_het", ctypes.c_int32), ("pcie_h2d_bytes", ctypes.c_int64),
                 ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
                 ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32),
-                ("brick_units_packed", ctypes.c_int32), ("brick_units_ragged", ctypes.c_int32)]
+                ("brick_units_packed", ctypes.c_int32), ("brick_units_ragged", ctypes.c_int32),
+                ("brick_stream", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("timed_steps", ctypes.c_int64),
+                ("t_step_us", ctypes.c_double), ("t_shell_us", ctypes.c_double), ("t_interior_us", ctypes.c_double),
+                ("t_chain_us", ctypes.c_double), ("t_chain_exposed_us", ctypes.c_double)]
 
 
 # hq_options (include/hq_solver.h): int32 fields in the header's order, two doubles, two more int32
@@ -83,7 +86,8 @@ class Options(ctypes.Structure):
     _fields_ = ([("size", ctypes.c_uint64)] + [(n, ctypes.c_int32) for n in OPTION_FIELDS] +
                 [("ipc_timeout_ms", ctypes.c_double), ("loopback_delay_us", ctypes.c_double),
                  ("verbose", ctypes.c_int32), ("quiet", ctypes.c_int32),
-                 ("brick_ragged", ctypes.c_int32), ("brick_ragged_minfill", ctypes.c_int32)])
+                 ("brick_ragged", ctypes.c_int32), ("brick_ragged_minfill", ctypes.c_int32),
+                 ("allow_env", ctypes.c_int32), ("phase_timing", ctypes.c_int32)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -99,7 +103,9 @@ class Options(ctypes.Structure):
 
 _lib = None
 _lib_f32 = None
-_LIBPATH_F32 = os.path.join(os.path.dirname(_LIBPATH), "libhq_solver_f32.so")
+# the float build stays anchored in the package (HQ_SOLVER_LIB names an experiment build of the fp64 library only);
+# HQ_SOLVER_LIB_F32 names an experiment build of the float one
+_LIBPATH_F32 = os.environ.get("HQ_SOLVER_LIB_F32") or os.path.join(_HERE, "csrc", "libhq_solver_f32.so")
 
 
 def load_library(path=None, precision="f64"):
@@ -122,7 +128,9 @@ def load_library(path=None, precision="f64"):
     # libhq_solver.so and its _f32 build export the same names: only the fp64 one joins the global scope (libhq_host.so's
     # references must never bind to the float build, whichever was loaded first); both are linked -Bsymbolic, so calls
     # between their own entry points stay inside the library they belong to
-    lib = ctypes.CDLL(p, mode=ctypes.RTLD_LOCAL if os.path.basename(p) == os.path.basename(_LIBPATH_F32) else ctypes.RTLD_GLOBAL)
+    # (which of the two a file is, is asked of the file -- hq_real_bytes -- not read off its name)
+    probe = ctypes.CDLL(p, mode=ctypes.RTLD_LOCAL)
+    lib = probe if probe.hq_real_bytes() == 4 else ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
     lib.hq_last_error.restype = ctypes.c_char_p
     lib.hq_dominant_kernel.restype = ctypes.c_char_p
     lib.hq_dominant_kernel.argtypes = [ctypes.c_void_p]
@@ -235,7 +243,7 @@ class Solver:
         return {k: getattr(i, k) for k, _ in _Info._fields_}
 
     def options(self):
-        """hq_get_options: what the context runs with (its options with the environment's overrides applied)."""
+        """hq_get_options: what the context runs with, as resolved at hq_create_opts."""
         o = Options()
         _check(self._lib.hq_get_options(self._h, ctypes.byref(o), ctypes.c_uint64(ctypes.sizeof(o))), self._lib)
         return o.as_dict()

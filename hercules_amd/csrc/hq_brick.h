@@ -634,6 +634,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         coff[u + 1] = coff[u] + (cols[(size_t)us[u].col].het ? (int64_t)(us[u].np + 1) * HQ_BH_THREADS * 3 : 0);
     B->coef.assign((size_t)coff[us.size()] + 8, 0.0);
     const bool try_pack = MS && MS->edata && MS->dt > 0 && !hq_opt_flag("HQ_BRICK_NO_PACK");
+    const bool no_ntsame = hq_opt_flag("HQ_BRICK_NO_NTSAME");     /* read here: the workers of the loop below see no options (hq_opts.h) */
     if (try_pack) { B->coef32.assign((size_t)coff[us.size()] + 8, 0.0f); B->nt2.assign(2 * (size_t)N, 0.0); }        /* [N]: a unit also LOADS the rows of its two cap planes, which may be anybody's nodes */
     int fault = 0;                                       /* written by many threads: atomic writes only */
     auto set_fault = [&]() {
@@ -748,7 +749,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                     const double* q = ntab + 7 * (int64_t)n;
                     if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) { sm = false; break; }
                 }
-        if (sm && !c.het && !hq_opt_flag("HQ_BRICK_NO_NTSAME")) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
+        if (sm && !c.het && !no_ntsame) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
         U.m0 = q0[0]; U.m2 = q0[1]; U.m1 = q0[4];
         U.coef = 0;
         if (c.het) {

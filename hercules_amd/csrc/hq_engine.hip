@@ -69,21 +69,26 @@ extern "C" const char* hq_last_error(void) { return g_err; }
 /* RCCL, resolved lazily so that single-GPU use never loads it              */
 /* ------------------------------------------------------------------------ */
 
-typedef struct { char internal[128]; } hq_nccl_id;
-typedef void* hq_nccl_comm;
+/* The prototypes, the id's size and the datatype enumerators are rccl.h's OWN (compile time); only the library is
+ * looked up at run time.  A header that moved an enumerator or changed a signature breaks the build, not a halo. */
+#include <rccl/rccl.h>
+typedef ncclUniqueId hq_nccl_id;
+typedef ncclComm_t hq_nccl_comm;
 struct hq_rccl {
     void* handle;
-    int (*GetUniqueId)(hq_nccl_id*);
-    int (*CommInitRank)(hq_nccl_comm*, int, hq_nccl_id, int);
-    int (*CommDestroy)(hq_nccl_comm);
-    int (*Send)(const void*, size_t, int, int, hq_nccl_comm, hipStream_t);
-    int (*Recv)(void*, size_t, int, int, hq_nccl_comm, hipStream_t);
-    int (*GroupStart)(void);
-    int (*GroupEnd)(void);
-    const char* (*GetErrorString)(int);
+    decltype(&ncclGetUniqueId) GetUniqueId;
+    decltype(&ncclCommInitRank) CommInitRank;
+    decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclSend) Send;
+    decltype(&ncclRecv) Recv;
+    decltype(&ncclGroupStart) GroupStart;
+    decltype(&ncclGroupEnd) GroupEnd;
+    decltype(&ncclGetErrorString) GetErrorString;
 };
 static hq_rccl g_rccl = {};
-enum { HQ_NCCL_INT64 = 4, HQ_NCCL_DOUBLE = 8 };   /* ncclInt64, ncclFloat64: rccl.h ncclDataType_t */
+static const ncclDataType_t HQ_NCCL_INT64 = ncclInt64, HQ_NCCL_DOUBLE = ncclFloat64;
+static_assert(sizeof(hq_nccl_id) == 128, "hq_comm_unique_id hands out 128 bytes (include/hq_solver.h)");
+static_assert(sizeof(double) == 8 && sizeof(int64_t) == 8, "halo records are ncclFloat64, check words ncclInt64");
 
 static int hq_rccl_load(void)
 {
@@ -109,8 +114,8 @@ static int hq_rccl_load(void)
 
 #define HQ_NCCL(call)                                                                     \
     do {                                                                                  \
-        int r_ = (call);                                                                  \
-        if (r_ != 0) return hq_fail(HQ_ERR_COMM, "%s: %s", #call, g_rccl.GetErrorString(r_)); \
+        ncclResult_t r_ = (call);                                                         \
+        if (r_ != ncclSuccess) return hq_fail(HQ_ERR_COMM, "%s: %s", #call, g_rccl.GetErrorString(r_)); \
     } while (0)
 
 /* ------------------------------------------------------------------------ */
@@ -247,6 +252,16 @@ struct hq_ctx {
     int64_t* d_gkey = nullptr;        /* [N] global identity of every harbored node          */
     int32_t* d_halo_err = nullptr;    /* [4] records whose identity did not match; non-finite values seen by hq_check_finite;
                                        * [2] IPC waits that timed out */
+    /* device-side phase split (hq_options.phase_timing; every hq_run_timed batch): per step six events -- step start,
+     * shell end, interior start / end, chain start / end -- in a ring of slots harvested when they are reused or asked for
+     * (hq_info.t_*_us: the library's print_timing_stat, psolve.c:6041-6266) */
+    enum { HQ_CLK_STEP0 = 0, HQ_CLK_SHELL1, HQ_CLK_INT0, HQ_CLK_INT1, HQ_CLK_CHAIN0, HQ_CLK_CHAIN1, HQ_CLK_N, HQ_CLK_SLOTS = 64 };
+    struct hq_clock_slot { hipEvent_t e[HQ_CLK_N] = {}; bool used[HQ_CLK_N] = {}; bool pending = false; };
+    bool phase_clock = false;
+    std::vector<hq_clock_slot> clock;
+    size_t clock_at = 0;
+    double clk_us[5] = { 0, 0, 0, 0, 0 };   /* step, shell, interior, chain, chain behind the interior's end */
+    int64_t clk_steps = 0;
     /* timing */
     std::vector<hipEvent_t> ev;     /* per-launch marks */
     hipEvent_t ev_span[2] = { nullptr, nullptr };
@@ -899,6 +914,63 @@ static hipError_t hq_quiesce(hq_ctx* c)
     return e;
 }
 
+/* ---- the phase clock ---- */
+static void hq_clock_harvest(hq_ctx* c, hq_ctx::hq_clock_slot& sl, bool wait)
+{
+    if (!sl.pending) return;
+    for (int k = 0; k < hq_ctx::HQ_CLK_N; k++)
+        if (sl.used[k] && (wait ? hipEventSynchronize(sl.e[k]) : hipEventQuery(sl.e[k])) != hipSuccess) return;   /* not done yet */
+    auto span = [&](int a, int b, double* us) {
+        float ms = 0;
+        if (!sl.used[a] || !sl.used[b] || hipEventElapsedTime(&ms, sl.e[a], sl.e[b]) != hipSuccess) return false;
+        *us = 1e3 * (double)ms;
+        return true;
+    };
+    double shell = 0, interior = 0, chain = 0, t_int_end = 0, t_chain_end = 0, t_shell_end = 0;
+    span(hq_ctx::HQ_CLK_STEP0, hq_ctx::HQ_CLK_SHELL1, &shell);
+    span(hq_ctx::HQ_CLK_INT0, hq_ctx::HQ_CLK_INT1, &interior);
+    span(hq_ctx::HQ_CLK_CHAIN0, hq_ctx::HQ_CLK_CHAIN1, &chain);
+    span(hq_ctx::HQ_CLK_STEP0, hq_ctx::HQ_CLK_SHELL1, &t_shell_end);
+    span(hq_ctx::HQ_CLK_STEP0, hq_ctx::HQ_CLK_INT1, &t_int_end);
+    span(hq_ctx::HQ_CLK_STEP0, hq_ctx::HQ_CLK_CHAIN1, &t_chain_end);
+    const double compute_end = std::max(t_shell_end, t_int_end);
+    c->clk_us[0] += std::max(compute_end, t_chain_end);
+    c->clk_us[1] += shell;
+    c->clk_us[2] += interior;
+    c->clk_us[3] += chain;
+    c->clk_us[4] += std::max(0.0, t_chain_end - compute_end);
+    c->clk_steps++;
+    sl.pending = false;
+    for (int k = 0; k < hq_ctx::HQ_CLK_N; k++) sl.used[k] = false;
+}
+
+static void hq_clock_harvest_all(hq_ctx* c, bool wait)
+{
+    for (auto& sl : c->clock) hq_clock_harvest(c, sl, wait);
+}
+
+static bool hq_clock_on(const hq_ctx* c) { return c->phase_clock || c->timing; }
+
+/* a new step: take the next slot of the ring (the step that used it HQ_CLK_SLOTS steps ago is long done) */
+static void hq_clock_begin(hq_ctx* c)
+{
+    if (!hq_clock_on(c)) return;
+    if (c->clock.empty()) c->clock.resize(hq_ctx::HQ_CLK_SLOTS);
+    c->clock_at = (c->clock_at + 1) % c->clock.size();
+    hq_ctx::hq_clock_slot& sl = c->clock[c->clock_at];
+    hq_clock_harvest(c, sl, true);
+    sl.pending = true;
+}
+
+static void hq_clock(hq_ctx* c, int k, hipStream_t st)
+{
+    if (!hq_clock_on(c) || c->clock.empty()) return;
+    hq_ctx::hq_clock_slot& sl = c->clock[c->clock_at];
+    if (!sl.pending) return;
+    if (!sl.e[k] && hipEventCreate(&sl.e[k]) != hipSuccess) { sl.e[k] = nullptr; return; }
+    if (hipEventRecord(sl.e[k], st) == hipSuccess) sl.used[k] = true;
+}
+
 static void hq_mark(hq_ctx* c)
 {
     if (c->timing && c->ev_used < c->ev.size()) hipEventRecord(c->ev[c->ev_used++], c->stream);
@@ -1094,7 +1166,21 @@ static int hq_phase(hq_ctx* c, int ph)
                 if (c->ev_shared) HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_shared, 0));
                 HQ_HIP(hipStreamWaitEvent(c->bstream, c->ev_patches, 0));
             }
+            auto launch_bricks = [&]() {
+                if (c->bricks.nunits > 0)
+                    hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2,
+                                    bs ? c->bstream : c->stream, c->opt_brick_light < 0 ? c->overlap : c->opt_brick_light != 0);
+                if (bs) hipEventRecord(c->ev_bricks, c->bstream);
+            };
             hq_mark(c);
+            hq_clock_begin(c);
+            hq_clock(c, hq_ctx::HQ_CLK_STEP0, c->stream);
+            if (bs) hq_clock(c, hq_ctx::HQ_CLK_INT0, c->bstream);       /* the bricks start beside the shell */
+            bool chain_marked = false;
+            auto chain_released = [&]() {                               /* the exchange stream may go: the interface patches are enqueued */
+                if (!chain_marked && c->overlap) hq_clock(c, hq_ctx::HQ_CLK_CHAIN0, c->cstream);
+                chain_marked = true;
+            };
             if (c->plan.ns > 0 || c->plan.nr > 0) {
                 /* ONE persistent launch for all element-form patches, the interface patches at the head of its
                  * queue; the exchange chain starts behind it and runs beside the stencil kernel -- the bulk of the
@@ -1109,6 +1195,7 @@ static int hq_phase(hq_ctx* c, int ph)
                 if (c->overlap) {
                     HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                     HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                    chain_released();
                     hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F, c->dt2,
                                     c->d_iforce, c->stream, c->reserve_cus);
                 }
@@ -1122,6 +1209,7 @@ static int hq_phase(hq_ctx* c, int ph)
                                     c->d_iforce, c->stream);
                     HQ_HIP(hipEventRecord(c->ev_bnd, c->stream));
                     HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_bnd, 0));
+                    chain_released();
                     hq_patch_launch(&c->plan, nb, ne, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->d_nt, F,
                                     c->dt2, c->d_iforce, c->stream, c->reserve_cus);
                 } else {                         /* one stream: one persistent launch over all of them */
@@ -1131,13 +1219,12 @@ static int hq_phase(hq_ctx* c, int ph)
             }
             /* the bricks: simple nodes only, never on the interface -- interior work beside the exchange chain */
             if (bs) HQ_HIP(hipEventRecord(c->ev_patches, c->stream));
-            if (c->bricks.nunits > 0)
-                hq_brick_launch(&c->bricks, c->d_u[c->now], c->d_u[c->prev], c->d_u[c->spare], c->plan.d_nt3, F, c->dt2,
-                                bs ? c->bstream : c->stream, c->opt_brick_light < 0 ? c->overlap : c->opt_brick_light != 0);
-            if (bs) {
-                HQ_HIP(hipEventRecord(c->ev_bricks, c->bstream));
-                if (c->timing) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));   /* the mark below closes the step's kernels */
-            }
+            hq_clock(c, hq_ctx::HQ_CLK_SHELL1, c->stream);
+            if (!bs) hq_clock(c, hq_ctx::HQ_CLK_INT0, c->stream);
+            launch_bricks();
+            hq_clock(c, hq_ctx::HQ_CLK_INT1, bs ? c->bstream : c->stream);
+            if (!c->overlap && hq_has_transport(c)) hq_clock(c, hq_ctx::HQ_CLK_CHAIN0, c->stream);   /* the chain follows on this stream */
+            if (bs && c->timing) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));   /* the mark below closes the step's kernels */
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -1233,6 +1320,7 @@ static int hq_phase(hq_ctx* c, int ph)
         HQ_TRY(hq_xchg_recv(c, &c->dn, unew, false, false));
         if (patch) {
             if (c->overlap) HQ_HIP(hipEventRecord(c->ev_shared, c->cstream));
+            if (hq_has_transport(c)) hq_clock(c, hq_ctx::HQ_CLK_CHAIN1, c->overlap ? c->cstream : c->stream);
             int n = c->now, p = c->prev, sp = c->spare;
             c->now = sp; c->prev = n; c->spare = p;
         } else {
@@ -1460,7 +1548,7 @@ static const double* hq_ntable64(const hq_desc* d, std::vector<double>& store)
 
 extern "C" void hq_options_init(hq_options* o, uint64_t size)
 {
-    if (!o) return;
+    if (!o || size < sizeof(uint64_t)) return;         /* a struct that cannot even hold its size field is left alone */
     hq_options full;
     hq_options_defaults(&full);
     memcpy(o, &full, (size_t)std::min<uint64_t>(size, sizeof(full)));
@@ -1471,7 +1559,7 @@ extern "C" int hq_create_opts(const hq_desc* d, int device, const hq_options* op
 {
     if (opts && opts->size < sizeof(uint64_t)) return hq_fail(HQ_ERR_ARG, "hq_options.size is not set (hq_options_init)%s", "");
     hq_options full;
-    hq_options_adopt(&full, opts);
+    hq_options_resolve(&full, opts);                   /* the environment is read here, once, and only if allowed */
     hq_opt_scope scope(&full);
     int rc = hq_create_impl(d, device, out);
     if (rc == HQ_OK && out && *out) (*out)->opts = full;
@@ -1483,11 +1571,8 @@ extern "C" int hq_create(const hq_desc* d, int device, hq_ctx** out) { return hq
 extern "C" int hq_get_options(hq_ctx* c, hq_options* out, uint64_t size)
 {
     if (!c || !out || size < sizeof(uint64_t)) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
-    hq_opt_scope scope(&c->opts);
-    hq_options eff;
-    hq_options_effective(&eff);
-    memcpy(out, &eff, (size_t)std::min<uint64_t>(size, sizeof(eff)));
-    out->size = std::min<uint64_t>(size, sizeof(eff));
+    memcpy(out, &c->opts, (size_t)std::min<uint64_t>(size, sizeof(c->opts)));
+    out->size = std::min<uint64_t>(size, sizeof(c->opts));
     return HQ_OK;
 }
 
@@ -1798,6 +1883,7 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
     if (hipDeviceSynchronize() != hipSuccess) return bail(hq_fail(HQ_ERR_DEVICE, "upload failed%s", ""));
     c->opt_brick_stream = hq_opt_has("HQ_BRICK_STREAM") ? (hq_opt_on("HQ_BRICK_STREAM") ? 1 : 0) : -1;
     c->opt_fused_share = !(hq_opt_on("HQ_NO_FUSED_SHARE"));
+    c->phase_clock = hq_opt_on("HQ_PHASE_TIMING");
     if (hq_opt_has("HQ_PATCH_MERGE_ROUNDS")) c->opt_merge_rounds = std::max(0, hq_opt_int("HQ_PATCH_MERGE_ROUNDS", 1));
     if (hq_opt_has("HQ_BRICK_BY_COMPONENT")) c->opt_brick_light = hq_opt_int("HQ_BRICK_BY_COMPONENT", 0) != 0;
     c->h2d_bytes = c->d2h_bytes = 0;          /* the counters of hq_info start with the first call behind hq_create */
@@ -1817,6 +1903,9 @@ static int hq_create_impl(const hq_desc* d, int device, hq_ctx** out)
  */
 extern "C" int hq_plan_check(const hq_desc* d, int64_t report[8])
 {
+    hq_options chk_opts;                              /* host-only diagnostic: the library defaults, the environment where HQ_ALLOW_ENV=1 */
+    hq_options_resolve(&chk_opts, nullptr);
+    hq_opt_scope chk_scope(&chk_opts);
     if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid))
         return hq_fail(HQ_ERR_ARG, "inconsistent mesh description%s", "");
     const int64_t E = d->lenum, N = d->nharbored;
@@ -1931,6 +2020,9 @@ extern "C" int hq_stencil_coefficients(double out[16])
  */
 extern "C" int hq_stencil_plan_check(const hq_desc* d, int64_t report[6])
 {
+    hq_options chk_opts;                              /* host-only diagnostic: the library defaults, the environment where HQ_ALLOW_ENV=1 */
+    hq_options_resolve(&chk_opts, nullptr);
+    hq_opt_scope chk_scope(&chk_opts);
     if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid) || !d->node_xyz)
         return hq_fail(HQ_ERR_ARG, "inconsistent mesh description (node_xyz is needed)%s", "");
     const int64_t E = d->lenum, N = d->nharbored;
@@ -2080,6 +2172,9 @@ static thread_local int64_t g_brick_check_extra[2];    /* the last check's ragge
 
 extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
 {
+    hq_options chk_opts;                              /* host-only diagnostic: the library defaults, the environment where HQ_ALLOW_ENV=1 */
+    hq_options_resolve(&chk_opts, nullptr);
+    hq_opt_scope chk_scope(&chk_opts);
     if (!d || !report || d->lenum < 0 || d->nharbored <= 0 || (d->lenum && !d->lnid) || !d->node_xyz || !d->eTable || !d->nTable)
         return hq_fail(HQ_ERR_ARG, "inconsistent mesh description (node_xyz is needed)%s", "");
     const int64_t E = d->lenum, N = d->nharbored;
@@ -2389,6 +2484,7 @@ extern "C" int hq_destroy(hq_ctx* c)
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->cstream) { hipStreamSynchronize(c->cstream); hipStreamDestroy(c->cstream); }
     if (c->bstream) { hipStreamSynchronize(c->bstream); hipStreamDestroy(c->bstream); }
+    for (auto& sl : c->clock) for (hipEvent_t e : sl.e) if (e) hipEventDestroy(e);
     if (c->ev_patches) hipEventDestroy(c->ev_patches);
     if (c->ev_bricks) hipEventDestroy(c->ev_bricks);
     if (c->ev_bnd) hipEventDestroy(c->ev_bnd);
@@ -2441,6 +2537,14 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.ipc_arena_coarse = (c->ipc && c->ipc->coarse) ? 1 : 0;
     v.ipc_arena_kind = c->ipc ? c->ipc->arena_kind : 0;
     v.debug_halo = c->debug_halo ? 1 : 0;
+    v.brick_stream = c->bstream ? 1 : 0;
+    hq_clock_harvest_all(c, false);                     /* what has finished; nothing is waited for */
+    v.timed_steps = c->clk_steps;
+    if (c->clk_steps > 0) {
+        const double n = (double)c->clk_steps;
+        v.t_step_us = c->clk_us[0] / n; v.t_shell_us = c->clk_us[1] / n; v.t_interior_us = c->clk_us[2] / n;
+        v.t_chain_us = c->clk_us[3] / n; v.t_chain_exposed_us = c->clk_us[4] / n;
+    }
     memset(info, 0, (size_t)size);
     memcpy(info, &v, (size_t)std::min<uint64_t>(size, sizeof(v)));
     return HQ_OK;
@@ -2973,6 +3077,7 @@ extern "C" int hq_sync(hq_ctx* c)
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_HIP(hipSetDevice(c->device));
     HQ_HIP(hq_quiesce(c));
+    hq_clock_harvest_all(c, true);
     if (c->ipc) {
         int32_t late = 0;
         HQ_HIP(hipMemcpy(&late, c->d_halo_err + 2, sizeof late, hipMemcpyDeviceToHost));
@@ -3041,6 +3146,7 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
     if (c->bstream) hipStreamWaitEvent(c->stream, c->ev_bricks, 0);
     hipEventRecord(c->ev_span[1], c->stream);
     hipError_t he = hq_quiesce(c);
+    if (he == hipSuccess) hq_clock_harvest_all(c, true);
     double tot = 0, ker = 0;
     if (rc == HQ_OK && he == hipSuccess) {
         float ms = 0;

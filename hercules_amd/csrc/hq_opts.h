@@ -1,11 +1,13 @@
 /*
  * hq_opts.h -- how the planners and the engine read their settings: hq_options (include/hq_solver.h; the typed,
  * per-context form, after the reference's explicit Param struct psolve.c:193-284) with the HQ_* environment variables
- * as overrides for experiments.  One resolver: env where set, else the field of the options in force, else the default.
+ * as overrides for experiments where the caller allows them (hq_options.allow_env).  One resolver, run once per context
+ * at hq_create_opts (hq_options_resolve): the field, overridden by the environment where allowed; else the default.
  *
  * The options "in force" are a thread-local pointer: hq_create_opts points it at the caller's struct while it plans,
  * every later entry point that reads a setting points it at the context's copy (hq_opt_scope).  Planners are called
- * with it in place; they never call getenv themselves.
+ * with it in place; they never call getenv themselves.  The pointer is thread-local: read every setting BEFORE an
+ * OpenMP region, never inside one (a worker thread sees no options at all).
  */
 #ifndef HQ_OPTS_H
 #define HQ_OPTS_H
@@ -34,10 +36,13 @@ static const hq_opt_entry g_opt_table[] = {
     HQ_OPT_I("HQ_DEBUG_HALO", debug_halo), HQ_OPT_I("HQ_IPC_ARENA", ipc_arena), HQ_OPT_D("HQ_IPC_TIMEOUT_MS", ipc_timeout_ms),
     HQ_OPT_D("HQ_LOOPBACK_DELAY_US", loopback_delay_us), HQ_OPT_I("HQ_PATCH_VERBOSE", verbose), HQ_OPT_I("HQ_QUIET", quiet),
     HQ_OPT_I("HQ_BRICK_RAGGED", brick_ragged), HQ_OPT_I("HQ_BRICK_RAGGED_MINFILL", brick_ragged_minfill),
+    HQ_OPT_I("HQ_PHASE_TIMING", phase_timing),
 };
 #undef HQ_OPT_I
 #undef HQ_OPT_D
 
+/* the RESOLVED options in force on this thread (hq_options_resolve): nothing below reads the environment for a setting
+ * that has a field */
 static thread_local const hq_options* g_opt_in_force = nullptr;
 
 static void hq_options_defaults(hq_options* o)
@@ -47,6 +52,7 @@ static void hq_options_defaults(hq_options* o)
         if (e.kind == 0) *(int32_t*)((char*)o + e.off) = -1;
         else *(double*)((char*)o + e.off) = -1.0;
     }
+    o->allow_env = -1;
 }
 
 /* the caller's struct (of its own size) into a full one */
@@ -65,30 +71,60 @@ static const hq_opt_entry* hq_opt_find(const char* env)
     return nullptr;
 }
 
-/* HQ_IPC_ARENA in the environment is a word */
+/* HQ_IPC_ARENA in the environment is a word; a switch that is set but empty (HQ_PATCH_NO_ISO=) is on */
 static int hq_opt_env_int(const char* env, const char* v)
 {
     if (!strcmp(env, "HQ_IPC_ARENA")) return !strcmp(v, "fine") ? 0 : (!strcmp(v, "uncached") ? 1 : (!strcmp(v, "coarse") ? 2 : atoi(v)));
+    if (!*v) return 1;
     return atoi(v);
 }
 
-/* was the setting given at all (environment, or a field that is not "default")? */
+/*
+ * hq_create_opts: the caller's options, completed, with the environment applied ONCE -- and only where the caller allows
+ * it: hq_options.allow_env = 1 honours HQ_* variables, 0 ignores them, -1 (default) honours them only in a process that
+ * says HQ_ALLOW_ENV=1 (experiments, the test suite, bench.py).  A host program that sets 0 (examples/psolve_hq_stub.inc)
+ * cannot be steered by a stray variable.  What comes out is what the context runs with and what hq_get_options returns:
+ * switches as 0 / 1 (HQ_X=0 in the environment is OFF), everything else as given; -1 = the library's default.
+ */
+static void hq_options_resolve(hq_options* out, const hq_options* caller)
+{
+    hq_options_adopt(out, caller);
+    const char* master = getenv("HQ_ALLOW_ENV");
+    const bool allow = out->allow_env >= 0 ? out->allow_env != 0 : (master && *master && strcmp(master, "0") != 0);
+    out->allow_env = allow ? 1 : 0;
+    if (!allow) return;
+    for (const hq_opt_entry& e : g_opt_table) {
+        const char* v = getenv(e.env);
+        if (!v) continue;
+        if (e.kind == 0) *(int32_t*)((char*)out + e.off) = hq_opt_env_int(e.env, v);
+        else if (*v) *(double*)((char*)out + e.off) = atof(v);
+    }
+}
+
+/* settings without a field (diagnostics of experiment builds: HQ_PATCH_NT, HQ_PATCH_DIAG, HQ_IPC_COARSE, ...): from the
+ * environment, and only where the options in force allow it */
+static const char* hq_opt_env_only(const char* env)
+{
+    if (!g_opt_in_force || g_opt_in_force->allow_env != 1) return nullptr;
+    const char* v = getenv(env);
+    return v;
+}
+
+/* was the setting given at all (a field that is not "default")? */
 static bool hq_opt_has(const char* env)
 {
-    const char* v = getenv(env);
-    if (v && *v) return true;
     const hq_opt_entry* e = hq_opt_find(env);
-    if (!e || !g_opt_in_force) return false;
+    if (!e) { const char* v = hq_opt_env_only(env); return v && *v; }
+    if (!g_opt_in_force) return false;
     return e->kind == 0 ? *(const int32_t*)((const char*)g_opt_in_force + e->off) >= 0
                         : *(const double*)((const char*)g_opt_in_force + e->off) >= 0.0;
 }
 
 static int hq_opt_int(const char* env, int def)
 {
-    const char* v = getenv(env);
-    if (v && *v) return hq_opt_env_int(env, v);
     const hq_opt_entry* e = hq_opt_find(env);
-    if (e && g_opt_in_force && e->kind == 0) {
+    if (!e) { const char* v = hq_opt_env_only(env); return v && *v ? atoi(v) : def; }
+    if (g_opt_in_force && e->kind == 0) {
         const int32_t f = *(const int32_t*)((const char*)g_opt_in_force + e->off);
         if (f >= 0) return f;
     }
@@ -97,10 +133,9 @@ static int hq_opt_int(const char* env, int def)
 
 static double hq_opt_double(const char* env, double def)
 {
-    const char* v = getenv(env);
-    if (v && *v) return atof(v);
     const hq_opt_entry* e = hq_opt_find(env);
-    if (e && g_opt_in_force && e->kind == 1) {
+    if (!e) { const char* v = hq_opt_env_only(env); return v && *v ? atof(v) : def; }
+    if (g_opt_in_force && e->kind == 1) {
         const double f = *(const double*)((const char*)g_opt_in_force + e->off);
         if (f >= 0.0) return f;
     }
@@ -110,24 +145,12 @@ static double hq_opt_double(const char* env, double def)
 static bool hq_opt_on(const char* env) { return hq_opt_int(env, 0) != 0; }
 /* explicitly switched off */
 static bool hq_opt_off(const char* env) { return hq_opt_has(env) && hq_opt_int(env, 1) == 0; }
-/* switches that the environment sets by their mere presence (HQ_PATCH_NO_ISO=anything): a field > 0 does the same */
+/* a switch: on where its field is > 0 (the environment's HQ_X=, HQ_X=1 came in as 1, HQ_X=0 as 0) */
 static bool hq_opt_flag(const char* env)
 {
-    const char* v = getenv(env);
-    if (v) return true;
     const hq_opt_entry* e = hq_opt_find(env);
-    return e && g_opt_in_force && e->kind == 0 && *(const int32_t*)((const char*)g_opt_in_force + e->off) > 0;
-}
-
-/* what is in force, the environment applied: every field resolved */
-static void hq_options_effective(hq_options* out)
-{
-    hq_options_defaults(out);
-    for (const hq_opt_entry& e : g_opt_table) {
-        if (!hq_opt_has(e.env) && !(getenv(e.env))) continue;
-        if (e.kind == 0) *(int32_t*)((char*)out + e.off) = getenv(e.env) && !*getenv(e.env) ? 1 : hq_opt_int(e.env, -1);
-        else *(double*)((char*)out + e.off) = hq_opt_double(e.env, -1.0);
-    }
+    if (!e) { const char* v = hq_opt_env_only(env); return v && strcmp(v, "0") != 0; }
+    return g_opt_in_force && e->kind == 0 && *(const int32_t*)((const char*)g_opt_in_force + e->off) > 0;
 }
 
 struct hq_opt_scope {

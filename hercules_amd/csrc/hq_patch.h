@@ -187,6 +187,7 @@ struct hq_patch_plan {
     int32_t* d_ds_ptr = nullptr;     /* hanging-node force distribution (compute_adjust) per patch */
     int32_t* d_ds_ent = nullptr;
     int32_t  max_nown = 0, max_nhalo = 0, max_npairs = 0;
+    int32_t  step_nl = 0;            /* rows of hq_k_patch_step's LDS image: max over patches of owned + halo nodes */
     std::vector<int32_t> h_halo;     /* host copies kept only for meshes with hanging nodes */
     std::vector<int64_t> h_halo_off;
     std::vector<int32_t> h_nvirt;
@@ -2292,6 +2293,12 @@ static int hq_patch_build(hq_patch_plan* P, int64_t E, int64_t N, const int32_t*
             }
         }
     }
+    {   /* what hq_k_patch_step's LDS image really needs: a thin shell's patches stage far fewer than cfg.nlmax nodes, and
+         * every KB less is a workgroup more per CU */
+        int32_t nl = 8;
+        for (auto& D : H.desc) nl = std::max(nl, std::max(D.nown + D.nhalo, (D.flags & HQ_PATCH_WFORM) ? 2 * D.nown : 0));
+        P->step_nl = std::min(P->cfg.nlmax, (nl + 7) & ~7);
+    }
     plap("uniform / n_t classes");
     /* stencil patches: uniform coefficients, nodes and elements a subset of the lattice, no hanging node's force to
      * distribute (full_only: only the full lattice without dashpot) */
@@ -2557,8 +2564,14 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
                             double* iforce, hipStream_t stream, int reserve_cus = 0)
 {
     if (count <= 0) return;
+#ifdef HQ_EXPERIMENT            /* profiles/tools only: what a step costs WITHOUT its shell (results are wrong) */
+    { static const bool skip = getenv("HQ_X_NO_SHELL") != nullptr; if (skip) return; }
+#endif
     int per_xcd = (count + 7) / 8;
-    size_t lds = (6 * (size_t)P->cfg.nlmax + 3 * (size_t)(P->cfg.pmax + P->cfg.vmax)) * sizeof(double);
+    /* the LDS image as large as the plan's patches need it (a thin shell stages far fewer than cfg.nlmax nodes) */
+    const int32_t step_nl = P->step_nl > 0 ? P->step_nl : P->cfg.nlmax;
+    const int32_t step_na = P->step_nl > 0 && P->max_nacc > 0 ? P->max_nacc : P->cfg.pmax + P->cfg.vmax;
+    size_t lds = (6 * (size_t)step_nl + 3 * (size_t)step_na) * sizeof(double);
     static const bool nt_hint = hq_opt_on("HQ_PATCH_NT");
 #ifdef HQ_PATCH_PROFILING
     if (getenv("HQ_PATCH_DIAG") && atoi(getenv("HQ_PATCH_DIAG")) == 6) {
@@ -2613,7 +2626,7 @@ static void hq_patch_launch(const hq_patch_plan* P, int32_t first, int32_t count
     if (diag == 6) kern = hq_k_patch_step<false, 6>;
 #endif
     kern<<<per_xcd * 8, P->cfg.threads, lds, stream>>>(
-        count, per_xcd, P->d_order ? P->d_order + first : nullptr, P->cfg.nlmax, P->d_desc, P->d_pidx, P->d_pc1,
+        count, per_xcd, P->d_order ? P->d_order + first : nullptr, step_nl, P->d_desc, P->d_pidx, P->d_pc1,
         P->d_pc2, P->d_pbeta, P->d_halo, u1, u2, un, nt, P->d_nt3, P->d_src_ptr, P->d_src_ent,
         (P->d_src_ptr ? F : nullptr), dt2, P->d_if_ptr, P->d_if_ent, iforce, P->d_ds_ptr, P->d_ds_ent,
         P->hstride);

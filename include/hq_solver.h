@@ -150,6 +150,22 @@ typedef struct {
     int32_t debug_halo;          /* 1: every halo record is checked on receipt (HQ_DEBUG_HALO / hq_options.debug_halo)     */
     int32_t brick_units_packed;  /* of brick_units_het: coefficients as three floats, n_t rows as two doubles (hq_desc.edata) */
     int32_t brick_units_ragged;  /* of the units with one n_t row: partly filled tiles (HQ_BK_RAGGED, hq_options.brick_ragged) */
+    /* ABI 6 */
+    int32_t brick_stream;        /* 1: the shell's patches run on the compute stream BESIDE the bricks, which have a stream of their own */
+    int32_t reserved1;
+    /* Where a step's device time goes -- the library's share of the reference's per-phase report (print_timing_stat,
+     * psolve.c:6041-6266: "Compute addforces e", "... schedule send data", ...), from HIP events, averaged over
+     * `timed_steps` steps: every step of a context with hq_options.phase_timing = 1 and of every hq_run_timed batch.
+     * microseconds per step; the phases overlap, so they do not add up to t_step_us. */
+    int64_t timed_steps;
+    double  t_step_us;           /* first kernel's start -> last kernel's end (compute streams and exchange chain)       */
+    double  t_shell_us;          /* patch launches: the shell behind the bricks, or every node where there are no bricks
+                                    (element force + nodal update + hanging nodes inside patches)                         */
+    double  t_interior_us;       /* brick launches (element force + nodal update of the bulk)                            */
+    double  t_chain_us;          /* exchange chain, its release (interface patches done) -> displacements shared: pack,
+                                    transport, interface update, unpack, compute_adjust between ranks -- waits for the
+                                    neighbours' records included                                                          */
+    double  t_chain_exposed_us;  /* of it, what ran AFTER the step's compute kernels had ended (not hidden)                */
 } hq_info;
 
 /* Number of gfx950 devices visible (0 if none / no HIP runtime). */
@@ -172,8 +188,11 @@ HQ_API int hq_create(const hq_desc* desc, int device, hq_ctx** out);
  * this is the library's: everything that selects kernels, plans or transports, per CONTEXT -- two contexts of one process
  * may differ, and nothing depends on the environment unless the caller wants it to.  hq_options_init fills every field
  * with "library default" (-1); hq_create_opts(desc, device, NULL, &ctx) == hq_create(desc, device, &ctx).
- * Precedence: an HQ_* environment variable of the same name, where set, still overrides the field (experiments,
- * profiles/tools); hq_get_options returns what the context really runs with, the environment applied.
+ * The environment: an HQ_* variable of a field's name overrides the field ONLY where the caller allows it --
+ * hq_options.allow_env = 1, or allow_env = -1 in a process that sets HQ_ALLOW_ENV=1 (experiments, profiles/tools, the
+ * test suite); a host program that passes allow_env = 0 cannot be steered by a stray variable.  Every setting is
+ * resolved ONCE, at hq_create_opts; hq_get_options returns exactly that: what the context runs with (switches as 0 / 1,
+ * -1 where the library's default applies).
  * `size` = sizeof(hq_options) of the caller: a newer library treats the fields an older client does not know as -1.
  */
 typedef struct {
@@ -230,11 +249,17 @@ typedef struct {
     int32_t brick_ragged;        /* HQ_BRICK_RAGGED       0: no partly filled tile columns beside level interfaces and material
                                                           boundaries (the second planner round is then brick_half_tiles')    */
     int32_t brick_ragged_minfill;/* HQ_BRICK_RAGGED_MINFILL fewest nodes a plane of such a column owns, of 512 (128)        */
+    /* (ABI 6) */
+    int32_t allow_env;           /* 1: HQ_* environment variables override the fields above; 0: the environment is ignored;
+                                    -1 (default): honoured only in a process that sets HQ_ALLOW_ENV=1 (experiments, tests) */
+    int32_t phase_timing;        /* HQ_PHASE_TIMING       1: every step records where its device time goes (six events per
+                                                          step; hq_info.t_*_us) -- the library's share of print_timing_stat
+                                                          (psolve.c:6041-6266); hq_run_timed batches always do          */
 } hq_options;
 
 HQ_API void hq_options_init(hq_options* opts, uint64_t size);
 HQ_API int  hq_create_opts(const hq_desc* desc, int device, const hq_options* opts, hq_ctx** out);
-/* what the context runs with (its options, the environment's overrides applied); writes min(size, sizeof) bytes */
+/* what the context runs with (resolved at hq_create_opts); writes min(size, sizeof) bytes */
 HQ_API int  hq_get_options(hq_ctx* ctx, hq_options* out, uint64_t size);
 
 /* solver_delete (psolve.c:3627-3649). */
@@ -248,7 +273,7 @@ HQ_API int hq_destroy(hq_ctx* ctx);
  * last of those ended its struct with brick_nodes, so the symbol writes those 56 bytes and never more.
  * hq_abi_version() == HQ_ABI_VERSION is the check a separately compiled client makes at start-up.
  */
-#define HQ_ABI_VERSION 5
+#define HQ_ABI_VERSION 6
 HQ_API int hq_abi_version(void);
 /* sizeof(hq_real) of the library that is loaded: 8 (libhq_solver.so), 4 (libhq_solver_f32.so) */
 HQ_API int hq_real_bytes(void);

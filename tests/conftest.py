@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the suite steers kernels and plans through HQ_* variables (monkeypatch.setenv): the library honours them only in a
+# process that says so (hq_options.allow_env, include/hq_solver.h)
+os.environ.setdefault("HQ_ALLOW_ENV", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

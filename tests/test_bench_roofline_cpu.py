@@ -204,8 +204,6 @@ def test_parity_windows_of_the_bench_line_against_a_whole_box_oracle(monkeypatch
     assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-13
     s.wrong = 1e-6
     checked_1000 = bench.parity_windows(args, box, s, 0, 1)[2]
-    args2 = argparse.Namespace(workload="o3")
-    assert bench.parity_windows(args2, box, s, 0, 2) is None          # a PARTITION of an octree mesh carries no windows: reported as null
     assert checked_1000 < 1e-13 or checked_1000 > 1e-9                  # node 1000 is either outside every window or caught
     box.close()
 
@@ -239,7 +237,56 @@ def test_octree_parity_windows_of_the_bench_line_against_a_whole_mesh_oracle():
 
     nwin, nchecked, worst = bench.parity_windows(argparse.Namespace(workload="o4s"), box, WholeMeshOracle(), 0, 1)
     assert nwin >= 4 and nchecked > 1000 and worst < 1e-12
-    assert bench.parity_windows(argparse.Namespace(workload="o4s"), box, None, 0, 2) is None     # partitions: no windows
+
+    # A PARTITION of the mesh (round-5 review 2a: an N > 1 octree line carries parity too).  The root rank builds the whole
+    # mesh, cuts windows around hanging nodes the partitions SHARE and hands (node key, expected value) records to every
+    # rank; here one process plays the root over a communicator of one, its "context" is rank 1 of 2's partition holding
+    # the whole-mesh oracle's values -- and one holding a wrong value at a shared node is caught
+    import numpy as np
+    import torch.distributed as dist
+    whole_ctx = WholeMeshOracle()
+    u1 = bench.seeded_field(box.node_xyz, bench.WORKLOADS["o4s"][0], bench.WORKLOADS["o4s"][1], it)
+    whole_ctx.upload(u1, u1 * (1.0 - 1e-3), 0)
+    whole_ctx.run(2)
+    part, _, _, itp = bench.make_octbox("o4s", 1, 2)
+    part.node_ijk, part.start_interfaces = part.node_xyz, itp
+    gid = part.gid.astype(np.int64)
+
+    class PartitionContext(WholeMeshOracle):
+        wrong_at = -1
+
+        def upload(self, tm1, tm2, step):
+            assert np.array_equal(tm1, u1[gid])               # a partition starts from the whole mesh's field
+
+        def run(self, k):
+            assert k == 2
+
+        def gather(self, ids):
+            a, b = whole_ctx.u1[gid[ids]].copy(), whole_ctx.u2[gid[ids]].copy()
+            a[ids == self.wrong_at] += 1e-6
+            return a, b
+
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(td, "rendezvous"), rank=0, world_size=1)
+        try:
+            ctx = PartitionContext()
+            nwin, nchecked, worst = bench.parity_windows(argparse.Namespace(workload="o4s"), part, ctx, 0, 2)
+            assert nwin >= 3 and nchecked > 500 and worst < 1e-12
+            sch = part.schedules()
+            shared_hanging = np.intersect1d(np.concatenate([m for _, m in sch["dn"]["c"] + sch["dn"]["s"]]), part.dangling[0])
+            assert len(shared_hanging) > 0                     # the windows sit where partition and level interfaces meet:
+            recs, _ = bench.octree_window_records(argparse.Namespace(workload="o4s"), box, it, 2,
+                                                  bench.node_keys(part.node_xyz[shared_hanging]))
+            keys = np.concatenate([r[0] for r in recs])
+            hit = shared_hanging[np.isin(bench.node_keys(part.node_xyz[shared_hanging]), keys)]
+            assert len(hit) > 0                                # ... shared hanging nodes are among the checked ones
+            ctx.wrong_at = int(hit[0])
+            assert bench.parity_windows(argparse.Namespace(workload="o4s"), part, ctx, 0, 2)[2] > 1e-9
+        finally:
+            dist.destroy_process_group()
+    part.close()
 
     # --precision f32: a float state stepped by the oracle's float build (compute_adjust on floats) on the rounded n_t rows
     import numpy as np
@@ -296,5 +343,4 @@ def test_parity_windows_of_a_single_precision_line(monkeypatch):
     assert nwin >= 4 and nchecked > 4 * 11 ** 3 and worst < 1e-6 and bench.parity_tol(args) == 2e-6
     assert bench.parity_tol(argparse.Namespace(workload="c1", precision="f64")) == 1e-9
     # a PARTITION of an octree workload carries no windows in either precision (reported as null)
-    assert bench.parity_windows(argparse.Namespace(workload="o3", precision="f32"), box, FloatBoxOracle(), 0, 2) is None
     box.close()
