@@ -74,6 +74,10 @@ OCT_LAYERED = {
     "o3": (1024, 1024, 100.0, 0.02, 0.5, 8, 800.0, 100,
            [(0.0, 1100.0, 600.0, 2000.0), (16000.0, 2000.0, 1100.0, 2300.0), (28800.0, 3600.0, 2000.0, 2500.0),
             (54400.0, 6000.0, 3464.0, 2700.0)]),
+    # a quarter of o3's footprint, all of its depth: 47M elements (tests: the basin in 8 per-rank-built partitions)
+    "o3q": (512, 512, 100.0, 0.02, 0.5, 8, 800.0, 100,
+            [(0.0, 1100.0, 600.0, 2000.0), (16000.0, 2000.0, 1100.0, 2300.0), (28800.0, 3600.0, 2000.0, 2500.0),
+             (54400.0, 6000.0, 3464.0, 2700.0)]),
     "o3s": (256, 256, 100.0, 0.02, 0.5, 8, 800.0, 25,
             [(0.0, 1100.0, 600.0, 2000.0), (4000.0, 2000.0, 1100.0, 2300.0), (7200.0, 3600.0, 2000.0, 2500.0),
              (13600.0, 6000.0, 3464.0, 2700.0)]),
@@ -93,6 +97,18 @@ OCT_BASIN = {
     "o4s": dict(domain=(25600.0, 25600.0, 12800.0), grid=64, h=100.0, dt=0.02, freq=0.5, ppw=8,
                 background=[(0.0, 2000.0, 1100.0, 2300.0), (1600.0, 3600.0, 2000.0, 2500.0), (4800.0, 6000.0, 3464.0, 2700.0)],
                 bowl=(0.42, 0.55, 0.40, 0.30, 6400.0, 1100.0, 600.0, 2000.0)),
+    # The same two basins with a VELOCITY GRADIENT (round-5 review 5): Vp and Vs times f = 1 + gx x/Lx + gy y/Ly + gz z/Lz
+    # (density times 1 + (f - 1) / 2) on a material grid of 200 m cells, so that no two neighbouring coarse elements share
+    # (c1, c2, beta) -- what setrec's 27-sample average gives on any real CVM (psolve.c:1307-1397).  The per-element
+    # kernels (hq_k_brick_het, element-form patches) then run INSIDE every octree level, beside the hanging nodes; no
+    # assembled-stencil fast path applies anywhere.  f >= 1: the Vs rule picks the levels it picks for o4 / o4s.
+    # Pinned in miniature on the real psolve: tests/golden/c5_gradient (make_cvm `grad`).
+    "o4g": dict(domain=(102400.0, 102400.0, 51200.0), grid=512, h=100.0, dt=0.02, freq=0.5, ppw=8,
+                background=[(0.0, 2000.0, 1100.0, 2300.0), (4000.0, 3600.0, 2000.0, 2500.0), (12800.0, 6000.0, 3464.0, 2700.0)],
+                bowl=(0.42, 0.55, 0.46, 0.40, 32000.0, 1100.0, 600.0, 2000.0), gradient=(0.08, 0.05, 0.10)),
+    "o4gs": dict(domain=(25600.0, 25600.0, 12800.0), grid=128, h=100.0, dt=0.02, freq=0.5, ppw=8,
+                 background=[(0.0, 2000.0, 1100.0, 2300.0), (1600.0, 3600.0, 2000.0, 2500.0), (4800.0, 6000.0, 3464.0, 2700.0)],
+                 bowl=(0.42, 0.55, 0.40, 0.30, 6400.0, 1100.0, 600.0, 2000.0), gradient=(0.08, 0.05, 0.10)),
 }
 for _k, _v in OCT_BASIN.items():
     WORKLOADS[_k] = (int(_v["domain"][0] / _v["h"]), int(_v["domain"][1] / _v["h"]), 0, _v["h"], _v["dt"], _v["freq"])
@@ -106,9 +122,14 @@ WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-coupl
                   "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
                   "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",
                   "o3s": "3M-element layered basin on four octree levels (small version of o3)",
+                  "o3q": "47M-element layered basin: a quarter of o3's footprint (51.2 km x 51.2 km x 80 km), four octree levels",
                   "o4": "laterally refined basin (102.4 km x 102.4 km x 51.2 km, 0.5 Hz): sediment bowl in a layered half-space, "
                         "octree levels of 100-800 m with x-, y- and z-normal interfaces (Vs rule + 2:1 balance as the reference's mesher)",
-                  "o4s": "small laterally refined basin (25.6 km x 25.6 km x 12.8 km), four octree levels"}
+                  "o4s": "small laterally refined basin (25.6 km x 25.6 km x 12.8 km), four octree levels",
+                  "o4g": "laterally refined basin with a velocity gradient (102.4 km x 102.4 km x 51.2 km, 0.5 Hz): the bowl and layers "
+                         "of o4, Vp / Vs / rho varying on a 200 m grid so that every coarse element has its own (c1, c2, beta) -- "
+                         "per-element-coefficient kernels inside every octree level, hanging nodes, no assembled-stencil fast path",
+                  "o4gs": "small laterally refined basin with a velocity gradient (25.6 km x 25.6 km x 12.8 km), four octree levels"}
 
 
 def usable_cores():
@@ -258,6 +279,13 @@ def basin_grid(spec):
     xc, yc, a, b, depth, bvp, bvs, brho = spec["bowl"]
     sed = z < depth * np.maximum(0.0, 1.0 - ((x - xc * Lx) / (a * Lx)) ** 2 - ((y - yc * Lx) / (b * Lx)) ** 2)
     vp[sed], vs[sed], rho[sed] = bvp, bvs, brho
+    del sed
+    if "gradient" in spec:
+        gx, gy, gz = spec["gradient"]
+        f = 1.0 + gx * x / Lx + gy * y / Ly + gz * z / Lz
+        del x, y, z
+        vp, vs = (vp * f).astype(np.float32), (vs * f).astype(np.float32)
+        rho = (rho * (1.0 + (f - 1.0) / 2.0)).astype(np.float32)
     return vp, vs, rho, cell
 
 
@@ -1219,7 +1247,7 @@ def main():
                          "counter_frac": counter_frac, "achieved_counter": achieved_counter,
                          "wasted": (traffic / compulsory) if traffic is not None else None,
                          "frac_incl_tables": (COMPULSORY_BYTES_PER_NODE_LATERAL / COMPULSORY_BYTES_PER_NODE * frac)
-                                             if args.workload in LATERAL else None,
+                                             if (args.workload in LATERAL or "gradient" in OCT_BASIN.get(args.workload, {})) else None,
                          "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_events": step_ms, "roofline_ms": roof_ms,
                          # hq_info.t_*_us: the device-side split of a step (HIP events; the phases overlap)
                          "phase_us": {k: round(float(info2.get(k, 0.0)), 2) for k in

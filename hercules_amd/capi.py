@@ -68,7 +68,7 @@ class _Info(ctypes.Structure):
                 ("pcie_d2h_bytes", ctypes.c_int64), ("transport", ctypes.c_int32), ("ipc_arena_coarse", ctypes.c_int32),
                 ("ipc_arena_kind", ctypes.c_int32), ("debug_halo", ctypes.c_int32),
                 ("brick_units_packed", ctypes.c_int32), ("brick_units_ragged", ctypes.c_int32),
-                ("brick_stream", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("timed_steps", ctypes.c_int64),
+                ("brick_stream", ctypes.c_int32), ("brick_units_ragged_het", ctypes.c_int32), ("timed_steps", ctypes.c_int64),
                 ("t_step_us", ctypes.c_double), ("t_shell_us", ctypes.c_double), ("t_interior_us", ctypes.c_double),
                 ("t_chain_us", ctypes.c_double), ("t_chain_exposed_us", ctypes.c_double)]
 
@@ -87,7 +87,8 @@ class Options(ctypes.Structure):
                 [("ipc_timeout_ms", ctypes.c_double), ("loopback_delay_us", ctypes.c_double),
                  ("verbose", ctypes.c_int32), ("quiet", ctypes.c_int32),
                  ("brick_ragged", ctypes.c_int32), ("brick_ragged_minfill", ctypes.c_int32),
-                 ("allow_env", ctypes.c_int32), ("phase_timing", ctypes.c_int32)])
+                 ("allow_env", ctypes.c_int32), ("brick_ragged_het", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                 ("phase_timing", ctypes.c_int32)])
 
     def __init__(self, **kw):
         super().__init__()
@@ -380,7 +381,7 @@ def stencil_plan_check(desc):
 
 
 BRICK_PLAN_REPORT = ("brick_nodes", "columns", "units", "units_one_nt_row", "het_units", "neighbours_checked",
-                     "patch_nodes", "faults", "ragged_units", "ragged_nodes")
+                     "patch_nodes", "faults", "ragged_units", "ragged_nodes", "ragged_het_units", "ragged_het_nodes")
 
 
 def brick_plan_check(desc):

@@ -101,6 +101,7 @@ struct hq_brick_cfg {
     int ragged = 1;              /* HQ_BRICK_RAGGED: the second planner round takes partly filled tiles (HQ_BK_RAGGED); 0: round 5's
                                   * first arrangement, 32-wide full tiles (HQ_BRICK_HALF_TILES)                                   */
     int minfill = 128;           /* HQ_BRICK_RAGGED_MINFILL: fewest owned nodes of a plane of a ragged tile column (of 512)      */
+    int ragged_het = 1;          /* HQ_BRICK_RAGGED_HET: (round 6) partly filled tiles of the per-element kernel too               */
 };
 
 static hq_brick_cfg hq_brick_cfg_from_env(void)
@@ -112,6 +113,7 @@ static hq_brick_cfg hq_brick_cfg_from_env(void)
     c.minnodes = std::max(1, geti("HQ_BRICK_MINNODES", c.minnodes));
     c.ragged = geti("HQ_BRICK_RAGGED", c.ragged) != 0;
     c.minfill = std::min(HQ_BK_THREADS, std::max(1, geti("HQ_BRICK_RAGGED_MINFILL", c.minfill)));
+    c.ragged_het = geti("HQ_BRICK_RAGGED_HET", c.ragged_het) != 0;
     return c;
 }
 
@@ -127,12 +129,13 @@ struct hq_brick_host {
     std::vector<double> nt2;                 /* [N][2] {mass_simple, mass_simple - mass_minusaM} of the nodes of packed units (0 elsewhere) */
     int32_t nhet = 0;                        /* HQ_BK_HET units: the last of the launch order                     */
     int32_t npacked = 0;                     /* of those, HQ_BK_PACKED: the last of the HET units                 */
+    int32_t nrhet = 0, nrpacked = 0;         /* HQ_BK_HET | HQ_BK_RAGGED units behind them, the packed ones last  */
     int32_t ncolumns = 0, nlevels = 0;
 };
 
 struct hq_brick_plan {
     int64_t nb = 0;
-    int32_t nunits = 0, nsame = 0, nrag = 0, nhet = 0, npacked = 0;
+    int32_t nunits = 0, nsame = 0, nrag = 0, nhet = 0, npacked = 0, nrhet = 0, nrpacked = 0;
     hq_brick_unit* d_units = nullptr;
     int32_t* d_tab = nullptr;
     double* d_coef = nullptr;
@@ -357,8 +360,13 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         /* ... or (the default since the ragged units exist) 64-wide tiles again that need not be full: HQ_BK_RAGGED */
         const int rag = cfg.ragged && stencil_ok && !hq_opt_flag("HQ_BRICK_NO_NTSAME") ? 1 : 0;
         const int half = rag || hq_opt_int("HQ_BRICK_HALF_TILES", 1) != 0 ? 1 : 0;
-        for (int round = 0; round < 2 + half; round++) {
-            const int pass = round == 1 + half ? 1 : 0;
+        /* ... and (round 6) behind the full het tiles a round of RAGGED het tiles: 62 x 7 footprints of which every plane of a
+         * run holds >= minfill simple nodes of ANY material (hq_k_brick_het<., RAGGED>) -- on a mesh whose material differs
+         * from element to element the one-material ragged columns above find nothing */
+        const int rag_het = cfg.ragged && want_het && cfg.ragged_het ? 1 : 0;
+        for (int round = 0; round < 2 + half + rag_het; round++) {
+            const bool rh_round = rag_het && round == 2 + half;
+            const int pass = (round == 1 + half || rh_round) ? 1 : 0;
             const bool rag_round = rag && round == 1;
             const int PTX = pass == 1 ? HQ_BH_TX : (round == 0 || rag_round ? TX : TX / 2), PTY = pass == 0 ? TY : HQ_BH_TY;
             /* pass 0: uniform simple nodes (2); pass 1: what is left of them and the per-element ones (1).  3 / 4 are face
@@ -376,7 +384,8 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             if (round == 0) ntx_lvl = ntx;
             const size_t f0 = found.size();
             found.resize(f0 + (size_t)nty);
-            std::vector<std::vector<ragged_t>> found_r(rag_round ? (size_t)nty : 0);
+            std::vector<std::vector<ragged_t>> found_r(rag_round || rh_round ? (size_t)nty : 0);
+            const int32_t minfill = rh_round ? std::max(1, cfg.minfill * (HQ_BH_TX * HQ_BH_TY) / HQ_BK_THREADS) : cfg.minfill;
 #pragma omp parallel for schedule(dynamic, 1)
             for (int32_t tj = 0; tj < nty; tj++) {
                 const int64_t y0 = sy0 + (int64_t)tj * PTY;
@@ -385,24 +394,27 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 for (int32_t ti = 0; ti < ntx; ti++) {
                     const int64_t x0 = sx0 + (int64_t)ti * PTX;
                     const int32_t nx = (int32_t)std::min<int64_t>(PTX, sx1 - x0 + 1);
-                    if (rag_round) {
+                    if (rag_round || rh_round) {
                         /* ragged tile columns: runs of planes each of which holds >= minfill uniform simple nodes of ONE
-                         * material and n_t row (the first candidate's; up to four materials per footprint, one after the other) */
+                         * material and n_t row (the first candidate's; up to four materials per footprint, one after the other);
+                         * rh_round: >= minfill simple nodes, whatever their elements' coefficients and their n_t rows */
                         cntz.assign((size_t)NZ, 0);
-                        for (int iter = 0; iter < 4; iter++) {
+                        for (int iter = 0; iter < (rh_round ? 1 : 4); iter++) {
                             int32_t n0 = -1;
                             int64_t Z0 = 0, X0 = 0, Y0 = 0;
+                            auto cand = [&](char v) { return rh_round ? (v == 1 || v == 2) : v == 2; };
                             for (int64_t Z = 1; Z < L.D[2] && n0 < 0; Z++)
                                 for (int64_t y = y0; y < y0 + ny && n0 < 0; y++) {
                                     const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
                                     for (int32_t x = 0; x < nx; x++)
-                                        if (row[x] == 2) { n0 = L.Ng[(size_t)((Z * NY + y) * NX + x0 + x)]; Z0 = Z; Y0 = y; X0 = x0 + x; break; }
+                                        if (cand(row[x])) { n0 = L.Ng[(size_t)((Z * NY + y) * NX + x0 + x)]; Z0 = Z; Y0 = y; X0 = x0 + x; break; }
                                 }
                             if (n0 < 0) break;
                             const int32_t e0 = L.Eg[(size_t)(((Z0 - 1) * L.D[1] + (Y0 - 1)) * L.D[0] + (X0 - 1))];
                             const double rc[3] = { c1[e0], c2[e0], beta[e0] };
                             const double* q0 = ntab + 7 * (int64_t)n0;
                             auto match = [&](int64_t X, int64_t Y, int64_t Z) -> bool {
+                                if (rh_round) return true;
                                 const double* q = ntab + 7 * (int64_t)L.Ng[(size_t)((Z * NY + Y) * NX + X)];
                                 if (q[0] != q0[0] || q[1] != q0[1] || q[4] != q0[4]) return false;
                                 const int32_t e = L.Eg[(size_t)(((Z - 1) * L.D[1] + (Y - 1)) * L.D[0] + (X - 1))];
@@ -412,13 +424,13 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                                 int32_t cnt = 0;
                                 for (int64_t y = y0; y < y0 + ny; y++) {
                                     const char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
-                                    for (int32_t x = 0; x < nx; x++) cnt += row[x] == 2 && match(x0 + x, y, Z);
+                                    for (int32_t x = 0; x < nx; x++) cnt += cand(row[x]) && match(x0 + x, y, Z);
                                 }
                                 cntz[(size_t)Z] = cnt;
                             }
                             int64_t ra = -1;
                             for (int64_t Z = Z0; Z <= L.D[2]; Z++) {
-                                const bool in = Z < L.D[2] && cntz[(size_t)Z] >= cfg.minfill;
+                                const bool in = Z < L.D[2] && cntz[(size_t)Z] >= minfill;
                                 if (in) { if (ra < 0) ra = Z; continue; }
                                 if (ra < 0) continue;
                                 const int64_t nz = Z - ra;
@@ -435,12 +447,12 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                                         for (int64_t y = y0; y < y0 + ny; y++) {
                                             char* row = &S[(size_t)((z * NY + y) * NX + x0)];
                                             for (int32_t x = 0; x < nx; x++)
-                                                if (row[x] == 2 && match(x0 + x, y, z)) { R.own[(size_t)(((z - ra) * ny + (y - y0)) * nx + x)] = 1; row[x] = 0; k++; }
+                                                if (cand(row[x]) && match(x0 + x, y, z)) { R.own[(size_t)(((z - ra) * ny + (y - y0)) * nx + x)] = 1; row[x] = 0; k++; }
                                         }
                                         R.pfx[(size_t)(z - ra) + 1] = R.pfx[(size_t)(z - ra)] + k;
                                     }
                                     found_r[(size_t)tj].push_back(std::move(R));
-                                    found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)ra, (int32_t)nz, ti, tj, 0, 0, 0, 0,
+                                    found[f0 + (size_t)tj].push_back({ lvl, (int32_t)x0, (int32_t)y0, nx, ny, (int32_t)ra, (int32_t)nz, ti, tj, 0, rh_round ? 1 : 0, 0, 0,
                                                                        (int)found_r[(size_t)tj].size() });
                                 }
                                 ra = -1;
@@ -449,7 +461,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                             for (int64_t Z = Z0; Z < L.D[2]; Z++)
                                 for (int64_t y = y0; y < y0 + ny; y++) {
                                     char* row = &S[(size_t)((Z * NY + y) * NX + x0)];
-                                    for (int32_t x = 0; x < nx; x++) if (row[x] == 2 && match(x0 + x, y, Z)) row[x] = 5;
+                                    for (int32_t x = 0; x < nx; x++) if (!rh_round && row[x] == 2 && match(x0 + x, y, Z)) row[x] = 5;
                                 }
                         }
                         continue;
@@ -507,7 +519,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         for (int32_t y = 0; y < c.ny; y++)
                             memset(&S[(size_t)(((int64_t)(c.z0 + z) * NY + (c.y0 + y)) * NX + c.x0)], 0, (size_t)c.nx);
                 }
-            if (rag_round) {
+            if (rag_round || rh_round) {
                 for (int32_t tj = 0; tj < nty; tj++) {
                     const size_t r0 = rags.size();
                     for (auto& c : found[f0 + (size_t)tj]) c.rag += (int)r0;
@@ -518,6 +530,7 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                 for (int64_t i = 0; i < nS; i++) if (S[(size_t)i] == 5) S[(size_t)i] = 2;
             }
             if (!want_het && round + 1 >= 1 + half) break;
+            if (rh_round) break;
         }
         lap("tile columns");
         const int32_t ntx = ntx_lvl;
@@ -702,12 +715,18 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
             U.tab = toff[(size_t)u];
             U.nx = nx; U.ny = ny; U.np = np; U.flags = HQ_BK_NTSAME | HQ_BK_RAGGED;
             memset(U.ft, 0, sizeof U.ft); memset(U.fb, 0, sizeof U.fb);
-            U.c1 = R.c[0]; U.c2 = R.c[1]; U.beta = R.c[2];
-            U.m0 = R.m[0]; U.m2 = R.m[1]; U.m1 = R.m[2];
             U.coef = 0;
-            same[(size_t)u] = 4;
-            continue;
+            if (!c.het) {
+                U.c1 = R.c[0]; U.c2 = R.c[1]; U.beta = R.c[2];
+                U.m0 = R.m[0]; U.m2 = R.m[1]; U.m1 = R.m[2];
+                same[(size_t)u] = 4;
+                continue;
+            }
+            /* a ragged unit of the per-element kernel: its coefficient block is filled with the full het units' below */
+            U.flags = HQ_BK_RAGGED;
+            U.c1 = U.c2 = U.beta = 0.0; U.m0 = 1.0; U.m2 = U.m1 = 0.0;
         }
+        if (!c.rag) {
         for (int32_t k = 0; k < np + 2; k++) {
             const int64_t Z = (int64_t)za - 1 + k;
             int32_t* r = t + (int64_t)k * nr;
@@ -752,9 +771,10 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
         if (sm && !c.het && !no_ntsame) { U.flags |= HQ_BK_NTSAME; same[(size_t)u] = 1; }
         U.m0 = q0[0]; U.m2 = q0[1]; U.m1 = q0[4];
         U.coef = 0;
+        }       /* (!c.rag) */
         if (c.het) {
             U.flags |= HQ_BK_HET;
-            same[(size_t)u] = 2;
+            same[(size_t)u] = c.rag ? 5 : 2;
             U.coef = coff[(size_t)u];
             double* cf = B->coef.data() + coff[(size_t)u];
             for (int32_t l = 0; l <= np; l++)
@@ -766,13 +786,24 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                         if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2])
                             e = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
                         if (e >= 0) { o[0] = c1[e]; o[HQ_BH_CS] = c2[e]; o[2 * HQ_BH_CS] = beta[e]; }
-                        else if (i <= nx && j <= ny) set_fault();       /* an element around an owned node is missing */
+                        else if (!c.rag && i <= nx && j <= ny) set_fault();       /* an element around an owned node is missing */
+                        /* (a ragged unit: cells without an element of this level keep their zeros -- no owned node touches
+                         *  them, a simple node's eight elements exist) */
                     }
             /* the packed form: every element of the block out of (rho, Vs, Vp) bit for bit, every owned node's n_t row out
              * of {m0, m0 - m1} (m1 exactly; m2 = 2 m0 - (m0 - m1) to 1e-15: it is summed in another order, psolve.c:3436-3471) */
             if (try_pack) {
                 bool ok = true;
-                const int32_t e0 = L.Eg[(size_t)(((int64_t)za * L.D[1] + c.y0) * L.D[0] + c.x0)];
+                int32_t e0 = L.Eg[(size_t)(((int64_t)za * L.D[1] + c.y0) * L.D[0] + c.x0)];
+                if (c.rag) {                 /* any element of the level will do for the edge length: the first one of the block */
+                    e0 = -1;
+                    for (int32_t l = 0; l <= np && e0 < 0; l++)
+                        for (int32_t j = 0; j < HQ_BH_WAVES && e0 < 0; j++)
+                            for (int32_t i = 0; i < 64 && e0 < 0; i++) {
+                                const int64_t cx = (int64_t)c.x0 - 1 + i, cy = (int64_t)c.y0 - 1 + j, cz = (int64_t)za - 1 + l;
+                                if (cx >= 0 && cy >= 0 && cz >= 0 && cx < L.D[0] && cy < L.D[1] && cz < L.D[2]) e0 = L.Eg[(size_t)((cz * L.D[1] + cy) * L.D[0] + cx)];
+                            }
+                }
                 const float hf = e0 >= 0 ? MS->edata[4 * (int64_t)e0] : 0.0f;
                 hq_mat_const K = { (MS->dt * MS->dt) * (double)hf, (double)hf, MS->dt, MS->bbase, MS->thr_damp, MS->thr_vpvs };
                 float* cq = B->coef32.data() + coff[(size_t)u];
@@ -796,17 +827,19 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
                             }
                             if (!hit) { ok = false; break; }
                         }
+                const int32_t* own_ids = c.rag ? t + (int64_t)(np + 2) * nr + (int64_t)nx * ny : nullptr;      /* plane 1 .. np of a ragged unit */
                 for (int32_t z = 0; z < np && ok; z++)
                     for (int32_t y = 0; y < ny && ok; y++)
                         for (int32_t x = 0; x < nx; x++) {
+                            if (own_ids && own_ids[((int64_t)z * ny + y) * nx + x] < 0) continue;            /* not this unit's node */
                             const int32_t n = L.Ng[(size_t)((((int64_t)za + z) * NY + (c.y0 + y)) * NX + (c.x0 + x))];
                             const double* q = ntab + 7 * (int64_t)n;
                             const double sdiff = q[0] - q[4];
                             if (q[0] - sdiff != q[4] || fabs((2.0 * q[0] - sdiff) - q[1]) > 1e-15 * fabs(q[1])) { ok = false; break; }
-                            double* o2 = B->nt2.data() + 2 * (U.base + ((int64_t)z * ny + y) * nx + x);
+                            double* o2 = B->nt2.data() + 2 * (own_ids ? (int64_t)own_ids[((int64_t)z * ny + y) * nx + x] : U.base + ((int64_t)z * ny + y) * nx + x);
                             o2[0] = q[0]; o2[1] = sdiff;
                         }
-                if (ok) { U.flags |= HQ_BK_PACKED; same[(size_t)u] = 3; U.c1 = K.A; U.c2 = K.h; }
+                if (ok) { U.flags |= HQ_BK_PACKED; same[(size_t)u] = c.rag ? 6 : 3; U.c1 = K.A; U.c2 = K.h; }
             }
         }
     }
@@ -815,20 +848,25 @@ static int hq_brick_plan_host(int64_t E, int64_t N, const int32_t* lnid, const i
     /* launch order: the units whose nodes share one n_t row (the row rides in the record), then those with per-node
      * rows, then the HET units -- a launch each */
     {
-        std::vector<hq_brick_unit> a, r, b, h, hp;
-        for (size_t u = 0; u < us.size(); u++) (same[u] == 1 ? a : (same[u] == 4 ? r : (same[u] == 2 ? h : (same[u] == 3 ? hp : b)))).push_back(B->units[u]);
+        std::vector<hq_brick_unit> a, r, b, h, hp, rh, rhp;
+        for (size_t u = 0; u < us.size(); u++)
+            (same[u] == 1 ? a : (same[u] == 4 ? r : (same[u] == 2 ? h : (same[u] == 3 ? hp : (same[u] == 5 ? rh : (same[u] == 6 ? rhp : b)))))).push_back(B->units[u]);
         B->nsame = (int32_t)(a.size() + r.size());
         B->nrag = (int32_t)r.size();
         B->nhet = (int32_t)(h.size() + hp.size());
         B->npacked = (int32_t)hp.size();
+        B->nrhet = (int32_t)(rh.size() + rhp.size());
+        B->nrpacked = (int32_t)rhp.size();
         a.insert(a.end(), r.begin(), r.end());
         a.insert(a.end(), b.begin(), b.end());
         a.insert(a.end(), h.begin(), h.end());
         a.insert(a.end(), hp.begin(), hp.end());
+        a.insert(a.end(), rh.begin(), rh.end());
+        a.insert(a.end(), rhp.begin(), rhp.end());
         B->units.swap(a);
-        if (B->npacked == 0) { std::vector<float>().swap(B->coef32); std::vector<double>().swap(B->nt2); }
-        if (verbose) fprintf(stderr, "  brick plan: %d units: %d with one n_t row of which %d ragged, %d per-element coefficients of which %d packed\n",
-                             (int)B->units.size(), B->nsame, B->nrag, B->nhet, B->npacked);
+        if (B->npacked + B->nrpacked == 0) { std::vector<float>().swap(B->coef32); std::vector<double>().swap(B->nt2); }
+        if (verbose) fprintf(stderr, "  brick plan: %d units: %d with one n_t row of which %d ragged, %d per-element coefficients of which %d packed, %d ragged per-element of which %d packed\n",
+                             (int)B->units.size(), B->nsame, B->nrag, B->nhet, B->npacked, B->nrhet, B->nrpacked);
         if (verbose && B->nrag) {
             int64_t pos = 0, own = 0, other = 0;
             for (const hq_brick_unit& U : B->units) {
@@ -1119,7 +1157,17 @@ static __device__ __forceinline__ double hq_dpp_from_next_lane(double v)
 /* PACKED (HQ_BK_PACKED units): `coef` holds three FLOATS per element (rho, Vs, Vp: hq_material_coef expands them to the
  * caller's very doubles, ~50 VALU operations per element and layer), `nt3` two doubles per node {m0, m0 - m1}: 28 bytes
  * per node and step instead of 52 */
-template <bool PACKED>
+/* RAGGED (round 6; HQ_BK_HET | HQ_BK_RAGGED units): the unit owns a SUBSET of its tile's positions -- beside a level
+ * interface that cuts the footprint sideways no 63 x 7 tile is full of simple nodes, and a mesh with material of its own in
+ * every element (any real CVM) has no one-material columns for hq_k_brick<.., RAGGED> either.  Every plane's positions come
+ * out of the id table [np + 2][ny][nx] behind the ring table, exactly as there (v >= 0: a node the unit owns, numbered plane
+ * by plane from U.base; v <= -2: node -v - 2 of somebody else, loaded because an owned node has it for a neighbour, never
+ * written; -1: nothing an owned node needs -- the lane loads node 0 instead, whose values only reach elements without an
+ * owned corner), read one plane ahead like the ring ids.  Elements that do not exist at this level carry zero coefficients
+ * (rho = 0 in the packed form).  Same march, same LDS image, same sums; only the stores are conditional. */
+static __device__ __forceinline__ int64_t hq_rag_node(int32_t v) { return v >= 0 ? (int64_t)v : (v <= -2 ? (int64_t)(-v - 2) : (int64_t)0); }
+
+template <bool PACKED, bool RAGGED = false>
 __global__ void __launch_bounds__(HQ_BH_THREADS, HQ_BH_WAVES == 12 ? 3 : 4)   /* 8 waves: 4 per SIMD = two workgroups per CU, <= 128 VGPRs */
 hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ units, const int32_t* __restrict__ tab,
                const void* __restrict__ coef_any, const hq_real* __restrict__ u1g, const hq_real* __restrict__ u2g,
@@ -1152,8 +1200,11 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     const int rrowA = ringA ? ring_row(rq) : 0, rrowB = ringB ? ring_row(rq + HQ_BH_NRT) : 0;
     const int32_t* __restrict__ rtabA = tab + U.tab + (ringA ? rq : 0);
     const int32_t* __restrict__ rtabB = tab + U.tab + (ringB ? rq + HQ_BH_NRT : 0);
-    const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;
-    const int64_t id_lo = cap[sidx], id_hi = cap[nxy + sidx];
+    const int32_t* __restrict__ cap = tab + U.tab + (int64_t)(np + 2) * nr;      /* RAGGED: [np + 2][nxy], every plane's ids */
+    const int64_t id_lo = RAGGED ? 0 : cap[sidx], id_hi = RAGGED ? 0 : cap[nxy + sidx];
+    /* RAGGED: vload = the table entry of the plane whose loads are in flight, vnext = of the plane behind it (read one plane
+     * ahead), idB / idA = of the planes whose accumulators are accB / accA (>= 0: this unit owns the node and stores it) */
+    int32_t vload = RAGGED ? cap[sidx] : 0, vnext = RAGGED ? cap[nxy + sidx] : 0, idA = -1, idB = -1;
     const double* __restrict__ cf = (const double*)coef_any + (PACKED ? 0 : U.coef + t);   /* [layer][c1 | c2 | beta][thread] */
     const float* __restrict__ cf32 = (const float*)coef_any + (PACKED ? U.coef + t : 0);      /* [layer][rho | Vs | Vp][thread] */
     hq_mat_const K = mat;
@@ -1171,6 +1222,10 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
     double mn[3] = { 1.0, 0.0, 0.0 };
     double accA[3] = { 0.0, 0.0, 0.0 }, accB[3] = { 0.0, 0.0, 0.0 }, m0A = 1.0, m0B = 1.0;    /* m0: 1 / mass_simple */
     int32_t ridA = rtabA[0], ridB = rtabB[0];
+    /* RAGGED: a ring position no owned node needs is -1 in the table -- node 0 is loaded in its place (its values reach only
+     * elements without an owned corner).  Clamped where the ids are TAKEN (here, and behind the PUT below), never beside
+     * their loads */
+    if (RAGGED) { ridA = ridA < 0 ? 0 : ridA; ridB = ridB < 0 ? 0 : ridB; }
 
     /* One load per register for all lanes of a wave, the address chosen per lane -- an owner's node or a ring thread's
      * ring node A into x1, x2; the owner's n_t row or u1 of ring node B into mn -- and no branch around them: two loads
@@ -1210,6 +1265,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                 acc_[d] = m2_ * a1_ - m1_ * a2_;                                                      \
             }                                                                                         \
             m0_ = 1.0 / mn[0];                                                                        \
+            if (RAGGED) idB = vload;                                                                  \
         }                                                                                             \
         if (ringA) { _Pragma("unroll") for (int d = 0; d < 3; d++) { const double a1_ = x1[d], a2_ = x2[d]; iu_[3 * rrowA + d] = a1_; iv_[3 * rrowA + d] = a1_ - a2_; } } \
         if (ringB) { _Pragma("unroll") for (int d = 0; d < 3; d++) { const double b1_ = SAME ? mn[d] : (double)rb1[d], b2_ = SAME ? accB[d] : (double)rb2[d]; iu_[3 * rrowB + d] = b1_; iv_[3 * rrowB + d] = b1_ - b2_; } } \
@@ -1223,14 +1279,17 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
         const int pp_ = (p_);                                                                         \
         if (HQ_BH_ABL != 2 && !PACKED) { const double* q_ = cf + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nc1 = q_[0]; nc2 = q_[HQ_BH_CS]; nbeta = q_[2 * HQ_BH_CS]; } \
         if (HQ_BH_ABL != 2 && PACKED) { const float* q_ = cf32 + (int64_t)(pp_ - 1) * (3 * HQ_BH_THREADS); nrho = q_[0]; nvs = q_[HQ_BH_CS]; nvp = q_[2 * HQ_BH_CS]; } \
-        HQ_BH_LOAD(pp_ == np + 1 ? id_hi : U.base + (int64_t)(pp_ - 1) * nxy + sidx)                  \
+        if (RAGGED) vload = vnext;                                                                    \
+        HQ_BH_LOAD(RAGGED ? hq_rag_node(vload) : (pp_ == np + 1 ? id_hi : U.base + (int64_t)(pp_ - 1) * nxy + sidx)) \
         HQ_BH_LOAD_B()                                                                                \
         { const int64_t r_ = (int64_t)(pp_ < np + 1 ? pp_ + 1 : np + 1) * nr; ridA = rtabA[r_]; ridB = rtabB[r_]; } \
+        if (RAGGED) vnext = cap[(int64_t)(pp_ < np + 1 ? pp_ + 1 : np + 1) * nxy + sidx];              \
     }
     if (HQ_BH_ABL == 2) { nc1 = dt2; nc2 = dt2; nbeta = dt2; }
-    HQ_BH_LOAD(id_lo)
+    HQ_BH_LOAD(RAGGED ? hq_rag_node(vload) : id_lo)
     HQ_BH_LOAD_B()
     ridA = rtabA[nr]; ridB = rtabB[nr];
+    if (RAGGED) { ridA = ridA < 0 ? 0 : ridA; ridB = ridB < 0 ? 0 : ridB; }
     /* The loop starts two steps early: steps -2 and -1 only put the planes 0 and 1 into LDS and request the planes 1
      * and 2.  ONE request site: a plane and the coefficients of the next layer are requested as soon as the registers
      * are free -- right behind the PUT of the plane before, ahead of the barrier -- and stay in flight through the
@@ -1271,11 +1330,11 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
                     H0[d] = G[1][0][d] + xch[d * HQ_BH_THREADS + t + 64];
                     H1[d] = G[1][1][d] + xch[(3 + d) * HQ_BH_THREADS + t + 64];
                 }
-                if (l >= 1) {                        /* plane l of the march = plane l - 1 of the unit is complete */
+                if (l >= 1 && (!RAGGED || idA >= 0)) {   /* plane l of the march = plane l - 1 of the unit is complete */
                     double f[3];
 #pragma unroll
                     for (int d = 0; d < 3; d++) f[d] = accA[d] + (H0[d] - H1[d]);
-                    const int local = (l - 1) * nxy + sidx;
+                    const int local = RAGGED ? (int)((int64_t)idA - U.base) : (l - 1) * nxy + sidx;
                     if (has_src) {                   /* compute_addforce_s, psolve.c:5917-5927 */
                         for (int i = src_ptr[slot]; i < src_ptr[slot + 1]; i++)
                             if (src_ent[2 * i] == local) {
@@ -1290,6 +1349,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
 #pragma unroll
                 for (int d = 0; d < 3; d++) accA[d] = accB[d] + (H0[d] + H1[d]);
                 m0A = m0B;
+                if (RAGGED) idA = idB;
             }
         }
         if (l < np) HQ_BH_PUT(l & 1, accB, m0B)
@@ -1299,6 +1359,7 @@ hq_k_brick_het(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__
          * wait for them further down would have to drain the loads requested next (the compiler cannot count loads
          * behind branches) */
         asm volatile("" : "+v"(c1), "+v"(c2), "+v"(beta), "+v"(ridA), "+v"(ridB));
+        if (RAGGED) { asm volatile("" : "+v"(vnext)); ridA = ridA < 0 ? 0 : ridA; ridB = ridB < 0 ? 0 : ridB; }
         if (l + 1 < np) HQ_BH_REQUEST(l + 3)
         __syncthreads();
     }
@@ -1327,15 +1388,17 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
     P->nrag = B.nrag;
     P->nhet = B.nhet;
     P->npacked = B.npacked;
+    P->nrhet = B.nrhet;
+    P->nrpacked = B.nrpacked;
     if (P->nunits == 0) return 0;
-    if (P->nhet > 0) {
+    if (P->nhet + P->nrhet > 0) {
         /* (the double block of a packed unit is never read: only the blocks of the unpacked ones travel) */
-        if (P->nhet > P->npacked) {
+        if (P->nhet > P->npacked || P->nrhet > P->nrpacked) {
             if (hipMalloc((void**)&P->d_coef, 8 * B.coef.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
             *bytes += (int64_t)(8 * B.coef.size());
             if (hipMemcpy(P->d_coef, B.coef.data(), 8 * B.coef.size(), hipMemcpyHostToDevice) != hipSuccess) { g_patch_err = "brick coefficient upload failed"; return -3; }
         }
-        if (P->npacked > 0) {
+        if (P->npacked + P->nrpacked > 0) {
             if (hipMalloc((void**)&P->d_coef32, 4 * B.coef32.size()) != hipSuccess || hipMalloc((void**)&P->d_nt2, 8 * B.nt2.size()) != hipSuccess) { g_patch_err = "hipMalloc failed"; return -2; }
             *bytes += (int64_t)(4 * B.coef32.size() + 8 * B.nt2.size());
             if (hipMemcpy(P->d_coef32, B.coef32.data(), 4 * B.coef32.size(), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1344,7 +1407,9 @@ static int hq_brick_upload(hq_brick_plan* P, const hq_brick_host& B, int64_t* by
         static bool attr_set = false;            /* 80.7 KB of dynamic LDS per workgroup */
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)hq_k_brick_het<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess ||
-                hipFuncSetAttribute((const void*)hq_k_brick_het<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess) { g_patch_err = "hq_k_brick_het: LDS attribute"; return -3; }
+                hipFuncSetAttribute((const void*)hq_k_brick_het<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)hq_k_brick_het<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)hq_k_brick_het<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HQ_BH_LDS) != hipSuccess) { g_patch_err = "hq_k_brick_het: LDS attribute"; return -3; }
             attr_set = true;
         }
     }
@@ -1409,10 +1474,11 @@ static int hq_brick_set_source(hq_brick_plan* P, int32_t nloaded, const int32_t*
 static void hq_brick_launch(const hq_brick_plan* P, const hq_real* u1, const hq_real* u2, hq_real* un, const double* nt3,
                             const double* F, double dt2, hipStream_t stream, bool light = false)
 {
-    const int32_t cnt[5] = { P->nsame - P->nrag, P->nunits - P->nsame - P->nhet, P->nhet - P->npacked, P->npacked, P->nrag };
+    const int32_t cnt[7] = { P->nsame - P->nrag, P->nunits - P->nsame - P->nhet - P->nrhet, P->nhet - P->npacked, P->npacked, P->nrag,
+                             P->nrhet - P->nrpacked, P->nrpacked };
     int32_t first = 0;
-    for (int k4 = 0; k4 < 5; k4++) {
-        const int k = k4 == 0 ? 0 : (k4 == 1 ? 4 : k4 - 1);       /* launch order = unit order: one row, ragged, per-node rows, HET, packed */
+    for (int k4 = 0; k4 < 7; k4++) {
+        const int k = k4 == 0 ? 0 : (k4 == 1 ? 4 : (k4 < 5 ? k4 - 1 : k4));       /* launch order = unit order: one row, ragged, per-node rows, HET, packed, ragged HET, ragged packed */
         const int32_t count = cnt[k];
         if (count <= 0) continue;
         const int per_xcd = (count + 7) / 8;
@@ -1426,8 +1492,12 @@ static void hq_brick_launch(const hq_brick_plan* P, const hq_real* u1, const hq_
         else if (k == 4) hq_k_brick<false, false, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 2) hq_k_brick_het<false><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
                                                                                                P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
-        else hq_k_brick_het<true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef32, u1, u2, un, P->d_nt2, sp,
+        else if (k == 3) hq_k_brick_het<true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef32, u1, u2, un, P->d_nt2, sp,
                                                                                    P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
+        else if (k == 5) hq_k_brick_het<false, true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef, u1, u2, un, nt3, sp,
+                                                                                                     P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
+        else hq_k_brick_het<true, true><<<per_xcd * 8, HQ_BH_THREADS, HQ_BH_LDS, stream>>>(count, per_xcd, P->d_units + first, P->d_tab, P->d_coef32, u1, u2, un, P->d_nt2, sp,
+                                                                                          P->d_src_ent, (sp ? F : nullptr), dt2, P->mat);
 #undef HQ_BK_ARGS
         first += count;
     }

@@ -2168,7 +2168,7 @@ static int hq_brick_excluded(const hq_desc* d, std::vector<char>& excl)
  * the unit, an entry of the unit's ring table or of its first / last plane's id list.
  * report = {brick nodes, tile columns, units, units with one n_t row, levels, neighbours checked, patch nodes, faults}
  */
-static thread_local int64_t g_brick_check_extra[2];    /* the last check's ragged units and the nodes they own (hq_brick_plan_check_n) */
+static thread_local int64_t g_brick_check_extra[4];    /* the last check's ragged units and the nodes they own (hq_brick_plan_check_n) */
 
 extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
 {
@@ -2226,8 +2226,12 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
             (!rag && U.base + (int64_t)nx * ny * np > B.nb)) { bad++; continue; }
         nsame += (U.flags & HQ_BK_NTSAME) != 0;
         if (((U.flags & HQ_BK_NTSAME) != 0) != (u < B.nsame)) bad++;
-        if (rag != (u >= B.nsame - B.nrag && u < B.nsame) || (rag && (het || (U.flags & (HQ_BK_TOPFACE | HQ_BK_BOTFACE))))) { bad++; continue; }
-        if (het != (u >= (int64_t)B.units.size() - B.nhet)) bad++;
+        /* the launch order: one n_t row | ragged (one row) | per-node rows | HET | HET packed | ragged HET | ragged HET packed */
+        const int64_t nu = (int64_t)B.units.size();
+        if ((rag && !het) != (u >= B.nsame - B.nrag && u < B.nsame) || (rag && (U.flags & (HQ_BK_TOPFACE | HQ_BK_BOTFACE)))) { bad++; continue; }
+        if ((rag && het) != (u >= nu - B.nrhet)) { bad++; continue; }
+        if (het != (u >= nu - B.nhet - B.nrhet)) bad++;
+        if (het && ((U.flags & HQ_BK_PACKED) != 0) != (rag ? u >= nu - B.nrpacked : (u >= nu - B.nrhet - B.npacked && u < nu - B.nrhet))) bad++;
         if (het && (U.coef < 0 || U.coef + (int64_t)(np + 1) * HQ_BH_THREADS * 3 > (int64_t)B.coef.size())) { bad++; continue; }
         const int32_t* ring = B.tab.data() + U.tab;
         const int32_t* cap = ring + (int64_t)(np + 2) * nr;
@@ -2416,13 +2420,15 @@ extern "C" int hq_brick_plan_check(const hq_desc* d, int64_t report[8])
         if (have != need) bad++;
     }
     report[0] = B.nb; report[1] = B.ncolumns; report[2] = (int64_t)B.units.size(); report[3] = nsame;
-    report[4] = B.nhet; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
+    report[4] = B.nhet + B.nrhet; report[5] = nchecked; report[6] = N - B.nb; report[7] = bad;
     g_brick_check_extra[0] = B.nrag;
     g_brick_check_extra[1] = 0;
+    g_brick_check_extra[2] = B.nrhet;
+    g_brick_check_extra[3] = 0;
     for (const hq_brick_unit& U : B.units) {
         if (!(U.flags & HQ_BK_RAGGED)) continue;
         const int32_t* pl = B.tab.data() + U.tab + (int64_t)(U.np + 2) * (2 * (U.nx + 2) + 2 * U.ny);
-        for (int64_t i = (int64_t)U.nx * U.ny; i < (int64_t)U.nx * U.ny * (U.np + 1); i++) g_brick_check_extra[1] += pl[i] >= 0;
+        for (int64_t i = (int64_t)U.nx * U.ny; i < (int64_t)U.nx * U.ny * (U.np + 1); i++) g_brick_check_extra[(U.flags & HQ_BK_HET) ? 3 : 1] += pl[i] >= 0;
     }
     if (bad) return hq_fail(HQ_ERR_STATE, "brick plan self-check failed%s", "");
     return HQ_OK;
@@ -2433,10 +2439,10 @@ extern "C" int hq_brick_plan_check_n(const hq_desc* d, int64_t* report, int32_t 
 {
     int64_t r8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (!report || n < 8) return hq_fail(HQ_ERR_ARG, "hq_brick_plan_check_n: a report of at least 8 entries%s", "");
-    g_brick_check_extra[0] = g_brick_check_extra[1] = 0;
+    for (int k = 0; k < 4; k++) g_brick_check_extra[k] = 0;
     const int rc = hq_brick_plan_check(d, r8);
     for (int k = 0; k < 8; k++) report[k] = r8[k];
-    for (int k = 8; k < n; k++) report[k] = k < 10 ? g_brick_check_extra[k - 8] : 0;
+    for (int k = 8; k < n; k++) report[k] = k < 12 ? g_brick_check_extra[k - 8] : 0;
     return rc;
 }
 
@@ -2527,10 +2533,11 @@ extern "C" int hq_get_info_sized(hq_ctx* c, hq_info* info, uint64_t size)
     v.ragged_patches = c->plan.nragged;
     v.brick_units = c->bricks.nunits;
     v.brick_nodes = c->bricks.nb;
-    v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet;
-    v.brick_units_het = c->bricks.nhet;
-    v.brick_units_packed = c->bricks.npacked;
+    v.brick_units_pernode = c->bricks.nunits - c->bricks.nsame - c->bricks.nhet - c->bricks.nrhet;
+    v.brick_units_het = c->bricks.nhet + c->bricks.nrhet;
+    v.brick_units_packed = c->bricks.npacked + c->bricks.nrpacked;
     v.brick_units_ragged = c->bricks.nrag;
+    v.brick_units_ragged_het = c->bricks.nrhet;
     v.pcie_h2d_bytes = c->h2d_bytes;
     v.pcie_d2h_bytes = c->d2h_bytes;
     v.transport = c->comm ? 1 : (hq_ipc_ready(c) ? (c->ipc->loopback ? 5 : 2) : (c->host_xchg ? 3 : (c->group ? 4 : 0)));

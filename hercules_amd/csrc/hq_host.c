@@ -2143,6 +2143,193 @@ done:
 }
 
 /* ------------------------------------------------------------------------ */
+/* a CVM etree as the mesher's material model (cvm_query, quake/cvm/cvm.c:266-311) */
+/* ------------------------------------------------------------------------ */
+
+struct hqh_cvm {
+    int64_t   n;                    /* leaf octants, in key (Z) order                                   */
+    uint32_t* ticks;                /* [n][3] lower-left corners, etree ticks (root cube 2^31)           */
+    int32_t*  level;                /* [n]                                                               */
+    float*    val;                  /* [n][3] Vp, Vs, density (cvmpayload_t, cvm.h)                      */
+    uint64_t* key;                  /* [n] Morton code of the corner: point location is a binary search */
+    double    region[3];            /* region_length_east_m, _north_m, depth_deep_m - depth_shallow_m    */
+    uint32_t  endpoint[3];          /* domain_endpoint_x / y / z, ticks                                  */
+    double    ticksize;             /* metres per tick = region_length_east_m / domain_endpoint_x (cvm.c:289) */
+    int32_t   minlevel, maxlevel;
+};
+
+static uint64_t hqh_morton63(uint32_t x, uint32_t y, uint32_t z)
+{
+    /* 21 bits per axis of the 31-bit tick coordinates' TOP bits would lose the low ones: interleave all 31 into the
+     * order etree keys have (bit 3 i + d = bit i of coordinate d) using two words; compared lexicographically */
+    uint64_t k = 0;
+    for (int i = 20; i >= 0; i--) k = (k << 3) | (uint64_t)(((z >> (i + 10)) & 1u) << 2 | ((y >> (i + 10)) & 1u) << 1 | ((x >> (i + 10)) & 1u));
+    return k;
+}
+
+void hqh_cvm_close(hqh_cvm* c)
+{
+    if (!c) return;
+    free(c->ticks); free(c->level); free(c->val); free(c->key); free(c);
+}
+
+/*
+ * Open a CVM etree: the leaves with their (Vp, Vs, density) payloads (hqh_etree_read's B-tree walk) and the database
+ * control block cvm_getdbctl parses out of the etree's application meta data (cvm.c:62-215: five creation strings,
+ * then origin latitude / longitude, region lengths east / north, depths shallow / deep, domain end point x y z), which
+ * the etree library keeps as a text trailer behind the last page (etree.c storeappmeta).
+ */
+int hqh_cvm_open(const char* path, hqh_cvm** out)
+{
+    if (!path || !out) return HQ_ERR_ARG;
+    *out = NULL;
+    int64_t n = 0; int32_t vsize = 0; uint32_t* tk = NULL; int32_t* lv = NULL; void* vals = NULL;
+    int rc = hqh_etree_read(path, &n, &vsize, &tk, &lv, &vals);
+    if (rc != HQ_OK) return rc;
+    hqh_cvm* c = (hqh_cvm*)calloc(1, sizeof *c);
+    char* meta = NULL;
+    rc = HQ_ERR_ARG;
+    if (!c) { rc = HQ_ERR_NOMEM; goto fail; }
+    if (n < 1 || vsize < 12) goto fail;                       /* "float Vp; float Vs; float density;" at least */
+    {
+        FILE* f = fopen(path, "rb");
+        unsigned char eh[17];
+        if (!f) goto fail;
+        if (fread(eh, 1, sizeof eh, f) != sizeof eh) { fclose(f); goto fail; }
+        const uint32_t msize = rd_u32(eh + 13);               /* appmetasize, the '\0' included */
+        if (msize < 2 || msize > (1u << 20) || fseeko(f, -(off_t)msize, SEEK_END) != 0) { fclose(f); goto fail; }
+        meta = (char*)malloc(msize + 1);
+        if (!meta || fread(meta, 1, msize, f) != msize) { fclose(f); goto fail; }
+        meta[msize] = 0;
+        fclose(f);
+    }
+    {
+        /* the LAST nine blank-separated tokens are the numbers (the creation strings in front may hold blanks) */
+        double v[9];
+        int got = 0;
+        char* end = meta + strlen(meta);
+        while (got < 9 && end > meta) {
+            while (end > meta && (end[-1] == ' ' || end[-1] == '\n' || end[-1] == '\t')) end--;
+            char* start = end;
+            while (start > meta && start[-1] != ' ' && start[-1] != '\n' && start[-1] != '\t') start--;
+            if (start == end) break;
+            char save = *end; *end = 0;
+            char* stop = NULL;
+            v[8 - got] = strtod(start, &stop);
+            const int ok = stop && *stop == 0;
+            *end = save;
+            if (!ok) break;
+            got++;
+            end = start;
+        }
+        if (got != 9) goto fail;
+        c->region[0] = v[2]; c->region[1] = v[3]; c->region[2] = v[5] - v[4];
+        for (int d = 0; d < 3; d++) { if (v[6 + d] < 1 || v[6 + d] > 2147483648.0) goto fail; c->endpoint[d] = (uint32_t)v[6 + d]; }
+        if (!(c->region[0] > 0)) goto fail;
+        c->ticksize = c->region[0] / (double)c->endpoint[0];
+    }
+    c->n = n; c->ticks = tk; c->level = lv; tk = NULL; lv = NULL;
+    c->val = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+    c->key = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+    if (!c->val || !c->key) { rc = HQ_ERR_NOMEM; goto fail; }
+    c->minlevel = 31; c->maxlevel = 0;
+    for (int64_t i = 0; i < n; i++) {
+        memcpy(c->val + 3 * i, (const unsigned char*)vals + (size_t)i * (size_t)vsize, 12);
+        if (c->level[i] < 1 || c->level[i] > 21) goto fail;   /* (octants below 2^10 ticks: not this reader's keys) */
+        if (c->level[i] < c->minlevel) c->minlevel = c->level[i];
+        if (c->level[i] > c->maxlevel) c->maxlevel = c->level[i];
+        c->key[i] = hqh_morton63(c->ticks[3 * i], c->ticks[3 * i + 1], c->ticks[3 * i + 2]);
+        if (i > 0 && c->key[i] <= c->key[i - 1]) goto fail;   /* leaves arrive in key order */
+    }
+    free(vals); free(meta);
+    *out = c;
+    return HQ_OK;
+fail:
+    free(tk); free(lv); free(vals); free(meta);
+    hqh_cvm_close(c);
+    return rc;
+}
+
+int hqh_cvm_info(const hqh_cvm* c, int64_t* nleaves, int32_t levels[2], double region_m[3], double* ticksize)
+{
+    if (!c) return HQ_ERR_ARG;
+    if (nleaves) *nleaves = c->n;
+    if (levels) { levels[0] = c->minlevel; levels[1] = c->maxlevel; }
+    if (region_m) for (int d = 0; d < 3; d++) region_m[d] = c->region[d];
+    if (ticksize) *ticksize = c->ticksize;
+    return HQ_OK;
+}
+
+/*
+ * cvm_query (cvm.c:266-311): the payload of the leaf octant that holds the point -- ticks = (etree_tick_t)(metres /
+ * tickSize) per axis, then etree_search's point location, here a binary search for the last leaf whose Morton code is
+ * <= the point's, followed by the containment check.  -> 0, or -1 where no octant holds the point (as cvm_query).
+ */
+int hqh_cvm_query(const hqh_cvm* c, double east_m, double north_m, double depth_m, float payload[3])
+{
+    if (!c || !payload || east_m < 0 || north_m < 0 || depth_m < 0) return -1;
+    const double q[3] = { east_m / c->ticksize, north_m / c->ticksize, depth_m / c->ticksize };
+    uint32_t t[3];
+    for (int d = 0; d < 3; d++) { if (!(q[d] < 2147483648.0)) return -1; t[d] = (uint32_t)q[d]; }
+    const uint64_t k = hqh_morton63(t[0], t[1], t[2]);
+    int64_t lo = 0, hi = c->n;                                 /* last i with key[i] <= k */
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (c->key[mid] <= k) lo = mid; else hi = mid; }
+    if (c->key[lo] > k) return -1;
+    const uint32_t edge = 1u << (31 - c->level[lo]);
+    for (int d = 0; d < 3; d++)
+        if (t[d] < c->ticks[3 * lo + d] || t[d] - c->ticks[3 * lo + d] >= edge) return -1;
+    memcpy(payload, c->val + 3 * lo, 12);
+    return 0;
+}
+
+/*
+ * The database on a regular grid in the MESH's axes [k][y][x] for hqh_octree_generate: cells of the FINEST leaf level
+ * present (every query that setrec makes, psolve.c:1307-1397, then finds the leaf it would find in the etree).  setrec
+ * calls cvm_query(east = the mesh's y, north = the mesh's x) (psolve.c:1352), so the database's x ticks run along mesh y.
+ * HQ_ERR_ARG where the leaves do not tile the domain or the grid would exceed 2^31 cells.  Release with hqh_free.
+ */
+int hqh_cvm_grid(const hqh_cvm* c, int32_t dims[3], double* cell_m, float** vp, float** vs, float** rho)
+{
+    if (!c || !dims || !cell_m || !vp || !vs || !rho) return HQ_ERR_ARG;
+    *vp = *vs = *rho = NULL;
+    const uint32_t ce = 1u << (31 - c->maxlevel);               /* cell edge, ticks */
+    int64_t nd[3];                                              /* database axes: x (east), y (north), z */
+    for (int d = 0; d < 3; d++) { if (c->endpoint[d] % ce) return HQ_ERR_ARG; nd[d] = c->endpoint[d] / ce; }
+    const int64_t cells = nd[0] * nd[1] * nd[2];
+    if (cells < 1 || cells > 0x7fffffffLL) return HQ_ERR_ARG;
+    float* a[3];
+    for (int q = 0; q < 3; q++) a[q] = (float*)malloc(sizeof(float) * (size_t)cells);
+    unsigned char* seen = (unsigned char*)calloc((size_t)cells, 1);
+    int rc = HQ_ERR_NOMEM;
+    if (!a[0] || !a[1] || !a[2] || !seen) goto fail;
+    rc = HQ_ERR_ARG;
+    /* mesh axes: x = database north (y ticks), y = database east (x ticks) */
+    const int64_t NX = nd[1], NY = nd[0];
+    for (int64_t i = 0; i < c->n; i++) {
+        const uint32_t edge = 1u << (31 - c->level[i]);
+        const int64_t w = edge / ce, x0 = c->ticks[3 * i] / ce, y0 = c->ticks[3 * i + 1] / ce, z0 = c->ticks[3 * i + 2] / ce;
+        if (c->ticks[3 * i] % ce || c->ticks[3 * i + 1] % ce || c->ticks[3 * i + 2] % ce) goto fail;
+        for (int64_t z = z0; z < z0 + w && z < nd[2]; z++)
+            for (int64_t xe = x0; xe < x0 + w && xe < nd[0]; xe++)
+                for (int64_t yn = y0; yn < y0 + w && yn < nd[1]; yn++) {
+                    const int64_t g = (z * NY + xe) * NX + yn;
+                    if (seen[g]) goto fail;                     /* two leaves over one cell */
+                    seen[g] = 1;
+                    a[0][g] = c->val[3 * i]; a[1][g] = c->val[3 * i + 1]; a[2][g] = c->val[3 * i + 2];
+                }
+    }
+    for (int64_t g = 0; g < cells; g++) if (!seen[g]) goto fail;     /* a hole in the database */
+    free(seen);
+    dims[0] = (int32_t)NX; dims[1] = (int32_t)NY; dims[2] = (int32_t)nd[2];
+    *cell_m = c->ticksize * (double)ce;
+    *vp = a[0]; *vs = a[1]; *rho = a[2];
+    return HQ_OK;
+fail:
+    free(a[0]); free(a[1]); free(a[2]); free(seen);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
 /* octree mesh from its leaves (octor_extractmesh + solver_init, one partition) */
 /* ------------------------------------------------------------------------ */
 

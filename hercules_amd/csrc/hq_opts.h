@@ -36,7 +36,7 @@ static const hq_opt_entry g_opt_table[] = {
     HQ_OPT_I("HQ_DEBUG_HALO", debug_halo), HQ_OPT_I("HQ_IPC_ARENA", ipc_arena), HQ_OPT_D("HQ_IPC_TIMEOUT_MS", ipc_timeout_ms),
     HQ_OPT_D("HQ_LOOPBACK_DELAY_US", loopback_delay_us), HQ_OPT_I("HQ_PATCH_VERBOSE", verbose), HQ_OPT_I("HQ_QUIET", quiet),
     HQ_OPT_I("HQ_BRICK_RAGGED", brick_ragged), HQ_OPT_I("HQ_BRICK_RAGGED_MINFILL", brick_ragged_minfill),
-    HQ_OPT_I("HQ_PHASE_TIMING", phase_timing),
+    HQ_OPT_I("HQ_PHASE_TIMING", phase_timing), HQ_OPT_I("HQ_BRICK_RAGGED_HET", brick_ragged_het),
 };
 #undef HQ_OPT_I
 #undef HQ_OPT_D
@@ -53,6 +53,7 @@ static void hq_options_defaults(hq_options* o)
         else *(double*)((char*)o + e.off) = -1.0;
     }
     o->allow_env = -1;
+    o->reserved0 = -1;
 }
 
 /* the caller's struct (of its own size) into a full one */

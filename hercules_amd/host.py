@@ -18,7 +18,8 @@ EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_des
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
            "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format", "hqh_station_format_derivs",
            "hqh_station_kinematics", "hqh_station_header", "hqh_wavefield_create", "hqh_wavefield_write",
-           "hqh_octbox_create", "hqh_octbox_destroy", "hqh_octbox_desc", "hqh_octbox_view"]
+           "hqh_octbox_create", "hqh_octbox_destroy", "hqh_octbox_desc", "hqh_octbox_view",
+           "hqh_cvm_open", "hqh_cvm_close", "hqh_cvm_info", "hqh_cvm_query", "hqh_cvm_grid"]
 
 
 class _BoxParams(ctypes.Structure):
@@ -624,6 +625,48 @@ def etree_read(path):
         for p in (pt, pl, pv):
             libc.free(p)
     return ticks, level, vals
+
+
+class Cvm:
+    """A CVM etree (hqh_cvm_*): the material database the reference's mesher queries -- cvm_query's point location on
+    this library's own etree reader.  grid() -> (vp, vs, rho [nz, ny, nx] float32 in the MESH's axes, cell edge in m):
+    the model hqh_octree_generate takes."""
+
+    def __init__(self, path):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        capi._check(self._lib.hqh_cvm_open(os.fsencode(path), ctypes.byref(self._h)))
+        n, lv, reg, tick = ctypes.c_int64(), (ctypes.c_int32 * 2)(), (ctypes.c_double * 3)(), ctypes.c_double()
+        capi._check(self._lib.hqh_cvm_info(self._h, ctypes.byref(n), lv, reg, ctypes.byref(tick)))
+        self.nleaves, self.levels, self.region, self.ticksize = n.value, (lv[0], lv[1]), tuple(reg), tick.value
+
+    def query(self, east_m, north_m, depth_m):
+        """cvm_query: (Vp, Vs, density) of the leaf octant that holds the point, or None outside the database."""
+        out = (ctypes.c_float * 3)()
+        rc = self._lib.hqh_cvm_query(self._h, ctypes.c_double(east_m), ctypes.c_double(north_m), ctypes.c_double(depth_m), out)
+        return None if rc != 0 else (out[0], out[1], out[2])
+
+    def grid(self):
+        dims, cell = (ctypes.c_int32 * 3)(), ctypes.c_double()
+        p = [ctypes.c_void_p() for _ in range(3)]
+        capi._check(self._lib.hqh_cvm_grid(self._h, dims, ctypes.byref(cell), *[ctypes.byref(q) for q in p]))
+        self._lib.hqh_free.argtypes = [ctypes.c_void_p]
+        self._lib.hqh_free.restype = None
+        try:
+            out = [_view(q.value, (dims[2], dims[1], dims[0]), np.float32).copy() for q in p]
+        finally:
+            for q in p:
+                self._lib.hqh_free(q)
+        return out[0], out[1], out[2], cell.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.hqh_cvm_close.argtypes = [ctypes.c_void_p]
+            self._lib.hqh_cvm_close.restype = None
+            self._lib.hqh_cvm_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
 
 
 def mesh_payload(values):

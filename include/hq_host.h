@@ -22,8 +22,10 @@
  *   hqh_etree_read, hqh_mesh_from_leaves   the reference's mesh.e -> octor's mesh tables
  *   hqh_forcefile_*, hqh_checkpoint_*, hqh_plane_*, hqh_station_*, hqh_wavefield_*   its file formats
  *
- * The octree mesher itself, the CVM query, the slip-function source generator and the IO-PE
- * pool stay in the reference (out of scope).
+ *   hqh_cvm_*         a CVM etree as the mesher's material model (cvm_query)
+ *
+ * The distributed octree mesher, the slip-function source generator and the IO-PE pool stay in the
+ * reference (out of scope).
  */
 #ifndef HQ_HOST_H
 #define HQ_HOST_H
@@ -403,6 +405,24 @@ typedef struct {
 HQ_API int  hqh_octree_generate(const hqh_grid_model* m, const hqh_mesher_params* p, int64_t* E, uint32_t** elem_ticks,
                                 uint32_t** elem_edge, float** edata, uint32_t far_ticks[3], double* ticksize);
 HQ_API void hqh_free(void* p);
+
+/*
+ * A CVM etree -- the material database the reference's mesher queries (cvmdb_input_file; quake/cvm/cvm.h:72 cvm_query,
+ * cvm.c:266-311; payload cvmpayload_t = float Vp, Vs, density; control block cvm_getdbctl cvm.c:62-215) -- read with this
+ * library's own etree reader, so that "the same input etree" needs neither the reference's mesher nor its etree library:
+ *   hqh_cvm_open   leaves + payloads + the control block (region lengths, domain end point -> metres per tick)
+ *   hqh_cvm_query  cvm_query: the payload of the leaf octant that holds (east, north, depth) in metres; -1 outside
+ *   hqh_cvm_grid   the database on a regular grid of its finest leaves' size, in the MESH's axes [k][y][x] (setrec queries
+ *                  east = mesh y, north = mesh x, psolve.c:1352): the hqh_grid_model of hqh_octree_generate
+ * tests/test_host_partition.py: from the very databases oracle/make_cvm wrote for the golden runs, the reference's meshes
+ * leaf for leaf; tests/test_gpu_parity.py: from the database to the reference's checkpoints on the GPU.
+ */
+typedef struct hqh_cvm hqh_cvm;
+HQ_API int  hqh_cvm_open(const char* path, hqh_cvm** out);
+HQ_API void hqh_cvm_close(hqh_cvm* c);
+HQ_API int  hqh_cvm_info(const hqh_cvm* c, int64_t* nleaves, int32_t levels[2], double region_m[3], double* ticksize);
+HQ_API int  hqh_cvm_query(const hqh_cvm* c, double east_m, double north_m, double depth_m, float payload[3]);
+HQ_API int  hqh_cvm_grid(const hqh_cvm* c, int32_t dims[3], double* cell_m, float** vp, float** vs, float** rho);
 
 /* Fill F[nsteps][nloaded][3] for steps [step0, step0+nsteps) of the ramp source. */
 HQ_API void hqh_source_table(const hqh_run_params* rp, double dt, int32_t step0, int32_t nsteps, double* F);

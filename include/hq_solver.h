@@ -152,7 +152,7 @@ typedef struct {
     int32_t brick_units_ragged;  /* of the units with one n_t row: partly filled tiles (HQ_BK_RAGGED, hq_options.brick_ragged) */
     /* ABI 6 */
     int32_t brick_stream;        /* 1: the shell's patches run on the compute stream BESIDE the bricks, which have a stream of their own */
-    int32_t reserved1;
+    int32_t brick_units_ragged_het; /* of brick_units_het: partly filled tiles (hq_k_brick_het<., RAGGED>, hq_options.brick_ragged_het) */
     /* Where a step's device time goes -- the library's share of the reference's per-phase report (print_timing_stat,
      * psolve.c:6041-6266: "Compute addforces e", "... schedule send data", ...), from HIP events, averaged over
      * `timed_steps` steps: every step of a context with hq_options.phase_timing = 1 and of every hq_run_timed batch.
@@ -252,6 +252,10 @@ typedef struct {
     /* (ABI 6) */
     int32_t allow_env;           /* 1: HQ_* environment variables override the fields above; 0: the environment is ignored;
                                     -1 (default): honoured only in a process that sets HQ_ALLOW_ENV=1 (experiments, tests) */
+    int32_t brick_ragged_het;    /* HQ_BRICK_RAGGED_HET   0: no partly filled tiles of the per-element kernel (hq_k_brick_het<., RAGGED>):
+                                                          beside level interfaces of a mesh whose material differs from element to
+                                                          element the nodes then stay with the patches                       */
+    int32_t reserved0;
     int32_t phase_timing;        /* HQ_PHASE_TIMING       1: every step records where its device time goes (six events per
                                                           step; hq_info.t_*_us) -- the library's share of print_timing_stat
                                                           (psolve.c:6041-6266); hq_run_timed batches always do          */
@@ -451,7 +455,8 @@ HQ_API int hq_stencil_plan_check(const hq_desc* desc, int64_t report[6]);
  *           (hq_k_brick_het), neighbours checked, patch nodes, faults}.
  */
 HQ_API int hq_brick_plan_check(const hq_desc* desc, int64_t report[8]);
-/* ... with report[8] = units that own only part of their tile (ragged), report[9] = the nodes those own; n >= 8 entries */
+/* ... with report[8] = units that own only part of their tile (ragged, one n_t row), report[9] = the nodes those own,
+ * report[10] / [11] = the same for the ragged units of the per-element kernel; n >= 8 entries */
 HQ_API int hq_brick_plan_check_n(const hq_desc* desc, int64_t* report, int32_t n);
 
 /*

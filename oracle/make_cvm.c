@@ -20,6 +20,10 @@
  *          box i0 i1 j0 j1 k0 k1 Vp Vs rho     octants with i0 <= i < i1, j0 <= j < j1, k0 <= k < k1
  *          dip a b c Vp Vs rho                 octants whose centre lies above the plane
  *                                              k + 0.5 < a + b (i + 0.5) + c (j + 0.5)     (a sediment wedge)
+ *          grad gx gy gz                       (no material) every octant's Vp and Vs times
+ *                                              f = 1 + gx (i + 0.5) / nx + gy (j + 0.5) / ny + gz (k + 0.5) / nz, its density
+ *                                              times 1 + (f - 1) / 2, evaluated in double and rounded to float: a model
+ *                                              whose material differs from octant to octant (a velocity gradient)
  *        The reference's Vs rule then refines wherever the soft material is (psolve.c:1308 setrec, :2185 toexpand,
  *        quake_util.c:215 vsrule), so refinement interfaces get x-, y- and z-normal faces and staircase corners.
  */
@@ -63,6 +67,11 @@ int main(int argc, char** argv)
                 reg_kind[r] = 1;
                 for (int q = 0; q < 3; q++) reg_dip[r][q] = atof(argv[a + 1 + q]);
                 a += 4;
+            } else if (a < argc && strcmp(argv[a], "grad") == 0 && a + 4 <= argc) {
+                reg_kind[r] = 2;
+                for (int q = 0; q < 3; q++) reg_dip[r][q] = atof(argv[a + 1 + q]);
+                a += 4;
+                continue;
             } else { fprintf(stderr, "bad region %d\n", r); return 2; }
             reg_mat[r].Vp = (float)atof(argv[a]); reg_mat[r].Vs = (float)atof(argv[a + 1]); reg_mat[r].rho = (float)atof(argv[a + 2]);
             a += 3;
@@ -106,16 +115,28 @@ int main(int argc, char** argv)
         int L = 0;
         for (int l = 0; l < nlay; l++) if ((int)k >= kstart[l]) L = l;
         const cvmpayload_t* mat = &lay[L];
+        cvmpayload_t graded;
+        double grade = 1.0;
         if (nreg >= 0) {
             mat = &background;
             for (int r = 0; r < nreg; r++) {
                 int in;
+                if (reg_kind[r] == 2) {
+                    grade = 1.0 + reg_dip[r][0] * (i + 0.5) / nx + reg_dip[r][1] * (j + 0.5) / ny + reg_dip[r][2] * (k + 0.5) / nz;
+                    continue;
+                }
                 if (reg_kind[r] == 0)
                     in = (int)i >= reg_box[r][0] && (int)i < reg_box[r][1] && (int)j >= reg_box[r][2] && (int)j < reg_box[r][3] &&
                          (int)k >= reg_box[r][4] && (int)k < reg_box[r][5];
                 else
                     in = k + 0.5 < reg_dip[r][0] + reg_dip[r][1] * (i + 0.5) + reg_dip[r][2] * (j + 0.5);
                 if (in) mat = &reg_mat[r];
+            }
+            if (grade != 1.0) {
+                graded.Vp = (float)((double)mat->Vp * grade);
+                graded.Vs = (float)((double)mat->Vs * grade);
+                graded.rho = (float)((double)mat->rho * (1.0 + (grade - 1.0) / 2.0));
+                mat = &graded;
             }
         }
         if (etree_append(ep, a, mat) != 0) {

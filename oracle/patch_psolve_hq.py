@@ -18,7 +18,8 @@ blindly):
   4. solver_run(): the block from solver_nonlinear_state() to solver_send_displacement_dangling() becomes
      hq_steps( step, n ) -- n = hq_batch_length( step ), the steps up to the next due output, enqueued in one
      go, the loop counter advanced by n - 1 -- between Timer_Start / Timer_Stop of the timers
-     solver_run_collect_timers() reduces; the context is destroyed behind the loop.
+     solver_run_collect_timers() reduces; behind the loop the device-side timing split is printed
+     (hq_print_timing) and the context destroyed.
 """
 import sys
 
@@ -65,7 +66,7 @@ def main():
     t = t[:i] + block + t[j:]
     a = "    solver_drm_close();\n    solver_output_wavefield_close();\n    solver_run_collect_timers();\n"
     i = once(t, a)
-    t = t[:i] + "    hq_sync( theHq );\n    hq_destroy( theHq );\n" + t[i:]
+    t = t[:i] + "    hq_sync( theHq );\n    hq_print_timing();\n    hq_destroy( theHq );\n" + t[i:]
     sys.stdout.write(t)
 
 

@@ -416,6 +416,15 @@ BASIN_CVM = ["regions", 4, 6000, 3464, 2700, 2,
              "box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800]        # a soft box at the surface against the far-x face
 
 
+# the same basin with a velocity gradient: every database octant has a material of its own (what a real CVM gives --
+# setrec's 27-sample average differs from element to element, psolve.c:1307-1397), so NO two neighbouring coarse elements
+# share (c1, c2, beta) and the per-element-coefficient kernels run inside every octree level, beside hanging nodes
+GRADIENT_CVM = ["regions", 4, 6000, 3464, 2700, 3,
+                "dip", 3.2, -0.3, -0.12, 3000, 1732, 2200,
+                "box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800,
+                "grad", 0.10, -0.06, 0.12]
+
+
 def case_basin():
     """A LATERALLY refined octree (BASELINE config 5's "basin" in miniature): the material varies with
     (i, j, k) -- a dipping sediment wedge and a soft box against a domain face -- so the reference's Vs rule
@@ -502,6 +511,8 @@ CASES = {
     "c5_two_level_np8": lambda: case_octree_np("c5_two_level_np8", "c5_two_level", 8, "0.5", 200,
                                                [2, 3000, 1732, 2200, 6000, 3464, 2700], 500, 5.0),
     "c5_basin": case_basin,
+    "c5_gradient": lambda: _octree_case("c5_gradient", "0.3", 100, GRADIENT_CVM, 100, 5.0),
+    "c5_gradient_np8": lambda: case_octree_np("c5_gradient_np8", "c5_gradient", 8, "0.3", 100, GRADIENT_CVM, 100, 5.0),
     "c5_basin_np8": lambda: case_octree_np("c5_basin_np8", "c5_basin", 8, "0.3", 100, BASIN_CVM, 100, 5.0),
     "c5_basin_np5": lambda: case_octree_np("c5_basin_np5", "c5_basin", 5, "0.3", 100, BASIN_CVM, 100, 5.0),
     # the reference's single-precision build on the uniform box (effective and conventional stiffness) and on the

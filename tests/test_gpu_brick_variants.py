@@ -155,9 +155,9 @@ def test_brick_kernel_in_the_form_partitions_launch(monkeypatch, pernode):
 
 
 def test_typed_options_select_kernels_per_context(monkeypatch):
-    """hq_options (ABI 5) instead of the environment: two contexts of ONE process differ -- one with bricks, one with
+    """hq_options (ABI 6) instead of the environment: two contexts of ONE process differ -- one with bricks, one with
     hq_options.no_bricks = 1 and hq_k_patch_pers (patch_pipe = 4) -- both against the oracle; hq_get_options returns what
-    each runs with; an HQ_* variable in the environment still overrides the field (experiments)."""
+    each runs with; an HQ_* variable in the environment overrides a field only where the caller allows it."""
     lnid, node_ijk, et, nt, dt = _box(96, 40, 24)
     rng = np.random.default_rng(11)
     u1 = rng.uniform(-1, 1, (len(nt), 3)) * 1e-3
@@ -170,6 +170,7 @@ def test_typed_options_select_kernels_per_context(monkeypatch):
                   options={"no_bricks": 1, "patch_pipe": 4})
     c = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH,
                   options=ha.capi.Options(brick_cz=6, brick_by_component=1))
+    a_nodes = a.info()["brick_nodes"]
     assert a.info()["brick_nodes"] > 0 and b.info()["brick_nodes"] == 0
     assert c.info()["brick_units"] > a.info()["brick_units"]
     oa, ob, oc = a.options(), b.options(), c.options()
@@ -179,10 +180,56 @@ def test_typed_options_select_kernels_per_context(monkeypatch):
         tm1, tm2 = s.download()
         assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
         s.close()
-    monkeypatch.setenv("HQ_NO_BRICKS", "1")                  # the environment still wins
-    d = ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH, options={"no_bricks": 0})
-    assert d.info()["brick_nodes"] == 0 and d.options()["no_bricks"] == 1
+    # The environment (ABI 6): an HQ_* variable overrides a field only where the caller allows it -- allow_env = 1, or the
+    # default in a process that says HQ_ALLOW_ENV=1 (this suite: tests/conftest.py); a host that passes allow_env = 0
+    # (examples/psolve_hq_stub.inc) is not steered by it.  Resolved once: hq_get_options returns what really runs.
+    mk = lambda **o: ha.Solver(lnid, et, nt, dt, tm1=u1, tm2=u2, node_xyz=_ticks(node_ijk), variant=ha.HQ_VARIANT_PATCH, options=o)
+    monkeypatch.setenv("HQ_NO_BRICKS", "1")
+    d = mk(no_bricks=0)
+    assert d.info()["brick_nodes"] == 0 and d.options()["no_bricks"] == 1 and d.options()["allow_env"] == 1
     d.close()
+    d = mk(no_bricks=0, allow_env=0)
+    assert d.info()["brick_nodes"] > 0 and d.options()["no_bricks"] == 0 and d.options()["allow_env"] == 0
+    d.close()
+    monkeypatch.delenv("HQ_ALLOW_ENV")                       # a process that does not opt in: the variable is ignored
+    d = mk()
+    assert d.info()["brick_nodes"] > 0 and d.options()["no_bricks"] == -1 and d.options()["allow_env"] == 0
+    d.close()
+    d = mk(allow_env=1)
+    assert d.info()["brick_nodes"] == 0
+    d.close()
+    monkeypatch.setenv("HQ_ALLOW_ENV", "1")
+    monkeypatch.setenv("HQ_NO_BRICKS", "0")                  # a switch set to 0 is OFF, and reported as 0 (round-5 advisor)
+    monkeypatch.setenv("HQ_BRICK_NO_FACES", "0")
+    d = mk()
+    assert d.info()["brick_nodes"] == a_nodes and d.options()["no_bricks"] == 0 and d.options()["brick_no_faces"] == 0
+    d.close()
+    monkeypatch.setenv("HQ_BRICK_NO_FACES", "1")
+    d = mk()
+    assert 0 < d.info()["brick_nodes"] < a_nodes and d.options()["brick_no_faces"] == 1
+    d.close()
+
+
+def test_no_ntsame_through_the_typed_options_reaches_every_unit():
+    """hq_options.brick_no_ntsame = 1 WITHOUT the environment (round-5 advisor, medium: the option was read inside an
+    OpenMP region, whose worker threads saw no options -- only the units filled by the calling thread obeyed): every
+    uniform unit must come out with n_t rows of its own, on a box large enough for the planner's loop to be shared
+    between threads; against the oracle."""
+    lnid, node_ijk, et, nt, dt = _box(128, 64, 32)
+    N = len(node_ijk)
+    rng = np.random.default_rng(5)
+    u1 = rng.uniform(-1, 1, (N, 3)) * 1e-3
+    u2 = u1 * 0.999
+    s = ha.Solver(lnid, et, nt, dt, node_xyz=_ticks(node_ijk, 1 << 22), tm1=u1, tm2=u2, variant=ha.HQ_VARIANT_PATCH,
+                  options={"brick_no_ntsame": 1, "allow_env": 0})
+    info = s.info()
+    assert info["brick_units"] >= 16 and info["brick_units_pernode"] == info["brick_units"] and info["brick_units_het"] == 0
+    s.run(6)
+    tm1, tm2 = s.download()
+    s.close()
+    o1, o2 = u2.copy(), u1.copy()
+    ho.solver_run(lnid, et.copy(), nt.copy(), o1, o2, 0, 6, dt)
+    assert H.rel_linf(tm1, o2) < TOL and H.rel_linf(tm2, o1) < TOL
 
 
 def test_two_materials_in_one_tile_footprint_against_the_oracle():

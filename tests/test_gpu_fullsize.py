@@ -203,6 +203,29 @@ def test_all_c_host_program(tmp_path):
     box.close()
 
 
+_WHOLE = {}     # the 64M box and ONE solver context on it, shared by the two tests that need the whole box (4 s of mesh and
+                # 8 s of hq_create each): test_eight_partitions...[c3] and test_dependency_cone_windows...[c3], which
+                # follows it in this file and releases both
+
+
+def _whole_box(wl):
+    """-> (Box, Solver) of a uniform box workload, built once; the solver is handed over with whatever state it has --
+    the caller uploads its start field and sets its source."""
+    import bench
+    if wl not in _WHOLE:
+        nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
+        box = host.Box(nx, ny, nz, h, dt, freq)
+        _WHOLE[wl] = (box, box.create_solver())
+    return _WHOLE[wl]
+
+
+def _release_whole_box(wl):
+    if wl in _WHOLE:
+        box, s = _WHOLE.pop(wl)
+        s.close()
+        box.close()
+
+
 @pytest.mark.parametrize("wl,overlap,ragged,bricks", [("m1", 1, 1, 0), ("m1", 0, 1, 1), ("c3", 1, 1, 1),
                                                       ("m1", 0, 1, 2), ("c2h", 1, 1, 1)])
 def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged, bricks, monkeypatch):
@@ -223,15 +246,26 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     ncls, amp = bench.LATERAL.get(wl, (0, 0.0))        # c2h: material of its own in every element (hq_k_brick_het in every partition)
     nsteps = 3
     lap = H.lap_timer(wl + " x 8")
-    one = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
-    u = _field(one, 31337)
-    lap("whole box + field")
-    ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
+    shared = wl == "c3"                                  # (the default build of the 64M box: the cone-window test reuses it)
+    if shared:
+        one, s_one = _whole_box(wl)
+        u = _field(one, 31337)
+        lap("whole box + field")
+        s_one.set_source(np.zeros(0, np.int32), np.zeros((0, 0, 3)))
+        s_one.upload(u, 0.999 * u, 0)
+        s_one.run(nsteps)
+        ref1, ref2 = s_one.download()
+    else:
+        one = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
+        u = _field(one, 31337)
+        lap("whole box + field")
+        ref1, ref2 = _run(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
     lap("whole box: hq_create, run, download")
     gid_one = (one.node_ijk[:, 2].astype(np.int64) * (ny + 1) + one.node_ijk[:, 1]) * (nx + 1) + one.node_ijk[:, 0]
     lut = np.empty(gid_one.max() + 1, np.int64)
     lut[gid_one] = np.arange(len(gid_one))
-    one.close()
+    if not shared:
+        one.close()
     # (the ranks' meshes side by side: the C host side releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(8) as pool:
@@ -267,6 +301,124 @@ def test_eight_partitions_of_the_8m_box_match_one_partition(wl, overlap, ragged,
     for b in boxes:
         b.close()
     lap("run, download, compare")
+
+
+def _cone_windows(nx, ny, nz, src_elem):
+    """Centres (element indices) of the windows: corners, edges, faces (all five dashpot faces and the free surface
+    z = 0), the far-face cubes, the source element, the borders of brick tiles / chunks and of the 8^3 patches, and
+    seeded interior points."""
+    c = []
+    for i in (0, nx - 1):
+        for j in (0, ny - 1):
+            for k in (0, nz - 1):
+                c.append((i, j, k))                                                  # 8 corners
+    mid = (nx // 2 + 3, ny // 2 - 5, nz // 2 + 1)
+    for a in range(3):                                                               # 12 edges, 6 + 6 face points
+        for s1 in (0, 1):
+            for s2 in (0, 1):
+                e = list(mid)
+                o = [d for d in range(3) if d != a]
+                e[o[0]] = 0 if s1 == 0 else (nx, ny, nz)[o[0]] - 1
+                e[o[1]] = 0 if s2 == 0 else (nx, ny, nz)[o[1]] - 1
+                c.append(tuple(e))
+        for s in (0, 1):
+            e = list(mid)
+            e[a] = 0 if s == 0 else (nx, ny, nz)[a] - 1
+            c.append(tuple(e))
+            e2 = [(nx, ny, nz)[d] // 3 + 2 for d in range(3)]
+            e2[a] = 1 if s == 0 else (nx, ny, nz)[a] - 2
+            c.append(tuple(e2))
+    c.append(tuple(src_elem))
+    # brick tiles start at node 1 and are 64 x 8 nodes, chunks 32 planes; round-2 patches are 8^3 node cubes
+    for i in (63, 64, 65, 128):
+        for j in (7, 8, 9, 16):
+            c.append((i, j, nz // 2 + 2))
+    for k in (31, 32, 33, 64):
+        c.append((nx // 2 - 7, ny // 2 + 9, k))
+        c.append((64, 8, k))
+    rng = np.random.default_rng(99)
+    for _ in range(16):
+        c.append((int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))))
+    return c
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3", "c3h"])
+def test_dependency_cone_windows_against_the_oracle(wl):
+    """Oracle parity AT BASELINE sizes: after k steps a node depends on its k-ring only, so a window of the full box
+    -- a block of 4^3 elements and k + 1 more layers around it, with the true eTable / nTable rows and the true start
+    field -- stepped by the oracle's reference loops gives the exact values of the nodes that lie at least k layers
+    inside every CUT face of the window (domain faces are no cuts).  >= 64 windows of the 8 M and the 64 M box (all
+    five dashpot faces, the free surface, edges, corners, the far-face cubes, the source element, tile / chunk /
+    patch borders, seeded interior points) against the GPU's whole-box result: <= 1e-9 of the field's scale.
+    c3h: the 64 M box whose material differs from element to element (every interior node in hq_k_brick_het, 62 x 7-node
+    tiles: the windows at i = 63..65, 128 and j = 7..9, 16 straddle their borders as well)."""
+    import bench
+    nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
+    k = 4
+    ncls, amp = bench.LATERAL.get(wl, (0, 0.0))
+    shared = wl == "c3"
+    box = _whole_box(wl)[0] if shared else host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
+    u = _field(box, 2718)
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt, source_window=k)
+    F = box.source_table(rp, 0, k)
+    if shared:
+        s = _whole_box(wl)[1]
+        s.upload(u, 0.999 * u, 0)
+    else:
+        s = box.create_solver(tm1=u, tm2=0.999 * u)
+    assert s.dominant_kernel() == "hq_k_brick"
+    if ncls:
+        rep = box.brick_plan_check() if nx <= 256 else None      # (the 64 M plan is checked by the run itself)
+        assert s.info()["brick_nodes"] > 0.97 * len(u) and (rep is None or rep["het_units"] == rep["units"])
+    s.set_source(loaded, F)
+    s.run(k)
+    ijk = box.node_ijk
+    gid = (ijk[:, 2].astype(np.int64) * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
+    lut = np.empty((nx + 1) * (ny + 1) * (nz + 1), np.int32)
+    lut[gid] = np.arange(len(gid), dtype=np.int32)
+    e_of = np.full(len(gid), -1, np.int32)                    # element whose corner 0 a node is
+    e_of[box.lnid[:, 0]] = np.arange(len(box.lnid), dtype=np.int32)
+    src_elem = ijk[loaded].min(axis=0)
+    scale = np.abs(u).max()
+    dims = (nx, ny, nz)
+    worst, nwin, nchecked = 0.0, 0, 0
+    for ctr in _cone_windows(nx, ny, nz, src_elem):
+        lo = [max(0, min(ctr[d], dims[d] - 4) - (k + 1)) for d in range(3)]
+        hi = [min(dims[d], lo[d] + 4 + 2 * (k + 1)) for d in range(3)]
+        ei, ej, ek = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), np.arange(lo[2], hi[2]), indexing="ij")
+        e = e_of[lut[(ek.ravel().astype(np.int64) * (ny + 1) + ej.ravel()) * (nx + 1) + ei.ravel()]]
+        assert (e >= 0).all()
+        nodes, inv = np.unique(box.lnid[e], return_inverse=True)
+        lnid_w = inv.reshape(-1, 8).astype(np.int32)
+        o1, o2 = (0.999 * u[nodes]).copy(), u[nodes].copy()
+        pos = {int(n): i for i, n in enumerate(nodes)}
+        lw = [(pos[int(n)], i) for i, n in enumerate(loaded) if int(n) in pos]
+        kw = {}
+        if lw:
+            kw = dict(loaded_lnid=np.array([a for a, _ in lw], np.int32),
+                      forces=np.ascontiguousarray(F[:, [b for _, b in lw], :]))
+        ho.solver_run(lnid_w, box.etable[e].copy(), box.ntable[nodes].copy(), o1, o2, 0, k, dt, **kw)
+        q = ijk[nodes]
+        ok = np.ones(len(nodes), bool)
+        for d in range(3):
+            if lo[d] > 0:
+                ok &= q[:, d] >= lo[d] + k
+            if hi[d] < dims[d]:
+                ok &= q[:, d] <= hi[d] - k
+        assert ok.sum() >= 27
+        tm1, tm2 = s.gather(nodes[ok].astype(np.int32))
+        worst = max(worst, np.abs(tm1 - o2[ok]).max() / scale, np.abs(tm2 - o1[ok]).max() / scale)
+        nwin += 1
+        nchecked += int(ok.sum())
+    if shared:
+        _release_whole_box(wl)
+    else:
+        s.close()
+        box.close()
+    assert nwin >= 64 and nchecked > 64 * 27
+    assert worst < 1e-9, worst
 
 
 def test_large_two_level_box_variants_agree():
@@ -396,7 +548,7 @@ def _basin_windows(nx, ny, nzt, interfaces, k):
     return out
 
 
-def test_full_basin_against_the_oracle_and_in_eight_partitions():
+def test_full_basin_against_the_oracle():
     """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging nodes.
     * Finiteness, hanging nodes = mean of their anchors (the scatter kernels and quiescence are compared on o3s).
     * ORACLE parity at this size: dependency-cone windows that straddle each of the three level interfaces -- hanging
@@ -404,12 +556,11 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
       -- in the interior, at a domain face and in a corner, stepped by the oracle's reference loops with the true table
       rows (tests/helpers.octree_window; the window logic itself is pinned on a whole-mesh oracle run in
       tests/test_octree_windows_cpu.py): <= 1e-9 of the field's scale.
-    * The basin in 8 partitions, every rank's tables built by that rank alone (octbox_local), in-process transport: all
-      four exchanges of a step on 3-7 neighbours each, against the single-partition run.
+    (The basin in 8 per-rank-built partitions: the next test, on a quarter of the footprint since round 6 -- the suite
+    must fit the driver's time limit; the 189M-element mesh in 8 partitions is `bench.py --inproc-parts 8 --workload o3`.)
     Host memory is kept lean: one field at a time, newest displacement only."""
     import gc
     import bench
-    from hercules_amd import capi
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 90 * 2 ** 30:
         pytest.skip("needs ~80 GiB of host memory for the 189M-element mesh tables")
@@ -419,7 +570,6 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     assert E > 180e6 and box.ldnnum > 1e6 and len(interfaces) == 3
     nsteps = 2
     scale0 = np.abs(u).max()
-    res = []
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
     assert s.info()["variant"] == ha.HQ_VARIANT_PATCH and s.info()["brick_nodes"] > 0.9 * N
     s.run(nsteps)
@@ -445,33 +595,49 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
     lap("oracle windows")
     assert nchecked > 400 and nhang > 20, (nchecked, nhang)
     assert worst < 1e-9, worst
-    tm1, _ = s.download(want_tm2=False)
-    s.close()
-    res.append(tm1)
-    gc.collect()
-    scale = np.abs(res[0]).max()
-    assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
-    # (hanging nodes = mean of their anchors over the whole field: checked on o3s, o4s and o4; here on a sample)
+    # finite; hanging nodes = mean of their anchors (over the whole field: o3s, o4s and o4; here on a sample, gathered)
+    nonfinite = s.check_finite()
+    assert nonfinite == 0
     ids, ptr, anc = box.dangling
-    pick = np.linspace(0, len(ids) - 1, 20000).astype(np.int64)
-    for k in pick[::400]:
-        assert np.abs(res[0][ids[k]] - res[0][anc[ptr[k]:ptr[k + 1]]].mean(axis=0)).max() <= 1e-13 * scale
+    for k in np.linspace(0, len(ids) - 1, 50).astype(np.int64):
+        hang = s.gather(ids[k:k + 1])[0][0]
+        mean = s.gather(anc[ptr[k]:ptr[k + 1]])[0].mean(axis=0)
+        assert np.abs(hang - mean).max() <= 1e-13 * scale0
+    s.close()
+    box.close()
     gc.collect()
-    # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
-    # of every rank through their coordinates
-    # (a dense table over the node lattice instead of a sort of 190 M keys: 3.4 GB for half a minute less)
+    lap("finite, anchors")
+
+
+def test_quarter_basin_in_eight_partitions_matches_one_partition():
+    """The layered basin in 8 partitions, every rank's tables built by that rank alone (octbox_local), in-process
+    transport: all four exchanges of a step on 3-7 neighbours each, against the single-partition run, node for node.
+    o3q = a quarter of o3's footprint and all of its depth and levels (47M elements, 0.26M hanging nodes; a rank of it
+    holds as many elements as a rank of the 64M box in 8) -- o3 itself until round 5 (170 s of the suite)."""
+    import gc
+    import bench
+    from hercules_amd import capi
+    lap = H.lap_timer("o3q")
+    box, E, N, u, interfaces = _basin("o3q", want_interfaces=True)
+    assert E > 45e6 and box.ldnnum > 2e5 and len(interfaces) == 3
+    nsteps = 2
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
+    s.run(nsteps)
+    ref, _ = s.download(want_tm2=False)
+    s.close()
+    scale = np.abs(ref).max()
+    assert np.isfinite(scale) and scale > 0
+    lap("whole mesh: build, hq_create, run, download")
     far = box.node_xyz.max(axis=0).astype(np.int64)
     key = lambda xyz: (xyz[:, 2].astype(np.int64) * (far[1] + 1) + xyz[:, 1]) * (far[0] + 1) + xyz[:, 0]
     lut = np.full(int((far[0] + 1) * (far[1] + 1) * (far[2] + 1)), -1, np.int32)
     lut[key(box.node_xyz)] = np.arange(box.N, dtype=np.int32)
     box.close()
     gc.collect()
-    lap("download, anchors, node table")
     solvers, maps = [], []
-    # the ranks' tables are built side by side (the C host side releases the GIL; a rank alone takes ~10 s)
     from concurrent.futures import ThreadPoolExecutor
     def make(r):                      # mesh, map to the single run's nodes and hq_create of one rank
-        b = bench.make_octbox("o3", r, 8)[0]
+        b = bench.make_octbox("o3q", r, 8)[0]
         m = lut[key(b.node_xyz)]
         ur = u[m]                     # (the start field is a function of the coordinates: the whole mesh's values there)
         sv = b.create_solver(tm1=ur, tm2=0.999 * ur)
@@ -483,17 +649,16 @@ def test_full_basin_against_the_oracle_and_in_eight_partitions():
             maps.append(m)
             solvers.append(sv)
             assert solvers[-1].info()["brick_nodes"] > 0
-    gc.collect()
     del lut, u
+    gc.collect()
     lap("8 ranks: meshes, maps, hq_create")
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     for sv, m in zip(solvers, maps):
         tm1, _ = sv.download(want_tm2=False)
-        assert np.abs(tm1 - res[0][m]).max() <= 1e-11 * scale
+        assert np.abs(tm1 - ref[m]).max() <= 1e-11 * scale
         sv.close()
-    del res
-    gc.collect()
+    lap("run, download, compare")
 
 
 @pytest.mark.parametrize("path", ["hq_k_brick", "hq_k_patch_stencil"])
@@ -523,116 +688,6 @@ def test_long_run_of_the_stencil_path_agrees_with_the_scatter_kernels(path, monk
     scale = np.abs(res[1]).max()
     assert scale > 0 and np.abs(res[0] - res[1]).max() <= 1e-11 * scale
     box.close()
-
-
-def _cone_windows(nx, ny, nz, src_elem):
-    """Centres (element indices) of the windows: corners, edges, faces (all five dashpot faces and the free surface
-    z = 0), the far-face cubes, the source element, the borders of brick tiles / chunks and of the 8^3 patches, and
-    seeded interior points."""
-    c = []
-    for i in (0, nx - 1):
-        for j in (0, ny - 1):
-            for k in (0, nz - 1):
-                c.append((i, j, k))                                                  # 8 corners
-    mid = (nx // 2 + 3, ny // 2 - 5, nz // 2 + 1)
-    for a in range(3):                                                               # 12 edges, 6 + 6 face points
-        for s1 in (0, 1):
-            for s2 in (0, 1):
-                e = list(mid)
-                o = [d for d in range(3) if d != a]
-                e[o[0]] = 0 if s1 == 0 else (nx, ny, nz)[o[0]] - 1
-                e[o[1]] = 0 if s2 == 0 else (nx, ny, nz)[o[1]] - 1
-                c.append(tuple(e))
-        for s in (0, 1):
-            e = list(mid)
-            e[a] = 0 if s == 0 else (nx, ny, nz)[a] - 1
-            c.append(tuple(e))
-            e2 = [(nx, ny, nz)[d] // 3 + 2 for d in range(3)]
-            e2[a] = 1 if s == 0 else (nx, ny, nz)[a] - 2
-            c.append(tuple(e2))
-    c.append(tuple(src_elem))
-    # brick tiles start at node 1 and are 64 x 8 nodes, chunks 32 planes; round-2 patches are 8^3 node cubes
-    for i in (63, 64, 65, 128):
-        for j in (7, 8, 9, 16):
-            c.append((i, j, nz // 2 + 2))
-    for k in (31, 32, 33, 64):
-        c.append((nx // 2 - 7, ny // 2 + 9, k))
-        c.append((64, 8, k))
-    rng = np.random.default_rng(99)
-    for _ in range(16):
-        c.append((int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))))
-    return c
-
-
-@pytest.mark.parametrize("wl", ["c2", "c3", "c3h"])
-def test_dependency_cone_windows_against_the_oracle(wl):
-    """Oracle parity AT BASELINE sizes: after k steps a node depends on its k-ring only, so a window of the full box
-    -- a block of 4^3 elements and k + 1 more layers around it, with the true eTable / nTable rows and the true start
-    field -- stepped by the oracle's reference loops gives the exact values of the nodes that lie at least k layers
-    inside every CUT face of the window (domain faces are no cuts).  >= 64 windows of the 8 M and the 64 M box (all
-    five dashpot faces, the free surface, edges, corners, the far-face cubes, the source element, tile / chunk /
-    patch borders, seeded interior points) against the GPU's whole-box result: <= 1e-9 of the field's scale.
-    c3h: the 64 M box whose material differs from element to element (every interior node in hq_k_brick_het, 62 x 7-node
-    tiles: the windows at i = 63..65, 128 and j = 7..9, 16 straddle their borders as well)."""
-    import bench
-    nx, ny, nz, h, dt, freq = bench.WORKLOADS[wl]
-    k = 4
-    ncls, amp = bench.LATERAL.get(wl, (0, 0.0))
-    box = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=ncls, lateral_amp=amp)
-    u = _field(box, 2718)
-    L = nx * h
-    loaded, pattern = box.point_source(L / 2, L / 2, L / 5, 0.0, 90.0, 0.0)
-    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e12, rise_time=20 * dt, source_window=k)
-    F = box.source_table(rp, 0, k)
-    s = box.create_solver(tm1=u, tm2=0.999 * u)
-    assert s.dominant_kernel() == "hq_k_brick"
-    if ncls:
-        rep = box.brick_plan_check() if nx <= 256 else None      # (the 64 M plan is checked by the run itself)
-        assert s.info()["brick_nodes"] > 0.97 * len(u) and (rep is None or rep["het_units"] == rep["units"])
-    s.set_source(loaded, F)
-    s.run(k)
-    ijk = box.node_ijk
-    gid = (ijk[:, 2].astype(np.int64) * (ny + 1) + ijk[:, 1]) * (nx + 1) + ijk[:, 0]
-    lut = np.empty((nx + 1) * (ny + 1) * (nz + 1), np.int32)
-    lut[gid] = np.arange(len(gid), dtype=np.int32)
-    e_of = np.full(len(gid), -1, np.int32)                    # element whose corner 0 a node is
-    e_of[box.lnid[:, 0]] = np.arange(len(box.lnid), dtype=np.int32)
-    src_elem = ijk[loaded].min(axis=0)
-    scale = np.abs(u).max()
-    dims = (nx, ny, nz)
-    worst, nwin, nchecked = 0.0, 0, 0
-    for ctr in _cone_windows(nx, ny, nz, src_elem):
-        lo = [max(0, min(ctr[d], dims[d] - 4) - (k + 1)) for d in range(3)]
-        hi = [min(dims[d], lo[d] + 4 + 2 * (k + 1)) for d in range(3)]
-        ei, ej, ek = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), np.arange(lo[2], hi[2]), indexing="ij")
-        e = e_of[lut[(ek.ravel().astype(np.int64) * (ny + 1) + ej.ravel()) * (nx + 1) + ei.ravel()]]
-        assert (e >= 0).all()
-        nodes, inv = np.unique(box.lnid[e], return_inverse=True)
-        lnid_w = inv.reshape(-1, 8).astype(np.int32)
-        o1, o2 = (0.999 * u[nodes]).copy(), u[nodes].copy()
-        pos = {int(n): i for i, n in enumerate(nodes)}
-        lw = [(pos[int(n)], i) for i, n in enumerate(loaded) if int(n) in pos]
-        kw = {}
-        if lw:
-            kw = dict(loaded_lnid=np.array([a for a, _ in lw], np.int32),
-                      forces=np.ascontiguousarray(F[:, [b for _, b in lw], :]))
-        ho.solver_run(lnid_w, box.etable[e].copy(), box.ntable[nodes].copy(), o1, o2, 0, k, dt, **kw)
-        q = ijk[nodes]
-        ok = np.ones(len(nodes), bool)
-        for d in range(3):
-            if lo[d] > 0:
-                ok &= q[:, d] >= lo[d] + k
-            if hi[d] < dims[d]:
-                ok &= q[:, d] <= hi[d] - k
-        assert ok.sum() >= 27
-        tm1, tm2 = s.gather(nodes[ok].astype(np.int32))
-        worst = max(worst, np.abs(tm1 - o2[ok]).max() / scale, np.abs(tm2 - o1[ok]).max() / scale)
-        nwin += 1
-        nchecked += int(ok.sum())
-    s.close()
-    box.close()
-    assert nwin >= 64 and nchecked > 64 * 27
-    assert worst < 1e-9, worst
 
 
 def test_small_basin_against_the_oracle():
@@ -698,9 +753,46 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     box.close()
 
 
-@pytest.mark.parametrize("nranks,overlap", [(8, 0), (8, 1)])       # (5 ranks: the reference's own 5-rank run of its basin, tests/test_gpu_parity.py and test_gpu_multiprocess.py)
-def test_small_lateral_basin_in_partitions_matches_one_partition(nranks, overlap, monkeypatch):
-    """o4s cut into octor's block partitions (hqh_mesh_from_leaves with rank / nranks: ownership by Z-order point
+def test_small_gradient_basin_against_the_oracle():
+    """o4gs (round 6): the same small basin with a VELOCITY GRADIENT -- 6 257 distinct materials, no two neighbouring coarse
+    elements alike (what setrec's 27-sample average gives on any real CVM, psolve.c:1307-1397) -- so the per-element kernels
+    run inside every octree level: full 62 x 7 tiles of hq_k_brick_het<PACKED>, beside the level interfaces the RAGGED ones
+    (hq_k_brick_het<PACKED, RAGGED>), element-form patches with hanging nodes around them.  The oracle's reference loops with
+    compute_adjust on the WHOLE mesh for three steps, forces on 3 000 nodes at every step, against the default path and
+    against the path without ragged per-element units (hq_options.brick_ragged_het = 0)."""
+    import bench
+    box, E, N, it = bench.make_octbox("o4gs", 0, 1)
+    u = it["field"]
+    assert len(np.unique(box.etable[:, :2], axis=0)) > 5000
+    nsteps = 3
+    free = np.setdiff1d(np.arange(N, dtype=np.int64), box.dangling[0])
+    loaded = free[np.linspace(0, len(free) - 1, 3000).astype(np.int64)].astype(np.int32)
+    rng = np.random.default_rng(77)
+    F = rng.uniform(-1.0, 1.0, (nsteps, len(loaded), 3)) * (1e-4 * np.abs(u).max() / box.dt ** 2) * box.ntable[loaded, 0][None, :, None]
+    o1, o2 = (0.999 * u).copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling,
+                  loaded_lnid=loaded, forces=F)
+    for ragged_het in (1, 0):
+        s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u, options={"brick_ragged_het": ragged_het})
+        info = s.info()
+        assert info["brick_units_het"] > 0 and info["brick_units_packed"] == info["brick_units_het"]
+        if ragged_het:
+            assert info["brick_units_ragged_het"] > 100 and info["brick_nodes"] > 0.8 * N
+        else:
+            assert info["brick_units_ragged_het"] == 0 and info["brick_nodes"] < 0.5 * N
+        s.set_source(loaded, F)
+        s.run(nsteps)
+        tm1, tm2 = s.download()
+        s.close()
+        assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
+    box.close()
+
+
+@pytest.mark.parametrize("wl,nranks,overlap", [("o4s", 8, 0), ("o4gs", 8, 1)])       # (5 ranks: the reference's own 5-rank run of its basin, tests/test_gpu_parity.py and test_gpu_multiprocess.py)
+def test_small_lateral_basin_in_partitions_matches_one_partition(wl, nranks, overlap, monkeypatch):
+    """(o4gs: the basin with a velocity gradient -- per-element kernels, the RAGGED per-element units among them, on
+    partitions with the chain on its own stream.)
+    o4s cut into octor's block partitions (hqh_mesh_from_leaves with rank / nranks: ownership by Z-order point
     location, anchors of shared hanging nodes across x- / y- / z-normal interfaces), patch variant with bricks, in-process
     transport, against the whole basin on one partition.  overlap: the exchange chain on its own stream beside the
     interior launches -- the 100-register forms of hq_k_brick, the ragged one among them."""
@@ -708,15 +800,15 @@ def test_small_lateral_basin_in_partitions_matches_one_partition(nranks, overlap
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))
     nsteps = 4
-    one, E, N, it = bench.make_octbox("o4s", 0, 1)
+    one, E, N, it = bench.make_octbox(wl, 0, 1)
     u = it["field"]
     ref1, ref2 = _run_oct(one, ha.HQ_VARIANT_PATCH, u, 0.999 * u, nsteps)
     one.close()
     solvers, gids = [], []
-    bench.make_octbox("o4s", 0, nranks)[0].close()        # (fills bench's cache of the leaves and the whole-mesh field)
+    bench.make_octbox(wl, 0, nranks)[0].close()        # (fills bench's cache of the leaves and the whole-mesh field)
 
     def make(r):
-        b, _, _, itr = bench.make_octbox("o4s", r, nranks)
+        b, _, _, itr = bench.make_octbox(wl, r, nranks)
         assert np.array_equal(itr["field"], u[b.gid])
         sv = b.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=itr["field"], tm2=0.999 * itr["field"])
         gid = b.gid.copy()
@@ -727,7 +819,7 @@ def test_small_lateral_basin_in_partitions_matches_one_partition(nranks, overlap
         for sv, gid in pool.map(make, range(nranks)):
             solvers.append(sv)
             gids.append(gid)
-    assert sum(sv.info()["brick_units_ragged"] for sv in solvers) > 0
+    assert sum(sv.info()["brick_units_ragged_het" if wl == "o4gs" else "brick_units_ragged"] for sv in solvers) > 0
     capi.group_link(solvers)
     capi.group_run(solvers, nsteps)
     scale = np.abs(ref1).max()

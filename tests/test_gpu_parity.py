@@ -299,7 +299,7 @@ def test_restart_from_reference_checkpoint_and_force_file(tmp_path):
     s.close(); s2.close(); box.close()
 
 
-@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level", "c5_layered", "c5_basin"])
+@pytest.mark.parametrize("mesh", ["c5_two_level", "c5_three_level", "c5_layered", "c5_basin", "c5_gradient"])
 @pytest.mark.parametrize("variant", VARIANTS + [ha.HQ_VARIANT_AUTO])
 def test_two_level_mesh_with_hanging_nodes_against_reference(variant, mesh):
     """compute_adjust on the reference's own two-level mesh (800 hanging nodes): scatter
@@ -346,6 +346,33 @@ def test_ragged_tile_columns_on_the_references_lateral_mesh_against_its_checkpoi
     s.close()
 
 
+@pytest.mark.parametrize("pack", [1, 0])
+def test_ragged_per_element_units_on_the_references_gradient_mesh_against_its_checkpoints(pack):
+    """c5_gradient -- the reference's laterally refined basin with a material of its own in every database octant -- with
+    the planner's thresholds lowered until the small mesh carries RAGGED units of the per-element kernel
+    (hq_k_brick_het<PACKED, RAGGED> with hq_desc.edata, <false, RAGGED> without): against the reference's own checkpoints."""
+    import os
+    p = H.c5_problem("c5_gradient")
+    g = p["golden"]
+    kw = dict(edata=p["edata"], material=H.c5_material(p)) if pack else {}      # (edata_t as solver_init left it)
+    s = ha.Solver(p["lnid"], p["etable"], p["ntable"], p["dt"], dangling=p["dangling"], variant=ha.HQ_VARIANT_PATCH,
+                  node_xyz=(p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32),
+                  options={"brick_ragged_minfill": 12, "brick_minnodes": 48, "brick_minz": 2}, **kw)
+    info = s.info()
+    if not os.environ.get("HQ_NO_BRICKS"):                   # (this file runs twice: see its fixture)
+        assert info["brick_units_ragged_het"] >= 2 and info["brick_units_het"] >= info["brick_units_ragged_het"]
+        assert (info["brick_units_packed"] > 0) == bool(pack)
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL
+        assert H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("shape", [(64, 64, 8, 12), (128, 96, 16, 20)])
 def test_larger_two_level_meshes_against_oracle(variant, shape):
@@ -371,7 +398,7 @@ def test_larger_two_level_meshes_against_oracle(variant, shape):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("name", ["c5_two_level_np8", "c5_basin_np8", "c5_basin_np5"])
+@pytest.mark.parametrize("name", ["c5_two_level_np8", "c5_basin_np8", "c5_basin_np5", "c5_gradient_np8"])
 def test_octree_mesh_on_eight_partitions_against_reference(variant, name):
     """The reference's 8-rank run of its two-level mesh: hanging nodes shared between
     ranks (dn_sched), anchors harbored indirectly, the four exchanges of a step and both
@@ -535,6 +562,48 @@ def test_from_the_references_mesh_database_to_its_checkpoints(tmp_path):
     done = 0
     for k, step in enumerate(g["ckpt_steps"]):
         ob.solver_run(s, rp, done, int(step) - done)        # hqh_octbox_solver_run: the force file in windows
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL
+    s.close()
+    ob.close()
+
+
+@pytest.mark.parametrize("name", ["c5_basin", "c5_gradient"])
+def test_from_the_cvm_database_to_the_references_checkpoints(name, tmp_path):
+    """End to end from "the same input etree" WITHOUT the reference's mesher (SURVEY s8 f4's parenthetical, round 6): the
+    CVM database of the golden run -- written here by oracle/make_cvm on the reference's own etree + cvm libraries, as
+    tests/golden/make_golden.py did -- read by hqh_cvm_open, meshed by hqh_octree_generate (Vs rule on setrec's 27-sample
+    record, 2:1 balance), tables by hqh_mesh_from_leaves, the reference's force file streamed by hqh_solver_run: the field
+    lands on the checkpoints the REAL psolve wrote from that database (laterally refined basin; the same with a
+    material of its own in every database octant)."""
+    import os
+    import subprocess
+    from hercules_amd import host
+    from tests.test_host_partition import MAKE_CVM, _cvm_args
+    if not os.path.exists(MAKE_CVM):
+        pytest.skip("oracle/_ref/make_cvm is not built")
+    db = str(tmp_path / "model.e")
+    subprocess.run([MAKE_CVM, db] + _cvm_args(name), check=True)
+    cvm = host.Cvm(db)
+    vp, vs, rho, cell = cvm.grid()
+    region = cvm.region
+    cvm.close()
+    g = H.load(name)
+    spec = H.CVM_MODELS[name]
+    # (the mesh's x is the database's north: setrec queries east = y, north = x)
+    ticks, edge, edata, far, ticksize = host.octree_generate(vp, vs, rho, cell, (region[1], region[0], region[2]),
+                                                             spec["freq"] * 8, spec["vscut"])
+    assert len(ticks) == int(g["total_elements"])
+    ob = host.OctBox.from_leaves(ticks, edge, edata, far, float(g["dt"]), float(g["freq"]))
+    assert ob.N == int(g["total_nodes"]) and ob.ldnnum == int(g["total_dangling"])
+    ff = tmp_path / "force_process.0"
+    host.forcefile_write(str(ff), g["loaded_lnid"], g["forces"])
+    s = ob.create_solver()
+    rp = ob.run_params(loaded=g["loaded_lnid"], force_file=str(ff), source_window=32)
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ob.solver_run(s, rp, done, int(step) - done)
         done = int(step)
         tm1, tm2 = s.download()
         assert H.rel_linf(tm1, g["ckpt_tm1"][k]) < TOL and H.rel_linf(tm2, g["ckpt_tm2"][k]) < TOL

@@ -159,7 +159,9 @@ def test_the_reference_program_on_eight_ranks_shares_one_gpu(transport):
     (HQ_TRANSPORT=ipc).  Against the per-rank checkpoint stripes and the station traces of the unmodified reference's
     8-rank run (tests/golden/c1_np8.npz)."""
     g = H.load("c1_np8")
-    run_hq, log = _run(PSOLVE_HQ, _params(float(g["end_time"]), 400, 1), nranks=8, env_extra={"HQ_TRANSPORT": transport})
+    # (stations every 10 steps: between outputs the eight processes enqueue whole batches instead of synchronising on
+    #  the one GPU they time-slice at every step -- 27 s -> a few; the every-step cadence is the one-rank test's)
+    run_hq, log = _run(PSOLVE_HQ, _params(float(g["end_time"]), 400, 10), nranks=8, env_extra={"HQ_TRANSPORT": transport})
     try:
         ck = _rank_stripes(run_hq)
         assert sorted(ck) == [int(s) for s in g["ckpt_steps"]]
@@ -172,9 +174,11 @@ def test_the_reference_program_on_eight_ranks_shares_one_gpu(transport):
                 scale = max(np.abs(ref1).max(), 1e-300)
                 assert scale > 0 and np.abs(tm1[:n] - ref1).max() <= 1e-9 * scale and np.abs(tm2[:n] - ref2).max() <= 1e-9 * scale
         st = _stations(run_hq)
-        assert st.shape == g["stations"].shape == (5, 1000, 4)
+        assert g["stations"].shape == (5, 1000, 4) and st.shape == (5, 100, 4)
         scale = np.abs(g["stations"][:, :, 1:]).max()
-        assert scale > 0 and np.abs(st - g["stations"]).max() <= 2e-6 * scale
+        assert scale > 0 and np.abs(st - g["stations"][:, ::10, :]).max() <= 2e-6 * scale
+        # the library's share of print_timing_stat (hq_print_timing in the stub): the device-side split of a step
+        assert "Device timers (libhq_solver" in log and "exchange chain" in log
     finally:
         shutil.rmtree(run_hq, ignore_errors=True)
 

@@ -2,6 +2,8 @@
 mesh order, solver_init constants, block partition, node ownership, schedules,
 point source and stations -- against the oracle and the reference's own
 8-rank run (tests/golden/c1_np8.npz)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -350,7 +352,7 @@ def test_mesh_etree_reader_and_mesh_from_leaves(tmp_path):
     ob.close()
 
 
-@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level", "c5_basin"])
+@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level", "c5_basin", "c5_gradient"])
 def test_mesh_from_leaves_on_the_references_other_meshes(name):
     """hqh_mesh_from_leaves on the element dumps of the reference's uniform, two-level and
     three-level meshes."""
@@ -411,7 +413,7 @@ def test_mesh_from_leaves_partitions_are_octors(name, nranks):
         ob.close()
 
 
-@pytest.mark.parametrize("name", ["c5_basin", "c5_two_level", "c5_three_level", "c5_layered"])
+@pytest.mark.parametrize("name", ["c5_basin", "c5_gradient", "c5_two_level", "c5_three_level", "c5_layered"])
 def test_octree_generate_makes_the_references_meshes(name):
     """hqh_octree_generate -- octor_newtree / refinetree (Vs rule on setrec's 27-sample record) / balancetree (2:1 across
     faces and edges) restated on per-level bitmaps -- from the material model alone: leaf for leaf (corner, edge,
@@ -428,6 +430,72 @@ def test_octree_generate_makes_the_references_meshes(name):
     assert np.array_equal(ticks.astype(np.int64), et[:, 0, :]) and np.array_equal(edge.astype(np.int64), et[:, 7, 0] - et[:, 0, 0])
     assert np.array_equal(edata[:, 1:], g["mat_vs_vp_rho"][:, [1, 0, 2]])
     assert np.array_equal(edata[:, 0], (edge * (1000.0 / 2 ** 30)).astype(np.float32))
+
+
+MAKE_CVM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "make_cvm")
+
+
+def _cvm_args(name):
+    """oracle/make_cvm's arguments for a model of tests/helpers.CVM_MODELS (as tests/golden/make_golden.py passed them)."""
+    spec = H.CVM_MODELS[name]
+    if "layers" in spec:
+        a = ["layers", len(spec["layers"])]
+        for row in spec["layers"]:
+            a += list(row)
+        return [str(v) for v in a]
+    a = ["regions", 4, *spec["background"], len(spec["regions"])]
+    for r in spec["regions"]:
+        a += list(r)
+    return [str(v) for v in a]
+
+
+@pytest.mark.skipif(not os.path.exists(MAKE_CVM), reason="oracle/_ref/make_cvm (oracle/build_ref.sh, the reference's etree + cvm libraries) is not built")
+@pytest.mark.parametrize("name", ["c5_basin", "c5_gradient", "c5_three_level"])
+def test_from_the_cvm_database_to_the_references_mesh(name, tmp_path):
+    """SURVEY s8 f4's parenthetical, round 6: "the same input etree" without the reference's mesher.  oracle/make_cvm --
+    the reference's OWN etree and cvm libraries -- writes the very material database the golden run meshed; hqh_cvm_open
+    reads it with this library's etree reader (B-tree pages, locational keys, the dbctl trailer of cvm_setdbctl),
+    hqh_cvm_query answers as cvm_query would (cvm.c:266-311: the leaf octant that holds the point), hqh_cvm_grid hands
+    the model to hqh_octree_generate in the mesh's axes (setrec queries east = y, north = x, psolve.c:1352) -- and out comes
+    the reference's mesh, leaf for leaf and record for record."""
+    import subprocess
+    db = str(tmp_path / "model.e")
+    subprocess.run([MAKE_CVM, db] + _cvm_args(name), check=True)
+    cvm = host.Cvm(db)
+    assert cvm.nleaves == 16 * 16 * 8 and cvm.levels == (4, 4) and cvm.region == (1000.0, 1000.0, 500.0)
+    assert cvm.ticksize == 1000.0 / 2 ** 31
+    vp, vs, rho, cell = cvm.grid()
+    evp, evs, erho, ecell = H.cvm_grid(name)
+    assert cell == ecell == 62.5 and vp.shape == (8, 16, 16)
+    assert np.array_equal(vp, evp) and np.array_equal(vs, evs) and np.array_equal(rho, erho)
+    # point queries as setrec makes them: (east = mesh y, north = mesh x, depth); outside the database: none
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        x, y, z = rng.uniform(0, 1000), rng.uniform(0, 1000), rng.uniform(0, 500)
+        got = cvm.query(y, x, z)
+        k, j, i = int(z // 62.5), int(y // 62.5), int(x // 62.5)
+        assert got == (evp[k, j, i], evs[k, j, i], erho[k, j, i])
+    assert cvm.query(1000.5, 10.0, 10.0) is None and cvm.query(10.0, 10.0, 500.5) is None
+    cvm.close()
+    g = H.load(name)
+    spec = H.CVM_MODELS[name]
+    ticks, edge, edata, far, ticksize = host.octree_generate(vp, vs, rho, cell, (1000.0, 1000.0, 500.0), spec["freq"] * 8, spec["vscut"])
+    et = g["elem_ticks"]
+    assert len(ticks) == len(et) == int(g["total_elements"])
+    assert np.array_equal(ticks.astype(np.int64), et[:, 0, :]) and np.array_equal(edge.astype(np.int64), et[:, 7, 0] - et[:, 0, 0])
+    assert np.array_equal(edata[:, 1:], g["mat_vs_vp_rho"][:, [1, 0, 2]])
+
+
+def test_the_references_shipped_cvm_database():
+    """examples/simple/simple_case.e (tests/golden/ref_inputs: the database the reference SHIPS, written by its own tools
+    years ago): 2 048 level-4 octants of one material, the region of its dbctl block."""
+    cvm = host.Cvm(os.path.join(H.GOLDEN, "ref_inputs", "simple_case.e"))
+    assert cvm.nleaves == 2048 and cvm.levels == (4, 4) and cvm.region == (1000.0, 1000.0, 500.0)
+    vp, vs, rho, cell = cvm.grid()
+    assert cell == 62.5 and vp.shape == (8, 16, 16)
+    assert (vp == 6000.0).all() and (vs == 3464.0).all() and (rho == 2700.0).all()
+    assert cvm.query(500.0, 500.0, 250.0) == (6000.0, 3464.0, 2700.0)
+    cvm.close()
 
 
 def test_octree_generate_refuses_what_it_cannot_mesh():

@@ -267,7 +267,27 @@ def test_basin_mesh_lateral_refinement_bitwise():
     assert np.abs(tm2).max() > 100.0
 
 
-@pytest.mark.parametrize("name", ["c5_basin_np8", "c5_basin_np5"])
+def test_gradient_basin_every_octant_its_own_material_bitwise():
+    """The same basin with a velocity gradient (make_cvm `grad`; tests/golden/make_golden.py GRADIENT_CVM): every database
+    octant has a material of its own, as any real CVM gives (setrec's 27-sample average, psolve.c:1307-1397) -- 286
+    distinct (Vp, Vs, rho) over the 5 429 elements, no two neighbouring coarse elements alike -- so solver_init's
+    single-precision material arithmetic (mu_and_lambda psolve.c:3236-3272, zeta = 10 / Vs) is exercised on hundreds of
+    values instead of three.  The reference's checkpoints bit for bit."""
+    p = H.c5_problem("c5_gradient")
+    g = p["golden"]
+    assert p["E"] == int(g["total_elements"]) == 5429 and len(p["dangling"][0]) == int(g["total_dangling"]) == 1196
+    assert len(np.unique(g["mat_vs_vp_rho"], axis=0)) > 250 and len(np.unique(p["etable"], axis=0)) > 250
+    tm1, tm2 = np.zeros((p["N"], 3)), np.zeros((p["N"], 3))
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        ho.solver_run(p["lnid"], p["etable"], p["ntable"], tm1, tm2, done, int(step) - done, p["dt"],
+                      loaded_lnid=g["loaded_lnid"], forces=g["forces"], dangling=p["dangling"])
+        done = int(step)
+        assert np.array_equal(tm1, g["ckpt_tm2"][k]) and np.array_equal(tm2, g["ckpt_tm1"][k])
+    assert np.abs(tm2).max() > 100.0
+
+
+@pytest.mark.parametrize("name", ["c5_basin_np8", "c5_basin_np5", "c5_gradient_np8"])
 def test_basin_mesh_on_several_ranks_tables_and_fields(name):
     """The basin mesh on 8 and on 5 MPI ranks of the reference: block partition of a mixed-level leaf
     list, ownership, direct and indirect sharing across x / y / z-normal level interfaces, hanging nodes

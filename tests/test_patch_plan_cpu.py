@@ -231,3 +231,42 @@ def test_ragged_columns_on_the_references_own_lateral_mesh(monkeypatch):
     rep = capi.brick_plan_check(d)
     assert rep["faults"] == 0 and rep["ragged_units"] >= 2 and rep["ragged_nodes"] > 500
     assert rep["brick_nodes"] + rep["patch_nodes"] == p["N"]
+
+
+def test_ragged_per_element_columns_on_the_references_gradient_mesh(monkeypatch):
+    """tests/golden/c5_gradient (the reference's laterally refined basin with a material of its own in every database
+    octant) with the planner's thresholds lowered until this small mesh carries RAGGED units of the per-element kernel
+    (hq_k_brick_het<., RAGGED>, round 6): no two neighbouring coarse elements share (c1, c2, beta), so the one-material
+    ragged columns find (next to) nothing and the nodes beside the level interfaces would stay with the patches.  Every
+    owned node's 26 neighbours through the id tables, its eight elements' coefficients in the unit's block."""
+    from hercules_amd import capi
+    from tests import helpers as H
+    p = H.c5_problem("c5_gradient")
+    for k, v in (("HQ_BRICK_RAGGED_MINFILL", "12"), ("HQ_BRICK_MINNODES", "48"), ("HQ_BRICK_MINZ", "2")):
+        monkeypatch.setenv(k, v)
+    lnid, et, nt = [np.ascontiguousarray(a) for a in (p["lnid"].astype(np.int32), p["etable"], p["ntable"])]
+    xyz = (p["node_q"].astype(np.int64) * p["emin"]).astype(np.int32)
+    ids, ptr, anc = [np.ascontiguousarray(x, np.int32) for x in p["dangling"]]
+    d = capi._Desc()
+    d.lenum, d.nharbored, d.ldnnum = len(lnid), len(nt), len(ids)
+    d.lnid, d.eTable, d.nTable, d.node_xyz = capi._ptr(lnid), capi._ptr(et), capi._ptr(nt), capi._ptr(xyz)
+    d.dn_ldnid, d.dn_ptr, d.dn_lanid = capi._ptr(ids), capi._ptr(ptr), capi._ptr(anc)
+    d.deltaT, d.rank, d.nranks = 1e-3, 0, 1
+    rep = capi.brick_plan_check(d)
+    assert rep["faults"] == 0 and rep["ragged_het_units"] >= 2 and rep["ragged_het_nodes"] > 500
+    assert rep["brick_nodes"] + rep["patch_nodes"] == p["N"]
+    monkeypatch.setenv("HQ_BRICK_RAGGED_HET", "0")
+    off = capi.brick_plan_check(d)
+    assert off["faults"] == 0 and off["ragged_het_units"] == 0 and off["brick_nodes"] < rep["brick_nodes"]
+
+
+def test_ragged_per_element_columns_of_the_small_gradient_basin():
+    """bench.py's o4gs (0.93 M elements on four levels, 6 257 distinct materials): the full 62 x 7 tiles of the per-element
+    kernel take 0.40 M of its 0.98 M nodes, the ragged ones 0.42 M more -- what is left to the patches drops from 0.58 M
+    to 0.16 M nodes."""
+    import bench
+    box, E, N, it = bench.make_octbox("o4gs", 0, 1)
+    rep = box.brick_plan_check()
+    box.close()
+    assert rep["faults"] == 0 and rep["units_one_nt_row"] == 0
+    assert rep["ragged_het_units"] > 100 and rep["ragged_het_nodes"] > 350000 and rep["patch_nodes"] < 0.2 * N
