@@ -74,10 +74,6 @@ OCT_LAYERED = {
     "o3": (1024, 1024, 100.0, 0.02, 0.5, 8, 800.0, 100,
            [(0.0, 1100.0, 600.0, 2000.0), (16000.0, 2000.0, 1100.0, 2300.0), (28800.0, 3600.0, 2000.0, 2500.0),
             (54400.0, 6000.0, 3464.0, 2700.0)]),
-    # a quarter of o3's footprint, all of its depth: 47M elements (tests: the basin in 8 per-rank-built partitions)
-    "o3q": (512, 512, 100.0, 0.02, 0.5, 8, 800.0, 100,
-            [(0.0, 1100.0, 600.0, 2000.0), (16000.0, 2000.0, 1100.0, 2300.0), (28800.0, 3600.0, 2000.0, 2500.0),
-             (54400.0, 6000.0, 3464.0, 2700.0)]),
     "o3s": (256, 256, 100.0, 0.02, 0.5, 8, 800.0, 25,
             [(0.0, 1100.0, 600.0, 2000.0), (4000.0, 2000.0, 1100.0, 2300.0), (7200.0, 3600.0, 2000.0, 2500.0),
              (13600.0, 6000.0, 3464.0, 2700.0)]),
@@ -122,7 +118,6 @@ WORKLOAD_NAMES = {"c3": "64M-element uniform box 512x512x256, point double-coupl
                   "o2": "184M-element two-level octree box (1024x1024x128 fine over 512x512x192 coarse, 1M hanging nodes)",
                   "o3": "189M-element layered basin (102.4 km x 102.4 km x 80 km, 0.5 Hz) on four octree levels (100-800 m)",
                   "o3s": "3M-element layered basin on four octree levels (small version of o3)",
-                  "o3q": "47M-element layered basin: a quarter of o3's footprint (51.2 km x 51.2 km x 80 km), four octree levels",
                   "o4": "laterally refined basin (102.4 km x 102.4 km x 51.2 km, 0.5 Hz): sediment bowl in a layered half-space, "
                         "octree levels of 100-800 m with x-, y- and z-normal interfaces (Vs rule + 2:1 balance as the reference's mesher)",
                   "o4s": "small laterally refined basin (25.6 km x 25.6 km x 12.8 km), four octree levels",

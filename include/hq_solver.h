@@ -120,7 +120,11 @@ typedef struct {
      * (psolve.h:95-97; mu_and_lambda may have rewritten Vp, psolve.c:3253-3263) and the constants it combined them with.
      * Where given, the kernel for meshes whose material differs from element to element (hq_k_brick_het) keeps 12 bytes per
      * element -- rho, Vs, Vp -- instead of the 24 of (c1, c2, beta), and rebuilds the caller's very doubles on the fly:
-     * hq_create checks every element bit for bit against eTable first and keeps the 24 bytes wherever one differs. */
+     * hq_create checks every element bit for bit against eTable first and keeps the 24 bytes wherever one differs.
+     * The n_t rows of such units travel as {mass_simple, mass_simple - mass_minusaM}: mass_minusaM comes out EXACTLY,
+     * mass2_minusaM as 2 m0 - (m0 - m1), equal to the caller's to 1e-15 relative (checked per node; a node that misses keeps
+     * its unit unpacked) -- NOT bit for bit: the reference sums it in another order (psolve.c:3436-3471).  The difference is
+     * of the class of the element sums' own order; tests/test_gpu_fullsize.py pins 10 000 steps against the unpacked form. */
     const float*  edata;         /* [lenum][4] edgesize (m), Vp, Vs, rho                                             */
     double mat_bbase;            /* Global.theBBase (compute_setab, psolve.c:5813-5876)                              */
     double mat_threshold_damping;/* Param.theThresholdDamping                                                        */

@@ -40,7 +40,8 @@ def _run(box, variant, u1, u2, nsteps, src=None, options=None, want=None):
     return out
 
 
-@pytest.mark.parametrize("wl", ["c2", "c2-nobricks"])     # (the 64M box: 75 oracle cone windows below, and 8 partitions against one)
+@pytest.mark.parametrize("wl", ["c2"])     # (the 64M box: 75 oracle cone windows below, and 8 partitions against one; round 6: the
+                                           # patches-only pass of the 8M box went -- patches alone on m1 / o4s / the parity file)
 def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
     if wl.endswith("-nobricks"):     # the patch kernels alone (lattice / ragged stencil patches, element form), as without node_xyz
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
@@ -131,6 +132,36 @@ def test_one_million_elements_with_lateral_material_against_oracle():
         s.close()
     for b in parts:
         b.close()
+
+
+def test_packed_n_t_rows_over_ten_thousand_steps():
+    """The packed per-element units carry n_t as {m0, m0 - m1}: m1 comes out exactly, m2 = 2 m0 - (m0 - m1) equals the
+    caller's to 1e-15 relative (checked per node at hq_create) -- the class of the summation-order difference, but a
+    difference in EVERY step (round-5 advisor).  10 000 steps of a 64 x 64 x 32 box whose material differs from element
+    to element, with a point source, packed against hq_options.brick_no_pack = 1 (the caller's 24-byte rows): the two fields
+    stay within 1e-10 of the field's scale -- no drift beyond what the rounding of a step allows (measured: ~1e-13)."""
+    nx, ny, nz, h, dt, freq = 64, 64, 32, 15.0, 3e-4, 30.0
+    box = host.Box(nx, ny, nz, h, dt, freq, lateral_classes=61, lateral_amp=0.1)
+    u = _field(box, 4242)
+    nsteps = 10000
+    L = nx * h
+    loaded, pattern = box.point_source(L / 2 + 3.0, L / 2 - 2.0, L / 5, 30.0, 70.0, 10.0)
+    rp = box.run_params(loaded=loaded, pattern=pattern, moment=1e13, rise_time=20 * dt, source_window=400)
+    F = box.source_table(rp, 0, 400)
+    out = []
+    for no_pack in (0, 1):
+        s = box.create_solver(tm1=u, tm2=0.999 * u, options={"brick_no_pack": no_pack})
+        info = s.info()
+        assert info["brick_units_het"] > 0 and (info["brick_units_packed"] == 0) == bool(no_pack)
+        s.set_source(loaded, F)
+        s.run(nsteps)
+        out.append(s.download())
+        assert s.check_finite() == 0
+        s.close()
+    box.close()
+    scale = max(np.abs(out[1][0]).max(), 1e-300)
+    assert scale > 0
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-10 * scale and np.abs(out[0][1] - out[1][1]).max() <= 1e-10 * scale
 
 
 def test_host_solver_run_with_stations():
@@ -495,12 +526,14 @@ def test_small_basin_variants_agree_and_step_is_linear():
     box.close()
 
 
-@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_SCATTER, 0)])    # (patch variant: the 189M basin in 8 partitions below; its
-                                                                             # overlap with hanging nodes: tests/test_gpu_multiprocess.py)
+@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 1)])      # (round 6: the patch variant with the chain on its own stream
+                                                                             # -- until round 5 the 189M basin itself in 8 partitions, 100 s of
+                                                                             # the suite; scatter kernels on partitions: tests/test_gpu_parity.py)
 def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap, monkeypatch):
-    """o3s cut into octor's 8 partitions by the C host (hanging nodes and their anchors on partition
-    interfaces: all four exchanges of a step, psolve.c:4298-4315), in-process transport, against the
-    whole basin on one partition."""
+    """o3s cut into octor's 8 partitions, every rank's tables built by that rank alone (octbox_local: hanging nodes and
+    their anchors on partition interfaces, all four exchanges of a step, psolve.c:4298-4315), in-process transport, against
+    the whole basin on one partition.  (The 189M-element basin in 8 partitions: `bench.py --inproc-parts 8 --workload o3`,
+    profiles/r05/inproc8_o3_lease_b8.json.)"""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))      # 1: the exchange chain beside the interior patches, as between GPUs
     nsteps = 5
@@ -556,8 +589,9 @@ def test_full_basin_against_the_oracle():
       -- in the interior, at a domain face and in a corner, stepped by the oracle's reference loops with the true table
       rows (tests/helpers.octree_window; the window logic itself is pinned on a whole-mesh oracle run in
       tests/test_octree_windows_cpu.py): <= 1e-9 of the field's scale.
-    (The basin in 8 per-rank-built partitions: the next test, on a quarter of the footprint since round 6 -- the suite
-    must fit the driver's time limit; the 189M-element mesh in 8 partitions is `bench.py --inproc-parts 8 --workload o3`.)
+    (The basin in 8 per-rank-built partitions: test_small_basin_on_eight_partitions_matches_one_partition since round 6 --
+    the suite must fit the driver's time limit; the 189M-element mesh in 8 partitions is `bench.py --inproc-parts 8
+    --workload o3`.)
     Host memory is kept lean: one field at a time, newest displacement only."""
     import gc
     import bench
@@ -607,58 +641,6 @@ def test_full_basin_against_the_oracle():
     box.close()
     gc.collect()
     lap("finite, anchors")
-
-
-def test_quarter_basin_in_eight_partitions_matches_one_partition():
-    """The layered basin in 8 partitions, every rank's tables built by that rank alone (octbox_local), in-process
-    transport: all four exchanges of a step on 3-7 neighbours each, against the single-partition run, node for node.
-    o3q = a quarter of o3's footprint and all of its depth and levels (47M elements, 0.26M hanging nodes; a rank of it
-    holds as many elements as a rank of the 64M box in 8) -- o3 itself until round 5 (170 s of the suite)."""
-    import gc
-    import bench
-    from hercules_amd import capi
-    lap = H.lap_timer("o3q")
-    box, E, N, u, interfaces = _basin("o3q", want_interfaces=True)
-    assert E > 45e6 and box.ldnnum > 2e5 and len(interfaces) == 3
-    nsteps = 2
-    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
-    s.run(nsteps)
-    ref, _ = s.download(want_tm2=False)
-    s.close()
-    scale = np.abs(ref).max()
-    assert np.isfinite(scale) and scale > 0
-    lap("whole mesh: build, hq_create, run, download")
-    far = box.node_xyz.max(axis=0).astype(np.int64)
-    key = lambda xyz: (xyz[:, 2].astype(np.int64) * (far[1] + 1) + xyz[:, 1]) * (far[0] + 1) + xyz[:, 0]
-    lut = np.full(int((far[0] + 1) * (far[1] + 1) * (far[2] + 1)), -1, np.int32)
-    lut[key(box.node_xyz)] = np.arange(box.N, dtype=np.int32)
-    box.close()
-    gc.collect()
-    solvers, maps = [], []
-    from concurrent.futures import ThreadPoolExecutor
-    def make(r):                      # mesh, map to the single run's nodes and hq_create of one rank
-        b = bench.make_octbox("o3q", r, 8)[0]
-        m = lut[key(b.node_xyz)]
-        ur = u[m]                     # (the start field is a function of the coordinates: the whole mesh's values there)
-        sv = b.create_solver(tm1=ur, tm2=0.999 * ur)
-        b.close()
-        return m, sv
-    with ThreadPoolExecutor(8) as pool:
-        for m, sv in pool.map(make, range(8)):
-            assert (m >= 0).all()
-            maps.append(m)
-            solvers.append(sv)
-            assert solvers[-1].info()["brick_nodes"] > 0
-    del lut, u
-    gc.collect()
-    lap("8 ranks: meshes, maps, hq_create")
-    capi.group_link(solvers)
-    capi.group_run(solvers, nsteps)
-    for sv, m in zip(solvers, maps):
-        tm1, _ = sv.download(want_tm2=False)
-        assert np.abs(tm1 - ref[m]).max() <= 1e-11 * scale
-        sv.close()
-    lap("run, download, compare")
 
 
 @pytest.mark.parametrize("path", ["hq_k_brick", "hq_k_patch_stencil"])
