@@ -950,7 +950,7 @@ hq_k_brick(int32_t count, int32_t per_xcd, const hq_brick_unit* __restrict__ uni
 
     /* (the registers the loads land in have the STATE's type: a float state is widened where it is used, at the PUT --
      *  a conversion beside the load would wait for it there and then, and the loads of a plane are meant to stay in flight
-     *  while the plane before is worked on: float build 0.95 -> see DESIGN.md s8.5) */
+     *  while the plane before is worked on: float build 0.95 -> see docs/LABNOTES.md, round 5) */
     hq_real x1[3] = { 0, 0, 0 }, x2[3] = { 0, 0, 0 }, y1[3] = { 0, 0, 0 }, y2[3] = { 0, 0, 0 };
     double mn[3] = { U.m0, U.m2, U.m1 };     /* n_t of the plane being loaded */
     double m0A = hq_uniform(1.0 / U.m0), m0B = m0A;      /* 1 / mass_simple of the output planes k - 1, k */

@@ -1463,7 +1463,11 @@ static int hq_setup_interface(hq_ctx* c, const hq_desc* d)
          * of the thousands of interior patch workgroups queued on the compute stream */
         int prio_lo = 0, prio_hi = 0;
         HQ_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HQ_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio_hi));
+        int prio = prio_hi;
+#ifdef HQ_EXPERIMENT            /* profiles/tools only: does the chain's priority cost the brick launch beside it? */
+        if (getenv("HQ_X_CHAIN_PRIO")) prio = !strcmp(getenv("HQ_X_CHAIN_PRIO"), "low") ? prio_lo : (prio_lo + prio_hi) / 2;
+#endif
+        HQ_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_shared, hipEventDisableTiming));
         HQ_HIP(hipEventCreateWithFlags(&c->ev_an_shared, hipEventDisableTiming));

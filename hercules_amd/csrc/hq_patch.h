@@ -48,7 +48,7 @@ static inline int omp_get_thread_num(void) { return 0; }
 /* Tuning knobs (environment overrides HQ_PATCH_THREADS / _PMAX / _PMERGE / _NLMAX are
  * read once per plan; defaults from the sweeps in profiles/). */
 /* Lattice-SUBSET patches (domain faces, dashpots, far-face cubes, partition interfaces) through hq_k_patch_stencil too,
- * not only the full lattices?  Measured: 2-3 % faster than the element form on the whole 64 M box, 9 % on
+ * not only the full lattices?  Measured (docs/LABNOTES.md): 2-3 % faster than the element form on the whole 64 M box, 9 % on
  * its eight in-process partitions -- the default is yes.  HQ_PATCH_RAGGED=0: element form; 2: stencil form except for
  * patches with partition-interface nodes.  -> -1 (not set) or the value. */
 static inline int hq_patch_ragged_env(void)
@@ -1863,7 +1863,7 @@ hq_k_stencil_entries(int32_t count, const int32_t* __restrict__ order, const hq_
  * patches), so three workgroups share a CU and the hardware overlaps one patch's loads with another's arithmetic; the
  * patches of a launch are in Z-order, so neighbours' rings meet in the XCD's L2.  (A persistent, software-pipelined
  * form -- next patch's rows requested before this patch's stencil, two images -- was measured and is slower, as are
- * two patches per workgroup and the ragged patches mixed into the full lattices' launch: DESIGN.md s7.)
+ * two patches per workgroup and the ragged patches mixed into the full lattices' launch: docs/LABNOTES.md.)
  * Thread t owns owned node t and loads it and halo node t.  Everything a thread needs is requested up front in the
  * order of the dependency chain: the patch's record and the thread's halo entry ride on the slot alone
  * (hq_k_stencil_entries), the owned rows and the table words need the record, the halo rows the halo entry;
