@@ -1193,7 +1193,7 @@ def main():
         # stream's marks see, so the step's own device time (events around the whole block / K) bounds it from below:
         # frac <= 72 N / step time / peak always holds (round-5 review 4)
         step_ms = total_ms / args.steps
-        roof_ms = max(kernel_ms, step_ms) if info.get("brick_stream", 0) else kernel_ms
+        roof_ms = max(kernel_ms, step_ms) if info2.get("brick_stream", 0) else kernel_ms
         achieved = compulsory / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
         achieved_counter = traffic / (roof_ms * 1e-3) / 1e9 if (traffic is not None and roof_ms > 0) else None
         ideal_ms = compulsory / (HBM_PEAK_GBS * 1e9) * 1e3

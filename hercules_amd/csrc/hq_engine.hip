@@ -1224,7 +1224,8 @@ static int hq_phase(hq_ctx* c, int ph)
             launch_bricks();
             hq_clock(c, hq_ctx::HQ_CLK_INT1, bs ? c->bstream : c->stream);
             if (!c->overlap && hq_has_transport(c)) hq_clock(c, hq_ctx::HQ_CLK_CHAIN0, c->stream);   /* the chain follows on this stream */
-            if (bs && c->timing) HQ_HIP(hipStreamWaitEvent(c->stream, c->ev_bricks, 0));   /* the mark below closes the step's kernels */
+            /* (bricks on their own stream: the marks on this stream see the shell only -- hq_run_timed takes the step's
+             *  kernel time from the phase clock's events instead, and a timed batch enqueues exactly what hq_run does) */
             hq_mark(c);
         } else {
             HQ_TRY(hq_launch_source(c));                                   /* :4288 */
@@ -1313,6 +1314,11 @@ static int hq_phase(hq_ctx* c, int ph)
                 HQ_HIP(hipEventRecord(c->ev_assigned, c->stream));
                 HQ_HIP(hipStreamWaitEvent(c->cstream, c->ev_assigned, 0));
             }
+            /* the bricks of the NEXT step read hanging nodes (a simple node beside a level interface has them for
+             * neighbours): where they run on a stream of their own, the event they wait for must lie BEHIND this
+             * assignment, not only behind the patches (round 6: in an hq_run_timed batch the assignment is held back until
+             * the step's bricks have ended and would otherwise run beside the next step's) */
+            if (c->bstream) HQ_HIP(hipEventRecord(c->ev_patches, c->stream));
         }
         return HQ_OK;
     case 7: return hq_xchg_send(c, &c->dn, unew, false, false);                      /* :4315 */
@@ -3147,6 +3153,9 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
     for (int k = 0; k < 2; k++)
         if (!c->ev_span[k]) HQ_HIP(hipEventCreate(&c->ev_span[k]));
     HQ_HIP(hq_quiesce(c));
+    hq_clock_harvest_all(c, true);
+    const double clk_us0 = c->clk_us[0];
+    const int64_t clk_n0 = c->clk_steps;
     c->ev_used = 0;
     HQ_HIP(hipEventRecord(c->ev_span[0], c->stream));
     c->timing = true;
@@ -3168,6 +3177,8 @@ extern "C" int hq_run_timed(hq_ctx* c, int32_t nsteps, double* total_ms, double*
             ker += ms;
         }
         if (c->ev_used >= 2) ker /= (double)(c->ev_used / 2);
+        /* a step whose bricks ran on a stream of their own: first kernel's start -> last kernel's end, from the phase clock */
+        if (c->bstream && c->clk_steps > clk_n0) ker = (c->clk_us[0] - clk_us0) / (double)(c->clk_steps - clk_n0) * 1e-3;
     }
     if (rc != HQ_OK) return rc;
     if (he != hipSuccess) return hq_fail(HQ_ERR_DEVICE, "timed run failed: %s", hipGetErrorString(he));

@@ -40,8 +40,7 @@ def _run(box, variant, u1, u2, nsteps, src=None, options=None, want=None):
     return out
 
 
-@pytest.mark.parametrize("wl", ["c2"])     # (the 64M box: 75 oracle cone windows below, and 8 partitions against one; round 6: the
-                                           # patches-only pass of the 8M box went -- patches alone on m1 / o4s / the parity file)
+@pytest.mark.parametrize("wl", ["c2", "c2-nobricks"])     # (the 64M box: 75 oracle cone windows below, and 8 partitions against one)
 def test_fullsize_variants_agree_and_step_is_linear(wl, monkeypatch):
     if wl.endswith("-nobricks"):     # the patch kernels alone (lattice / ragged stencil patches, element form), as without node_xyz
         monkeypatch.setenv("HQ_NO_BRICKS", "1")
@@ -526,14 +525,12 @@ def test_small_basin_variants_agree_and_step_is_linear():
     box.close()
 
 
-@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 1)])      # (round 6: the patch variant with the chain on its own stream
-                                                                             # -- until round 5 the 189M basin itself in 8 partitions, 100 s of
-                                                                             # the suite; scatter kernels on partitions: tests/test_gpu_parity.py)
+@pytest.mark.parametrize("variant,overlap", [(ha.HQ_VARIANT_PATCH, 1)])      # (round 6: the patch variant with the chain on its own stream;
+                                                                             # scatter kernels on partitions: tests/test_gpu_parity.py)
 def test_small_basin_on_eight_partitions_matches_one_partition(variant, overlap, monkeypatch):
     """o3s cut into octor's 8 partitions, every rank's tables built by that rank alone (octbox_local: hanging nodes and
     their anchors on partition interfaces, all four exchanges of a step, psolve.c:4298-4315), in-process transport, against
-    the whole basin on one partition.  (The 189M-element basin in 8 partitions: `bench.py --inproc-parts 8 --workload o3`,
-    profiles/r05/inproc8_o3_lease_b8.json.)"""
+    the whole basin on one partition.  (The 189M-element basin itself in 8 partitions: the next test but one.)"""
     from hercules_amd import capi
     monkeypatch.setenv("HQ_OVERLAP", str(overlap))      # 1: the exchange chain beside the interior patches, as between GPUs
     nsteps = 5
@@ -581,7 +578,7 @@ def _basin_windows(nx, ny, nzt, interfaces, k):
     return out
 
 
-def test_full_basin_against_the_oracle():
+def test_full_basin_against_the_oracle_and_in_eight_partitions():
     """o3 = BASELINE config 5 at scale on ONE GPU: 189M elements on four octree levels, 1.0M hanging nodes.
     * Finiteness, hanging nodes = mean of their anchors (the scatter kernels and quiescence are compared on o3s).
     * ORACLE parity at this size: dependency-cone windows that straddle each of the three level interfaces -- hanging
@@ -589,12 +586,12 @@ def test_full_basin_against_the_oracle():
       -- in the interior, at a domain face and in a corner, stepped by the oracle's reference loops with the true table
       rows (tests/helpers.octree_window; the window logic itself is pinned on a whole-mesh oracle run in
       tests/test_octree_windows_cpu.py): <= 1e-9 of the field's scale.
-    (The basin in 8 per-rank-built partitions: test_small_basin_on_eight_partitions_matches_one_partition since round 6 --
-    the suite must fit the driver's time limit; the 189M-element mesh in 8 partitions is `bench.py --inproc-parts 8
-    --workload o3`.)
+    * The basin in 8 partitions, every rank's tables built by that rank alone (octbox_local), in-process transport: all
+      four exchanges of a step on 3-7 neighbours each, against the single-partition run.
     Host memory is kept lean: one field at a time, newest displacement only."""
     import gc
     import bench
+    from hercules_amd import capi
     psutil = pytest.importorskip("psutil")
     if psutil.virtual_memory().available < 90 * 2 ** 30:
         pytest.skip("needs ~80 GiB of host memory for the 189M-element mesh tables")
@@ -604,6 +601,7 @@ def test_full_basin_against_the_oracle():
     assert E > 180e6 and box.ldnnum > 1e6 and len(interfaces) == 3
     nsteps = 2
     scale0 = np.abs(u).max()
+    res = []
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u)
     assert s.info()["variant"] == ha.HQ_VARIANT_PATCH and s.info()["brick_nodes"] > 0.9 * N
     s.run(nsteps)
@@ -629,18 +627,55 @@ def test_full_basin_against_the_oracle():
     lap("oracle windows")
     assert nchecked > 400 and nhang > 20, (nchecked, nhang)
     assert worst < 1e-9, worst
-    # finite; hanging nodes = mean of their anchors (over the whole field: o3s, o4s and o4; here on a sample, gathered)
-    nonfinite = s.check_finite()
-    assert nonfinite == 0
-    ids, ptr, anc = box.dangling
-    for k in np.linspace(0, len(ids) - 1, 50).astype(np.int64):
-        hang = s.gather(ids[k:k + 1])[0][0]
-        mean = s.gather(anc[ptr[k]:ptr[k + 1]])[0].mean(axis=0)
-        assert np.abs(hang - mean).max() <= 1e-13 * scale0
+    tm1, _ = s.download(want_tm2=False)
     s.close()
+    res.append(tm1)
+    gc.collect()
+    scale = np.abs(res[0]).max()
+    assert np.isfinite(scale) and scale > 0 and np.isfinite(res[0]).all()
+    # (hanging nodes = mean of their anchors over the whole field: checked on o3s, o4s and o4; here on a sample)
+    ids, ptr, anc = box.dangling
+    pick = np.linspace(0, len(ids) - 1, 20000).astype(np.int64)
+    for k in pick[::400]:
+        assert np.abs(res[0][ids[k]] - res[0][anc[ptr[k]:ptr[k + 1]]].mean(axis=0)).max() <= 1e-13 * scale
+    gc.collect()
+    # eight partitions, each built by its rank alone, against the single run (res[0]); compared at the harbored nodes
+    # of every rank through their coordinates
+    # (a dense table over the node lattice instead of a sort of 190 M keys: 3.4 GB for half a minute less)
+    far = box.node_xyz.max(axis=0).astype(np.int64)
+    key = lambda xyz: (xyz[:, 2].astype(np.int64) * (far[1] + 1) + xyz[:, 1]) * (far[0] + 1) + xyz[:, 0]
+    lut = np.full(int((far[0] + 1) * (far[1] + 1) * (far[2] + 1)), -1, np.int32)
+    lut[key(box.node_xyz)] = np.arange(box.N, dtype=np.int32)
     box.close()
     gc.collect()
-    lap("finite, anchors")
+    lap("download, anchors, node table")
+    solvers, maps = [], []
+    # the ranks' tables are built side by side (the C host side releases the GIL; a rank alone takes ~10 s)
+    from concurrent.futures import ThreadPoolExecutor
+    def make(r):                      # mesh, map to the single run's nodes and hq_create of one rank
+        b = bench.make_octbox("o3", r, 8)[0]
+        m = lut[key(b.node_xyz)]
+        ur = u[m]                     # (the start field is a function of the coordinates: the whole mesh's values there)
+        sv = b.create_solver(tm1=ur, tm2=0.999 * ur)
+        b.close()
+        return m, sv
+    with ThreadPoolExecutor(8) as pool:
+        for m, sv in pool.map(make, range(8)):
+            assert (m >= 0).all()
+            maps.append(m)
+            solvers.append(sv)
+            assert solvers[-1].info()["brick_nodes"] > 0
+    gc.collect()
+    del lut, u
+    lap("8 ranks: meshes, maps, hq_create")
+    capi.group_link(solvers)
+    capi.group_run(solvers, nsteps)
+    for sv, m in zip(solvers, maps):
+        tm1, _ = sv.download(want_tm2=False)
+        assert np.abs(tm1 - res[0][m]).max() <= 1e-11 * scale
+        sv.close()
+    del res
+    gc.collect()
 
 
 @pytest.mark.parametrize("path", ["hq_k_brick", "hq_k_patch_stencil"])
@@ -695,7 +730,7 @@ def test_small_basin_against_the_oracle():
 # with x-, y- and z-normal faces and staircase corners, hanging nodes of every orientation
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["bricks", "full-tiles-only", "patches-only", "scatter"])
+@pytest.mark.parametrize("mode", ["bricks", "full-tiles-only", "patches-only", "scatter", "brick-stream-timed"])
 def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     """o4s (0.93 M elements on four levels, 62 k hanging nodes of all six kinds): the oracle's reference loops with
     compute_adjust on the WHOLE mesh for three steps against the default path (bricks where a level's interior is
@@ -718,8 +753,13 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     o1, o2 = (0.999 * u).copy(), u.copy()
     ho.solver_run(box.lnid, box.etable.copy(), box.ntable.copy(), o1, o2, 0, nsteps, box.dt, dangling=box.dangling,
                   loaded_lnid=loaded, forces=F)
+    # brick-stream-timed (round 6): the arrangement the 100 M-element basins step in -- the shell's patches on the compute
+    # stream BESIDE the bricks on a stream of their own (hq_options.brick_stream; by default only above 4 096 patches) --
+    # through hq_run_timed, where the hanging-node assignment is held back until the step's bricks have ended: the next
+    # step's bricks, which read hanging nodes as neighbours, must wait for it (a dependency round 5 did not record)
     s = box.create_solver(variant=ha.HQ_VARIANT_SCATTER if mode == "scatter" else ha.HQ_VARIANT_PATCH, tm1=u, tm2=0.999 * u,
-                          options={"brick_ragged": 0} if mode == "full-tiles-only" else None)
+                          options={"brick_ragged": 0} if mode == "full-tiles-only" else
+                                  ({"brick_stream": 1} if mode == "brick-stream-timed" else None))
     info = s.info()
     if mode == "bricks":
         assert info["brick_nodes"] > 0.6 * N and info["brick_units_ragged"] > 0
@@ -728,7 +768,12 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     elif mode == "patches-only":
         assert info["brick_nodes"] == 0
     s.set_source(loaded, F)
-    s.run(nsteps)
+    if mode == "brick-stream-timed":
+        assert s.info()["brick_stream"] == 0          # (the stream is made at the first step)
+        s.run_timed(nsteps)
+        assert s.info()["brick_stream"] == 1 and s.info()["timed_steps"] == nsteps and s.info()["t_interior_us"] > 0
+    else:
+        s.run(nsteps)
     tm1, tm2 = s.download()
     s.close()
     assert H.rel_linf(tm1, o2) < 1e-9 and H.rel_linf(tm2, o1) < 1e-9
