@@ -1128,7 +1128,11 @@ static bool hq_use_brick_stream(hq_ctx* c)
     if (!c->bstream) {
         int prio_lo = 0, prio_hi = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return false;
-        if (hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, prio_lo) != hipSuccess) { c->bstream = nullptr; return false; }
+        int prio = prio_lo;
+#ifdef HQ_EXPERIMENT            /* profiles/tools only: which of the two streams should the dispatcher prefer? */
+        if (getenv("HQ_X_BRICK_PRIO")) prio = !strcmp(getenv("HQ_X_BRICK_PRIO"), "high") ? prio_hi : (prio_lo + prio_hi) / 2;
+#endif
+        if (hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, prio) != hipSuccess) { c->bstream = nullptr; return false; }
         if (hipEventCreateWithFlags(&c->ev_patches, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_bricks, hipEventDisableTiming) != hipSuccess) return false;
         /* everything enqueued so far is on the compute stream: the first brick launch goes behind it */
