@@ -159,7 +159,7 @@ typedef struct {
     int32_t brick_units_ragged_het; /* of brick_units_het: partly filled tiles (hq_k_brick_het<., RAGGED>, hq_options.brick_ragged_het) */
     /* Where a step's device time goes -- the library's share of the reference's per-phase report (print_timing_stat,
      * psolve.c:6041-6266: "Compute addforces e", "... schedule send data", ...), from HIP events, averaged over
-     * `timed_steps` steps: every step of a context with hq_options.phase_timing = 1 and of every hq_run_timed batch.
+     * `timed_steps` steps: every step of a context with hq_options.phase_timing = 1, every fourth step of an hq_run_timed batch.
      * microseconds per step; the phases overlap, so they do not add up to t_step_us. */
     int64_t timed_steps;
     double  t_step_us;           /* first kernel's start -> last kernel's end (compute streams and exchange chain)       */

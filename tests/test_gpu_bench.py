@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(*argv, env_extra=None, timeout=900):
-    """One bench.py run -> its JSON line.  No retry: round 5 started a failed bring-up of ranks sharing the GPU a second time
-    (one unexplained failure in ~20 runs, output not kept); round 6 ran the 8-rank IPC bring-up 100 times back to back with
-    every stderr kept (profiles/r06/ipc_bring_up_loop_100x8_ranks.txt: 100 of 100 clean), so a failure here is a finding
-    again -- its stdout and stderr are written to gpurun_out/bench_failures/ before the assertion fires."""
+    """One bench.py run -> its JSON line.  No retry: round 5 started a failed run of ranks sharing the GPU a second time
+    (one unexplained failure in ~20 runs, output not kept).  Round 6 kept the output, and the one failure that came was a
+    PARITY failure (0.37): hq_upload's null-stream hipMemset landing behind the first step's kernels when eight processes
+    time-slice one GPU -- fixed (docs/LABNOTES.md, round 6; profiles/r06/ipc_8_ranks_with_parity_loop_40x.txt: 40 of 40
+    afterwards).  A failure here is a finding: its stdout and stderr go to gpurun_out/bench_failures/ first."""
     import time
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})

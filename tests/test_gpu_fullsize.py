@@ -771,7 +771,8 @@ def test_small_lateral_basin_against_the_oracle(mode, monkeypatch):
     if mode == "brick-stream-timed":
         assert s.info()["brick_stream"] == 0          # (the stream is made at the first step)
         s.run_timed(nsteps)
-        assert s.info()["brick_stream"] == 1 and s.info()["timed_steps"] == nsteps and s.info()["t_interior_us"] > 0
+        # (a timed batch samples every fourth step's phase events; hq_options.phase_timing = 1 records every step)
+        assert s.info()["brick_stream"] == 1 and s.info()["timed_steps"] >= 1 and s.info()["t_interior_us"] > 0
     else:
         s.run(nsteps)
     tm1, tm2 = s.download()
