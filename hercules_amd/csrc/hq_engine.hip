@@ -2911,7 +2911,9 @@ extern "C" int hq_comm_init_ipc(hq_ctx* c, const void* blobs)
     if (!c->ipc) return hq_fail(HQ_ERR_STATE, "hq_comm_init_ipc needs the blobs of hq_comm_ipc_export (this rank's among them)%s", "");
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
     HQ_HIP(hipSetDevice(c->device));
-    return hq_ipc_connect(c, (const char*)blobs);
+    HQ_TRY(hq_ipc_connect(c, (const char*)blobs));
+    HQ_HIP(hipDeviceSynchronize());              /* the destination / flag tables are in place before a step reads them */
+    return HQ_OK;
 }
 
 /* the same with the number of blobs the caller holds: a short all-gather is refused instead of read out of bounds */
@@ -2927,7 +2929,9 @@ extern "C" int hq_comm_init_loopback(hq_ctx* c)
     if (!c) return hq_fail(HQ_ERR_ARG, "null argument%s", "");
     HQ_TRY(hq_ipc_prepare(c));
     if (hq_has_transport(c)) return hq_fail(HQ_ERR_STATE, "context already has a transport%s", "");
-    return hq_ipc_connect(c, nullptr);
+    HQ_TRY(hq_ipc_connect(c, nullptr));
+    HQ_HIP(hipDeviceSynchronize());
+    return HQ_OK;
 }
 
 extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
@@ -3022,6 +3026,9 @@ extern "C" int hq_group_link(hq_ctx** ctxs, int32_t n)
         (tables[k].contribution ? s->d_c_dst : s->d_s_dst) = uploaded[k];
         tables[k].c->bytes += (int64_t)(sizeof(double*) * tables[k].dst.size());
     }
+    for (int32_t i = 0; i < n; i++) {            /* the tables are in place on every member's device before a step reads them */
+        if (hipSetDevice(ctxs[i]->device) == hipSuccess) (void)hipDeviceSynchronize();
+    }
     return HQ_OK;
 }
 
@@ -3068,6 +3075,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
     if (same_nodes) {
         c->src_step0 = step0; c->src_nsteps = nsteps;
         HQ_HIP(hipMemcpy(c->d_F, F, sizeof(double) * 3 * nloaded * (size_t)nsteps, hipMemcpyHostToDevice));
+        HQ_HIP(hipStreamSynchronize(nullptr));
         c->h2d_bytes += 24 * (int64_t)nloaded * nsteps;
         return HQ_OK;
     }
@@ -3089,6 +3097,7 @@ extern "C" int hq_set_source(hq_ctx* c, int32_t nloaded, const int32_t* loaded, 
         if (r == 0) r = hq_brick_set_source(&c->bricks, (nloaded && nsteps) ? nloaded : 0, loaded, &c->bytes);
         if (r != 0) return hq_fail(HQ_ERR_NOMEM, "source table allocation failed%s", "");
     }
+    HQ_HIP(hipStreamSynchronize(nullptr));       /* the tables went through the null stream; the steps read them on other streams */
     return HQ_OK;
 }
 
@@ -3300,6 +3309,7 @@ extern "C" int hq_upload(hq_ctx* c, const hq_real* tm1, const hq_real* tm2, int3
         HQ_HIP(hipMemsetAsync(c->d_u[c->spare], 0, bytes, c->stream));
         HQ_HIP(hipStreamSynchronize(c->stream));
     }
+    HQ_HIP(hipStreamSynchronize(nullptr));       /* (the copies above went through the null stream: nothing of them may be in flight) */
     c->step = step;
     return HQ_OK;
 }
