@@ -70,6 +70,31 @@ def test_round3_lines_follow_from_their_counter_passes(tag, line_file, kernel):
     assert 0.0 < r["frac"] <= r["counter_frac"] <= 1.0
 
 
+def test_round6_line_follows_from_its_counter_passes():
+    """The final tree's default line (profiles/r06/bench_default.json) and the two --pmc passes of that very run:
+    traffic, counter_frac, wasted and frac recomputed; the written bytes are u(t + dt) once; the line carries the median of
+    five timed blocks, its parity windows, the device-side phase split and the CPU baseline's element count."""
+    R06 = os.path.join(ROOT, "profiles", "r06")
+    pmc = {"FETCH_SIZE": _per_kernel(os.path.join(R06, "pmc_default_fetch_size.csv"), "FETCH_SIZE"),
+           "WRITE_SIZE": _per_kernel(os.path.join(R06, "pmc_default_write_size.csv"), "WRITE_SIZE")}
+    line = json.load(open(os.path.join(R06, "bench_default.json")))
+    r, c = line["roofline"], line["config"]
+    total, rd, wr, steps = bench.traffic_of(pmc, r["kernel"])
+    assert steps == 4 and abs(total - r["traffic"]) <= 1e-6 * total
+    nodes = c["nodes"]
+    comp = bench.COMPULSORY_BYTES_PER_NODE * nodes
+    assert r["compulsory_bytes_per_launch"] == comp and abs(wr - 24.0 * nodes) <= 0.01 * wr
+    t = r["roofline_ms"] * 1e-3
+    assert abs(r["frac"] - comp / t / 1e9 / bench.HBM_PEAK_GBS) < 1e-9 and abs(r["counter_frac"] - total / t / 1e9 / bench.HBM_PEAK_GBS) < 1e-9
+    assert 0.5 < r["frac"] <= r["counter_frac"] <= 1.0 and abs(r["wasted"] - total / comp) < 1e-9
+    runs = c["ms_per_step_runs"]
+    assert c["repeats"] == len(runs) == 5 and abs(sorted(runs)[2] - line["ms_per_step"]) < 1e-4
+    assert c["parity_windows"] >= 4 and c["parity_worst"] <= 1e-9
+    assert r["phase_us"]["t_interior_us"] > 10 * r["phase_us"]["t_shell_us"] > 0
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["elements"] == 8388608
+    assert line["cpu_baseline"]["recorded_64m"]["elements"] == 67108864
+
+
 def test_step_count_does_not_depend_on_which_kernels_a_step_launches():
     """hq_k_patch_stencil<512> runs twice per step and <768> once on the 64M box; a mesh without far-face cubes has
     no <768> rows at all.  The bytes per step must come out as the sum over the kernels divided by the steps the
