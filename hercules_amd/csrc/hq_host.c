@@ -330,6 +330,53 @@ static int corner_dashpot(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek, 
     return 1;
 }
 
+/*
+ * solver_float (psolve.h:60-64).  An n_t row is a sum of double terms into solver_float fields (psolve.c:3440-3471; the
+ * hanging nodes' share, compute_adjust :5958-5990): built with -DSINGLE_PRECISION_SOLVER every `+=` there rounds to
+ * float.  The tables stay double arrays in this library; with solver_float = 4 every update is rounded as the float field
+ * rounds it -- (double) field + term -> float -- so that a row holds exactly the float build's values (a double sum or
+ * quotient of two floats, rounded once more to float, IS the float operation: 53 >= 2 x 24 + 2 bits), in the summation
+ * order of ONE rank's element loop.  A partition's rows are cut out of those: the float reference on N ranks adds the
+ * ranks' partial sums in its messengers' order (:5040-5060), which differs from this in the last float digit of <= 8
+ * terms (6e-8; the float parity tolerances are 2e-6 and 2e-5).
+ */
+#define HQH_SF(f32, x) ((f32) ? (double)(float)(x) : (x))
+
+static inline int hqh_sf_valid(int32_t solver_float) { return solver_float == 0 || solver_float == 4 || solver_float == 8; }
+
+/* one element's share of its corner's row: psolve.c:3440-3471 */
+static inline void nt_accumulate(double* np, int f32, double dt, double a, double M, int bnd, const double* dash)
+{
+    np[0] = HQH_SF(f32, np[0] + M);
+    for (int ax = 0; ax < 3; ax++) {
+        np[4 + ax] = HQH_SF(f32, np[4 + ax] - (dt * a * M));
+        np[1 + ax] = HQH_SF(f32, np[1 + ax] - (dt * a * M));
+        if (bnd) {
+            np[4 + ax] = HQH_SF(f32, np[4 + ax] - (dt * dash[ax]));
+            np[1 + ax] = HQH_SF(f32, np[1 + ax] - (dt * dash[ax]));
+        }
+        np[4 + ax] = HQH_SF(f32, np[4 + ax] + M);
+        np[1 + ax] = HQH_SF(f32, np[1 + ax] + (M * 2));
+    }
+}
+
+/* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:5958-5990: a hanging node's row, divided by its anchors' number, to every
+ * anchor */
+static void nt_distribute(double* ntable, int f32, int32_t ldnnum, const int32_t* dn_id, const int32_t* dn_ptr,
+                          const int32_t* dn_anchor)
+{
+    for (int32_t k = 0; k < ldnnum; k++) {
+        double part[7];
+        uint32_t deps = (uint32_t)(dn_ptr[k + 1] - dn_ptr[k]);
+        for (int q = 0; q < 7; q++) part[q] = HQH_SF(f32, ntable[7 * (int64_t)dn_id[k] + q] / deps);
+        for (int32_t a = dn_ptr[k]; a < dn_ptr[k + 1]; a++)
+            for (int q = 0; q < 7; q++) {
+                double* v = &ntable[7 * (int64_t)dn_anchor[a] + q];
+                *v = HQH_SF(f32, *v + part[q]);
+            }
+    }
+}
+
 /* n_t of node (i,j,k): psolve.c:3440-3471 summed over its elements in Z-order */
 static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, double np[7])
 {
@@ -359,17 +406,7 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, do
         const int64_t mi = mat_index(b, ee[q][0], ee[q][1], ek);
         double M = b->k_M[mi], a = b->k_a[mi], dash[3];
         int bnd = corner_dashpot(b, ee[q][0], ee[q][1], ek, cn[q], dash);
-        np[0] += M;
-        for (int ax = 0; ax < 3; ax++) {
-            np[4 + ax] -= (dt * a * M);
-            np[1 + ax] -= (dt * a * M);
-            if (bnd) {
-                np[4 + ax] -= (dt * dash[ax]);
-                np[1 + ax] -= (dt * dash[ax]);
-            }
-            np[4 + ax] += M;
-            np[1 + ax] += (M * 2);
-        }
+        nt_accumulate(np, p->solver_float == 4, dt, a, M, bnd, dash);
     }
 }
 
@@ -411,6 +448,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     if (ax < 0 || ay < 0 || az < 0 || ax > 10 || ay > 10 || az > 10) return HQ_ERR_ARG;
     if (p->nlayers < 1 || !p->layer_ztop || !p->layer_vp || !p->layer_vs || !p->layer_rho) return HQ_ERR_ARG;
     if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    if (!hqh_sf_valid(p->solver_float)) return HQ_ERR_ARG;
     hqh_box* b = (hqh_box*)calloc(1, sizeof(hqh_box));
     if (!b) return HQ_ERR_NOMEM;
     b->p = *p;
@@ -1537,14 +1575,7 @@ static uint64_t oct_node_row(const oct_ctx_t* C, const int32_t c[3], double np[7
         double dash[3];
         const int bnd = face_dashpot(face, corner[k], b->p.halfspace, C->lh[q], C->lvp[q], b->vs[q], b->rho[q], dash);
         const double M = C->lM[q], a = C->la[q];
-        np[0] += M;
-        for (int ax = 0; ax < 3; ax++) {
-            np[4 + ax] -= (dt * a * M);
-            np[1 + ax] -= (dt * a * M);
-            if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
-            np[4 + ax] += M;
-            np[1 + ax] += (M * 2);
-        }
+        nt_accumulate(np, b->p.solver_float == 4, dt, a, M, bnd, dash);
         bits |= 1ull << OCT_ERANK(C, leaf[k].e);
     }
     return bits;
@@ -1574,6 +1605,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                         const double* lM, const float* lvp, const float* lh)
 {
     oct_ctx_t C;
+    const int f32 = b->p.solver_float == 4;
     C.b = b; C.ek = ek; C.E = b->E; C.P = P;
     C.far[0] = b->far_q[0]; C.far[1] = b->far_q[1]; C.far[2] = b->far_q[2];
     C.lc = lc; C.la = la; C.lM = lM; C.lvp = lvp; C.lh = lh;
@@ -1696,7 +1728,10 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                     int pd;
                     oct_node_hangs(&C, hc[k], pa, &pd);
                     oct_node_row(&C, hc[k], hp);
-                    for (int q = 0; q < 7; q++) np[q] += hp[q] / (uint32_t)pd;
+                    for (int q = 0; q < 7; q++) {
+                        const double part = HQH_SF(f32, hp[q] / (uint32_t)pd);
+                        np[q] = HQH_SF(f32, np[q] + part);
+                    }
                     const int ho = oct_owner(&C, hc[k]);
                     if (ho >= 0) bits |= 1ull << ho;                     /* indirect sharing */
                 }
@@ -1842,7 +1877,7 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
     if (NL < 1 || NL > HQH_MAXLEVELS || !p->layers || !p->vp || !p->vs || !p->rho) return HQ_ERR_ARG;
     const int32_t nx = p->nx, ny = p->ny;
     if (nx < 1 || ny < 1 || (nx & ((1 << (NL - 1)) - 1)) || (ny & ((1 << (NL - 1)) - 1))) return HQ_ERR_ARG;
-    if (p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
+    if (p->h <= 0 || p->deltaT <= 0 || !hqh_sf_valid(p->solver_float)) return HQ_ERR_ARG;
     const int P = p->nranks > 1 ? p->nranks : 1;
     if (P > 64 || p->rank < 0 || p->rank >= P) return HQ_ERR_ARG;
     hqh_octbox* b = (hqh_octbox*)calloc(1, sizeof *b);
@@ -2039,27 +2074,14 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
             double dash[3];
             int bnd = face_dashpot(face, c, p->halfspace, lh[q], lvp[q], b->vs[q], b->rho[q], dash);
             double* np = &b->ntable[7 * (int64_t)n];
-            np[0] += M;
-            for (int ax = 0; ax < 3; ax++) {
-                np[4 + ax] -= (dt * a * M);
-                np[1 + ax] -= (dt * a * M);
-                if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
-                np[4 + ax] += M;
-                np[1 + ax] += (M * 2);
-            }
+            nt_accumulate(np, p->solver_float == 4, dt, a, M, bnd, dash);
         }
     }
     free(lc); free(la); free(lM); free(lvp); free(lh);
 #undef HQH_LOC
     free(loc);
     /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors */
-    for (int32_t k = 0; k < b->ldnnum; k++) {
-        double part[7];
-        uint32_t deps = (uint32_t)(b->dn_ptr[k + 1] - b->dn_ptr[k]);
-        for (int q = 0; q < 7; q++) part[q] = b->ntable[7 * (int64_t)b->dn_id[k] + q] / deps;
-        for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
-            for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
-    }
+    nt_distribute(b->ntable, p->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
     if (P > 1) {
         int rc = octbox_cut(b, ek, p->rank, P);
         if (rc != HQ_OK) { free(ek); hqh_octbox_destroy(b); return rc; }
@@ -2359,8 +2381,8 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     int rc = HQ_ERR_NOMEM;
     if (!b || !ck) goto fail;
     const int P = ip->nranks > 1 ? ip->nranks : 1;
-    if (P > 64 || ip->rank < 0 || ip->rank >= P) { rc = HQ_ERR_ARG; goto fail; }
-    b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.rank = ip->rank; b->p.nranks = P;
+    if (P > 64 || ip->rank < 0 || ip->rank >= P || !hqh_sf_valid(ip->solver_float)) { rc = HQ_ERR_ARG; goto fail; }
+    b->p.nlevels = 0; b->p.deltaT = ip->deltaT; b->p.rank = ip->rank; b->p.nranks = P; b->p.solver_float = ip->solver_float;
     for (int d = 0; d < 3; d++) b->far_q[d] = (int32_t)nq[d];
     b->E = E;
     b->lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)E);
@@ -2515,25 +2537,12 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
                 double dash[3];
                 int bnd = face_dashpot(face, c, ip->halfspace, h, Vp, Vs, rho, dash);
                 double* np = &b->ntable[7 * (int64_t)b->lnid[8 * e + c]];
-                np[0] += M;
-                for (int ax = 0; ax < 3; ax++) {
-                    np[4 + ax] -= (dt * a * M);
-                    np[1 + ax] -= (dt * a * M);
-                    if (bnd) { np[4 + ax] -= (dt * dash[ax]); np[1 + ax] -= (dt * dash[ax]); }
-                    np[4 + ax] += M;
-                    np[1 + ax] += (M * 2);
-                }
+                nt_accumulate(np, ip->solver_float == 4, dt, a, M, bnd, dash);
             }
         }
     }
     /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502 */
-    for (int32_t k = 0; k < b->ldnnum; k++) {
-        double part[7];
-        uint32_t deps = (uint32_t)(b->dn_ptr[k + 1] - b->dn_ptr[k]);
-        for (int q = 0; q < 7; q++) part[q] = b->ntable[7 * (int64_t)b->dn_id[k] + q] / deps;
-        for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++)
-            for (int q = 0; q < 7; q++) b->ntable[7 * (int64_t)b->dn_anchor[a] + q] += part[q];
-    }
+    nt_distribute(b->ntable, ip->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
     if (P > 1) {
         /* the leaves' corners in Z-order = octree pre-order (checked), for point location */
         uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
@@ -2646,7 +2655,7 @@ int hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out)
     q.vp = m; q.vs = m + nlay; q.rho = m + 2 * nlay;
     q.deltaT = p->deltaT; q.freq = p->freq; q.damping = p->damping;
     q.threshold_damping = p->threshold_damping; q.threshold_vpvs = p->threshold_vpvs; q.halfspace = p->halfspace;
-    q.rank = p->rank; q.nranks = p->nranks;
+    q.rank = p->rank; q.nranks = p->nranks; q.solver_float = p->solver_float;
     int rc = hqh_octbox_create_levels(&q, out);
     free(m);
     return rc;

@@ -30,7 +30,8 @@ class _BoxParams(ctypes.Structure):
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
                 ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("lateral_classes", ctypes.c_int32), ("lateral_amp", ctypes.c_double), ("origin", ctypes.c_int32 * 3)]
+                ("lateral_classes", ctypes.c_int32), ("lateral_amp", ctypes.c_double), ("origin", ctypes.c_int32 * 3),
+                ("solver_float", ctypes.c_int32)]
 
 
 class _BoxInfo(ctypes.Structure):
@@ -204,7 +205,8 @@ class Box:
 
     def __init__(self, nx, ny, nz, h, dt, freq, vp=6000.0, vs=3464.0, rho=2700.0, layers=None,
                  damping="rayleigh", threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True,
-                 rank=0, nranks=1, lateral_classes=0, lateral_amp=0.0, origin=(0, 0, 0)):
+                 rank=0, nranks=1, lateral_classes=0, lateral_amp=0.0, origin=(0, 0, 0), solver_float=8):
+        """solver_float = 4: the n_t rows as the reference's -DSINGLE_PRECISION_SOLVER build sums them (hq_host.h)."""
         lib = load_library()
         if layers is None:
             layers = [(0.0, vp, vs, rho)]
@@ -215,7 +217,8 @@ class Box:
         p = _BoxParams(nx, ny, nz, h, len(layers), zt.ctypes.data, lvp.ctypes.data, lvs.ctypes.data,
                        lrho.ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
                        int(halfspace), rank, nranks, int(lateral_classes), float(lateral_amp),
-                       (ctypes.c_int32 * 3)(*[int(v) for v in origin]))
+                       (ctypes.c_int32 * 3)(*[int(v) for v in origin]), int(solver_float))
+        self.solver_float = int(solver_float)
         self._h = ctypes.c_void_p()
         rc = lib.hqh_box_create(ctypes.byref(p), ctypes.byref(self._h))
         if rc != 0:
@@ -340,7 +343,8 @@ class _OctParams(ctypes.Structure):
                 ("vp_bot", ctypes.c_float), ("vs_bot", ctypes.c_float), ("rho_bot", ctypes.c_float),
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("solver_float", ctypes.c_int32)]
 
 
 class _Layered(ctypes.Structure):
@@ -389,7 +393,8 @@ class _OctLevels(ctypes.Structure):
                 ("vp", ctypes.c_void_p), ("vs", ctypes.c_void_p), ("rho", ctypes.c_void_p),
                 ("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("solver_float", ctypes.c_int32)]
 
 
 class OctBox:
@@ -400,7 +405,7 @@ class OctBox:
 
     def __init__(self, nx, ny, nz_fine, nz_coarse, h, dt, freq, top=(3000.0, 1732.0, 2200.0),
                  bottom=(6000.0, 3464.0, 2700.0), damping="rayleigh", threshold_damping=0.05,
-                 threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1, levels=None):
+                 threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1, levels=None, solver_float=8):
         lib = load_library()
         lib.hqh_octbox_view.restype = ctypes.c_void_p
         lib.hqh_octbox_view.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
@@ -408,8 +413,8 @@ class OctBox:
         lib.hqh_octbox_destroy.argtypes = [ctypes.c_void_p]
         p = _OctParams(nx, ny, nz_fine, nz_coarse, h, top[0], top[1], top[2], bottom[0], bottom[1], bottom[2],
                        dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace),
-                       int(rank), int(nranks))
-        self.rank, self.nranks = int(rank), int(nranks)
+                       int(rank), int(nranks), int(solver_float))
+        self.rank, self.nranks, self.solver_float = int(rank), int(nranks), int(solver_float)
         self._h = ctypes.c_void_p()
         if levels is not None:
             lay = np.array([l[0] for l in levels], np.int32)
@@ -421,7 +426,7 @@ class OctBox:
             mats = [np.array([m[c] for m in per], np.float32) for c in range(3)]
             q = _OctLevels(nx, ny, len(levels), lay.ctypes.data, h, mats[0].ctypes.data, mats[1].ctypes.data,
                            mats[2].ctypes.data, dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs,
-                           int(halfspace), int(rank), int(nranks))
+                           int(halfspace), int(rank), int(nranks), int(solver_float))
             rc = lib.hqh_octbox_create_levels(ctypes.byref(q), ctypes.byref(self._h))
         else:
             rc = lib.hqh_octbox_create(ctypes.byref(p), ctypes.byref(self._h))
@@ -451,7 +456,7 @@ class OctBox:
 
     @classmethod
     def from_leaves(cls, elem_ticks, elem_edge, edata, far_ticks, dt, freq, damping="rayleigh",
-                    threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1):
+                    threshold_damping=0.05, threshold_vpvs=3.0, halfspace=True, rank=0, nranks=1, solver_float=8):
         """An octree mesh from its leaves in pre-order (hqh_mesh_from_leaves), e.g. those of a
         mesh.e read with etree_read."""
         lib = load_library()
@@ -464,9 +469,9 @@ class OctBox:
         ed = np.ascontiguousarray(edata, np.float32).reshape(-1, 4)
         far = (ctypes.c_uint32 * 3)(*[int(v) for v in far_ticks])
         ip = _InitParams(dt, freq, DAMPING[damping], threshold_damping, threshold_vpvs, int(halfspace),
-                         int(rank), int(nranks))
+                         int(rank), int(nranks), int(solver_float))
         self = cls.__new__(cls)
-        self.rank, self.nranks = int(rank), int(nranks)
+        self.rank, self.nranks, self.solver_float = int(rank), int(nranks), int(solver_float)
         self._h = ctypes.c_void_p()
         rc = lib.hqh_mesh_from_leaves(ctypes.c_int64(len(et)), et.ctypes.data_as(ctypes.c_void_p),
                                       ee.ctypes.data_as(ctypes.c_void_p), ed.ctypes.data_as(ctypes.c_void_p), far,
@@ -540,9 +545,9 @@ class OctBox:
 
 
 def _solver_from_desc(d, ntable, variant, device, tm1, tm2, options, precision):
-    """capi.Solver on a description the C host side filled.  precision "f32": libhq_solver_f32.so -- the C host side builds
-    its tables in double (it mirrors the double-precision reference), so the n_t rows are handed over ROUNDED to float;
-    tm1 / tm2 are taken as float32."""
+    """capi.Solver on a description the C host side filled.  precision "f32": libhq_solver_f32.so -- the n_t rows go over as a
+    float array: exact where the box was made with solver_float=4 (the float reference's own sums, hq_host.h), ROUNDED from
+    the double build's rows otherwise; tm1 / tm2 are taken as float32."""
     d.variant = variant
     real = np.float32 if precision == "f32" else np.float64
     keep = []
@@ -678,7 +683,8 @@ def mesh_payload(values):
 class _InitParams(ctypes.Structure):
     _fields_ = [("deltaT", ctypes.c_double), ("freq", ctypes.c_double), ("damping", ctypes.c_int32),
                 ("threshold_damping", ctypes.c_double), ("threshold_vpvs", ctypes.c_double),
-                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32)]
+                ("halfspace", ctypes.c_int32), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("solver_float", ctypes.c_int32)]
 
 
 def forcefile_info(path):

@@ -65,6 +65,9 @@ typedef struct {
     int32_t       origin[3];         /* this box is a WINDOW of a larger one whose element (origin + (i, j, k)) it holds:
                                       * classes and layers are taken at the larger box's indices (bench.py's parity
                                       * windows); {0, 0, 0} otherwise                                             */
+    int32_t       solver_float;      /* 0 | 8: the n_t rows as the reference's double build sums them; 4: as its
+                                      * -DSINGLE_PRECISION_SOLVER build does (psolve.h:60-64: float fields, every `+=` of
+                                      * psolve.c:3440-3471 rounds to float) -- still handed over as doubles, exact floats */
 } hqh_box_params;
 
 typedef struct {
@@ -285,6 +288,7 @@ typedef struct {
     int32_t halfspace;
     int32_t rank, nranks;        /* this partition / number of partitions (0, 0 or 1 = the whole
                                     box); nranks <= 64 */
+    int32_t solver_float;        /* as hqh_box_params.solver_float */
 } hqh_octbox_params;
 
 HQ_API int  hqh_octbox_create(const hqh_octbox_params* p, hqh_octbox** out);
@@ -307,6 +311,7 @@ typedef struct {
     double         threshold_damping, threshold_vpvs;
     int32_t        halfspace;
     int32_t        rank, nranks;
+    int32_t        solver_float; /* as hqh_box_params.solver_float */
 } hqh_octlevels_params;
 
 HQ_API int  hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out);
@@ -374,6 +379,7 @@ typedef struct {
     double  threshold_damping, threshold_vpvs;
     int32_t halfspace;
     int32_t rank, nranks;        /* cut into octor's per-rank tables as hqh_octbox_create does (0, 0 or 1: whole mesh) */
+    int32_t solver_float;        /* as hqh_box_params.solver_float */
 } hqh_init_params;
 
 HQ_API int hqh_mesh_from_leaves(int64_t E, const uint32_t* elem_ticks, const uint32_t* elem_edge, const float* edata,

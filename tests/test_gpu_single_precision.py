@@ -81,15 +81,17 @@ def _field32(box, seed, amp=1e-3):
 
 def test_one_million_elements_bricks_against_the_float_oracle_and_in_eight_partitions():
     """The 1 M-element box: hq_k_brick on a float state (z faces with their columns), the shell's patches, gather /
-    gather3 / upload in floats -- against the oracle's float build stepping the same (rounded) tables; then cut 8 ways
-    (in-process transport: the records travel as doubles, what arrives is rounded as the owner's own copy is)."""
+    gather3 / upload in floats -- against the oracle's float build stepping the same tables: the C host side's with
+    solver_float = 4, the float reference's own sums (tests/test_host_float_tables.py); then cut 8 ways (in-process
+    transport: the records travel as doubles, what arrives is rounded as the owner's own copy is)."""
     from hercules_amd import capi
     nx, ny, nz, h, dt, freq = 128, 128, 64, 1000.0 / 128, 3.6e-4, 50.0
-    box = host.Box(nx, ny, nz, h, dt, freq)
+    box = host.Box(nx, ny, nz, h, dt, freq, solver_float=4)
     u = _field32(box, 4242)
     u2 = (0.999 * u.astype(np.float64)).astype(np.float32)
     nsteps = 3
     nt32 = np.ascontiguousarray(box.ntable, np.float32)
+    assert np.array_equal(nt32.astype(np.float64), box.ntable)      # exact floats: nothing is rounded on the way over
     o1, o2 = u2.copy(), u.copy()                                    # oracle arrays are pre-swap
     ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, nsteps, dt)
     s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=u2, precision="f32")
@@ -117,7 +119,7 @@ def test_one_million_elements_bricks_against_the_float_oracle_and_in_eight_parti
     lut = np.empty(gid.max() + 1, np.int64)
     lut[gid] = np.arange(len(gid))
     box.close()
-    parts = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8) for r in range(8)]
+    parts = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, solver_float=4) for r in range(8)]
     maps = [lut[(b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]] for b in parts]
     solvers = [b.create_solver(tm1=u[m], tm2=u2[m], precision="f32") for b, m in zip(parts, maps)]
     capi.group_link(solvers)

@@ -1,0 +1,126 @@
+"""solver_float = 4 in the C host side (hq_host.h): the n_t rows as the reference's -DSINGLE_PRECISION_SOLVER build sums them
+(psolve.h:60-64: mass_simple, mass2_minusaM[3], mass_minusaM[3] are float fields; every `+=` / `-=` of psolve.c:3440-3471
+and of the hanging nodes' mass distribution :5958-5990 rounds to float).  Checked against the oracle built with the same
+define (oracle/libherc_oracle_f32.so), which the float reference's own checkpoints pin (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+from hercules_amd import capi, host
+from oracle import herc_oracle as ho
+from tests import helpers as H
+
+LAYERS = [(0.0, 1500.0, 300.0, 1800.0), (50.0, 3000.0, 1400.0, 2200.0), (120.0, 6000.0, 3464.0, 2700.0)]
+
+
+def _exact_floats(t):
+    return np.array_equal(t, t.astype(np.float32).astype(np.float64))
+
+
+@pytest.mark.parametrize("shape,layers,damping", [((16, 16, 8), None, "rayleigh"), ((8, 32, 4), LAYERS, "rayleigh"),
+                                                  ((16, 8, 8), LAYERS, "mass"), ((4, 4, 2), None, "none")])
+def test_uniform_box_rows_are_the_float_builds(shape, layers, damping):
+    nx, ny, nz = shape
+    h, dt, freq = 62.5, 1e-3, 5.0
+    b = host.Box(nx, ny, nz, h, dt, freq, layers=layers, damping=damping, solver_float=4)
+    d = host.Box(nx, ny, nz, h, dt, freq, layers=layers, damping=damping)
+    elem_ijk, lnid, node_ijk = ho.uniform_mesh(nx, ny, nz)
+    edata = np.empty((len(lnid), 4), np.float32)
+    edata[:, 0] = h
+    edata[:, 1:] = d.material()
+    et, nt = ho.solver_init(lnid, edata, ho.face_bits(elem_ijk, nx, ny, nz), len(node_ijk), dt, freq,
+                            damping=ho.DAMPING_BY_NAME[damping], real=np.float32)
+    assert nt.dtype == np.float32
+    assert np.array_equal(b.etable, et) and np.array_equal(b.etable, d.etable)   # e_t is double in both builds (psolve.h:196-199)
+    assert _exact_floats(b.ntable) and np.array_equal(b.ntable.astype(np.float32), nt)
+    # not the double build's rows rounded once: sums of eight float-rounded steps
+    assert not np.array_equal(b.ntable, d.ntable) and np.abs(b.ntable / d.ntable - 1).max() < 4e-7
+    b.close()
+    d.close()
+
+
+@pytest.mark.parametrize("nranks", [3, 8])
+def test_a_partitions_rows_are_cut_from_the_whole_boxs(nranks):
+    """hq_host.h: a partition's float rows are those of ONE rank's element loop (the float reference on N ranks adds the
+    ranks' partial sums in its messengers' order: the last float digit of <= 8 terms)."""
+    nx, ny, nz, h, dt, freq = 16, 16, 8, 62.5, 1e-3, 5.0
+    whole = host.Box(nx, ny, nz, h, dt, freq, layers=LAYERS, lateral_classes=61, lateral_amp=0.1, solver_float=4)
+    gid = {tuple(v): i for i, v in enumerate(whole.node_ijk.tolist())}
+    for r in range(nranks):
+        b = host.Box(nx, ny, nz, h, dt, freq, layers=LAYERS, lateral_classes=61, lateral_amp=0.1, rank=r, nranks=nranks,
+                     solver_float=4)
+        g = np.array([gid[tuple(v)] for v in b.node_ijk.tolist()])
+        assert np.array_equal(b.ntable, whole.ntable[g])
+        b.close()
+    whole.close()
+
+
+@pytest.mark.parametrize("name", ["c1_short", "c5_two_level", "c5_three_level", "c5_basin", "c5_gradient"])
+def test_mesh_from_leaves_on_the_references_meshes(name):
+    """The reference's own meshes (hanging nodes of every kind in c5_basin / c5_gradient): rows incl. the mass the hanging
+    nodes hand to their anchors, bit for bit the float oracle's."""
+    g = H.load(name)
+    et = g["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = g["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    real = H.c1_problem(real=np.float32) if name == "c1_short" else H.c5_problem(name, real=np.float32)
+    assert real["ntable"].dtype == np.float32
+    ob = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]), solver_float=4)
+    assert np.array_equal(ob.etable, real["etable"])
+    assert _exact_floats(ob.ntable) and np.array_equal(ob.ntable.astype(np.float32), real["ntable"])
+    ob.close()
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 4, 6), (8, 12, 2, 1)])
+def test_two_level_box_rows(shape):
+    nx, ny, nzf, nzc = shape
+    ob = host.OctBox(nx, ny, nzf, nzc, 31.25, 1e-3, 5.0, solver_float=4)
+    if shape == (32, 32, 4, 6):
+        real = H.c5_problem(real=np.float32)
+        assert np.array_equal(ob.lnid, real["lnid"]) and np.array_equal(ob.ntable.astype(np.float32), real["ntable"])
+    assert _exact_floats(ob.ntable)
+    from_leaves = host.OctBox.from_leaves(ob.node_xyz[ob.lnid[:, 0]] * (1 << 25), (ob.node_xyz[ob.lnid[:, 7], 0] -
+                                          ob.node_xyz[ob.lnid[:, 0], 0]) * (1 << 25), _edata_of(ob, 31.25),
+                                          (nx << 25, ny << 25, (nzf + 2 * nzc) << 25), 1e-3, 5.0, solver_float=4)
+    assert np.array_equal(from_leaves.lnid, ob.lnid) and np.array_equal(from_leaves.ntable, ob.ntable)
+    from_leaves.close()
+    ob.close()
+
+
+def _edata_of(ob, h):
+    """edata of a two-level box made with the defaults of host.OctBox (top / bottom material)."""
+    size = ob.node_xyz[ob.lnid[:, 7], 0] - ob.node_xyz[ob.lnid[:, 0], 0]
+    ed = np.empty((ob.E, 4), np.float32)
+    ed[:, 0] = (h * size).astype(np.float32)
+    fine = size == 1
+    ed[fine, 1:] = (3000.0, 1732.0, 2200.0)
+    ed[~fine, 1:] = (6000.0, 3464.0, 2700.0)
+    return ed
+
+
+@pytest.mark.parametrize("nranks", [3, 8])
+def test_octree_partitions_built_locally_equal_the_cut_of_the_whole_box(nranks, monkeypatch):
+    """Both constructions of a partition (cut out of the whole box | from the sorted leaf keys alone) round at the same
+    places: equal rows, and equal to the whole box's rows of the same nodes."""
+    whole = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, solver_float=4)
+    key = {tuple(v): i for i, v in enumerate(whole.node_xyz.tolist())}
+    for rank in range(nranks):
+        monkeypatch.setenv("HQH_OCTBOX_LOCAL", "0")
+        a = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, rank=rank, nranks=nranks, solver_float=4)
+        monkeypatch.setenv("HQH_OCTBOX_LOCAL", "1")
+        b = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, rank=rank, nranks=nranks, solver_float=4)
+        assert np.array_equal(a.node_xyz, b.node_xyz) and np.array_equal(a.ntable, b.ntable)
+        g = np.array([key[tuple(v)] for v in a.node_xyz.tolist()])
+        assert np.array_equal(a.ntable, whole.ntable[g])
+        a.close()
+        b.close()
+    whole.close()
+
+
+def test_a_solver_float_that_is_neither_is_refused():
+    with pytest.raises(capi.HqError):
+        host.Box(4, 4, 2, 62.5, 1e-3, 5.0, solver_float=2)
+    with pytest.raises(capi.HqError):
+        host.OctBox(8, 8, 2, 1, 31.25, 1e-3, 5.0, solver_float=16)
