@@ -69,6 +69,34 @@ def test_two_level_octree_against_the_float_references_checkpoints():
         s.close()
 
 
+def test_from_the_float_references_leaves_to_its_checkpoints_through_the_c_host():
+    """The whole float path without the oracle's tables: the leaves of the mesh the float reference made (its element dump)
+    -> hqh_mesh_from_leaves with solver_float = 4 (connectivity, hanging nodes, e_t, the n_t rows in the float build's own
+    sums incl. the mass the hanging nodes hand to their anchors) -> libhq_solver_f32.so -> the float reference's checkpoints."""
+    g = H.load("c5_two_level_f32")
+    et = g["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = g["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    ob = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]), solver_float=4)
+    p = H.c5_problem("c5_two_level_f32", real=np.float32)
+    assert np.array_equal(ob.lnid, p["lnid"]) and np.array_equal(ob.ntable.astype(np.float32), p["ntable"])
+    s = ob.create_solver(variant=ha.HQ_VARIANT_PATCH, precision="f32")
+    s.set_source(g["loaded_lnid"], g["forces"])
+    done = 0
+    for k, step in enumerate(g["ckpt_steps"]):
+        s.run(int(step) - done)
+        done = int(step)
+        tm1, tm2 = s.download()
+        assert tm1.dtype == np.float32
+        assert H.rel_linf(tm1.astype(np.float64), g["ckpt_tm1"][k].astype(np.float64)) < TOL_RUN
+        assert H.rel_linf(tm2.astype(np.float64), g["ckpt_tm2"][k].astype(np.float64)) < TOL_RUN
+    s.close()
+    ob.close()
+
+
 def _field32(box, seed, amp=1e-3):
     ijk = box.node_ijk.astype(np.int64)
     gid = (ijk[:, 2] * (box.ny + 1) + ijk[:, 1]) * (box.nx + 1) + ijk[:, 0]
