@@ -1484,6 +1484,19 @@ static void hq_brick_launch(const hq_brick_plan* P, const hq_real* u1, const hq_
         const int per_xcd = (count + 7) / 8;
         const int32_t* sp = P->d_src_ptr ? P->d_src_ptr + first : nullptr;
 #define HQ_BK_ARGS count, per_xcd, P->d_units + first, P->d_tab, u1, u2, un, nt3, sp, P->d_src_ent, (sp ? F : nullptr), dt2, hq_stencil().c
+#ifdef HQ_EXPERIMENT            /* profiles/tools only: unused dynamic LDS so that ONE brick workgroup fits a CU -- does half the residency still stream? */
+        static const unsigned xpad = getenv("HQ_X_BRICK_LDS_PAD") ? (unsigned)atoi(getenv("HQ_X_BRICK_LDS_PAD")) : 0u;
+        if (xpad && k == 0) {
+            static bool once = false;
+            if (!once) {
+                once = true;
+                hipFuncSetAttribute((const void*)hq_k_brick<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xpad);
+                hipFuncSetAttribute((const void*)hq_k_brick<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xpad);
+            }
+            if (light) hq_k_brick<false, true><<<per_xcd * 8, HQ_BK_THREADS, xpad, stream>>>(HQ_BK_ARGS);
+            else hq_k_brick<false, false><<<per_xcd * 8, HQ_BK_THREADS, xpad, stream>>>(HQ_BK_ARGS);
+        } else
+#endif
         if (k == 0 && light) hq_k_brick<false, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 0) hq_k_brick<false, false><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
         else if (k == 1 && light) hq_k_brick<true, true><<<per_xcd * 8, HQ_BK_THREADS, 0, stream>>>(HQ_BK_ARGS);
