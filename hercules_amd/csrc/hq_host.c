@@ -599,6 +599,13 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     return HQ_OK;
 }
 
+int hqh_ntable_to_float(const double* ntable, int64_t rows, float* out)
+{
+    if (!ntable || !out || rows < 0) return HQ_ERR_ARG;
+    for (int64_t i = 0; i < 7 * rows; i++) out[i] = (float)ntable[i];
+    return HQ_OK;
+}
+
 /* edata_t of this partition's elements as solver_init reads them (psolve.c:3372-3385): out[lenum][3] = Vp, Vs, rho */
 int hqh_box_material(const hqh_box* b, float* out)
 {

@@ -13,7 +13,7 @@ _LIBPATH = os.environ.get("HQ_HOST_LIB") or os.path.join(_HERE, "csrc", "libhq_h
 
 DAMPING = {"none": 0, "rayleigh": 1, "mass": 2}
 EXPORTS = ["hqh_box_create", "hqh_box_destroy", "hqh_box_get_info", "hqh_box_desc", "hqh_box_lnid",
-           "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner", "hqh_box_material",
+           "hqh_box_node_ijk", "hqh_box_etable", "hqh_box_ntable", "hqh_box_owner", "hqh_box_material", "hqh_ntable_to_float",
            "hqh_point_source", "hqh_stations", "hqh_solver_run", "hqh_source_table",
            "hqh_forcefile_info", "hqh_forcefile_read", "hqh_forcefile_write",
            "hqh_checkpoint_write", "hqh_checkpoint_read", "hqh_station_format", "hqh_station_format_derivs",
@@ -552,7 +552,12 @@ def _solver_from_desc(d, ntable, variant, device, tm1, tm2, options, precision):
     real = np.float32 if precision == "f32" else np.float64
     keep = []
     if precision == "f32":
-        nt = np.ascontiguousarray(ntable, np.float32)
+        nt = np.empty(ntable.shape, np.float32)
+        src = np.ascontiguousarray(ntable, np.float64)
+        rc = load_library().hqh_ntable_to_float(src.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(src)),
+                                                nt.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise capi.HqError("hqh_ntable_to_float failed: %d" % rc)
         keep.append(nt)
         d.nTable = nt.ctypes.data
     for name, a in (("tm1", tm1), ("tm2", tm2)):

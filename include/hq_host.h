@@ -92,6 +92,9 @@ HQ_API const int32_t* hqh_box_node_ijk(const hqh_box* box);
 HQ_API const double*  hqh_box_etable(const hqh_box* box);
 HQ_API const double*  hqh_box_ntable(const hqh_box* box);
 HQ_API const int32_t* hqh_box_owner(const hqh_box* box);
+/* the n_t rows of any of this library's tables as the float array a reference built with -DSINGLE_PRECISION_SOLVER holds
+ * (hq_desc.nTable of libhq_solver_f32.so): out[rows][7]; exact where the tables were made with solver_float = 4 */
+HQ_API int hqh_ntable_to_float(const double* ntable, int64_t rows, float* out);
 /* edata_t of this partition's elements as solver_init reads them (psolve.c:3372-3385): out[lenum][3] = Vp, Vs, rho */
 HQ_API int hqh_box_material(const hqh_box* box, float* out);
 

@@ -124,3 +124,16 @@ def test_a_solver_float_that_is_neither_is_refused():
         host.Box(4, 4, 2, 62.5, 1e-3, 5.0, solver_float=2)
     with pytest.raises(capi.HqError):
         host.OctBox(8, 8, 2, 1, 31.25, 1e-3, 5.0, solver_float=16)
+
+
+def test_the_rows_as_the_float_array_a_float_reference_holds():
+    """hqh_ntable_to_float: hq_desc.nTable of libhq_solver_f32.so from this library's double arrays -- exact with solver_float = 4."""
+    import ctypes
+    b = host.Box(8, 8, 4, 62.5, 1e-3, 5.0, layers=LAYERS, solver_float=4)
+    out = np.empty(b.ntable.shape, np.float32)
+    lib = host.load_library()
+    assert lib.hqh_ntable_to_float(b.ntable.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(b.ntable)),
+                                   out.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(out.astype(np.float64), b.ntable)
+    assert lib.hqh_ntable_to_float(None, ctypes.c_int64(1), out.ctypes.data_as(ctypes.c_void_p)) != 0
+    b.close()
