@@ -335,10 +335,9 @@ static int corner_dashpot(const hqh_box* b, int32_t ei, int32_t ej, int32_t ek, 
  * hanging nodes' share, compute_adjust :5958-5990): built with -DSINGLE_PRECISION_SOLVER every `+=` there rounds to
  * float.  The tables stay double arrays in this library; with solver_float = 4 every update is rounded as the float field
  * rounds it -- (double) field + term -> float -- so that a row holds exactly the float build's values (a double sum or
- * quotient of two floats, rounded once more to float, IS the float operation: 53 >= 2 x 24 + 2 bits), in the summation
- * order of ONE rank's element loop.  A partition's rows are cut out of those: the float reference on N ranks adds the
- * ranks' partial sums in its messengers' order (:5040-5060), which differs from this in the last float digit of <= 8
- * terms (6e-8; the float parity tolerances are 2e-6 and 2e-5).
+ * quotient of two floats, rounded once more to float, IS the float operation: 53 >= 2 x 24 + 2 bits).  One rank: the
+ * summation order of its element loop.  N ranks: every rank's elements apart and solver_init's three mass exchanges on
+ * the partial rows -- nt_rank_rows / nt_parts_combine below.
  */
 #define HQH_SF(f32, x) ((f32) ? (double)(float)(x) : (x))
 
@@ -377,8 +376,179 @@ static void nt_distribute(double* ntable, int f32, int32_t ldnnum, const int32_t
     }
 }
 
-/* n_t of node (i,j,k): psolve.c:3440-3471 summed over its elements in Z-order */
-static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, double np[7])
+/*
+ * The float build on N ranks.  Every rank sums the rows over ITS elements (psolve.c:3440-3471, float fields), then
+ * solver_init's three exchanges run on those partial rows (:3498-3507): (A) the sharers of a hanging node send theirs to
+ * its owner, which adds them in the order of its messenger list (schedule_senddata, CONTRIBUTION: :5040-5060; the lists
+ * in ascending rank, as this library builds them); (B) the owner of a hanging node hands its row / deps to the anchors
+ * (compute_adjust, its own dnodeTable in order); (C) the sharers of an anchored node send their rows -- their elements'
+ * sums plus what (B) gave them -- to its owner, which adds them the same way.  In float every one of those additions
+ * rounds, and a run is sensitive to WHICH roundings its rows carry (m2 - m1 = m0 holds only up to them): against the float
+ * reference's own 8-rank checkpoints a field stepped on rows in this order is 1e-6 off, on rows in one rank's order 5e-5
+ * (tests/test_gpu_single_precision.py).  So with solver_float = 4 a partition's rows follow this order; every harbored
+ * copy of a node gets what its OWNER ends up with (the reference leaves a partial sum in the other copies, which the
+ * sharing of the displacements makes irrelevant, psolve.c:4312-4315).
+ * nt_rank_rows: rows[0..n) of ranks rk[0..n) (ascending) -> out = the owner's row + the others' in ascending rank.
+ */
+static void nt_rank_rows(int n, const int* rk, double (*rows)[7], int owner, double out[7])
+{
+    for (int t = 0; t < 7; t++) out[t] = 0.0;
+    for (int q = 0; q < n; q++) if (rk[q] == owner) for (int t = 0; t < 7; t++) out[t] = rows[q][t];
+    for (int q = 0; q < n; q++) if (rk[q] != owner) for (int t = 0; t < 7; t++) out[t] = HQH_SF(1, out[t] + rows[q][t]);
+}
+
+/* The same for the whole-mesh builders (hqh_octbox_create_levels, hqh_mesh_from_leaves: every rank builds the whole mesh and
+ * cuts its part out): their element loops run over the elements in global order, so a node's row is summed in RUNS of
+ * ranks; nt_parts_row closes a run when the rank changes (the row so far becomes a record, the row restarts at zero),
+ * nt_parts_combine (octbox_cut, where the owners are known) replays the three exchanges on the records. */
+typedef struct {
+    int P;
+    int64_t E, n, cap;
+    int32_t *node, *rank, *cur;     /* records' node and rank; cur[node]: rank of the run its row is in, -1 none yet */
+    double* row;                    /* records' rows [n][7] */
+} nt_parts;
+
+static void nt_parts_free(nt_parts* pp)
+{
+    if (!pp) return;
+    free(pp->node); free(pp->rank); free(pp->cur); free(pp->row); free(pp);
+}
+
+static nt_parts* nt_parts_new(int64_t N, int P, int64_t E)
+{
+    nt_parts* pp = (nt_parts*)calloc(1, sizeof(nt_parts));
+    if (!pp) return NULL;
+    pp->P = P; pp->E = E;
+    pp->cur = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+    if (!pp->cur) { nt_parts_free(pp); return NULL; }
+    for (int64_t i = 0; i < N; i++) pp->cur[i] = -1;
+    return pp;
+}
+
+static int nt_parts_push(nt_parts* pp, int32_t node, int32_t rank, const double* row)
+{
+    if (pp->n == pp->cap) {
+        const int64_t cap = pp->cap ? 2 * pp->cap : 1 << 16;
+        int32_t* a = (int32_t*)realloc(pp->node, sizeof(int32_t) * (size_t)cap);
+        if (a) pp->node = a;
+        int32_t* r = (int32_t*)realloc(pp->rank, sizeof(int32_t) * (size_t)cap);
+        if (r) pp->rank = r;
+        double* w = (double*)realloc(pp->row, sizeof(double) * 7 * (size_t)cap);
+        if (w) pp->row = w;
+        if (!a || !r || !w) return -1;
+        pp->cap = cap;
+    }
+    pp->node[pp->n] = node; pp->rank[pp->n] = rank;
+    for (int t = 0; t < 7; t++) pp->row[7 * pp->n + t] = row ? row[t] : 0.0;
+    pp->n++;
+    return 0;
+}
+
+/* ahead of adding element e's share to node n's row in `ntable` */
+static inline int nt_parts_row(nt_parts* pp, double* ntable, int32_t n, int64_t e)
+{
+    const int r = (int)(((e + 1) * pp->P - 1) / pp->E);                /* octor.c:4939-4944 */
+    if (pp->cur[n] == r) return 0;
+    if (pp->cur[n] >= 0) {
+        if (nt_parts_push(pp, n, pp->cur[n], &ntable[7 * (int64_t)n])) return -1;
+        for (int t = 0; t < 7; t++) ntable[7 * (int64_t)n + t] = 0.0;
+    }
+    pp->cur[n] = r;
+    return 0;
+}
+
+/* the runs still open, then exchanges (A), (B), (C) -> ntable[N][7] as every node's owner holds it */
+static int nt_parts_combine(nt_parts* pp, int64_t N, double* ntable, const int32_t* gowner, int32_t ldnnum, const int32_t* dn_id,
+                            const int32_t* dn_ptr, const int32_t* dn_anchor)
+{
+    for (int64_t n = 0; n < N; n++)
+        if (pp->cur[n] >= 0 && nt_parts_push(pp, (int32_t)n, pp->cur[n], &ntable[7 * n])) return HQ_ERR_NOMEM;
+    /* a rank that owns a hanging node holds its anchors (octor.c: indirect sharing) even where it has no element at them */
+    for (int32_t k = 0; k < ldnnum; k++)
+        for (int32_t a = dn_ptr[k]; a < dn_ptr[k + 1]; a++)
+            if (nt_parts_push(pp, dn_anchor[a], gowner[dn_id[k]], NULL)) return HQ_ERR_NOMEM;
+    const int64_t M = pp->n;
+    int64_t* off = (int64_t*)calloc((size_t)N + 1, sizeof(int64_t));
+    int64_t* ord = (int64_t*)malloc(sizeof(int64_t) * (size_t)(M ? M : 1));
+    double* full = (double*)malloc(sizeof(double) * 7 * (size_t)(ldnnum ? ldnnum : 1));
+    int rc = HQ_ERR_NOMEM;
+    if (!off || !ord || !full) goto done;
+    for (int64_t i = 0; i < M; i++) off[pp->node[i] + 1]++;
+    for (int64_t n = 0; n < N; n++) off[n + 1] += off[n];
+    {
+        int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(N ? N : 1));
+        if (!fill) goto done;
+        memcpy(fill, off, sizeof(int64_t) * (size_t)N);
+        for (int64_t i = 0; i < M; i++) ord[fill[pp->node[i]]++] = i;          /* stable: push order inside a node */
+        free(fill);
+    }
+    /* inside a node: ascending rank (stable: the run of elements, pushed first, ahead of the empty records of the same rank) */
+    for (int64_t n = 0; n < N; n++) {
+        int64_t* o = ord + off[n];
+        const int64_t c = off[n + 1] - off[n];
+        for (int64_t i = 1; i < c; i++) {
+            const int64_t v = o[i];
+            int64_t j = i;
+            while (j > 0 && pp->rank[o[j - 1]] > pp->rank[v]) { o[j] = o[j - 1]; j--; }
+            o[j] = v;
+        }
+    }
+    rc = HQ_OK;
+    {
+        /* several records of one (node, rank): the first holds the elements' run (or is empty too), the others are empty: dropped */
+        for (int64_t n = 0; n < N; n++) {
+            int last = -1;
+            for (int64_t i = off[n]; i < off[n + 1]; i++) {
+                const int r = pp->rank[ord[i]];
+                if (r == last) pp->rank[ord[i]] = -1 - r;                      /* dropped (negative), order kept */
+                else last = r;
+            }
+        }
+#define NTP_GATHER(n_, rows_, rk_, cnt_)                                                               \
+        { cnt_ = 0;                                                                                    \
+          for (int64_t i_ = off[n_]; i_ < off[(n_) + 1]; i_++) {                                       \
+              if (pp->rank[ord[i_]] < 0) continue;                                                     \
+              if (cnt_ >= 64) { rc = HQ_ERR_STATE; goto done; }                                        \
+              rk_[cnt_] = pp->rank[ord[i_]];                                                           \
+              for (int t_ = 0; t_ < 7; t_++) rows_[cnt_][t_] = pp->row[7 * ord[i_] + t_];              \
+              cnt_++; } }
+        double rows[64][7];
+        int rk[64], cnt;
+        /* (A) */
+        for (int32_t k = 0; k < ldnnum; k++) {
+            const int32_t d = dn_id[k];
+            NTP_GATHER(d, rows, rk, cnt)
+            nt_rank_rows(cnt, rk, rows, gowner[d], &full[7 * (int64_t)k]);
+        }
+        /* (B): every owner through its dnodeTable -- the global table's order restricted to its nodes */
+        for (int32_t k = 0; k < ldnnum; k++) {
+            const int r = gowner[dn_id[k]];
+            const uint32_t deps = (uint32_t)(dn_ptr[k + 1] - dn_ptr[k]);
+            double part[7];
+            for (int t = 0; t < 7; t++) part[t] = HQH_SF(1, full[7 * (int64_t)k + t] / deps);
+            for (int32_t a = dn_ptr[k]; a < dn_ptr[k + 1]; a++) {
+                const int32_t an = dn_anchor[a];
+                int64_t hit = -1;
+                for (int64_t i = off[an]; i < off[an + 1]; i++) if (pp->rank[ord[i]] == r) { hit = ord[i]; break; }
+                if (hit < 0) { rc = HQ_ERR_STATE; goto done; }
+                for (int t = 0; t < 7; t++) pp->row[7 * hit + t] = HQH_SF(1, pp->row[7 * hit + t] + part[t]);
+            }
+        }
+        /* (C); a hanging node's row is what (A) left (nothing is handed TO it) */
+        for (int64_t n = 0; n < N; n++) {
+            NTP_GATHER(n, rows, rk, cnt)
+            nt_rank_rows(cnt, rk, rows, gowner[n], &ntable[7 * n]);
+        }
+#undef NTP_GATHER
+    }
+done:
+    free(off); free(ord); free(full);
+    return rc;
+}
+
+/* n_t of node (i,j,k): psolve.c:3440-3471 summed over its elements in Z-order (solver_float = 4 on partitions: every
+ * rank's elements apart, then the owner's row + the sharers', see above) */
+static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, int owner, double np[7])
 {
     const hqh_box_params* p = &b->p;
     int64_t idx[8];
@@ -400,14 +570,24 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, do
         cn[pos] = (1 - (c & 1)) | ((1 - ((c >> 1) & 1)) << 1) | ((1 - ((c >> 2) & 1)) << 2);
     }
     double dt = p->deltaT;
+    const int f32 = p->solver_float == 4, by_rank = f32 && p->nranks > 1;
+    double rows[8][7];
+    int rk[8], nr = 0;
     for (int t = 0; t < 7; t++) np[t] = 0.0;
     for (int q = 0; q < cnt; q++) {
         int32_t ek = ee[q][2];
         const int64_t mi = mat_index(b, ee[q][0], ee[q][1], ek);
         double M = b->k_M[mi], a = b->k_a[mi], dash[3];
         int bnd = corner_dashpot(b, ee[q][0], ee[q][1], ek, cn[q], dash);
-        nt_accumulate(np, p->solver_float == 4, dt, a, M, bnd, dash);
+        double* acc = np;
+        if (by_rank) {                           /* (ranks hold runs of the Z-ordered elements: ascending with idx) */
+            const int r = rank_of_elem(b, idx[q]);
+            if (nr == 0 || rk[nr - 1] != r) { rk[nr] = r; for (int t = 0; t < 7; t++) rows[nr][t] = 0.0; nr++; }
+            acc = rows[nr - 1];
+        }
+        nt_accumulate(acc, f32, dt, a, M, bnd, dash);
     }
+    if (by_rank) nt_rank_rows(nr, rk, rows, owner, np);
 }
 
 /* HQH_VERBOSE=1: where the host side's time goes */
@@ -557,7 +737,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
                 ok = c[2] < p->nz ? c[2] : p->nz - 1;
         b->owner[n] = rank_of_elem(b, elem_index(b, oi, oj, ok));
         if (b->owner[n] == p->rank) nown++;
-        node_constants(b, c[0], c[1], c[2], &b->ntable[7 * n]);
+        node_constants(b, c[0], c[1], c[2], b->owner[n], &b->ntable[7 * n]);
     }
     b->nowned = nown;
     free(keys);
@@ -1287,7 +1467,7 @@ static int octbox_level_at(const hqh_octbox* b, int32_t z)
 
 /* Cut rank `me`'s part out of the whole box in `b` (see hq_host.h); `ek` = the sorted Z-values
  * of the element corners (element id = position). */
-static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
+static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts* parts)
 {
     const int32_t nx = b->far_q[0], ny = b->far_q[1], nzt = b->far_q[2], NL = b->p.nlevels;
     const int64_t E = b->E, N = b->N;
@@ -1337,6 +1517,10 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P)
         hang[b->dn_id[k]] = 1;
         const uint64_t bit = 1ull << gowner[b->dn_id[k]];
         for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++) harb[b->dn_anchor[a]] |= bit;
+    }
+    if (parts) {                     /* solver_float = 4: the whole mesh's rows in the N-rank build's order (nt_parts_combine) */
+        const int prc = nt_parts_combine(parts, N, b->ntable, gowner, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
+        if (prc != HQ_OK) { rc = prc; goto done; }
     }
     {
         const uint64_t mebit = 1ull << me;
@@ -1588,6 +1772,29 @@ static uint64_t oct_node_row(const oct_ctx_t* C, const int32_t c[3], double np[7
     return bits;
 }
 
+/* the same in runs of ranks (solver_float = 4 on a partition, see nt_rank_rows): rows[0 .. *nr) of ranks rk[] ascending */
+static void oct_node_rows(const oct_ctx_t* C, const int32_t c[3], double (*rows)[7], int* rk, int* nr)
+{
+    const hqh_octbox* b = C->b;
+    oct_leaf_t leaf[8];
+    int corner[8];
+    const int n = oct_leaves_of_node(C, c, leaf, corner);
+    const double dt = b->p.deltaT;
+    *nr = 0;
+    for (int k = 0; k < n; k++) {
+        const int L = leaf[k].L, s = 1 << L;
+        const int32_t q = b->lay0[L] + ((leaf[k].o[2] - b->ztop[L]) >> L);
+        const int face = (leaf[k].o[0] == 0) | ((leaf[k].o[1] == 0) << 1) | ((leaf[k].o[2] == 0) << 2) |
+                         ((leaf[k].o[0] + s == C->far[0]) << 3) | ((leaf[k].o[1] + s == C->far[1]) << 4) |
+                         ((leaf[k].o[2] + s == C->far[2]) << 5);
+        double dash[3];
+        const int bnd = face_dashpot(face, corner[k], b->p.halfspace, C->lh[q], C->lvp[q], b->vs[q], b->rho[q], dash);
+        const int r = OCT_ERANK(C, leaf[k].e);
+        if (*nr == 0 || rk[*nr - 1] != r) { rk[*nr] = r; for (int t = 0; t < 7; t++) rows[*nr][t] = 0.0; (*nr)++; }
+        nt_accumulate(rows[*nr - 1], 1, dt, C->la[q], C->lM[q], bnd, dash);
+    }
+}
+
 static uint64_t oct_node_key(const oct_ctx_t* C, const int32_t c[3])
 {
     uint32_t d[3];
@@ -1612,7 +1819,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                         const double* lM, const float* lvp, const float* lh)
 {
     oct_ctx_t C;
-    const int f32 = b->p.solver_float == 4;
+    const int f32 = b->p.solver_float == 4, by_rank = f32 && P > 1;
     C.b = b; C.ek = ek; C.E = b->E; C.P = P;
     C.far[0] = b->far_q[0]; C.far[1] = b->far_q[1]; C.far[2] = b->far_q[2];
     C.lc = lc; C.la = la; C.lM = lM; C.lvp = lvp; C.lh = lh;
@@ -1698,6 +1905,9 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
         uint64_t bits = oct_node_row(&C, c, np);
         const int o = oct_owner(&C, c);
         if (o < 0 || !bits) { fault = 1; continue; }
+        double rrows[16][7];                                             /* by_rank: this node's row on every rank that holds it */
+        int rrk[16], rn = 0;
+        if (by_rank) oct_node_rows(&C, c, rrows, rrk, &rn);
         own[l] = o;
         bits |= 1ull << o;
         int32_t an[4][3];
@@ -1734,16 +1944,34 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                     int32_t pa[4][3];
                     int pd;
                     oct_node_hangs(&C, hc[k], pa, &pd);
+                    const int ho = oct_owner(&C, hc[k]);
+                    if (ho >= 0) bits |= 1ull << ho;                     /* indirect sharing */
+                    if (by_rank) {
+                        /* exchange (A) for the hanging node, then (B): its owner `ho` adds row / deps to ITS row of this anchor */
+                        double hrows[8][7];
+                        int hrk[8], hn, at = -1;
+                        oct_node_rows(&C, hc[k], hrows, hrk, &hn);
+                        nt_rank_rows(hn, hrk, hrows, ho, hp);
+                        for (int q = 0; q < rn; q++) if (rrk[q] == ho) at = q;
+                        if (at < 0) {                                    /* `ho` has no element at the anchor: a row of shares only */
+                            if (rn >= 16) { fault = 1; continue; }
+                            at = rn++;
+                            while (at > 0 && rrk[at - 1] > ho) { rrk[at] = rrk[at - 1]; memcpy(rrows[at], rrows[at - 1], sizeof rrows[0]); at--; }
+                            rrk[at] = ho;
+                            for (int q = 0; q < 7; q++) rrows[at][q] = 0.0;
+                        }
+                        for (int q = 0; q < 7; q++) rrows[at][q] = HQH_SF(1, rrows[at][q] + HQH_SF(1, hp[q] / (uint32_t)pd));
+                        continue;
+                    }
                     oct_node_row(&C, hc[k], hp);
                     for (int q = 0; q < 7; q++) {
                         const double part = HQH_SF(f32, hp[q] / (uint32_t)pd);
                         np[q] = HQH_SF(f32, np[q] + part);
                     }
-                    const int ho = oct_owner(&C, hc[k]);
-                    if (ho >= 0) bits |= 1ull << ho;                     /* indirect sharing */
                 }
             }
         }
+        if (by_rank) nt_rank_rows(rn, rrk, rrows, o, np);                /* exchange (C); a hanging node: (A) */
         harb[l] = bits;
         if (!(bits & (1ull << me))) fault = 1;
     }
@@ -2067,7 +2295,9 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
         lM[q] = mass / 8;
     }
     /* connectivity, eTable, nTable (the reference's element loop, psolve.c:3360-3473) */
-    for (int64_t e = 0; e < E; e++) {
+    nt_parts* parts = (p->solver_float == 4 && P > 1) ? nt_parts_new(b->N, P, E) : NULL;
+    int nomem = (p->solver_float == 4 && P > 1 && !parts);
+    for (int64_t e = 0; e < E && !nomem; e++) {
         int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
         int L = octbox_level_at(b, k), s = 1 << L;
         const int32_t q = b->lay0[L] + ((k - b->ztop[L]) >> L);  /* element layer */
@@ -2081,18 +2311,22 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
             double dash[3];
             int bnd = face_dashpot(face, c, p->halfspace, lh[q], lvp[q], b->vs[q], b->rho[q], dash);
             double* np = &b->ntable[7 * (int64_t)n];
+            if (parts && nt_parts_row(parts, b->ntable, n, e)) { nomem = 1; break; }
             nt_accumulate(np, p->solver_float == 4, dt, a, M, bnd, dash);
         }
     }
     free(lc); free(la); free(lM); free(lvp); free(lh);
 #undef HQH_LOC
     free(loc);
-    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors */
-    nt_distribute(b->ntable, p->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
+    if (nomem) { nt_parts_free(parts); free(ek); hqh_octbox_destroy(b); return HQ_ERR_NOMEM; }
+    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502: hanging-node mass to the anchors (the float build on N ranks:
+     * by the hanging nodes' owners, between the two exchanges -- nt_parts_combine in octbox_cut) */
+    if (!parts) nt_distribute(b->ntable, p->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
     if (P > 1) {
-        int rc = octbox_cut(b, ek, p->rank, P);
-        if (rc != HQ_OK) { free(ek); hqh_octbox_destroy(b); return rc; }
+        int rc = octbox_cut(b, ek, p->rank, P, parts);
+        if (rc != HQ_OK) { nt_parts_free(parts); free(ek); hqh_octbox_destroy(b); return rc; }
     }
+    nt_parts_free(parts);
     free(ek);
     *out = b;
     return HQ_OK;
@@ -2386,6 +2620,7 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
     uint64_t* nkey = NULL;
     int32_t *touch = NULL, *small = NULL;
     int rc = HQ_ERR_NOMEM;
+    nt_parts* parts = NULL;          /* solver_float = 4 on a partition: the rows in runs of ranks (nt_parts_combine) */
     if (!b || !ck) goto fail;
     const int P = ip->nranks > 1 ? ip->nranks : 1;
     if (P > 64 || ip->rank < 0 || ip->rank >= P || !hqh_sf_valid(ip->solver_float)) { rc = HQ_ERR_ARG; goto fail; }
@@ -2520,6 +2755,10 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
         if (!b->edata) goto fail;
         memcpy(b->edata, edata, sizeof(float) * 4 * (size_t)E);
         b->bbase = bBase; b->thr_damp = ip->threshold_damping; b->thr_vpvs = ip->threshold_vpvs;
+        if (ip->solver_float == 4 && P > 1) {
+            parts = nt_parts_new(b->N, P, E);
+            if (!parts) goto fail;
+        }
         for (int64_t e = 0; e < E; e++) {
             float h = edata[4 * e], Vp = edata[4 * e + 1], Vs = edata[4 * e + 2], rho = edata[4 * e + 3];
             double mu = rho * Vs * Vs, lambda;
@@ -2544,12 +2783,13 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
                 double dash[3];
                 int bnd = face_dashpot(face, c, ip->halfspace, h, Vp, Vs, rho, dash);
                 double* np = &b->ntable[7 * (int64_t)b->lnid[8 * e + c]];
+                if (parts && nt_parts_row(parts, b->ntable, b->lnid[8 * e + c], e)) { rc = HQ_ERR_NOMEM; goto fail; }
                 nt_accumulate(np, ip->solver_float == 4, dt, a, M, bnd, dash);
             }
         }
     }
-    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502 */
-    nt_distribute(b->ntable, ip->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
+    /* compute_adjust(nTable, 7, DISTRIBUTION), psolve.c:3502 (the float build on N ranks: nt_parts_combine in octbox_cut) */
+    if (!parts) nt_distribute(b->ntable, ip->solver_float == 4, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
     if (P > 1) {
         /* the leaves' corners in Z-order = octree pre-order (checked), for point location */
         uint64_t* ek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
@@ -2558,13 +2798,15 @@ int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, c
             ek[e] = zvalue(et[3 * e] / emin, et[3 * e + 1] / emin, et[3 * e + 2] / emin);
             if (e && ek[e] <= ek[e - 1]) { free(ek); rc = HQ_ERR_ARG; goto fail; }
         }
-        rc = octbox_cut(b, ek, ip->rank, P);
+        rc = octbox_cut(b, ek, ip->rank, P, parts);
         free(ek);
         if (rc != HQ_OK) goto fail;
     }
+    nt_parts_free(parts);
     *out = b;
     return HQ_OK;
 fail:
+    nt_parts_free(parts);
     free(ck); free(nkey); free(touch); free(small);
     hqh_octbox_destroy(b);
     return rc;

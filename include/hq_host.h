@@ -67,7 +67,13 @@ typedef struct {
                                       * windows); {0, 0, 0} otherwise                                             */
     int32_t       solver_float;      /* 0 | 8: the n_t rows as the reference's double build sums them; 4: as its
                                       * -DSINGLE_PRECISION_SOLVER build does (psolve.h:60-64: float fields, every `+=` of
-                                      * psolve.c:3440-3471 rounds to float) -- still handed over as doubles, exact floats */
+                                      * psolve.c:3440-3471 rounds to float) -- still handed over as doubles, exact floats.
+                                      * On a partition: as that build's N RANKS sum them -- each rank its own elements,
+                                      * then solver_init's three mass exchanges (psolve.c:3498-3507: sharers' rows added
+                                      * to the owner's in messenger order, hanging nodes' shares handed out by their
+                                      * owners in between); every harbored copy holds its owner's row.  Bit for bit the
+                                      * multi-rank float oracle's (tests/test_host_float_tables.py), which the float
+                                      * reference's 8-rank checkpoints pin */
 } hqh_box_params;
 
 typedef struct {

@@ -147,7 +147,20 @@ def test_one_million_elements_bricks_against_the_float_oracle_and_in_eight_parti
     lut = np.empty(gid.max() + 1, np.int64)
     lut[gid] = np.arange(len(gid))
     box.close()
-    parts = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8, solver_float=4) for r in range(8)]
+    # cut 8 ways.  "The partitions give what the single context gives" needs the SAME rows on both sides, and with
+    # solver_float = 4 a partition's rows are the N-rank float build's (other roundings than one rank's loop leaves,
+    # tests/test_host_float_tables.py): this half runs on the double build's rows rounded to float, whole and cut
+    box = host.Box(nx, ny, nz, h, dt, freq)
+    nt32 = np.ascontiguousarray(box.ntable, np.float32)
+    o1, o2 = u2.copy(), u.copy()
+    ho.solver_run(box.lnid, box.etable.copy(), nt32, o1, o2, 0, nsteps, dt)
+    s = box.create_solver(variant=ha.HQ_VARIANT_PATCH, tm1=u, tm2=u2, precision="f32")
+    s.run(nsteps)
+    tm1, _ = s.download()
+    s.close()
+    box.close()
+    assert H.rel_linf(tm1.astype(np.float64), o2.astype(np.float64)) < TOL_STEPS
+    parts = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=8) for r in range(8)]
     maps = [lut[(b.node_ijk[:, 2].astype(np.int64) * (ny + 1) + b.node_ijk[:, 1]) * (nx + 1) + b.node_ijk[:, 0]] for b in parts]
     solvers = [b.create_solver(tm1=u[m], tm2=u2[m], precision="f32") for b, m in zip(parts, maps)]
     capi.group_link(solvers)
@@ -267,3 +280,45 @@ def test_eight_partitions_against_the_float_references_eight_rank_stripes(varian
             assert np.abs(tm2.astype(np.float64) - ref2).max() <= TOL_RUN * scale
     for s in solvers:
         s.close()
+
+
+def test_eight_float_partitions_from_the_c_host_against_the_float_references_stripes():
+    """The multi-rank float path without the oracle's tables: the leaves of the mesh -> hqh_mesh_from_leaves per rank (octor's
+    partition, ownership, messenger lists; n_t rows with solver_float = 4: the N-rank float build's own sums -- every rank's
+    elements apart, the three mass exchanges replayed, hq_host.c nt_rank_rows) -> eight contexts of libhq_solver_f32.so over
+    the in-process transport -> the stripes the float reference's 8 MPI ranks wrote (its own per-rank force files).
+    Measured (round 6): 2.3e-6 of the field's scale after 200 steps on these rows; 6e-5 on rows summed in ONE rank's order,
+    1.8e-5 on the double build's rows rounded to float -- a float run feels which roundings its rows carry.  Bound: 5e-6."""
+    from hercules_amd import capi
+    g = H.load("c5_two_level_np8_f32")
+    base = H.load(str(g["base"]))
+    nranks = int(g["nranks"])
+    et = base["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = base["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    boxes = [host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(base["freq"]), rank=r, nranks=nranks,
+                                     solver_float=4) for r in range(nranks)]
+    solvers = [b.create_solver(precision="f32") for b in boxes]
+    for r, s in enumerate(solvers):
+        assert boxes[r].E == len(g["elem_ticks_%d" % r])               # octor's share of the elements
+        if len(g["loaded_lnid_%d" % r]):
+            s.set_source(g["loaded_lnid_%d" % r], g["forces_%d" % r])
+    capi.group_link(solvers)
+    done = 0
+    for step in g["ckpt_steps"]:
+        capi.group_run(solvers, int(step) - done)
+        done = int(step)
+        stripes = [H.np8_stripe(g, step, r, boxes[r].N) for r in range(nranks)]
+        scale = max(float(np.abs(ref1).max()) for _, ref1 in stripes)
+        for (ref2, ref1), s in zip(stripes, solvers):
+            tm1, tm2 = s.download()
+            assert tm1.dtype == np.float32
+            assert np.abs(tm1.astype(np.float64) - ref1).max() <= 5e-6 * scale
+            assert np.abs(tm2.astype(np.float64) - ref2).max() <= 5e-6 * scale
+    for s in solvers:
+        s.close()
+    for b in boxes:
+        b.close()

@@ -38,19 +38,49 @@ def test_uniform_box_rows_are_the_float_builds(shape, layers, damping):
     d.close()
 
 
+def _multi_rank_float_oracle(elem_ticks, edata, nranks, dt, freq, far=H.C1_FAR_TICKS):
+    """octor's partition restated from the global view + solver_init on every rank + the three mass exchanges, all in float
+    (ho.multi_rank_init: pinned on the float reference's 8-rank stripes, tests/test_oracle_single_precision.py)."""
+    m = ho.octree_mesh_from_elem_ticks(elem_ticks, far)
+    parts = ho.octree_partition(m, nranks, [f // m["emin"] for f in far])
+    eds = [np.ascontiguousarray(edata[p["elems"]]) for p in parts]
+    fcs = [np.ascontiguousarray(m["face"][p["elems"]]) for p in parts]
+    _, nts = ho.multi_rank_init(parts, eds, fcs, dt, freq, real=np.float32)
+    return m, parts, nts
+
+
 @pytest.mark.parametrize("nranks", [3, 8])
-def test_a_partitions_rows_are_cut_from_the_whole_boxs(nranks):
-    """hq_host.h: a partition's float rows are those of ONE rank's element loop (the float reference on N ranks adds the
-    ranks' partial sums in its messengers' order: the last float digit of <= 8 terms)."""
+def test_a_box_partitions_rows_are_the_n_rank_float_builds(nranks):
+    """hq_host.c, nt_rank_rows: on N ranks the float build sums every rank's elements apart and adds the sharers' rows to the
+    owner's in messenger order -- other roundings than one rank's loop leaves, and a run feels them (5e-5 against 1e-6 on the
+    reference's own 8-rank checkpoints, tests/test_gpu_single_precision.py).  A partition's rows, material differing from
+    element to element: bit for bit the multi-rank float oracle's on every node the rank owns; the other copies hold their
+    owner's row."""
     nx, ny, nz, h, dt, freq = 16, 16, 8, 62.5, 1e-3, 5.0
-    whole = host.Box(nx, ny, nz, h, dt, freq, layers=LAYERS, lateral_classes=61, lateral_amp=0.1, solver_float=4)
+    kw = dict(layers=LAYERS, lateral_classes=61, lateral_amp=0.1)
+    whole = host.Box(nx, ny, nz, h, dt, freq, **kw)
+    edata = np.empty((len(whole.lnid), 4), np.float32)
+    edata[:, 0] = h
+    edata[:, 1:] = whole.material()
+    m, parts, nts = _multi_rank_float_oracle(whole.node_ijk[whole.lnid].astype(np.int64) << 26, edata, nranks, dt, freq)
+    assert np.array_equal(m["lnid"], whole.lnid)
     gid = {tuple(v): i for i, v in enumerate(whole.node_ijk.tolist())}
-    for r in range(nranks):
-        b = host.Box(nx, ny, nz, h, dt, freq, layers=LAYERS, lateral_classes=61, lateral_amp=0.1, rank=r, nranks=nranks,
-                     solver_float=4)
+    rows = np.zeros((len(gid), 7), np.float32)
+    boxes = [host.Box(nx, ny, nz, h, dt, freq, rank=r, nranks=nranks, solver_float=4, **kw) for r in range(nranks)]
+    one_rank = host.Box(nx, ny, nz, h, dt, freq, solver_float=4, **kw)
+    differ = 0
+    for r, b in enumerate(boxes):
+        own = b.owner == r
+        assert _exact_floats(b.ntable) and np.array_equal(b.ntable[own].astype(np.float32), nts[r][own])
         g = np.array([gid[tuple(v)] for v in b.node_ijk.tolist()])
-        assert np.array_equal(b.ntable, whole.ntable[g])
+        rows[g[own]] = nts[r][own]
+        differ += int((b.ntable[own] != one_rank.ntable[g[own]]).any(axis=1).sum())
+    for b in boxes:                                       # every harbored copy = the owner's row
+        g = np.array([gid[tuple(v)] for v in b.node_ijk.tolist()])
+        assert np.array_equal(b.ntable.astype(np.float32), rows[g])
         b.close()
+    assert differ > 0                                     # not the one-rank order
+    one_rank.close()
     whole.close()
 
 
@@ -102,18 +132,23 @@ def _edata_of(ob, h):
 
 @pytest.mark.parametrize("nranks", [3, 8])
 def test_octree_partitions_built_locally_equal_the_cut_of_the_whole_box(nranks, monkeypatch):
-    """Both constructions of a partition (cut out of the whole box | from the sorted leaf keys alone) round at the same
-    places: equal rows, and equal to the whole box's rows of the same nodes."""
-    whole = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, solver_float=4)
-    key = {tuple(v): i for i, v in enumerate(whole.node_xyz.tolist())}
+    """Both constructions of a partition (cut out of the whole box | from the sorted leaf keys alone) replay the N-rank float
+    build's three mass exchanges (runs of ranks, the hanging nodes' shares at their owners): equal rows, bit for bit the
+    multi-rank float oracle's where the rank owns the node."""
+    whole = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0)
+    size = whole.node_xyz[whole.lnid[:, 7], 0] - whole.node_xyz[whole.lnid[:, 0], 0]
+    et = whole.node_xyz[whole.lnid].astype(np.int64) << 25
+    _, parts, nts = _multi_rank_float_oracle(et, _edata_of(whole, 31.25), nranks, 1e-3, 5.0, far=(32 << 25, 16 << 25, 16 << 25))
+    assert (size > 1).any()
     for rank in range(nranks):
         monkeypatch.setenv("HQH_OCTBOX_LOCAL", "0")
         a = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, rank=rank, nranks=nranks, solver_float=4)
         monkeypatch.setenv("HQH_OCTBOX_LOCAL", "1")
         b = host.OctBox(32, 16, 6, 5, 31.25, 1e-3, 5.0, rank=rank, nranks=nranks, solver_float=4)
         assert np.array_equal(a.node_xyz, b.node_xyz) and np.array_equal(a.ntable, b.ntable)
-        g = np.array([key[tuple(v)] for v in a.node_xyz.tolist()])
-        assert np.array_equal(a.ntable, whole.ntable[g])
+        assert np.array_equal(a.lnid, parts[rank]["lnid"])
+        own = a.owner == rank
+        assert np.array_equal(a.ntable[own].astype(np.float32), nts[rank][own])
         a.close()
         b.close()
     whole.close()
@@ -137,3 +172,51 @@ def test_the_rows_as_the_float_array_a_float_reference_holds():
     assert np.array_equal(out.astype(np.float64), b.ntable)
     assert lib.hqh_ntable_to_float(None, ctypes.c_int64(1), out.ctypes.data_as(ctypes.c_void_p)) != 0
     b.close()
+
+
+def test_partition_rows_against_the_multi_rank_float_oracle():
+    """hqh_mesh_from_leaves on 8 partitions of the float reference's own two-level mesh (800 hanging nodes, shared between
+    ranks): the rows a rank OWNS bit for bit the multi-rank float oracle's -- the tables the float reference's 8 ranks
+    stepped to the stripes in tests/golden/c5_two_level_np8_f32.npz."""
+    g = H.load("c5_two_level_np8_f32")
+    base = H.load(str(g["base"]))
+    et = base["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = base["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    pr = H.c5_np8_problem("c5_two_level_np8_f32", real=np.float32)
+    one = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(base["freq"]), solver_float=4)
+    differing = 0
+    for r in range(8):
+        b = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(base["freq"]), rank=r, nranks=8,
+                                    solver_float=4)
+        assert np.array_equal(b.lnid, pr["parts"][r]["lnid"])
+        own = b.owner == r
+        assert _exact_floats(b.ntable) and np.array_equal(b.ntable[own].astype(np.float32), pr["nts"][r][own])
+        differing += int((b.ntable[own] != one.ntable[b.gid[own]]).any(axis=1).sum())
+        b.close()
+    one.close()
+    assert differing > 0                                # one rank's order would have given other floats on the interfaces
+
+
+@pytest.mark.parametrize("name,nranks", [("c5_basin", 5), ("c5_gradient", 8)])
+def test_lateral_basin_partitions_against_the_multi_rank_float_oracle(name, nranks):
+    """The same on the laterally refined basins (hanging nodes of every kind, anchors held through indirect sharing, material
+    differing from element to element in c5_gradient)."""
+    g = H.load(name)
+    et = g["elem_ticks"]
+    edge = et[:, 7, 0] - et[:, 0, 0]
+    mat = g["mat_vs_vp_rho"]
+    edata = np.empty((len(et), 4), np.float32)
+    edata[:, 0] = (edge * (1000.0 / 2 ** 30)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    _, parts, nts = _multi_rank_float_oracle(et, edata, nranks, 1e-3, float(g["freq"]))
+    for r in range(nranks):
+        b = host.OctBox.from_leaves(et[:, 0, :], edge, edata, H.C1_FAR_TICKS, 1e-3, float(g["freq"]), rank=r, nranks=nranks,
+                                    solver_float=4)
+        assert np.array_equal(b.lnid, parts[r]["lnid"])
+        own = b.owner == r
+        assert np.array_equal(b.ntable[own].astype(np.float32), nts[r][own])
+        b.close()
