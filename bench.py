@@ -941,6 +941,9 @@ def main():
 
     # torchrun pins OMP_NUM_THREADS=1; the C host side builds the partition with OpenMP
     os.environ["OMP_NUM_THREADS"] = str(max(1, usable_cores() // max(world, 1)))
+    # the host driver of this pool exports memory between processes through dmabuf only (hipIpcGetMemHandle fails without
+    # this); the image exports it already -- a launcher that scrubs the environment must not cost the IPC transport
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # Before this process touches the GPU: the traffic passes (child processes under rocprofv3) and
     # the CPU baseline (threads / MPI ranks on the host cores).  N = 1 only.
