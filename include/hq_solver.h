@@ -336,6 +336,9 @@ HQ_API int hq_comm_init_host(hq_ctx* ctx, hq_host_exchange_fn fn, void* user);
  * receiver's check and the next hq_sync returns HQ_ERR_COMM.  Every rank of the run must set it.  The receive arena is
  * fine-grained device memory, uncached device memory where the runtime will not export that, coarse-grained as the last
  * resort (ranks of one device only): hq_info.ipc_arena_kind says which.
+ * Where the host driver exports device memory through dmabuf only (the MI355X pool this was built on), the process needs
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE its first HIP call, or hipIpcGetMemHandle fails with "invalid
+ * argument" (hq_comm_ipc_export then returns HQ_ERR_DEVICE with that text; RCCL needs the same setting).
  */
 #define HQ_IPC_BLOB_BYTES 4096
 HQ_API int hq_comm_ipc_export(hq_ctx* ctx, void* blob);
