@@ -2596,14 +2596,6 @@ fail:
 /* octree mesh from its leaves (octor_extractmesh + solver_init, one partition) */
 /* ------------------------------------------------------------------------ */
 
-typedef struct { uint64_t key; int64_t idx; } hqh_keyidx;
-
-static int cmp_keyidx(const void* a, const void* b)
-{
-    const hqh_keyidx* x = (const hqh_keyidx*)a; const hqh_keyidx* y = (const hqh_keyidx*)b;
-    return x->key < y->key ? -1 : (x->key > y->key ? 1 : (x->idx < y->idx ? -1 : (x->idx > y->idx)));
-}
-
 int hqh_mesh_from_leaves(int64_t E, const uint32_t* et, const uint32_t* eedge, const float* edata,
                          const uint32_t far_ticks[3], const hqh_init_params* ip, hqh_octbox** out)
 {
