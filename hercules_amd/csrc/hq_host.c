@@ -388,13 +388,39 @@ static void nt_distribute(double* ntable, int f32, int32_t ldnnum, const int32_t
  * (tests/test_gpu_single_precision.py).  So with solver_float = 4 a partition's rows follow this order; every harbored
  * copy of a node gets what its OWNER ends up with (the reference leaves a partial sum in the other copies, which the
  * sharing of the displacements makes irrelevant, psolve.c:4312-4315).
- * nt_rank_rows: rows[0..n) of ranks rk[0..n) (ascending) -> out = the owner's row + the others' in ascending rank.
+ * nt_rank_rows: rows[0..n) of ranks rk[0..n) -> out = the owner's row + the others' in the order of the owner's messenger
+ * list (pos[rank] = the rank's place in it; schedule_build's order, see build_schedule).
  */
-static void nt_rank_rows(int n, const int* rk, double (*rows)[7], int owner, double out[7])
+static void nt_rank_rows(int n, const int* rk, double (*rows)[7], int owner, const int* pos, double out[7])
 {
+    int ord[64], m = 0;
     for (int t = 0; t < 7; t++) out[t] = 0.0;
-    for (int q = 0; q < n; q++) if (rk[q] == owner) for (int t = 0; t < 7; t++) out[t] = rows[q][t];
-    for (int q = 0; q < n; q++) if (rk[q] != owner) for (int t = 0; t < 7; t++) out[t] = HQH_SF(1, out[t] + rows[q][t]);
+    for (int q = 0; q < n && q < 64; q++) {
+        if (rk[q] == owner) { for (int t = 0; t < 7; t++) out[t] = rows[q][t]; continue; }
+        int u = m++;
+        while (u > 0 && pos[rk[ord[u - 1]]] > pos[rk[q]]) { ord[u] = ord[u - 1]; u--; }
+        ord[u] = q;
+    }
+    for (int q = 0; q < m; q++) for (int t = 0; t < 7; t++) out[t] = HQH_SF(1, out[t] + rows[ord[q]][t]);
+}
+
+/* Every rank's messenger lists of one schedule, as places: the nodes in global (= every rank's local) order, an owned
+ * node's sharers in ascending rank (anchored nodes) or descending rank (hanging nodes); a rank met for the first time goes
+ * to the HEAD of the owner's list.  first[o * P + r] (in: the order number of the first meeting, < 0 never) ->
+ * pos[o * P + r] = place of r in o's list. */
+static void nt_list_places(int P, const int64_t* first, int* pos)
+{
+    for (int o = 0; o < P; o++) {
+        int seq[64], n = 0;
+        for (int r = 0; r < P; r++) {
+            pos[o * P + r] = 0;
+            if (first[o * P + r] < 0) continue;
+            int u = n++;
+            while (u > 0 && first[o * P + seq[u - 1]] > first[o * P + r]) { seq[u] = seq[u - 1]; u--; }
+            seq[u] = r;
+        }
+        for (int q = 0; q < n; q++) pos[o * P + seq[q]] = n - 1 - q;          /* the last one met is the first of the list */
+    }
 }
 
 /* The same for the whole-mesh builders (hqh_octbox_create_levels, hqh_mesh_from_leaves: every rank builds the whole mesh and
@@ -459,8 +485,9 @@ static inline int nt_parts_row(nt_parts* pp, double* ntable, int32_t n, int64_t 
 
 /* the runs still open, then exchanges (A), (B), (C) -> ntable[N][7] as every node's owner holds it */
 static int nt_parts_combine(nt_parts* pp, int64_t N, double* ntable, const int32_t* gowner, int32_t ldnnum, const int32_t* dn_id,
-                            const int32_t* dn_ptr, const int32_t* dn_anchor)
+                            const int32_t* dn_ptr, const int32_t* dn_anchor, const int* pos_an, const int* pos_dn)
 {
+    const int P = pp->P;
     for (int64_t n = 0; n < N; n++)
         if (pp->cur[n] >= 0 && nt_parts_push(pp, (int32_t)n, pp->cur[n], &ntable[7 * n])) return HQ_ERR_NOMEM;
     /* a rank that owns a hanging node holds its anchors (octor.c: indirect sharing) even where it has no element at them */
@@ -518,7 +545,7 @@ static int nt_parts_combine(nt_parts* pp, int64_t N, double* ntable, const int32
         for (int32_t k = 0; k < ldnnum; k++) {
             const int32_t d = dn_id[k];
             NTP_GATHER(d, rows, rk, cnt)
-            nt_rank_rows(cnt, rk, rows, gowner[d], &full[7 * (int64_t)k]);
+            nt_rank_rows(cnt, rk, rows, gowner[d], pos_dn + gowner[d] * P, &full[7 * (int64_t)k]);
         }
         /* (B): every owner through its dnodeTable -- the global table's order restricted to its nodes */
         for (int32_t k = 0; k < ldnnum; k++) {
@@ -534,11 +561,12 @@ static int nt_parts_combine(nt_parts* pp, int64_t N, double* ntable, const int32
                 for (int t = 0; t < 7; t++) pp->row[7 * hit + t] = HQH_SF(1, pp->row[7 * hit + t] + part[t]);
             }
         }
-        /* (C); a hanging node's row is what (A) left (nothing is handed TO it) */
+        /* (C); a hanging node's row is what (A) left (nothing is handed TO it; its owner's OTHER list ordered it) */
         for (int64_t n = 0; n < N; n++) {
             NTP_GATHER(n, rows, rk, cnt)
-            nt_rank_rows(cnt, rk, rows, gowner[n], &ntable[7 * n]);
+            nt_rank_rows(cnt, rk, rows, gowner[n], pos_an + gowner[n] * P, &ntable[7 * n]);
         }
+        for (int32_t k = 0; k < ldnnum; k++) memcpy(&ntable[7 * (int64_t)dn_id[k]], &full[7 * (int64_t)k], 7 * sizeof(double));
 #undef NTP_GATHER
     }
 done:
@@ -548,7 +576,7 @@ done:
 
 /* n_t of node (i,j,k): psolve.c:3440-3471 summed over its elements in Z-order (solver_float = 4 on partitions: every
  * rank's elements apart, then the owner's row + the sharers', see above) */
-static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, int owner, double np[7])
+static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, int owner, const int* places, double np[7])
 {
     const hqh_box_params* p = &b->p;
     int64_t idx[8];
@@ -587,7 +615,59 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, in
         }
         nt_accumulate(acc, f32, dt, a, M, bnd, dash);
     }
-    if (by_rank) nt_rank_rows(nr, rk, rows, owner, np);
+    if (by_rank) nt_rank_rows(nr, rk, rows, owner, places + owner * p->nranks, np);
+}
+
+/* every rank's s-list of the box as places (nt_list_places): one pass over the whole grid for the node of smallest key that
+ * an owner shares with each of the others (solver_float = 4 on partitions only) */
+static int box_list_places(const hqh_box* b, int* pos)
+{
+    const hqh_box_params* p = &b->p;
+    const int P = p->nranks;
+    int64_t* first = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
+    if (!first) return HQ_ERR_NOMEM;
+    for (int q = 0; q < P * P; q++) first[q] = -1;
+    int nomem = 0;
+#pragma omp parallel
+    {
+        int64_t* mine = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
+        if (!mine) {
+#pragma omp atomic write
+            nomem = 1;
+        } else {
+            for (int q = 0; q < P * P; q++) mine[q] = -1;
+#pragma omp for schedule(static)
+            for (int32_t k = 0; k <= p->nz; k++)
+                for (int32_t j = 0; j <= p->ny; j++)
+                    for (int32_t i = 0; i <= p->nx; i++) {
+                        int rk[8], n = 0;
+                        for (int c = 0; c < 8; c++) {
+                            const int32_t ei = i - 1 + (c & 1), ej = j - 1 + ((c >> 1) & 1), ek = k - 1 + ((c >> 2) & 1);
+                            if (ei < 0 || ej < 0 || ek < 0 || ei >= p->nx || ej >= p->ny || ek >= p->nz) continue;
+                            const int r = rank_of_elem(b, elem_index(b, ei, ej, ek));
+                            int seen = 0;
+                            for (int t = 0; t < n; t++) seen |= (rk[t] == r);
+                            if (!seen) rk[n++] = r;
+                        }
+                        if (n < 2) continue;
+                        const int32_t oi = i < p->nx ? i : p->nx - 1, oj = j < p->ny ? j : p->ny - 1, ok = k < p->nz ? k : p->nz - 1;
+                        const int o = rank_of_elem(b, elem_index(b, oi, oj, ok));
+                        const int64_t key = (int64_t)node_key(b, i, j, k);
+                        for (int t = 0; t < n; t++) {
+                            if (rk[t] == o) continue;
+                            int64_t* f = &mine[o * P + rk[t]];
+                            if (*f < 0 || key < *f) *f = key;
+                        }
+                    }
+#pragma omp critical
+            for (int q = 0; q < P * P; q++)
+                if (mine[q] >= 0 && (first[q] < 0 || mine[q] < first[q])) first[q] = mine[q];
+            free(mine);
+        }
+    }
+    if (!nomem) nt_list_places(P, first, pos);      /* (two sharers met at one node: ascending rank -- the insertion is stable) */
+    free(first);
+    return nomem ? HQ_ERR_NOMEM : HQ_OK;
 }
 
 /* HQH_VERBOSE=1: where the host side's time goes */
@@ -723,6 +803,11 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     int amax = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
     int32_t edge_ticks = (int32_t)1 << (30 - amax);
     int32_t nown = 0;
+    int* places = NULL;              /* solver_float = 4 on a partition: every rank's messenger list, for the order of the sums */
+    if (p->solver_float == 4 && p->nranks > 1) {
+        places = (int*)malloc(sizeof(int) * (size_t)p->nranks * (size_t)p->nranks);
+        if (!places || box_list_places(b, places) != HQ_OK) { free(places); free(keys); hqh_box_destroy(b); return HQ_ERR_NOMEM; }
+    }
 #pragma omp parallel for schedule(static) reduction(+ : nown)
     for (int64_t n = 0; n < nh; n++) {
         uint32_t d[3] = { compact3(keys[n]), compact3(keys[n] >> 1), compact3(keys[n] >> 2) };
@@ -737,10 +822,11 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
                 ok = c[2] < p->nz ? c[2] : p->nz - 1;
         b->owner[n] = rank_of_elem(b, elem_index(b, oi, oj, ok));
         if (b->owner[n] == p->rank) nown++;
-        node_constants(b, c[0], c[1], c[2], b->owner[n], &b->ntable[7 * n]);
+        node_constants(b, c[0], c[1], c[2], b->owner[n], places, &b->ntable[7 * n]);
     }
     b->nowned = nown;
     free(keys);
+    free(places);
     hqh_lap(&t_lap, "box: node tables");
 
     /* elements */
@@ -814,7 +900,14 @@ static int build_schedule(hqh_box* b)
     if (P == 1) return HQ_OK;
     int64_t* ccount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
     int64_t* scount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
-    if (!ccount || !scount) { free(ccount); free(scount); return HQ_ERR_NOMEM; }
+    /* the order of the lists: schedule_build walks the nodes in local order (and an owned node's sharers in ascending rank)
+     * and puts a NEW messenger at the HEAD of its list (psolve.c:4736-4745, 4776-4785) -- the reverse of the order of first
+     * encounter.  schedule_senddata adds what arrives messenger by messenger in that order (:5035-5073): with it the
+     * oracle's multi-rank runs are bit-identical to the reference's per-rank checkpoints (tests/test_oracle_golden.py) */
+    int* cseq = (int*)malloc(sizeof(int) * (size_t)P);
+    int* sseq = (int*)malloc(sizeof(int) * (size_t)P);
+    int ncseq = 0, nsseq = 0;
+    if (!ccount || !scount || !cseq || !sseq) { free(ccount); free(scount); free(cseq); free(sseq); return HQ_ERR_NOMEM; }
     for (int pass = 0; pass < 2; pass++) {
         int64_t *cfill = NULL, *sfill = NULL;
         if (pass == 1) {
@@ -827,19 +920,23 @@ static int build_schedule(hqh_box* b)
             b->mc = (hq_messenger*)calloc((size_t)(b->nc ? b->nc : 1), sizeof(hq_messenger));
             b->ms = (hq_messenger*)calloc((size_t)(b->ns ? b->ns : 1), sizeof(hq_messenger));
             if (!cfill || !sfill || !b->cmap || !b->smap || !b->mc || !b->ms) {
-                free(cfill); free(sfill); free(ccount); free(scount); return HQ_ERR_NOMEM;
+                free(cfill); free(sfill); free(ccount); free(scount); free(cseq); free(sseq); return HQ_ERR_NOMEM;
             }
             int64_t co = 0, so = 0;
             int ic = 0, is = 0;
-            for (int r = 0; r < P; r++) {            /* messengers in ascending rank order */
-                if (ccount[r]) { b->mc[ic].procid = r; b->mc[ic].nodecount = (int32_t)ccount[r]; b->mc[ic].mapping = b->cmap + co; cfill[r] = co; co += ccount[r]; ic++; }
-                if (scount[r]) { b->ms[is].procid = r; b->ms[is].nodecount = (int32_t)scount[r]; b->ms[is].mapping = b->smap + so; sfill[r] = so; so += scount[r]; is++; }
+            for (int q = ncseq - 1; q >= 0; q--) {
+                const int r = cseq[q];
+                b->mc[ic].procid = r; b->mc[ic].nodecount = (int32_t)ccount[r]; b->mc[ic].mapping = b->cmap + co; cfill[r] = co; co += ccount[r]; ic++;
+            }
+            for (int q = nsseq - 1; q >= 0; q--) {
+                const int r = sseq[q];
+                b->ms[is].procid = r; b->ms[is].nodecount = (int32_t)scount[r]; b->ms[is].mapping = b->smap + so; sfill[r] = so; so += scount[r]; is++;
             }
         }
         for (int32_t n = 0; n < b->nharbored; n++) {
             int32_t i = b->node_ijk[3 * n], j = b->node_ijk[3 * n + 1], k = b->node_ijk[3 * n + 2];
             if (b->owner[n] != me) {
-                if (pass == 0) { ccount[b->owner[n]]++; b->shared_nodes++; }
+                if (pass == 0) { if (!ccount[b->owner[n]]++) cseq[ncseq++] = b->owner[n]; b->shared_nodes++; }
                 else b->cmap[cfill[b->owner[n]]++] = n;
                 continue;
             }
@@ -854,14 +951,20 @@ static int build_schedule(hqh_box* b)
                 if (!seen) sh[nsh++] = r;
             }
             if (pass == 0 && nsh) b->shared_nodes++;
+            for (int t = 1; t < nsh; t++) {                     /* a node's sharers in ascending rank */
+                const int v = sh[t];
+                int u = t;
+                while (u > 0 && sh[u - 1] > v) { sh[u] = sh[u - 1]; u--; }
+                sh[u] = v;
+            }
             for (int t = 0; t < nsh; t++) {
-                if (pass == 0) scount[sh[t]]++;
+                if (pass == 0) { if (!scount[sh[t]]++) sseq[nsseq++] = sh[t]; }
                 else b->smap[sfill[sh[t]]++] = n;
             }
         }
         free(cfill); free(sfill);
     }
-    free(ccount); free(scount);
+    free(ccount); free(scount); free(cseq); free(sseq);
     return HQ_OK;
 }
 
@@ -1519,7 +1622,25 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
         for (int32_t a = b->dn_ptr[k]; a < b->dn_ptr[k + 1]; a++) harb[b->dn_anchor[a]] |= bit;
     }
     if (parts) {                     /* solver_float = 4: the whole mesh's rows in the N-rank build's order (nt_parts_combine) */
-        const int prc = nt_parts_combine(parts, N, b->ntable, gowner, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor);
+        int64_t* first = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)P * (size_t)P);
+        int* pos = (int*)malloc(sizeof(int) * 2 * (size_t)P * (size_t)P);
+        int prc = HQ_ERR_NOMEM;
+        if (first && pos) {
+            for (int q = 0; q < 2 * P * P; q++) first[q] = -1;
+            int64_t met = 0;
+            for (int64_t n = 0; n < N; n++) {                                     /* every rank's schedule_build at once */
+                const int o = gowner[n], sdn = hang[n];
+                const uint64_t m = harb[n] & ~(1ull << o);
+                for (int t = 0; t < P; t++) {
+                    const int r = sdn ? P - 1 - t : t;
+                    if (((m >> r) & 1) && first[((int64_t)sdn * P + o) * P + r] < 0) first[((int64_t)sdn * P + o) * P + r] = met++;
+                }
+            }
+            nt_list_places(P, first, pos);
+            nt_list_places(P, first + (int64_t)P * P, pos + P * P);
+            prc = nt_parts_combine(parts, N, b->ntable, gowner, b->ldnnum, b->dn_id, b->dn_ptr, b->dn_anchor, pos, pos + P * P);
+        }
+        free(first); free(pos);
         if (prc != HQ_OK) { rc = prc; goto done; }
     }
     {
@@ -1567,6 +1688,7 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
          * dn_sched, the rest in an_sched */
         for (int s = 0; s < 2; s++) {
             int64_t ccount[64], scount[64], cfill[64], sfill[64];
+            int cseq[64], sseq[64], ncseq = 0, nsseq = 0;     /* ranks in the order of first encounter */
             memset(ccount, 0, sizeof ccount); memset(scount, 0, sizeof scount);
             for (int pass = 0; pass < 2; pass++) {
                 if (pass == 1) {
@@ -1579,21 +1701,30 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
                     if (!b->cmap[s] || !b->smap[s] || !b->mc[s] || !b->ms[s]) goto done;
                     int64_t co = 0, so = 0;
                     int ic = 0, is = 0;
-                    for (int r = 0; r < P; r++) {            /* messengers in ascending rank order */
-                        if (ccount[r]) { b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++; }
-                        if (scount[r]) { b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++; }
+                    for (int q = ncseq - 1; q >= 0; q--) {   /* a new messenger goes to the HEAD of its list (build_schedule) */
+                        const int r = cseq[q];
+                        b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++;
+                    }
+                    for (int q = nsseq - 1; q >= 0; q--) {
+                        const int r = sseq[q];
+                        b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++;
                     }
                 }
                 for (int64_t l = 0; l < nh; l++) {
                     const int64_t g = gid[l];
                     if ((int)hang[g] != s) continue;
                     if (own[l] != me) {
-                        if (pass == 0) ccount[own[l]]++; else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
+                        if (pass == 0) { if (!ccount[own[l]]++) cseq[ncseq++] = own[l]; } else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
                         continue;
                     }
-                    uint64_t m = harb[g] & ~mebit;
-                    for (int r = 0; m; r++, m >>= 1)
-                        if (m & 1) { if (pass == 0) scount[r]++; else b->smap[s][sfill[r]++] = (int32_t)l; }
+                    /* a node's sharers: ascending rank for an anchored node, descending for a hanging one -- the order in
+                     * which the reference's multi-rank runs come out bit for bit (oracle/herc_oracle.py: octree_partition) */
+                    const uint64_t m = harb[g] & ~mebit;
+                    for (int t = 0; t < P; t++) {
+                        const int r = s == 0 ? t : P - 1 - t;
+                        if (!((m >> r) & 1)) continue;
+                        if (pass == 0) { if (!scount[r]++) sseq[nsseq++] = r; } else b->smap[s][sfill[r]++] = (int32_t)l;
+                    }
                 }
             }
         }
@@ -1772,29 +1903,6 @@ static uint64_t oct_node_row(const oct_ctx_t* C, const int32_t c[3], double np[7
     return bits;
 }
 
-/* the same in runs of ranks (solver_float = 4 on a partition, see nt_rank_rows): rows[0 .. *nr) of ranks rk[] ascending */
-static void oct_node_rows(const oct_ctx_t* C, const int32_t c[3], double (*rows)[7], int* rk, int* nr)
-{
-    const hqh_octbox* b = C->b;
-    oct_leaf_t leaf[8];
-    int corner[8];
-    const int n = oct_leaves_of_node(C, c, leaf, corner);
-    const double dt = b->p.deltaT;
-    *nr = 0;
-    for (int k = 0; k < n; k++) {
-        const int L = leaf[k].L, s = 1 << L;
-        const int32_t q = b->lay0[L] + ((leaf[k].o[2] - b->ztop[L]) >> L);
-        const int face = (leaf[k].o[0] == 0) | ((leaf[k].o[1] == 0) << 1) | ((leaf[k].o[2] == 0) << 2) |
-                         ((leaf[k].o[0] + s == C->far[0]) << 3) | ((leaf[k].o[1] + s == C->far[1]) << 4) |
-                         ((leaf[k].o[2] + s == C->far[2]) << 5);
-        double dash[3];
-        const int bnd = face_dashpot(face, corner[k], b->p.halfspace, C->lh[q], C->lvp[q], b->vs[q], b->rho[q], dash);
-        const int r = OCT_ERANK(C, leaf[k].e);
-        if (*nr == 0 || rk[*nr - 1] != r) { rk[*nr] = r; for (int t = 0; t < 7; t++) rows[*nr][t] = 0.0; (*nr)++; }
-        nt_accumulate(rows[*nr - 1], 1, dt, C->la[q], C->lM[q], bnd, dash);
-    }
-}
-
 static uint64_t oct_node_key(const oct_ctx_t* C, const int32_t c[3])
 {
     uint32_t d[3];
@@ -1819,7 +1927,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                         const double* lM, const float* lvp, const float* lh)
 {
     oct_ctx_t C;
-    const int f32 = b->p.solver_float == 4, by_rank = f32 && P > 1;
+    const int f32 = b->p.solver_float == 4;          /* (one rank's order: the float build on partitions never comes here) */
     C.b = b; C.ek = ek; C.E = b->E; C.P = P;
     C.far[0] = b->far_q[0]; C.far[1] = b->far_q[1]; C.far[2] = b->far_q[2];
     C.lc = lc; C.la = la; C.lM = lM; C.lvp = lvp; C.lh = lh;
@@ -1905,9 +2013,6 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
         uint64_t bits = oct_node_row(&C, c, np);
         const int o = oct_owner(&C, c);
         if (o < 0 || !bits) { fault = 1; continue; }
-        double rrows[16][7];                                             /* by_rank: this node's row on every rank that holds it */
-        int rrk[16], rn = 0;
-        if (by_rank) oct_node_rows(&C, c, rrows, rrk, &rn);
         own[l] = o;
         bits |= 1ull << o;
         int32_t an[4][3];
@@ -1946,23 +2051,6 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                     oct_node_hangs(&C, hc[k], pa, &pd);
                     const int ho = oct_owner(&C, hc[k]);
                     if (ho >= 0) bits |= 1ull << ho;                     /* indirect sharing */
-                    if (by_rank) {
-                        /* exchange (A) for the hanging node, then (B): its owner `ho` adds row / deps to ITS row of this anchor */
-                        double hrows[8][7];
-                        int hrk[8], hn, at = -1;
-                        oct_node_rows(&C, hc[k], hrows, hrk, &hn);
-                        nt_rank_rows(hn, hrk, hrows, ho, hp);
-                        for (int q = 0; q < rn; q++) if (rrk[q] == ho) at = q;
-                        if (at < 0) {                                    /* `ho` has no element at the anchor: a row of shares only */
-                            if (rn >= 16) { fault = 1; continue; }
-                            at = rn++;
-                            while (at > 0 && rrk[at - 1] > ho) { rrk[at] = rrk[at - 1]; memcpy(rrows[at], rrows[at - 1], sizeof rrows[0]); at--; }
-                            rrk[at] = ho;
-                            for (int q = 0; q < 7; q++) rrows[at][q] = 0.0;
-                        }
-                        for (int q = 0; q < 7; q++) rrows[at][q] = HQH_SF(1, rrows[at][q] + HQH_SF(1, hp[q] / (uint32_t)pd));
-                        continue;
-                    }
                     oct_node_row(&C, hc[k], hp);
                     for (int q = 0; q < 7; q++) {
                         const double part = HQH_SF(f32, hp[q] / (uint32_t)pd);
@@ -1971,7 +2059,6 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                 }
             }
         }
-        if (by_rank) nt_rank_rows(rn, rrk, rrows, o, np);                /* exchange (C); a hanging node: (A) */
         harb[l] = bits;
         if (!(bits & (1ull << me))) fault = 1;
     }
@@ -2018,6 +2105,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
         const uint64_t mebit = 1ull << me;
         for (int s = 0; s < 2; s++) {
             int64_t ccount[64], scount[64], cfill[64], sfill[64];
+            int cseq[64], sseq[64], ncseq = 0, nsseq = 0;     /* ranks in the order of first encounter */
             memset(ccount, 0, sizeof ccount); memset(scount, 0, sizeof scount);
             for (int pass = 0; pass < 2; pass++) {
                 if (pass == 1) {
@@ -2030,20 +2118,27 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                     if (!b->cmap[s] || !b->smap[s] || !b->mc[s] || !b->ms[s]) goto done;
                     int64_t co = 0, so = 0;
                     int ic = 0, is = 0;
-                    for (int r = 0; r < P; r++) {
-                        if (ccount[r]) { b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++; }
-                        if (scount[r]) { b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++; }
+                    for (int q = ncseq - 1; q >= 0; q--) {   /* a new messenger goes to the HEAD of its list (build_schedule) */
+                        const int r = cseq[q];
+                        b->mc[s][ic].procid = r; b->mc[s][ic].nodecount = (int32_t)ccount[r]; b->mc[s][ic].mapping = b->cmap[s] + co; cfill[r] = co; co += ccount[r]; ic++;
+                    }
+                    for (int q = nsseq - 1; q >= 0; q--) {
+                        const int r = sseq[q];
+                        b->ms[s][is].procid = r; b->ms[s][is].nodecount = (int32_t)scount[r]; b->ms[s][is].mapping = b->smap[s] + so; sfill[r] = so; so += scount[r]; is++;
                     }
                 }
                 for (int64_t l = 0; l < nh; l++) {
                     if ((int)hang[l] != s) continue;
                     if (own[l] != me) {
-                        if (pass == 0) ccount[own[l]]++; else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
+                        if (pass == 0) { if (!ccount[own[l]]++) cseq[ncseq++] = own[l]; } else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
                         continue;
                     }
-                    uint64_t m = harb[l] & ~mebit;
-                    for (int r = 0; m; r++, m >>= 1)
-                        if (m & 1) { if (pass == 0) scount[r]++; else b->smap[s][sfill[r]++] = (int32_t)l; }
+                    const uint64_t m = harb[l] & ~mebit;
+                    for (int t = 0; t < P; t++) {            /* (ascending for anchored, descending for hanging nodes: octbox_cut) */
+                        const int r = s == 0 ? t : P - 1 - t;
+                        if (!((m >> r) & 1)) continue;
+                        if (pass == 0) { if (!scount[r]++) sseq[nsseq++] = r; } else b->smap[s][sfill[r]++] = (int32_t)l;
+                    }
                 }
             }
         }
@@ -2146,9 +2241,12 @@ int hqh_octbox_create_levels(const hqh_octlevels_params* p, hqh_octbox** out)
     if (E > 0x7fffffff / 8 || N > 0x7fffffff / 8) { hqh_octbox_destroy(b); return HQ_ERR_ARG; }
     b->E = E; b->N = N;
     {
-        /* partitions of a large box: this rank's tables alone (octbox_local); HQH_OCTBOX_LOCAL = 1 / 0 forces / forbids */
+        /* partitions of a large box: this rank's tables alone (octbox_local); HQH_OCTBOX_LOCAL = 1 / 0 forces / forbids.
+         * Not with solver_float = 4: the N-rank float build adds the sharers' rows in the order of EVERY owner's messenger
+         * list (nt_rank_rows), and a rank that sees its own neighbourhood only cannot know where another owner first met
+         * whom -- those partitions are cut out of the whole box */
         const char* le = getenv("HQH_OCTBOX_LOCAL");
-        if (P > 1 && (le ? atoi(le) != 0 : E >= 4000000)) {
+        if (P > 1 && p->solver_float != 4 && (le ? atoi(le) != 0 : E >= 4000000)) {
             uint64_t* lek = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)E);
             if (!lek) { hqh_octbox_destroy(b); return HQ_ERR_NOMEM; }
             int64_t te = 0;

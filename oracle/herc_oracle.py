@@ -397,7 +397,7 @@ def octree_partition(m, nranks, far_q):
                  sharing, node_harboranchored octor.c:3916-4042, :5795-6040); Z-ordered
       sharers  : ranks that have an owned node as element vertex, or harbor it as an anchor
       dnodeTable: the hanging nodes the rank OWNS, anchors as local ids
-      an_sched / dn_sched: schedule_build (psolve.c:4704-4863); messengers by ascending rank
+      an_sched / dn_sched: schedule_build (psolve.c:4704-4863); messengers in the reference's list order
 
     -> list of per-rank dicts."""
     lnid, node_q, elem_q, size = m["lnid"], m["node_q"], m["elem_q"], m["elem_size"]
@@ -436,17 +436,45 @@ def octree_partition(m, nranks, far_q):
                 d_loc.append(i)
                 d_anc += [loc[int(a)] for a in dn_anc[dn_ptr[k]:dn_ptr[k + 1]]]
                 d_ptr.append(len(d_anc))
-        # schedules
+        # the order in which this rank met its neighbours (com_allocpctl, octor.c:2640-2741): its leaves in order, around each
+        # the 4 x 4 x 4 points at half-edge spacing from (corner - edge / 2), z outermost; the rank that holds a point's pixel
+        met = []
+        for e in e_ids:
+            sz = float(size[e])
+            for kk in range(4):
+                z = elem_q[e][2] - sz / 2 + sz / 2 * kk
+                if z < 0 or z >= far_q[2]:
+                    continue
+                for jj in range(4):
+                    y = elem_q[e][1] - sz / 2 + sz / 2 * jj
+                    if y < 0 or y >= far_q[1]:
+                        continue
+                    for ii in range(4):
+                        x = elem_q[e][0] - sz / 2 + sz / 2 * ii
+                        if x < 0 or x >= far_q[0]:
+                            continue
+                        q = int(erank[cell[int(math.floor(x)), int(math.floor(y)), int(math.floor(z))]])
+                        if q != r and q not in met:
+                            met.append(q)
+        # schedules.  A vertex's share list (octor.c:5700-5793, 5990-6050): the ranks that have it as an element vertex, in the
+        # order this rank met them (their messages are taken in the reverse order and each sender goes to the HEAD of the
+        # list); ahead of them the ranks that hold it only as an anchor of a hanging node of theirs, in descending rank
         sched = {"an": {"c": {}, "s": {}}, "dn": {"c": {}, "s": {}}}
         for i, g in enumerate(nodes):
             kind = "dn" if dn_of[g] >= 0 else "an"
             if own[i] != r:
                 sched[kind]["c"].setdefault(int(own[i]), []).append(i)
             else:
-                for q in range(nranks):
-                    if q != r and int(g) in harbored[q]:
-                        sched[kind]["s"].setdefault(q, []).append(i)
-        pack = lambda d: [(q, np.array(v, np.int32)) for q, v in sorted(d.items())]
+                direct = [q for q in met if int(g) in verts[q]]
+                indirect = [q for q in range(nranks - 1, -1, -1) if q != r and int(g) in harbored[q] and int(g) not in verts[q]]
+                for q in indirect + direct:
+                    sched[kind]["s"].setdefault(q, []).append(i)
+                assert len(indirect) + len(direct) == sum(1 for q in range(nranks) if q != r and int(g) in harbored[q])
+        # schedule_build (psolve.c:4711-4795) walks the nodes in local order and a node's sharers in ascending rank, and
+        # puts a NEW messenger at the HEAD of its list: the lists end up in the reverse of the order of first encounter.
+        # schedule_senddata adds the incoming records messenger by messenger in list order (:5035-5073) -- with that order
+        # the multi-rank runs below are bit-identical to the reference's per-rank checkpoint stripes, float and double
+        pack = lambda d: [(q, np.array(v, np.int32)) for q, v in reversed(list(d.items()))]
         out.append(dict(rank=r, elems=e_ids, nodes=nodes, owner=own.astype(np.int32), lnid=l_lnid,
                         dangling=(np.array(d_loc, np.int32), np.array(d_ptr, np.int32), np.array(d_anc, np.int32)),
                         an_sched={k: pack(v) for k, v in sched["an"].items()},

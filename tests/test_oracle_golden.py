@@ -292,7 +292,9 @@ def test_basin_mesh_on_several_ranks_tables_and_fields(name):
     """The basin mesh on 8 and on 5 MPI ranks of the reference: block partition of a mixed-level leaf
     list, ownership, direct and indirect sharing across x / y / z-normal level interfaces, hanging nodes
     whose anchors live on other ranks -- octor's per-rank statistics and psolve's schedule summary
-    EXACTLY, per-rank checkpoint stripes to 1e-12."""
+    EXACTLY, per-rank checkpoint stripes BIT FOR BIT (round 6: with the messenger lists in schedule_build's own order --
+    a new messenger at the head of its list, a vertex's sharers in the order its owner met them as neighbours -- every sum
+    of every exchange runs in the reference's order; before that: 1e-12)."""
     import re
     pr = H.c5_np8_problem(name)
     g, parts, nr = pr["golden"], pr["parts"], pr["nranks"]
@@ -315,9 +317,7 @@ def test_basin_mesh_on_several_ranks_tables_and_fields(name):
         done = int(step)
         for p in parts:
             ref2, ref1 = H.np8_stripe(g, step, p["rank"], len(p["nodes"]))
-            scale = max(np.abs(ref1).max(), 1.0)
-            assert np.abs(tm1s[p["rank"]] - ref2).max() <= 1e-12 * scale
-            assert np.abs(tm2s[p["rank"]] - ref1).max() <= 1e-12 * scale
+            assert np.array_equal(tm1s[p["rank"]], ref2) and np.array_equal(tm2s[p["rank"]], ref1)
     assert max(np.abs(t).max() for t in tm2s) > 100.0
 
 
@@ -326,7 +326,7 @@ def test_octree_mesh_on_eight_ranks_tables_and_fields():
     restated from the global view (block partition, ownership by containing leaf, direct +
     indirect sharing, dnodeTable of owned hanging nodes, an/dn schedules) reproduce its
     per-rank statistics EXACTLY, and the multi-rank oracle (mass exchange at init, the four
-    exchanges + compute_adjust per step) its per-rank checkpoint stripes."""
+    exchanges + compute_adjust per step) its per-rank checkpoint stripes BIT FOR BIT."""
     import re
     pr = H.c5_np8_problem()
     g, parts = pr["golden"], pr["parts"]
@@ -350,9 +350,41 @@ def test_octree_mesh_on_eight_ranks_tables_and_fields():
         done = int(step)
         for p in parts:
             ref2, ref1 = H.np8_stripe(g, step, p["rank"], len(p["nodes"]))
-            scale = max(np.abs(ref1).max(), 1.0)
-            assert np.abs(tm1s[p["rank"]] - ref2).max() <= 1e-12 * scale
-            assert np.abs(tm2s[p["rank"]] - ref1).max() <= 1e-12 * scale
+            assert np.array_equal(tm1s[p["rank"]], ref2) and np.array_equal(tm2s[p["rank"]], ref1)
+
+
+def test_uniform_box_on_eight_ranks_bit_for_bit():
+    """examples/simple on 8 MPI ranks of the reference (tests/golden/c1_np8: the domain's centre node is shared by all eight,
+    its edges by four): the multi-rank oracle -- every rank's solver_init, the mass exchange, two exchanges per step in the
+    messengers' list order -- against the per-rank checkpoints at steps 400 and 800, BIT FOR BIT.  This is the case that pins
+    the ORDER of the lists: a vertex's share list holds the ranks in the order its owner met them as neighbours
+    (com_allocpctl's scan, octor.c:2640-2741), schedule_build puts a new messenger at the head of its list, and
+    schedule_senddata adds what arrives messenger by messenger; ascending or descending rank gives 1e-14, not zero."""
+    g, base = H.load("c1_np8"), H.load("c1_short")
+    m = ho.octree_mesh_from_elem_ticks(base["elem_ticks"], H.C1_FAR_TICKS)
+    parts = ho.octree_partition(m, 8, [f // m["emin"] for f in H.C1_FAR_TICKS])
+    mat = base["mat_vs_vp_rho"]
+    edata = np.empty((len(m["lnid"]), 4), np.float32)
+    edata[:, 0] = (1000.0 / 2 ** 30 * m["emin"] * m["elem_size"].astype(np.float64)).astype(np.float32)
+    edata[:, 1], edata[:, 2], edata[:, 3] = mat[:, 1], mat[:, 0], mat[:, 2]
+    eds = [np.ascontiguousarray(edata[p["elems"]]) for p in parts]
+    fcs = [np.ascontiguousarray(m["face"][p["elems"]]) for p in parts]
+    ets, nts = ho.multi_rank_init(parts, eds, fcs, 1e-3, 5.0)
+    for r, p in enumerate(parts):
+        assert np.array_equal(g["elem_ticks_%d" % r], base["elem_ticks"][p["elems"]])
+    assert max(len(p["an_sched"]["s"]) for p in parts) == 7          # the owner of the centre node hears from all the others
+    tm1s = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    tm2s = [np.zeros((len(p["nodes"]), 3)) for p in parts]
+    loaded, forces = [g["loaded_lnid_%d" % r] for r in range(8)], [g["forces_%d" % r] for r in range(8)]
+    done = 0
+    for step in g["ckpt_steps"]:
+        ho.multi_rank_run(parts, ets, nts, tm1s, tm2s, done, int(step) - done, 1e-3, loaded, forces)
+        done = int(step)
+        for r, p in enumerate(parts):
+            n = len(p["nodes"])
+            assert np.array_equal(tm1s[r], g["ckpt%d_tm2_%d" % (done, r)][:n])
+            assert np.array_equal(tm2s[r], g["ckpt%d_tm1_%d" % (done, r)][:n])
+    assert max(np.abs(t).max() for t in tm2s) > 100.0
 
 
 def test_output_planes_against_the_reference_files():

@@ -55,8 +55,8 @@ def test_single_precision_two_level_octree_bitwise():
 def test_single_precision_on_eight_ranks_against_the_float_references_stripes():
     """The float reference on 8 MPI ranks (two-level octree: hanging nodes shared across ranks): the mass exchange on float
     n_t rows at init, four exchanges of float records and compute_adjust on floats per step (psolve.c:3498-3507, 4298-4315,
-    4985-5073).  The in-memory exchange sums a node's contributions in rank order, the reference in arrival order: a float
-    ulp or two, not bit for bit."""
+    4985-5073).  Bit for bit, as in double: the in-memory exchange adds a node's contributions messenger by messenger in
+    schedule_build's list order (oracle/herc_oracle.py: octree_partition), as schedule_senddata does (psolve.c:5035-5073)."""
     pr = H.c5_np8_problem("c5_two_level_np8_f32", real=np.float32)
     g, parts = pr["golden"], pr["parts"]
     assert all(nt.dtype == np.float32 for nt in pr["nts"])
@@ -69,7 +69,6 @@ def test_single_precision_on_eight_ranks_against_the_float_references_stripes():
         stripes = [H.np8_stripe(g, step, p["rank"], len(p["nodes"])) for p in parts]
         scale = max(float(np.abs(ref1).max()) for _, ref1 in stripes)          # of the field, not of a rank's quiet corner
         for p, (ref2, ref1) in zip(parts, stripes):
-            assert ref1.dtype == np.float32
-            assert np.abs(tm1s[p["rank"]].astype(np.float64) - ref2).max() <= 2e-6 * scale
-            assert np.abs(tm2s[p["rank"]].astype(np.float64) - ref1).max() <= 2e-6 * scale
+            assert ref1.dtype == np.float32 and scale > 0
+            assert np.array_equal(tm1s[p["rank"]], ref2) and np.array_equal(tm2s[p["rank"]], ref1)
     assert max(float(np.abs(t).max()) for t in tm2s) > 0
