@@ -380,7 +380,7 @@ static void nt_distribute(double* ntable, int f32, int32_t ldnnum, const int32_t
  * The float build on N ranks.  Every rank sums the rows over ITS elements (psolve.c:3440-3471, float fields), then
  * solver_init's three exchanges run on those partial rows (:3498-3507): (A) the sharers of a hanging node send theirs to
  * its owner, which adds them in the order of its messenger list (schedule_senddata, CONTRIBUTION: :5040-5060; the lists
- * in ascending rank, as this library builds them); (B) the owner of a hanging node hands its row / deps to the anchors
+ * in schedule_build's own order, hqh_share_list below); (B) the owner of a hanging node hands its row / deps to the anchors
  * (compute_adjust, its own dnodeTable in order); (C) the sharers of an anchored node send their rows -- their elements'
  * sums plus what (B) gave them -- to its owner, which adds them the same way.  In float every one of those additions
  * rounds, and a run is sensitive to WHICH roundings its rows carry (m2 - m1 = m0 holds only up to them): against the float
@@ -405,9 +405,9 @@ static void nt_rank_rows(int n, const int* rk, double (*rows)[7], int owner, con
 }
 
 /* Every rank's messenger lists of one schedule, as places: the nodes in global (= every rank's local) order, an owned
- * node's sharers in ascending rank (anchored nodes) or descending rank (hanging nodes); a rank met for the first time goes
- * to the HEAD of the owner's list.  first[o * P + r] (in: the order number of the first meeting, < 0 never) ->
- * pos[o * P + r] = place of r in o's list. */
+ * node's sharers in its share list's order (hqh_share_list); a rank that turns up for the first time goes to the HEAD of
+ * the owner's list.  first[o * P + r] (in: the order number of that first time, < 0 never) -> pos[o * P + r] = place of r
+ * in o's list. */
 static void nt_list_places(int P, const int64_t* first, int* pos)
 {
     for (int o = 0; o < P; o++) {
@@ -421,6 +421,43 @@ static void nt_list_places(int P, const int64_t* first, int* pos)
         }
         for (int q = 0; q < n; q++) pos[o * P + seq[q]] = n - 1 - q;          /* the last one met is the first of the list */
     }
+}
+
+/*
+ * The ORDER of a vertex's share list, and with it of the messenger lists (the reference's multi-rank runs come out bit for
+ * bit only in it: tests/test_oracle_golden.py).  octor_extractmesh: every rank sends each vertex of its elements to the
+ * ranks that hold one of the 8 pixels around it; the owner takes the messages in the order of its processor-controller
+ * list and puts each sender at the HEAD of the vertex's list (octor.c:5700-5793) -- and that controller list has the
+ * neighbours in the REVERSE of the order in which com_allocpctl met them (:2640-2741: the rank's leaves in order, around
+ * each the 4 x 4 x 4 points at half-edge spacing from corner - edge / 2, z outermost, a new rank to the head).  So the share
+ * list has the element-vertex sharers in the order the owner MET them; ahead of them, in descending rank, the ranks that
+ * hold the vertex only as an anchor of a hanging node of theirs (:5800-5830, 5990-6050: a list of all ranks in ascending
+ * order, each sender to the head).  schedule_build (psolve.c:4711-4795) then walks the owned nodes in local order and
+ * each one's share list, a NEW messenger to the head of the schedule's list.
+ * met[r] = when the owner met rank r (smaller = earlier; < 0: never); -> out[0..n): the sharers in share-list order.
+ */
+static int hqh_share_list(uint64_t all, uint64_t direct, int owner, int P, const int64_t* met, int* out)
+{
+    int n = 0;
+    const uint64_t me = 1ull << owner, ind = all & ~direct & ~me, dir = direct & ~me;
+    for (int r = P - 1; r >= 0; r--) if ((ind >> r) & 1) out[n++] = r;
+    const int n0 = n;
+    for (int r = 0; r < P; r++) {
+        if (!((dir >> r) & 1)) continue;
+        int u = n++;
+        while (u > n0 && (met[out[u - 1]] < 0 || (met[r] >= 0 && met[out[u - 1]] > met[r]))) { out[u] = out[u - 1]; u--; }
+        out[u] = r;
+    }
+    return n;
+}
+
+/* probe k = 0 .. 3 of com_allocpctl along one axis, for a leaf at l of edge s (finest-edge units): the cell that holds the
+ * point l - s/2 + k s/2, or -1 out of bounds */
+static inline int64_t hqh_probe_cell(int64_t l, int64_t s, int k, int64_t far)
+{
+    const int64_t p2 = 2 * l + (k - 1) * s;          /* twice the coordinate */
+    if (p2 < 0 || p2 >= 2 * far) return -1;
+    return p2 >> 1;
 }
 
 /* The same for the whole-mesh builders (hqh_octbox_create_levels, hqh_mesh_from_leaves: every rank builds the whole mesh and
@@ -618,6 +655,56 @@ static void node_constants(const hqh_box* b, int32_t i, int32_t j, int32_t k, in
     if (by_rank) nt_rank_rows(nr, rk, rows, owner, places + owner * p->nranks, np);
 }
 
+/* when did rank o meet rank q (hqh_share_list)?  met[o * P + q] = 64 x (index of o's first element with a probe point in
+ * q's part) + the probe's number; only = -1: for every o (a pass over the whole box), else for that rank alone */
+static int box_met(const hqh_box* b, int only, int64_t* met)
+{
+    const hqh_box_params* p = &b->p;
+    const int P = p->nranks;
+    for (int q = 0; q < P * P; q++) met[q] = -1;
+    int nomem = 0;
+#pragma omp parallel
+    {
+        int64_t* mine = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
+        if (!mine) {
+#pragma omp atomic write
+            nomem = 1;
+        } else {
+            for (int q = 0; q < P * P; q++) mine[q] = -1;
+#pragma omp for schedule(static)
+            for (int32_t k = 0; k < p->nz; k++)
+                for (int32_t j = 0; j < p->ny; j++)
+                    for (int32_t i = 0; i < p->nx; i++) {
+                        const int64_t idx = elem_index(b, i, j, k);
+                        const int o = rank_of_elem(b, idx);
+                        if (only >= 0 && o != only) continue;
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int64_t z = hqh_probe_cell(k, 1, kk, p->nz);
+                            if (z < 0) continue;
+                            for (int jj = 0; jj < 4; jj++) {
+                                const int64_t y = hqh_probe_cell(j, 1, jj, p->ny);
+                                if (y < 0) continue;
+                                for (int ii = 0; ii < 4; ii++) {
+                                    const int64_t x = hqh_probe_cell(i, 1, ii, p->nx);
+                                    if (x < 0) continue;
+                                    const int q = rank_of_elem(b, elem_index(b, (int32_t)x, (int32_t)y, (int32_t)z));
+                                    if (q == o) continue;
+                                    const int64_t when = 64 * idx + (kk * 4 + jj) * 4 + ii;
+                                    int64_t* f = &mine[o * P + q];
+                                    if (*f < 0 || when < *f) *f = when;
+                                }
+                            }
+                        }
+                    }
+#pragma omp critical
+            for (int q = 0; q < P * P; q++)
+                if (mine[q] >= 0 && (met[q] < 0 || mine[q] < met[q])) met[q] = mine[q];
+            free(mine);
+        }
+    }
+    return nomem ? HQ_ERR_NOMEM : HQ_OK;
+}
+
 /* every rank's s-list of the box as places (nt_list_places): one pass over the whole grid for the node of smallest key that
  * an owner shares with each of the others (solver_float = 4 on partitions only) */
 static int box_list_places(const hqh_box* b, int* pos)
@@ -625,7 +712,8 @@ static int box_list_places(const hqh_box* b, int* pos)
     const hqh_box_params* p = &b->p;
     const int P = p->nranks;
     int64_t* first = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
-    if (!first) return HQ_ERR_NOMEM;
+    int64_t* met = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
+    if (!first || !met || box_met(b, -1, met) != HQ_OK) { free(first); free(met); return HQ_ERR_NOMEM; }
     for (int q = 0; q < P * P; q++) first[q] = -1;
     int nomem = 0;
 #pragma omp parallel
@@ -653,10 +741,14 @@ static int box_list_places(const hqh_box* b, int* pos)
                         const int32_t oi = i < p->nx ? i : p->nx - 1, oj = j < p->ny ? j : p->ny - 1, ok = k < p->nz ? k : p->nz - 1;
                         const int o = rank_of_elem(b, elem_index(b, oi, oj, ok));
                         const int64_t key = (int64_t)node_key(b, i, j, k);
-                        for (int t = 0; t < n; t++) {
-                            if (rk[t] == o) continue;
-                            int64_t* f = &mine[o * P + rk[t]];
-                            if (*f < 0 || key < *f) *f = key;
+                        uint64_t bits = 0;
+                        int sl[8];
+                        for (int t = 0; t < n; t++) bits |= 1ull << rk[t];
+                        const int ns = hqh_share_list(bits, bits, o, P, met + o * P, sl);
+                        for (int t = 0; t < ns; t++) {                   /* the node's share list: its place breaks the tie */
+                            int64_t* f = &mine[o * P + sl[t]];
+                            const int64_t when = 8 * key + t;
+                            if (*f < 0 || when < *f) *f = when;
                         }
                     }
 #pragma omp critical
@@ -665,8 +757,8 @@ static int box_list_places(const hqh_box* b, int* pos)
             free(mine);
         }
     }
-    if (!nomem) nt_list_places(P, first, pos);      /* (two sharers met at one node: ascending rank -- the insertion is stable) */
-    free(first);
+    if (!nomem) nt_list_places(P, first, pos);
+    free(first); free(met);
     return nomem ? HQ_ERR_NOMEM : HQ_OK;
 }
 
@@ -900,14 +992,17 @@ static int build_schedule(hqh_box* b)
     if (P == 1) return HQ_OK;
     int64_t* ccount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
     int64_t* scount = (int64_t*)calloc((size_t)P, sizeof(int64_t));
-    /* the order of the lists: schedule_build walks the nodes in local order (and an owned node's sharers in ascending rank)
+    /* the order of the lists: schedule_build walks the nodes in local order and an owned node's share list (hqh_share_list)
      * and puts a NEW messenger at the HEAD of its list (psolve.c:4736-4745, 4776-4785) -- the reverse of the order of first
      * encounter.  schedule_senddata adds what arrives messenger by messenger in that order (:5035-5073): with it the
      * oracle's multi-rank runs are bit-identical to the reference's per-rank checkpoints (tests/test_oracle_golden.py) */
     int* cseq = (int*)malloc(sizeof(int) * (size_t)P);
     int* sseq = (int*)malloc(sizeof(int) * (size_t)P);
+    int64_t* met = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);
     int ncseq = 0, nsseq = 0;
-    if (!ccount || !scount || !cseq || !sseq) { free(ccount); free(scount); free(cseq); free(sseq); return HQ_ERR_NOMEM; }
+    if (!ccount || !scount || !cseq || !sseq || !met || box_met(b, me, met) != HQ_OK) {
+        free(ccount); free(scount); free(cseq); free(sseq); free(met); return HQ_ERR_NOMEM;
+    }
     for (int pass = 0; pass < 2; pass++) {
         int64_t *cfill = NULL, *sfill = NULL;
         if (pass == 1) {
@@ -920,7 +1015,7 @@ static int build_schedule(hqh_box* b)
             b->mc = (hq_messenger*)calloc((size_t)(b->nc ? b->nc : 1), sizeof(hq_messenger));
             b->ms = (hq_messenger*)calloc((size_t)(b->ns ? b->ns : 1), sizeof(hq_messenger));
             if (!cfill || !sfill || !b->cmap || !b->smap || !b->mc || !b->ms) {
-                free(cfill); free(sfill); free(ccount); free(scount); free(cseq); free(sseq); return HQ_ERR_NOMEM;
+                free(cfill); free(sfill); free(ccount); free(scount); free(cseq); free(sseq); free(met); return HQ_ERR_NOMEM;
             }
             int64_t co = 0, so = 0;
             int ic = 0, is = 0;
@@ -951,11 +1046,10 @@ static int build_schedule(hqh_box* b)
                 if (!seen) sh[nsh++] = r;
             }
             if (pass == 0 && nsh) b->shared_nodes++;
-            for (int t = 1; t < nsh; t++) {                     /* a node's sharers in ascending rank */
-                const int v = sh[t];
-                int u = t;
-                while (u > 0 && sh[u - 1] > v) { sh[u] = sh[u - 1]; u--; }
-                sh[u] = v;
+            {                                                   /* the node's share list (hqh_share_list) */
+                uint64_t bits = 0;
+                for (int t = 0; t < nsh; t++) bits |= 1ull << sh[t];
+                nsh = hqh_share_list(bits, bits, me, P, met + (size_t)me * P, sh);
             }
             for (int t = 0; t < nsh; t++) {
                 if (pass == 0) { if (!scount[sh[t]]++) sseq[nsseq++] = sh[t]; }
@@ -964,7 +1058,7 @@ static int build_schedule(hqh_box* b)
         }
         free(cfill); free(sfill);
     }
-    free(ccount); free(scount); free(cseq); free(sseq);
+    free(ccount); free(scount); free(cseq); free(sseq); free(met);
     return HQ_OK;
 }
 
@@ -1583,9 +1677,11 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
     int32_t* gowner = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
     int32_t* g2l = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
     uint8_t* hang = (uint8_t*)calloc((size_t)N, 1);
+    uint64_t* vharb = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(N ? N : 1));   /* the ranks that have the node as an element vertex */
+    int64_t* met = (int64_t*)malloc(sizeof(int64_t) * (size_t)P * (size_t)P);       /* when rank o met rank q (hqh_share_list) */
     int32_t *lnid = NULL, *xyz = NULL, *own = NULL, *gid = NULL, *dn_id = NULL, *dn_ptr = NULL, *dn_anchor = NULL;
     double *et = NULL, *nt = NULL;
-    if (!harb || !gowner || !g2l || !hang) goto done;
+    if (!harb || !gowner || !g2l || !hang || !vharb || !met) goto done;
     for (int L = 0; L < NL; L++) {
         int64_t n = (int64_t)(nx >> L) * (ny >> L) * b->layers[L];
         cell[L] = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
@@ -1601,20 +1697,53 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
         const uint64_t bit = 1ull << HQH_ERANK(e);
         for (int c = 0; c < 8; c++) harb[b->lnid[8 * e + c]] |= bit;             /* element vertices */
     }
+    memcpy(vharb, harb, sizeof(uint64_t) * (size_t)N);
+    /* the leaf that holds the cell (x, y, z), finest-edge units */
+#define HQH_LEAF_AT(x_, y_, z_, e_)                                                                                \
+    if (NL > 0) e_ = HQH_CELL(octbox_level_at(b, (int32_t)(z_)), (int32_t)(x_), (int32_t)(y_), (int32_t)(z_));    \
+    else {                                                                                                         \
+        const uint64_t key_ = zvalue((uint32_t)(x_), (uint32_t)(y_), (uint32_t)(z_));                              \
+        int64_t lo_ = 0, hi_ = E - 1;                                                                              \
+        while (lo_ < hi_) { int64_t m_ = (lo_ + hi_ + 1) / 2; if (ek[m_] <= key_) lo_ = m_; else hi_ = m_ - 1; }   \
+        e_ = lo_;                                                                                                  \
+    }
     for (int64_t n = 0; n < N; n++) {                                            /* owners */
         const int32_t* c = &b->node_xyz[3 * n];
         int32_t ax = c[0] < nx ? c[0] : nx - 1, ay = c[1] < ny ? c[1] : ny - 1, az = c[2] < nzt ? c[2] : nzt - 1;
         int64_t e;
-        if (NL > 0) e = HQH_CELL(octbox_level_at(b, az), ax, ay, az);
-        else {
-            const uint64_t key = zvalue((uint32_t)ax, (uint32_t)ay, (uint32_t)az);
-            int64_t lo = 0, hi = E - 1;
-            while (lo < hi) { int64_t m = (lo + hi + 1) / 2; if (ek[m] <= key) lo = m; else hi = m - 1; }
-            e = lo;
-        }
+        HQH_LEAF_AT(ax, ay, az, e)
         gowner[n] = HQH_ERANK(e);
         harb[n] |= 1ull << gowner[n];
     }
+    /* when every rank met its neighbours (com_allocpctl's scan, see hqh_share_list): only a leaf with a vertex that another
+     * rank's leaf has too can see another rank's pixel -- on a 2:1 mesh every leaf at an interface has such a vertex */
+    for (int q = 0; q < P * P; q++) met[q] = -1;
+    for (int64_t e = 0; e < E; e++) {
+        const int o = HQH_ERANK(e);
+        if (!parts && o != me) continue;                                          /* (all ranks' lists: the float rows only) */
+        int edge = 0;
+        for (int c = 0; c < 8; c++) edge |= (vharb[b->lnid[8 * e + c]] & ~(1ull << o)) != 0;
+        if (!edge) continue;
+        const int32_t* c0 = &b->node_xyz[3 * (int64_t)b->lnid[8 * e]];
+        const int64_t sz = b->node_xyz[3 * (int64_t)b->lnid[8 * e + 7]] - c0[0];
+        for (int kk = 0; kk < 4; kk++) {
+            const int64_t z = hqh_probe_cell(c0[2], sz, kk, nzt);
+            if (z < 0) continue;
+            for (int jj = 0; jj < 4; jj++) {
+                const int64_t y = hqh_probe_cell(c0[1], sz, jj, ny);
+                if (y < 0) continue;
+                for (int ii = 0; ii < 4; ii++) {
+                    const int64_t x = hqh_probe_cell(c0[0], sz, ii, nx);
+                    if (x < 0) continue;
+                    int64_t e2;
+                    HQH_LEAF_AT(x, y, z, e2)
+                    const int q = HQH_ERANK(e2);
+                    if (q != o && met[o * P + q] < 0) met[o * P + q] = 64 * e + (kk * 4 + jj) * 4 + ii;
+                }
+            }
+        }
+    }
+#undef HQH_LEAF_AT
 #undef HQH_CELL
     for (int32_t k = 0; k < b->ldnnum; k++) {                                    /* indirect sharing */
         hang[b->dn_id[k]] = 1;
@@ -1627,14 +1756,13 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
         int prc = HQ_ERR_NOMEM;
         if (first && pos) {
             for (int q = 0; q < 2 * P * P; q++) first[q] = -1;
-            int64_t met = 0;
+            int64_t seen = 0;
             for (int64_t n = 0; n < N; n++) {                                     /* every rank's schedule_build at once */
                 const int o = gowner[n], sdn = hang[n];
-                const uint64_t m = harb[n] & ~(1ull << o);
-                for (int t = 0; t < P; t++) {
-                    const int r = sdn ? P - 1 - t : t;
-                    if (((m >> r) & 1) && first[((int64_t)sdn * P + o) * P + r] < 0) first[((int64_t)sdn * P + o) * P + r] = met++;
-                }
+                int sl[64];
+                const int ns = hqh_share_list(harb[n], vharb[n], o, P, met + o * P, sl);
+                for (int t = 0; t < ns; t++)
+                    if (first[((int64_t)sdn * P + o) * P + sl[t]] < 0) first[((int64_t)sdn * P + o) * P + sl[t]] = seen++;
             }
             nt_list_places(P, first, pos);
             nt_list_places(P, first + (int64_t)P * P, pos + P * P);
@@ -1717,12 +1845,10 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
                         if (pass == 0) { if (!ccount[own[l]]++) cseq[ncseq++] = own[l]; } else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
                         continue;
                     }
-                    /* a node's sharers: ascending rank for an anchored node, descending for a hanging one -- the order in
-                     * which the reference's multi-rank runs come out bit for bit (oracle/herc_oracle.py: octree_partition) */
-                    const uint64_t m = harb[g] & ~mebit;
-                    for (int t = 0; t < P; t++) {
-                        const int r = s == 0 ? t : P - 1 - t;
-                        if (!((m >> r) & 1)) continue;
+                    int sl[64];                                  /* the node's share list, in its order */
+                    const int nsl = hqh_share_list(harb[g], vharb[g], me, P, met + (size_t)me * P, sl);
+                    for (int t = 0; t < nsl; t++) {
+                        const int r = sl[t];
                         if (pass == 0) { if (!scount[r]++) sseq[nsseq++] = r; } else b->smap[s][sfill[r]++] = (int32_t)l;
                     }
                 }
@@ -1745,7 +1871,7 @@ static int octbox_cut(hqh_octbox* b, const uint64_t* ek, int me, int P, nt_parts
 #undef HQH_ERANK
 done:
     for (int L = 0; L < HQH_MAXLEVELS; L++) free(cell[L]);
-    free(harb); free(gowner); free(g2l); free(hang);
+    free(harb); free(gowner); free(g2l); free(hang); free(vharb); free(met);
     free(lnid); free(xyz); free(own); free(gid); free(dn_id); free(dn_ptr); free(dn_anchor); free(et); free(nt);
     return rc;
 }
@@ -1947,8 +2073,9 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
     uint64_t* keys = NULL;
     int32_t *lnid = NULL, *xyz = NULL, *own = NULL, *gid = NULL, *dn_id = NULL, *dn_ptr = NULL, *dn_anchor = NULL;
     double *et = NULL, *nt = NULL;
-    uint64_t* harb = NULL;
+    uint64_t *harb = NULL, *vh = NULL;           /* vh: the ranks that have the node as an element vertex */
     uint8_t* hang = NULL;
+    int64_t met[64];                             /* when this rank met the others (hqh_share_list) */
     /* 1. candidates: the vertices of my elements; the hanging nodes on top of my elements (their containing leaf is
      *    mine when I own them) and their anchors */
     int64_t cap = 8 * ne + 64, nk = 8 * ne;
@@ -1997,10 +2124,11 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
     gid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nh ? nh : 1));
     nt = (double*)malloc(sizeof(double) * 7 * (size_t)(nh ? nh : 1));
     harb = (uint64_t*)calloc((size_t)(nh ? nh : 1), sizeof(uint64_t));
+    vh = (uint64_t*)calloc((size_t)(nh ? nh : 1), sizeof(uint64_t));
     hang = (uint8_t*)calloc((size_t)(nh ? nh : 1), 1);
     lnid = (int32_t*)malloc(sizeof(int32_t) * 8 * (size_t)(ne ? ne : 1));
     et = (double*)malloc(sizeof(double) * 4 * (size_t)(ne ? ne : 1));
-    if (!xyz || !own || !gid || !nt || !harb || !hang || !lnid || !et) goto done;
+    if (!xyz || !own || !gid || !nt || !harb || !vh || !hang || !lnid || !et) goto done;
     int fault = 0;
     int64_t ndn = 0, nan = 0;
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : ndn, nan) reduction(| : fault)
@@ -2014,6 +2142,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
         const int o = oct_owner(&C, c);
         if (o < 0 || !bits) { fault = 1; continue; }
         own[l] = o;
+        vh[l] = bits;
         bits |= 1ull << o;
         int32_t an[4][3];
         int deps = 0;
@@ -2078,6 +2207,32 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
         }
     }
     if (fault) { rc = HQ_ERR_STATE; goto done; }
+    /* when I met my neighbours (com_allocpctl's scan over my leaves, see hqh_share_list) */
+    for (int q = 0; q < 64; q++) met[q] = -1;
+    for (int64_t e = elo; e < ehi; e++) {
+        int edge = 0;
+        for (int c = 0; c < 8; c++) edge |= (vh[lnid[8 * (e - elo) + c]] & ~(1ull << me)) != 0;
+        if (!edge) continue;
+        const int32_t i = (int32_t)compact3(ek[e]), j = (int32_t)compact3(ek[e] >> 1), k = (int32_t)compact3(ek[e] >> 2);
+        const int64_t sz = 1 << octbox_level_at(b, k);
+        for (int kk = 0; kk < 4; kk++) {
+            const int64_t z = hqh_probe_cell(k, sz, kk, C.far[2]);
+            if (z < 0) continue;
+            for (int jj = 0; jj < 4; jj++) {
+                const int64_t y = hqh_probe_cell(j, sz, jj, C.far[1]);
+                if (y < 0) continue;
+                for (int ii = 0; ii < 4; ii++) {
+                    const int64_t x = hqh_probe_cell(i, sz, ii, C.far[0]);
+                    if (x < 0) continue;
+                    oct_leaf_t lf;
+                    if (!oct_leaf_of_cell(&C, (int32_t)x, (int32_t)y, (int32_t)z, &lf)) { fault = 1; continue; }
+                    const int q = OCT_ERANK(&C, lf.e);
+                    if (q != me && met[q] < 0) met[q] = 64 * e + (kk * 4 + jj) * 4 + ii;
+                }
+            }
+        }
+    }
+    if (fault) { rc = HQ_ERR_STATE; goto done; }
     /* 4. dnodeTable of the hanging nodes I own, node order, anchors in octor's list order */
     dn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ndn ? ndn : 1));
     dn_ptr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ndn + 1));
@@ -2102,7 +2257,6 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
     }
     /* 5. schedule_build (psolve.c:4704-4863), as octbox_cut */
     {
-        const uint64_t mebit = 1ull << me;
         for (int s = 0; s < 2; s++) {
             int64_t ccount[64], scount[64], cfill[64], sfill[64];
             int cseq[64], sseq[64], ncseq = 0, nsseq = 0;     /* ranks in the order of first encounter */
@@ -2133,10 +2287,10 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
                         if (pass == 0) { if (!ccount[own[l]]++) cseq[ncseq++] = own[l]; } else b->cmap[s][cfill[own[l]]++] = (int32_t)l;
                         continue;
                     }
-                    const uint64_t m = harb[l] & ~mebit;
-                    for (int t = 0; t < P; t++) {            /* (ascending for anchored, descending for hanging nodes: octbox_cut) */
-                        const int r = s == 0 ? t : P - 1 - t;
-                        if (!((m >> r) & 1)) continue;
+                    int sl[64];                                  /* the node's share list, in its order */
+                    const int nsl = hqh_share_list(harb[l], vh[l], me, P, met, sl);
+                    for (int t = 0; t < nsl; t++) {
+                        const int r = sl[t];
                         if (pass == 0) { if (!scount[r]++) sseq[nsseq++] = r; } else b->smap[s][sfill[r]++] = (int32_t)l;
                     }
                 }
@@ -2150,7 +2304,7 @@ static int octbox_local(hqh_octbox* b, const uint64_t* ek, int me, int P, const 
     b->E = ne; b->N = nh; b->ldnnum = (int32_t)ndn;
     rc = HQ_OK;
 done:
-    free(keys); free(harb); free(hang); free(bucket);
+    free(keys); free(harb); free(vh); free(hang); free(bucket);
     free(lnid); free(xyz); free(own); free(gid); free(dn_id); free(dn_ptr); free(dn_anchor); free(et); free(nt);
     return rc;
 }

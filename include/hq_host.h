@@ -72,9 +72,8 @@ typedef struct {
                                       * then solver_init's three mass exchanges (psolve.c:3498-3507: sharers' rows added
                                       * to the owner's in messenger order, hanging nodes' shares handed out by their
                                       * owners in between); every harbored copy holds its owner's row.  Bit for bit the
-                                      * multi-rank float oracle's (tests/test_host_float_tables.py: messengers in ascending
-                                      * rank; the reference walks octor's list order, a float ulp apart), which a run agrees
-                                      * with the float reference's 8-rank checkpoints on to 2e-6 */
+                                      * multi-rank float oracle's (tests/test_host_float_tables.py), which steps to the float
+                                      * reference's 8-rank checkpoints bit for bit (tests/test_oracle_single_precision.py) */
 } hqh_box_params;
 
 typedef struct {

@@ -72,6 +72,12 @@ def test_a_box_partitions_rows_are_the_n_rank_float_builds(nranks):
     for r, b in enumerate(boxes):
         own = b.owner == r
         assert _exact_floats(b.ntable) and np.array_equal(b.ntable[own].astype(np.float32), nts[r][own])
+        sch = b.schedule()                                # the messenger lists in schedule_build's order (hq_host.c: hqh_share_list)
+        for lst in ("c", "s"):
+            exp = parts[r]["an_sched"].get(lst, [])
+            assert [q for q, _ in sch[lst]] == [q for q, _ in exp]
+            for (_, a), (_, e) in zip(sch[lst], exp):
+                assert np.array_equal(a, e)
         g = np.array([gid[tuple(v)] for v in b.node_ijk.tolist()])
         rows[g[own]] = nts[r][own]
         differ += int((b.ntable[own] != one_rank.ntable[g[own]]).any(axis=1).sum())
