@@ -278,9 +278,12 @@ HQ_API int hqh_station_kinematics(const double* phi, const double* tm1, const do
  * the rank harbors the vertices of its elements, the nodes it owns (direct sharing,
  * octor.c:5516-5793) and the anchors of the hanging nodes it owns (indirect sharing,
  * node_harboranchored octor.c:3916-4042, :5795-6040); dnodeTable lists the hanging nodes it
- * OWNS; an_sched / dn_sched are schedule_build's (psolve.c:4704-4863), messengers by ascending
- * rank; nTable carries the summed masses of shared nodes (what solver_init's exchange leaves,
- * psolve.c:3498-3507).  Every rank builds the whole box first and cuts its part out.
+ * OWNS; an_sched / dn_sched are schedule_build's (psolve.c:4704-4863), the messengers in ITS
+ * order (a new messenger at the head of its list; a node's sharers as octor's share list has
+ * them: the ranks its owner met as neighbours, in that order -- the reference's multi-rank
+ * runs are reproduced bit for bit only in it); nTable carries the summed masses of shared nodes
+ * (what solver_init's exchange leaves, psolve.c:3498-3507).  Every rank builds the whole box
+ * first and cuts its part out.
  */
 typedef struct hqh_octbox hqh_octbox;
 

@@ -470,7 +470,7 @@ def octree_partition(m, nranks, far_q):
                 for q in indirect + direct:
                     sched[kind]["s"].setdefault(q, []).append(i)
                 assert len(indirect) + len(direct) == sum(1 for q in range(nranks) if q != r and int(g) in harbored[q])
-        # schedule_build (psolve.c:4711-4795) walks the nodes in local order and a node's sharers in ascending rank, and
+        # schedule_build (psolve.c:4711-4795) walks the nodes in local order and a node's share list (above), and
         # puts a NEW messenger at the HEAD of its list: the lists end up in the reverse of the order of first encounter.
         # schedule_senddata adds the incoming records messenger by messenger in list order (:5035-5073) -- with that order
         # the multi-rank runs below are bit-identical to the reference's per-rank checkpoint stripes, float and double
