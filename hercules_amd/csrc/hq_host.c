@@ -800,7 +800,7 @@ int hqh_box_create(const hqh_box_params* p, hqh_box** out)
     if (ax < 0 || ay < 0 || az < 0 || ax > 10 || ay > 10 || az > 10) return HQ_ERR_ARG;
     if (p->nlayers < 1 || !p->layer_ztop || !p->layer_vp || !p->layer_vs || !p->layer_rho) return HQ_ERR_ARG;
     if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks || p->h <= 0 || p->deltaT <= 0) return HQ_ERR_ARG;
-    if (!hqh_sf_valid(p->solver_float)) return HQ_ERR_ARG;
+    if (!hqh_sf_valid(p->solver_float) || p->nranks > 64) return HQ_ERR_ARG;       /* (a node's sharers are a 64-bit set, as in the octree boxes) */
     hqh_box* b = (hqh_box*)calloc(1, sizeof(hqh_box));
     if (!b) return HQ_ERR_NOMEM;
     b->p = *p;

@@ -56,7 +56,7 @@ typedef struct {
     double        threshold_damping; /* the_threshold_damping                      */
     double        threshold_vpvs;    /* the_threshold_Vp_over_Vs                   */
     int32_t       halfspace;         /* 1: z = 0 is a free surface (-DHALFSPACE)   */
-    int32_t       rank, nranks;      /* this partition / number of partitions      */
+    int32_t       rank, nranks;      /* this partition / number of partitions (<= 64) */
     int32_t       lateral_classes;   /* > 1: the element (i, j, k) belongs to class hash(i, j, k) mod this and its
                                       * Vp, Vs, rho are its layer's times 1 + lateral_amp (2 class / (classes - 1) - 1):
                                       * material that differs from element to element, as on a real CVM mesh
